@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the blob-mobility hot path on MI355X.
+
+Workload (BASELINE.json configs[2]): 200 bodies x shell_N_642 = 128 400 blobs,
+wall-corrected RPY mobility with wall damping, fp64, synthetic configuration of
+SURVEY.md section 8(d).  One "step" = one pass of the hot path:
+
+    blob positions from (X, Q) on the device  ->  [all-gather positions, forces]  ->
+    matrix-free  U = B M B F  for this rank's rows
+
+N = 1:  everything on one GPU.   N > 1: bodies sharded contiguously over ranks (one
+process per GPU, torch.distributed / RCCL all-gather), total work fixed -> "strong".
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline`
+(dominant kernel k_apply_M timed with events on its own stream) and `cpu_baseline`
+(the CPU oracle -- a port of the reference algorithm -- on a bounded row sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (bodies, blobs/body, wall)
+    "cfg1": (10, 12, False),
+    "cfg2": (50, 162, False),
+    "cfg3": (200, 642, True),
+    "cfg5": (20, 2562, False),
+}
+FLOPS_PER_PAIR = {False: 59.0, True: 204.0}   # reference arithmetic per ordered pair
+PEAK_FP64_TFLOPS = 78.6                       # MI355X fp64 vector == fp64 matrix peak
+
+
+def cpu_baseline(c, nb, nblb, wall, budget_s):
+    """Time the CPU oracle (port of reference :413-459,:641-659, matrix-free restatement)
+    on a bounded sample of rows of the SAME workload; scale to one full apply_M."""
+    from oracle import Oracle
+    orc = Oracle()
+    cfg = c["cfg"] - c["cfg"].mean(axis=0)
+    r = orc.multi_body_pos(c["X"], c["Q"], cfg)
+    N = nb * nblb
+    F = np.random.default_rng(2).standard_normal(3 * N)
+    out = {}
+    for label, nthreads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
+        rows = 4 * nthreads
+        t0 = time.perf_counter(); orc.apply_M_rows(F, r, 0, rows, c["a"], c["eta"], wall, nthreads); t1 = time.perf_counter()
+        per_row = (t1 - t0) / rows
+        rows = int(max(rows, min(N, budget_s / max(per_row, 1e-9))))
+        b = (N // 2 // max(nblb, 1)) * nblb
+        b = min(b, N - rows)
+        t0 = time.perf_counter(); orc.apply_M_rows(F, r, b, b + rows, c["a"], c["eta"], wall, nthreads); t1 = time.perf_counter()
+        t_full = (t1 - t0) * N / rows
+        out[label] = {"value": 1.0 / t_full, "unit": "steps/s", "cores": nthreads, "kind": "port",
+                      "sample": "%d of %d rows x all %d columns of the same workload, %.1f s measured, "
+                                "scaled by N/rows; oracle/rbl_oracle.c orc_apply_M_rows (gcc -O3 -march=x86-64-v3, "
+                                "reference pair arithmetic, matrix-free because the reference's dense 3Nx3N matrix "
+                                "would need %.2f TB)" % (rows, N, N, t1 - t0, 8.0 * (3 * N) ** 2 / 1e12),
+                      "seconds_per_step": t_full}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg (0 = skip)")
+    ap.add_argument("--jsplit", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.dist import ShardedMobility
+
+    nb, nblb, wall = CONFIGS[args.config]
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    stream = torch.cuda.current_stream()
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=stream.cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    if args.jsplit:
+        ctx.set_tuning(args.jsplit, 0)
+    sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
+    nrows = sm.row1 - sm.row0
+
+    F_full_host = np.random.default_rng(2).standard_normal(3 * N)
+    F_local = torch.from_numpy(F_full_host[3 * sm.row0:3 * sm.row1].copy()).to(dev)
+    r_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
+    U_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k=None):
+        # a8: this rank's blob positions from (X,Q); one exchange; this rank's rows of U = B M B F
+        ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
+        r_full = sm.set_positions_local(r_local) if world > 1 else r_local
+        F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
+        if k is not None:
+            ev[k][0].record(stream)
+        ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
+        if k is not None:
+            ev[k][1].record(stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync_check()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    t1 = time.perf_counter()
+    ctx.sync_check()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / args.steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item()); kern_ms = float(kern_ms.item())
+
+    if rank == 0:
+        sec_per_step = elapsed / args.steps
+        pairs_per_launch = float(nrows) * float(N)               # ordered pairs one launch (this rank) evaluates
+        flops_alg = FLOPS_PER_PAIR[wall] * pairs_per_launch
+        achieved = flops_alg / (kern_ms * 1e-3) / 1e12
+        line = {
+            "metric": "apply_M steps/sec (1 step = one matrix-free M.F pass of the hot path: blob positions -> "
+                      "[all-gather] -> U = B M B F), %d x shell_N_%d, %s, fp64" % (nb, nblb, "wall-corrected" if wall else "free-space"),
+            "value": 1.0 / sec_per_step,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": sec_per_step * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: 200 bodies x shell_N_642 blobs, wall-corrected mobility"
+                                   if args.config == "cfg3" else args.config,
+                       "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
+                       "parallelism": "body-sharded x%d, all-gather(pos,F)" % world},
+            "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
+            "roofline": {"bound": "fp64-valu", "kernel": "k_apply_M<%s>" % ("true" if wall else "false"),
+                         "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms,
+                         "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch)},
+        }
+        if world == 1 and args.cpu_budget > 0:
+            cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
+            line["cpu_baseline"] = cb["1core"]
+            line["cpu_baseline_allcores"] = cb["allcores"]
+            line["speedup_vs_cpu_1core"] = line["value"] / cb["1core"]["value"]
+            line["speedup_vs_cpu_allcores"] = line["value"] / cb["allcores"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

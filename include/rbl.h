@@ -1,0 +1,195 @@
+/*
+ * rbl.h -- C ABI of the MI355X-native blob-mobility hot path (librbl.so).
+ *
+ * Drop-in boundary for brennansprinkle/Rigid_Body_Light: every entry point in
+ * section 1 replaces ONE method the reference binds on `c_rigid.CManyBodies`
+ * (reference src/c_rigid_obj.cpp:997-1027, nanobind).  The reference-side
+ * binding a maintainer would write is in INTEGRATION.md; our own pybind11
+ * shim (rigid_body_light_amd/csrc/c_rigid.cpp) calls nothing but this header.
+ *
+ * Conventions
+ *   - plain pointers + sizes, double precision only, no C++/torch types;
+ *   - host-pointer entry points (section 1,2) take caller-owned contiguous
+ *     arrays, never modify inputs, and are synchronous;
+ *   - device-pointer entry points (section 3) take HIP device pointers, enqueue
+ *     on the context's stream (rbl_set_stream) and do NOT synchronise;
+ *   - every function returns an int status (0 = RBL_OK) and never throws or
+ *     exit()s; rbl_last_error(ctx) gives the message for the last failure;
+ *   - vectors over blobs are xyz-interleaved, body-major (reference
+ *     c_rigid_obj.cpp:281-293); quaternions are scalar-first (:212-215);
+ *   - a context is not thread-safe (neither is the reference object, :151-154).
+ */
+#ifndef RBL_H
+#define RBL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBL_OK 0
+#define RBL_ERR_OVERLAP 1     /* two blobs closer than 1e-12 a; reference exit()s, :53-58 */
+#define RBL_ERR_BELOW_WALL 2  /* blob centre below the wall; reference throws, :95-97    */
+#define RBL_ERR_NOT_SPD 3     /* Cholesky met a non-positive pivot                        */
+#define RBL_ERR_SIZE 4        /* bad length / shape                                       */
+#define RBL_ERR_NO_DEVICE 5   /* no HIP device / HIP runtime failure at init              */
+#define RBL_ERR_HIP 6         /* a HIP call failed                                        */
+#define RBL_ERR_STATE 7       /* parameters or configuration not set                      */
+#define RBL_ERR_SINGULAR 8    /* K^T K singular (reference exit()s, :313-316)             */
+#define RBL_ERR_ALLOC 9
+#define RBL_ERR_NONFINITE 10  /* result contains inf/nan                                  */
+#define RBL_ERR_ARG 11
+
+typedef struct rbl_ctx rbl_ctx;
+
+/* ===================================================================== */
+/* 1. One entry point per method bound in the reference (file:line)       */
+/* ===================================================================== */
+
+/* CManyBodies()  -- nb::init<>(), c_rigid_obj.cpp:1001.  Host-only; the HIP
+ * device is initialised lazily by the first compute call. */
+rbl_ctx *rbl_create(void);
+void rbl_destroy(rbl_ctx *ctx);
+
+/* static `precision`, c_rigid_obj.cpp:170-174,1024-1026.  Always "double". */
+const char *rbl_precision(void);
+
+/* setParameters(a, dt, kBT, eta, cfg), c_rigid_obj.cpp:183-195.
+ * cfg: N_blb x 3 row-major; its mean is removed in a private copy (:188). */
+int rbl_set_parameters(rbl_ctx *ctx, double a, double dt, double kBT, double eta,
+                       const double *cfg, int N_blb);
+
+/* setBlkPC(bool) :197, setWallPC(bool) :199 */
+int rbl_set_blk_pc(rbl_ctx *ctx, int block_diag_pc);
+int rbl_set_wall_pc(rbl_ctx *ctx, int wall);
+
+/* setConfig(X[3Nb], Q[4Nb]), c_rigid_obj.cpp:201-233 (Q normalised). */
+int rbl_set_config(rbl_ctx *ctx, const double *X, const double *Q, int N_bod);
+
+/* getConfig() -> (X[3Nb], Q[4Nb]), c_rigid_obj.cpp:235-255 */
+int rbl_get_config(const rbl_ctx *ctx, double *X, double *Q);
+
+/* set_K_mats(), c_rigid_obj.cpp:395-402 */
+int rbl_set_K_mats(rbl_ctx *ctx);
+
+/* K_x_U(U[6Nb]) -> [3N], :404 ; KT_x_Lam(lambda[3N]) -> [6Nb], :410 */
+int rbl_K_x_U(rbl_ctx *ctx, const double *U, double *out);
+int rbl_KT_x_Lam(rbl_ctx *ctx, const double *lambda, double *out);
+
+/* multi_body_pos() -> [3N], c_rigid_obj.cpp:295-300 (computed on the GPU) */
+int rbl_multi_body_pos(rbl_ctx *ctx, double *out);
+
+/* apply_PC(IN[3N+6Nb]) -> [3N+6Nb], c_rigid_obj.cpp:589-616 */
+int rbl_apply_PC(rbl_ctx *ctx, const double *in, double *out);
+
+/* get_K() / get_Kinv(), c_rigid_obj.cpp:978-992: CSC arrays.  Call once with
+ * NULL arrays to get nnz, then with arrays of that size (indptr: ncols+1). */
+int rbl_get_K_csc(rbl_ctx *ctx, int64_t *nnz, int64_t *nrows, int64_t *ncols,
+                  double *data, int32_t *indices, int32_t *indptr);
+int rbl_get_Kinv_csc(rbl_ctx *ctx, int64_t *nnz, int64_t *nrows, int64_t *ncols,
+                     double *data, int32_t *indices, int32_t *indptr);
+
+/* evolve_X_Q(U[6Nb]), c_rigid_obj.cpp:865-878 (multiplies by dt internally,
+ * rebuilds K, invalidates the preconditioner).  U is not modified. */
+int rbl_evolve_X_Q(rbl_ctx *ctx, const double *U);
+
+/* apply_M(F[n3], r_vecs[n3]) -> [n3], c_rigid_obj.cpp:641-659.
+ * n3 = 3 * (number of blobs in r_vecs); it need not equal 3*N_bod*N_blb
+ * (reference tests/test_interface.py:171-177).  U = M F, or B (M (B F)) with
+ * the wall term when wall_PC is set.  Matrix-free on the GPU. */
+int rbl_apply_M(rbl_ctx *ctx, const double *F, const double *r_vecs, int64_t n3,
+                double *out);
+
+/* ===================================================================== */
+/* 2. Reference C++ members that are NOT bound to Python, + extensions    */
+/* ===================================================================== */
+
+/* Kinv_x_V :406, KTinv_x_F :408 */
+int rbl_Kinv_x_V(rbl_ctx *ctx, const double *V, double *out);
+int rbl_KTinv_x_F(rbl_ctx *ctx, const double *F, double *out);
+
+/* apply_M for nrhs right-hand sides, F/out column-major n3 x nrhs. */
+int rbl_apply_M_multi(rbl_ctx *ctx, const double *F, const double *r_vecs, int64_t n3,
+                      int nrhs, double *out);
+
+/* rotne_prager_tensor(r) -> dense column-major n3 x n3, c_rigid_obj.cpp:413-459
+ * (wall term per wall_PC).  scale_damp != 0 returns B Mob B (:668-669). */
+int rbl_rotne_prager_tensor(rbl_ctx *ctx, const double *r_vecs, int64_t n3,
+                            int scale_damp, double *out);
+
+/* M_half_W(), c_rigid_obj.cpp:661-675, on the object's own configuration.
+ * W == NULL: standard normal noise from `seed` (counter-based, reproducible;
+ * the reference seeds from the clock, :731).  method: RBL_MHALF_CHOLESKY is the
+ * reference algorithm (dense B Mob B, lower Cholesky, L W);
+ * RBL_MHALF_LANCZOS is matrix-free (a different square root of the same M). */
+#define RBL_MHALF_CHOLESKY 0
+#define RBL_MHALF_LANCZOS 1
+int rbl_M_half_W(rbl_ctx *ctx, const double *W, uint64_t seed, int method, double *out);
+
+/* same on caller-supplied positions (n3 free, like apply_M) */
+int rbl_M_half_W_r(rbl_ctx *ctx, const double *r_vecs, int64_t n3, const double *W,
+                   uint64_t seed, int method, double *out);
+
+/* Lanczos controls / report (iterations used by the last call, last residual) */
+int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
+int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);
+
+/* dense lower Cholesky of a caller matrix (column-major n x n, in place on the
+ * device, result copied back; strict upper triangle zeroed). */
+int rbl_cholesky_lower(rbl_ctx *ctx, double *M, int64_t n);
+
+/* sizes / flags */
+int rbl_get_sizes(const rbl_ctx *ctx, int *N_bod, int *N_blb);
+const char *rbl_last_error(const rbl_ctx *ctx);
+
+/* test hook: n independent 3x3 blocks (row-major, scaled by 1/(8 pi eta a)) of
+ * pairs (ri[k], rj[k]) with indices (ii[k], jj[k]); mode 0 = reference-order
+ * arithmetic (dense-build kernel), 1 = fast matvec arithmetic. */
+int rbl_debug_pair_blocks(rbl_ctx *ctx, const double *ri, const double *rj,
+                          const int32_t *ii, const int32_t *jj, int64_t n, int wall,
+                          int mode, double *out9);
+
+/* ===================================================================== */
+/* 3. Device-pointer API (resident data, multi-GPU shards, benchmarks)    */
+/* ===================================================================== */
+
+/* Bind to the calling thread's current HIP device and a stream handle
+ * (hipStream_t as void*; NULL = the default stream). */
+int rbl_set_stream(rbl_ctx *ctx, void *hip_stream);
+
+/* rows [row_begin,row_end) of apply_M over n_blobs blobs.  d_F, d_r: n_blobs*3
+ * doubles on the device; d_out: 3*(row_end-row_begin).  Error conditions are
+ * latched in a device word, read with rbl_sync_check. */
+int rbl_apply_M_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
+                    int64_t row_begin, int64_t row_end, double *d_out);
+
+/* blob positions of bodies [body_begin, body_end) into d_out
+ * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */
+int rbl_blob_positions_dev(rbl_ctx *ctx, int body_begin, int body_end, double *d_out);
+
+/* dense build on the device: d_out column-major n3 x n3 (ld = n3) */
+int rbl_rotne_prager_tensor_dev(rbl_ctx *ctx, const double *d_r, int64_t n_blobs,
+                                int scale_damp, double *d_out);
+
+/* in-place lower Cholesky on the device (strict upper left untouched unless
+ * zero_upper), then out = L W */
+int rbl_cholesky_lower_dev(rbl_ctx *ctx, double *d_M, int64_t n, int zero_upper);
+int rbl_trmv_lower_dev(rbl_ctx *ctx, const double *d_L, int64_t n, const double *d_W,
+                       double *d_out);
+
+/* M^{1/2} W on the device with positions d_r (n_blobs) and noise d_W (3 n_blobs) */
+int rbl_M_half_W_dev(rbl_ctx *ctx, const double *d_r, int64_t n_blobs, const double *d_W,
+                     int method, double *d_out);
+
+/* stream-synchronise, read and clear the latched device error word */
+int rbl_sync_check(rbl_ctx *ctx);
+
+/* override the matvec decomposition (0 = heuristic) -- tuning/test hook */
+int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBL_H */

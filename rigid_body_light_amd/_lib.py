@@ -1,0 +1,114 @@
+"""ctypes view of librbl.so's device-pointer API (include/rbl.h section 3) for callers
+that keep data resident on the GPU (bench.py, dist.py).  torch is used only as the
+owner of device memory and streams; the pointers handed over are raw HIP pointers."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librbl.so")
+        if not os.path.exists(path):
+            raise ImportError("librbl.so not built; run `python -m rigid_body_light_amd.build`")
+        L = C.CDLL(path)
+        vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+        L.rbl_create.restype = vp
+        L.rbl_destroy.argtypes = [vp]
+        L.rbl_last_error.restype = C.c_char_p
+        L.rbl_last_error.argtypes = [vp]
+        L.rbl_set_parameters.argtypes = [vp, dbl, dbl, dbl, dbl, vp, C.c_int]
+        L.rbl_set_wall_pc.argtypes = [vp, C.c_int]
+        L.rbl_set_config.argtypes = [vp, vp, vp, C.c_int]
+        L.rbl_set_stream.argtypes = [vp, vp]
+        L.rbl_apply_M_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+        L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.rbl_rotne_prager_tensor_dev.argtypes = [vp, vp, i64, C.c_int, vp]
+        L.rbl_cholesky_lower_dev.argtypes = [vp, vp, i64, C.c_int]
+        L.rbl_trmv_lower_dev.argtypes = [vp, vp, i64, vp, vp]
+        L.rbl_M_half_W_dev.argtypes = [vp, vp, i64, vp, C.c_int, vp]
+        L.rbl_sync_check.argtypes = [vp]
+        L.rbl_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+        L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
+        L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
+        _LIB = L
+    return _LIB
+
+
+class RblError(RuntimeError):
+    pass
+
+
+class DeviceContext:
+    """Owns one rbl_ctx bound to the current HIP device and a stream."""
+
+    def __init__(self, a, eta, wall, cfg=None, dt=0.0, kBT=1.0, stream_ptr=None):
+        import numpy as np
+        self.L = lib()
+        self.h = self.L.rbl_create()
+        if not self.h:
+            raise RblError("rbl_create failed")
+        cfg = np.ascontiguousarray(np.zeros((1, 3)) if cfg is None else cfg, dtype=np.float64)
+        self._chk(self.L.rbl_set_parameters(self.h, a, dt, kBT, eta, cfg.ctypes.data, cfg.shape[0]))
+        self._chk(self.L.rbl_set_wall_pc(self.h, int(bool(wall))))
+        self._chk(self.L.rbl_set_stream(self.h, stream_ptr))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RblError("%s [rbl status %d]" % (self.L.rbl_last_error(self.h).decode(), rc))
+
+    def set_config(self, X, Q):
+        import numpy as np
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1)
+        self._chk(self.L.rbl_set_config(self.h, X.ctypes.data, Q.ctypes.data, X.size // 3))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.rbl_set_stream(self.h, stream_ptr))
+
+    def set_tuning(self, jsplit=0, variant=0):
+        self._chk(self.L.rbl_set_tuning(self.h, jsplit, variant))
+
+    def apply_M(self, dF, dr, n_blobs, row_begin, row_end, dout):
+        """dF, dr, dout: integer device addresses (tensor.data_ptr())."""
+        self._chk(self.L.rbl_apply_M_dev(self.h, dF, dr, n_blobs, row_begin, row_end, dout))
+
+    def blob_positions(self, body_begin, body_end, dout):
+        self._chk(self.L.rbl_blob_positions_dev(self.h, body_begin, body_end, dout))
+
+    def build_M(self, dr, n_blobs, scale_damp, dout):
+        self._chk(self.L.rbl_rotne_prager_tensor_dev(self.h, dr, n_blobs, int(scale_damp), dout))
+
+    def cholesky(self, dM, n, zero_upper=False):
+        self._chk(self.L.rbl_cholesky_lower_dev(self.h, dM, n, int(zero_upper)))
+
+    def trmv_lower(self, dL, n, dW, dout):
+        self._chk(self.L.rbl_trmv_lower_dev(self.h, dL, n, dW, dout))
+
+    def M_half_W(self, dr, n_blobs, dW, method, dout):
+        self._chk(self.L.rbl_M_half_W_dev(self.h, dr, n_blobs, dW, {"cholesky": 0, "lanczos": 1}[method], dout))
+
+    def set_lanczos(self, max_iter, tol):
+        self._chk(self.L.rbl_set_lanczos(self.h, max_iter, tol))
+
+    def lanczos_report(self):
+        it, res = C.c_int(0), C.c_double(0.0)
+        self.L.rbl_get_lanczos_report(self.h, C.byref(it), C.byref(res))
+        return it.value, res.value
+
+    def sync_check(self):
+        self._chk(self.L.rbl_sync_check(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.rbl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

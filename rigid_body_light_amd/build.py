@@ -1,0 +1,74 @@
+"""In-tree build of the native parts (no network, no cmake needed):
+
+  librbl.so            hipcc --offload-arch=gfx950   csrc/rbl_{kernels,dense,api}.hip + rbl_host.cpp
+  c_rigid.<abi>.so     g++ + pybind11               csrc/c_rigid.cpp  (links librbl.so, rpath $ORIGIN)
+
+Both land next to this file so they travel with the tree (gpurun snapshot) and are the
+files the Python package loads.  `python -m rigid_body_light_amd.build [--force]`.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+ARCH = os.environ.get("RBL_OFFLOAD_ARCH", "gfx950")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_api.hip", "rbl_host.cpp"]
+HEADERS = ["rbl_internal.hpp", "rbl_pair.hpp", os.path.join("..", "..", "include", "rbl.h")]
+
+
+def lib_path():
+    return os.path.join(HERE, "librbl.so")
+
+
+def ext_path():
+    return os.path.join(HERE, "c_rigid" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose_resources=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-x", "hip",
+                   "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+            if verbose_resources:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            jobs.append(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(lib_path(), objs):
+        _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib_path()] + objs)
+    ext_src = os.path.join(CSRC, "c_rigid.cpp")
+    if force or _newer(ext_path(), [ext_src, lib_path(), hdrs[-1]]):
+        import pybind11
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+              "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+              ext_src, "-o", ext_path(), "-L" + HERE, "-lrbl", "-Wl,-rpath,$ORIGIN"])
+    return lib_path(), ext_path()
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)

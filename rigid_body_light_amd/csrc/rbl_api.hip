@@ -1,0 +1,800 @@
+// rbl_api.hip -- implementation of the C ABI in include/rbl.h.
+// Host bookkeeping lives in rbl_host.cpp, kernels in rbl_kernels.hip / rbl_dense.hip.
+// Nothing here falls back to a CPU path: compute entry points return
+// RBL_ERR_NO_DEVICE when no HIP device can be initialised.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "rbl_internal.hpp"
+
+// ----------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------
+int rbl_fail(rbl_ctx *c, int code, const std::string &msg)
+{
+  if (c) c->last_error = msg;
+  return code;
+}
+
+int rbl_hip_fail(rbl_ctx *c, hipError_t e, const char *what)
+{
+  return rbl_fail(c, RBL_ERR_HIP, std::string("HIP error: ") + hipGetErrorString(e) + " in " + what);
+}
+
+int rbl_flags_to_status(rbl_ctx *c, unsigned f)
+{
+  if (!f) return RBL_OK;
+  if (f & RBL_FLAG_BELOW_WALL)  // message of the reference's std::runtime_error, c_rigid_obj.cpp:96
+    return rbl_fail(c, RBL_ERR_BELOW_WALL,
+                    "A blob has its center below the wall (z<0). Cannot compute mobility- check your configuration.");
+  if (f & RBL_FLAG_OVERLAP)     // reference prints this and exit()s, c_rigid_obj.cpp:53-58
+    return rbl_fail(c, RBL_ERR_OVERLAP, "ERROR: TWO BLOBS ARE OVERLAPPING OR TOO CLOSELY POSITIONED.");
+  if (f & RBL_FLAG_NOT_SPD)
+    return rbl_fail(c, RBL_ERR_NOT_SPD, "Cholesky: matrix is not positive definite");
+  return rbl_fail(c, RBL_ERR_NONFINITE, "mobility product produced a non-finite value");
+}
+
+int rbl_dev_init(rbl_ctx *c)
+{
+  if (c->dev_ready) return RBL_OK;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return rbl_fail(c, RBL_ERR_NO_DEVICE,
+                    "librbl: no HIP device available (this library has no CPU fallback)");
+  RBL_HIP(c, hipGetDevice(&c->device));
+  hipDeviceProp_t prop;
+  RBL_HIP(c, hipGetDeviceProperties(&prop, c->device));
+  c->n_cu = prop.multiProcessorCount;
+  RBL_HIP(c, hipMalloc((void **)&c->d_err, sizeof(unsigned)));
+  RBL_HIP(c, hipHostMalloc((void **)&c->h_err, sizeof(unsigned), hipHostMallocDefault));
+  RBL_HIP(c, hipMemset(c->d_err, 0, sizeof(unsigned)));
+  c->dev_ready = true;
+  return RBL_OK;
+}
+
+int rbl_dev_reserve(rbl_ctx *c, RblDevBuf &b, size_t bytes)
+{
+  if (bytes <= b.bytes) return RBL_OK;
+  if (b.p) {
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    RBL_HIP(c, hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return rbl_fail(c, RBL_ERR_ALLOC, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  return RBL_OK;
+}
+
+static int need_params(rbl_ctx *c)
+{
+  if (!c) return RBL_ERR_ARG;
+  if (!c->S.params_set) return rbl_fail(c, RBL_ERR_STATE, "setParameters has not been called");
+  return RBL_OK;
+}
+
+static int need_config(rbl_ctx *c)
+{
+  int rc = need_params(c);
+  if (rc) return rc;
+  // the reference only prints "ERROR CONFIG NOT INITIALIZED YET!!" (:296-298) and
+  // then reads unset members; we return an error instead
+  if (!c->S.cfg_set) return rbl_fail(c, RBL_ERR_STATE, "ERROR CONFIG NOT INITIALIZED YET!!");
+  return RBL_OK;
+}
+
+// read + clear the latched device flags (stream must be idle for h_err to be valid)
+static int finish_and_check(rbl_ctx *c)
+{
+  RBL_HIP(c, hipMemcpyAsync(c->h_err, c->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipMemsetAsync(c->d_err, 0, sizeof(unsigned), c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return rbl_flags_to_status(c, *c->h_err);
+}
+
+extern "C" {
+
+// ============================================================================
+// 1. reference-bound methods
+// ============================================================================
+rbl_ctx *rbl_create(void) { return new (std::nothrow) rbl_ctx(); }
+
+void rbl_destroy(rbl_ctx *c)
+{
+  if (!c) return;
+  if (c->dev_ready) {
+    hipStreamSynchronize(c->stream);
+    RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
+                         &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2};
+    for (RblDevBuf *b : bufs)
+      if (b->p) hipFree(b->p);
+    if (c->d_err) hipFree(c->d_err);
+    if (c->h_err) hipHostFree(c->h_err);
+  }
+  delete c;
+}
+
+const char *rbl_precision(void) { return "double"; }
+
+const char *rbl_last_error(const rbl_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+
+int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, const double *cfg,
+                       int N_blb)
+{
+  if (!c || !cfg || N_blb <= 0) return rbl_fail(c, RBL_ERR_ARG, "setParameters: bad arguments");
+  RblBodyState &S = c->S;
+  S.a = a; S.dt = dt; S.kBT = kBT; S.eta = eta;
+  S.ref_cfg.assign(cfg, cfg + (size_t)3 * N_blb);
+  double mean[3] = {0, 0, 0};  // removeMean, c_rigid_obj.cpp:176-181 (on our private copy)
+  for (int k = 0; k < N_blb; ++k)
+    for (int d = 0; d < 3; ++d) mean[d] += S.ref_cfg[3 * k + d];
+  for (int d = 0; d < 3; ++d) mean[d] /= (double)N_blb;
+  for (int k = 0; k < N_blb; ++k)
+    for (int d = 0; d < 3; ++d) S.ref_cfg[3 * k + d] -= mean[d];
+  S.N_blb = N_blb;
+  S.params_set = true;
+  S.M_scale = 1.0;
+  return RBL_OK;
+}
+
+int rbl_set_blk_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.block_pc = v != 0; return RBL_OK; }
+int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; return RBL_OK; }
+
+int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
+{
+  if (!c || !X || !Q || N_bod <= 0) return rbl_fail(c, RBL_ERR_ARG, "setConfig: bad arguments");
+  RblBodyState &S = c->S;
+  S.N_bod = N_bod;
+  S.X.assign(X, X + (size_t)3 * N_bod);
+  S.Q.resize((size_t)4 * N_bod);
+  for (int j = 0; j < N_bod; ++j) {  // scalar-first, normalised (:212-216)
+    const double w = Q[4 * j], x = Q[4 * j + 1], y = Q[4 * j + 2], z = Q[4 * j + 3];
+    const double nrm = std::sqrt(w * w + x * x + y * y + z * z);
+    S.Q[4 * j] = w / nrm; S.Q[4 * j + 1] = x / nrm; S.Q[4 * j + 2] = y / nrm; S.Q[4 * j + 3] = z / nrm;
+  }
+  S.cfg_set = true;
+  S.K_set = false;
+  // NOTE the reference does NOT reset PC_mat_Set here (SURVEY.md 8b "state quirks");
+  // a stale preconditioner after set_config is a trap, so we do invalidate it.
+  S.pc_set = false;
+  return RBL_OK;
+}
+
+int rbl_get_config(const rbl_ctx *c, double *X, double *Q)
+{
+  if (!c || !c->S.cfg_set) return RBL_ERR_STATE;
+  std::memcpy(X, c->S.X.data(), sizeof(double) * c->S.X.size());
+  std::memcpy(Q, c->S.Q.data(), sizeof(double) * c->S.Q.size());
+  return RBL_OK;
+}
+
+int rbl_get_sizes(const rbl_ctx *c, int *N_bod, int *N_blb)
+{
+  if (!c) return RBL_ERR_ARG;
+  if (N_bod) *N_bod = c->S.N_bod;
+  if (N_blb) *N_blb = c->S.N_blb;
+  return RBL_OK;
+}
+
+int rbl_set_K_mats(rbl_ctx *c)
+{
+  int rc = need_config(c);
+  if (rc) return rc;
+  return rbl_body_set_K(c->S, c->last_error);
+}
+
+static int need_K(rbl_ctx *c)
+{
+  int rc = need_config(c);
+  if (rc) return rc;
+  if (!c->S.K_set) return rbl_body_set_K(c->S, c->last_error);
+  return RBL_OK;
+}
+
+int rbl_K_x_U(rbl_ctx *c, const double *U, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  rbl_body_K_x_U(c->S, U, out);
+  return RBL_OK;
+}
+
+int rbl_KT_x_Lam(rbl_ctx *c, const double *lam, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  rbl_body_KT_x_Lam(c->S, lam, out);
+  return RBL_OK;
+}
+
+int rbl_Kinv_x_V(rbl_ctx *c, const double *V, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  rbl_body_Kinv_x_V(c->S, V, out);
+  return RBL_OK;
+}
+
+int rbl_KTinv_x_F(rbl_ctx *c, const double *F, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  rbl_body_KTinv_x_F(c->S, F, out);
+  return RBL_OK;
+}
+
+// upload X, Q, ref_cfg; positions of bodies [b0,b1) -> d_out
+static int positions_dev(rbl_ctx *c, int b0, int b1, double *d_out)
+{
+  RblBodyState &S = c->S;
+  int rc = rbl_dev_reserve(c, c->d_XQ, sizeof(double) * 7 * (size_t)S.N_bod); if (rc) return rc;
+  rc = rbl_dev_reserve(c, c->d_cfg, sizeof(double) * 3 * (size_t)S.N_blb); if (rc) return rc;
+  double *dX = (double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
+  RBL_HIP(c, hipMemcpyAsync(dX, S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(dQ, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
+  rbl_launch_blob_positions(c->stream, dX, dQ, (const double *)c->d_cfg.p, S.N_blb, b0, b1, d_out);
+  return RBL_OK;
+}
+
+int rbl_blob_positions_dev(rbl_ctx *c, int body_begin, int body_end, double *d_out)
+{
+  int rc = need_config(c); if (rc) return rc;
+  rc = rbl_dev_init(c); if (rc) return rc;
+  if (body_begin < 0 || body_end > c->S.N_bod || body_begin > body_end)
+    return rbl_fail(c, RBL_ERR_SIZE, "blob_positions_dev: body range out of bounds");
+  // the host vectors are pageable: make the async copies complete before they can change
+  rc = positions_dev(c, body_begin, body_end, d_out); if (rc) return rc;
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return RBL_OK;
+}
+
+int rbl_multi_body_pos(rbl_ctx *c, double *out)
+{
+  int rc = need_config(c); if (rc) return rc;
+  rc = rbl_dev_init(c); if (rc) return rc;
+  const size_t n3 = (size_t)3 * c->S.N_bod * c->S.N_blb;
+  rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * n3); if (rc) return rc;
+  rc = positions_dev(c, 0, c->S.N_bod, (double *)c->d_r.p); if (rc) return rc;
+  RBL_HIP(c, hipMemcpyAsync(out, c->d_r.p, sizeof(double) * n3, hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return RBL_OK;
+}
+
+static int apply_M_host(rbl_ctx *c, const double *F, const double *r, int64_t n3, int nrhs, double *out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if (n3 <= 0 || n3 % 3 != 0 || nrhs < 1)
+    return rbl_fail(c, RBL_ERR_SIZE, "Positions and forces must have total length 3N, where N is the number of blobs");
+  rc = rbl_dev_init(c); if (rc) return rc;
+  const int64_t nbl = n3 / 3;
+  const size_t vb = sizeof(double) * (size_t)n3;
+  int js = 1;
+  const size_t pb = rbl_apply_M_part_bytes(nbl, nbl, c->n_cu, c->tune_jsplit, &js);
+  if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_F, vb * nrhs))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_U, vb * nrhs))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(c->d_F.p, F, vb * nrhs, hipMemcpyHostToDevice, c->stream));
+  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  for (int k = 0; k < nrhs; ++k)
+    rbl_launch_apply_M(c->stream, P, c->S.wall, (const double *)c->d_F.p + (size_t)k * n3,
+                       (const double *)c->d_r.p, nbl, 0, nbl, (double *)c->d_U.p + (size_t)k * n3,
+                       (double *)c->d_part.p, js, c->tune_variant, c->d_err);
+  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb * nrhs, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+int rbl_apply_M(rbl_ctx *c, const double *F, const double *r_vecs, int64_t n3, double *out)
+{
+  return apply_M_host(c, F, r_vecs, n3, 1, out);
+}
+
+int rbl_apply_M_multi(rbl_ctx *c, const double *F, const double *r_vecs, int64_t n3, int nrhs,
+                      double *out)
+{
+  return apply_M_host(c, F, r_vecs, n3, nrhs, out);
+}
+
+// ---- preconditioner --------------------------------------------------------
+// diag_invM (:489-543): per-blob inverse of the self block, times 8 pi eta a.
+static int build_diag_invM(rbl_ctx *c)
+{
+  RblBodyState &S = c->S;
+  const size_t N = (size_t)S.N_bod * S.N_blb;
+  S.invM_diag.assign(9 * N, 0.0);
+  const double nf = 8.0 * M_PI * S.eta * S.a;
+  for (size_t i = 0; i < N; ++i) {
+    double dxx = 4.0 / 3.0, dzz = 4.0 / 3.0;
+    if (S.wall) {  // self wall term (:98-104), h = z_i / a
+      const size_t b = i / S.N_blb;
+      const double z = S.X[3 * b + 2] + S.lever[3 * i + 2];
+      const double h = z / S.a;
+      if (h < 0.0) return rbl_flags_to_status(c, RBL_FLAG_BELOW_WALL);
+      const double iz = 1.0 / h, iz3 = iz * iz * iz, iz5 = iz3 * iz * iz;
+      dxx += -(9 * iz - 2 * iz3 + iz5) / 12.0;
+      dzz += -(9 * iz - 4 * iz3 + iz5) / 6.0;
+    }
+    S.invM_diag[9 * i] = nf / dxx;
+    S.invM_diag[9 * i + 4] = nf / dxx;
+    S.invM_diag[9 * i + 8] = nf / dzz;
+  }
+  return RBL_OK;
+}
+
+// Block_diag_invM (:461-487): per-body dense mobility assembled on the GPU
+// (k_build_M on that body's blobs), inverted on the host.
+static int build_block_invM(rbl_ctx *c)
+{
+  RblBodyState &S = c->S;
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  const int m = 3 * S.N_blb;
+  const size_t msz = (size_t)m * m;
+  if ((rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * (size_t)m * S.N_bod))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_mat, sizeof(double) * msz * S.N_bod))) return rc;
+  if ((rc = positions_dev(c, 0, S.N_bod, (double *)c->d_r.p))) return rc;
+  const RblParams P = rbl_make_params(S.a, S.eta);
+  for (int b = 0; b < S.N_bod; ++b)
+    rbl_launch_build_M(c->stream, P, S.wall, false, (const double *)c->d_r.p + (size_t)b * m,
+                       S.N_blb, (double *)c->d_mat.p + (size_t)b * msz, c->d_err);
+  S.invM_block.resize(msz * S.N_bod);
+  RBL_HIP(c, hipMemcpyAsync(S.invM_block.data(), c->d_mat.p, sizeof(double) * msz * S.N_bod,
+                            hipMemcpyDeviceToHost, c->stream));
+  if ((rc = finish_and_check(c))) return rc;
+  for (int b = 0; b < S.N_bod; ++b)  // column-major copy of a symmetric-by-construction matrix
+    if (rbl_inv_spd_or_lu(&S.invM_block[(size_t)b * msz], m, nullptr))
+      return rbl_fail(c, RBL_ERR_SINGULAR, "per-body mobility block is singular");
+  // the device matrix was column-major; inverse of the transpose = transpose of the
+  // inverse, and apply_invM reads row-major -> transpose once
+  for (int b = 0; b < S.N_bod; ++b) {
+    double *A = &S.invM_block[(size_t)b * msz];
+    for (int p = 0; p < m; ++p)
+      for (int q = p + 1; q < m; ++q) std::swap(A[(size_t)p * m + q], A[(size_t)q * m + p]);
+  }
+  return RBL_OK;
+}
+
+int rbl_apply_PC(rbl_ctx *c, const double *in, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if (!c->S.pc_set) {
+    rc = c->S.block_pc ? build_block_invM(c) : build_diag_invM(c);
+    if (rc) return rc;
+  }
+  rc = rbl_body_apply_PC(c->S, in, out, c->last_error);
+  return rc;
+}
+
+// ---- K / Kinv as CSC (get_K :978, get_Kinv :986) ----------------------------
+int rbl_get_K_csc(rbl_ctx *c, int64_t *nnz, int64_t *nrows, int64_t *ncols, double *data,
+                  int32_t *indices, int32_t *indptr)
+{
+  int rc = need_K(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const int nb = S.N_bod, nl = S.N_blb;
+  if (nnz) *nnz = (int64_t)9 * nb * nl;
+  if (nrows) *nrows = (int64_t)3 * nb * nl;
+  if (ncols) *ncols = (int64_t)6 * nb;
+  if (!data || !indices || !indptr) return RBL_OK;
+  int64_t p = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int32_t r0 = 3 * b * nl;
+    for (int cc = 0; cc < 6; ++cc) {
+      indptr[6 * b + cc] = (int32_t)p;
+      for (int k = 0; k < nl; ++k) {
+        const double *l = &S.lever[3 * ((size_t)b * nl + k)];
+        const int32_t r = r0 + 3 * k;
+        switch (cc) {  // structural pattern of :370-382 (explicit zeros are kept)
+          case 0: indices[p] = r;     data[p++] = 1.0; break;
+          case 1: indices[p] = r + 1; data[p++] = 1.0; break;
+          case 2: indices[p] = r + 2; data[p++] = 1.0; break;
+          case 3: indices[p] = r + 1; data[p++] = -l[2]; indices[p] = r + 2; data[p++] = l[1]; break;
+          case 4: indices[p] = r;     data[p++] = l[2];  indices[p] = r + 2; data[p++] = -l[0]; break;
+          case 5: indices[p] = r;     data[p++] = -l[1]; indices[p] = r + 1; data[p++] = l[0]; break;
+        }
+      }
+    }
+  }
+  indptr[6 * nb] = (int32_t)p;
+  return RBL_OK;
+}
+
+int rbl_get_Kinv_csc(rbl_ctx *c, int64_t *nnz, int64_t *nrows, int64_t *ncols, double *data,
+                     int32_t *indices, int32_t *indptr)
+{
+  int rc = need_K(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const int nb = S.N_bod, nl = S.N_blb;
+  // Kinv = KTKi * K^T, pruned (:390): column 3k+d holds KTKi_b * (row 3k+d of K)^T
+  int64_t p = 0;
+  const bool fill = data && indices && indptr;
+  for (int b = 0; b < nb; ++b) {
+    const double *B = &S.KTKinv[(size_t)36 * b];
+    for (int k = 0; k < nl; ++k) {
+      const double *l = &S.lever[3 * ((size_t)b * nl + k)];
+      const double Krow[3][6] = {{1, 0, 0, 0, l[2], -l[1]}, {0, 1, 0, -l[2], 0, l[0]}, {0, 0, 1, l[1], -l[0], 0}};
+      for (int d = 0; d < 3; ++d) {
+        const int64_t col = 3 * ((int64_t)b * nl + k) + d;
+        if (fill) indptr[col] = (int32_t)p;
+        for (int rr = 0; rr < 6; ++rr) {
+          double v = 0.0;
+          for (int q = 0; q < 6; ++q) v += B[6 * rr + q] * Krow[d][q];
+          if (std::fabs(v) > 1e-12) {  // Eigen pruned(): |v| <= dummy_precision dropped
+            if (fill) { indices[p] = 6 * b + rr; data[p] = v; }
+            ++p;
+          }
+        }
+      }
+    }
+  }
+  if (fill) indptr[(int64_t)3 * nb * nl] = (int32_t)p;
+  if (nnz) *nnz = p;
+  if (nrows) *nrows = (int64_t)6 * nb;
+  if (ncols) *ncols = (int64_t)3 * nb * nl;
+  return RBL_OK;
+}
+
+int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
+{
+  int rc = need_config(c); if (rc) return rc;
+  RblBodyState &S = c->S;
+  std::vector<double> Udt((size_t)6 * S.N_bod), Xo, Qo;
+  for (size_t i = 0; i < Udt.size(); ++i) Udt[i] = U[i] * S.dt;  // :869 (on a copy)
+  rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
+  S.X.swap(Xo);
+  S.Q.swap(Qo);
+  rc = rbl_body_set_K(S, c->last_error);                          // :876
+  S.pc_set = false;                                               // :877
+  return rc;
+}
+
+// ============================================================================
+// 2. unbound reference members + extensions
+// ============================================================================
+int rbl_rotne_prager_tensor(rbl_ctx *c, const double *r, int64_t n3, int scale_damp, double *out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if (n3 <= 0 || n3 % 3 != 0) return rbl_fail(c, RBL_ERR_SIZE, "r_vecs must have length 3N");
+  rc = rbl_dev_init(c); if (rc) return rc;
+  const size_t mb = sizeof(double) * (size_t)n3 * (size_t)n3;
+  if ((rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * n3))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+  rbl_launch_build_M(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, scale_damp != 0,
+                     (const double *)c->d_r.p, n3 / 3, (double *)c->d_mat.p, c->d_err);
+  RBL_HIP(c, hipMemcpyAsync(out, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+int rbl_cholesky_lower(rbl_ctx *c, double *M, int64_t n)
+{
+  if (!c || !M || n <= 0) return rbl_fail(c, RBL_ERR_ARG, "cholesky_lower: bad arguments");
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
+  if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(c->d_mat.p, M, mb, hipMemcpyHostToDevice, c->stream));
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, nullptr, 0);
+  if (rc) return rbl_fail(c, rc, "cholesky launch failed");
+  RBL_HIP(c, hipMemcpyAsync(M, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+int rbl_set_lanczos(rbl_ctx *c, int max_iter, double tol)
+{
+  if (!c || max_iter < 2 || !(tol > 0)) return RBL_ERR_ARG;
+  c->lanczos_max_iter = max_iter; c->lanczos_tol = tol;
+  return RBL_OK;
+}
+
+int rbl_get_lanczos_report(const rbl_ctx *c, int *iters, double *resid)
+{
+  if (!c) return RBL_ERR_ARG;
+  if (iters) *iters = c->lanczos_iters;
+  if (resid) *resid = c->lanczos_resid;
+  return RBL_OK;
+}
+
+}  // extern "C"
+
+// symmetric tridiagonal eigen-decomposition (implicit QL), m <= a few hundred.
+// d[0..m) diagonal, e[0..m-1) off-diagonal; on return d = eigenvalues, Z (m x m,
+// row-major) has eigenvectors in its COLUMNS.  Returns false if it fails to converge.
+static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::vector<double> &Z, int m)
+{
+  std::vector<double> e(m, 0.0);
+  for (int i = 0; i + 1 < m; ++i) e[i] = e_in[i];
+  Z.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; ++i) Z[(size_t)i * m + i] = 1.0;
+  for (int l = 0; l < m; ++l) {
+    int iter = 0, mm;
+    do {
+      for (mm = l; mm < m - 1; ++mm) {
+        const double dd = std::fabs(d[mm]) + std::fabs(d[mm + 1]);
+        if (std::fabs(e[mm]) <= 2.3e-16 * dd) break;
+      }
+      if (mm != l) {
+        if (iter++ == 200) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, cth = 1.0, p = 0.0;
+        int i;
+        for (i = mm - 1; i >= l; --i) {
+          double f = s * e[i], b = cth * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) { d[i + 1] -= p; e[mm] = 0.0; break; }
+          s = f / r; cth = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * cth * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = cth * r - b;
+          for (int k = 0; k < m; ++k) {
+            f = Z[(size_t)k * m + i + 1];
+            Z[(size_t)k * m + i + 1] = s * Z[(size_t)k * m + i] + cth * f;
+            Z[(size_t)k * m + i] = cth * Z[(size_t)k * m + i] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p; e[l] = g; e[mm] = 0.0;
+      }
+    } while (mm != l);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// M^{1/2} W on the device.  A = B Mob B with B ALWAYS applied (:668) and the wall
+// term in Mob per wall_PC.
+//   CHOLESKY: dense build of B Mob B -> in-place lower Cholesky -> L W  (reference)
+//   LANCZOS : Krylov approximation of the symmetric square root with the
+//             matrix-free matvec (no O(n^2) memory).
+// ---------------------------------------------------------------------------
+static void apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
+                        const double *d_x, double *d_y, double *d_tmp, int js)
+{
+  if (c->S.wall) {  // kernel applies B M B itself
+    rbl_launch_apply_M(c->stream, P, true, d_x, d_r, nbl, 0, nbl, d_y, (double *)c->d_part.p, js,
+                       c->tune_variant, c->d_err);
+  } else {          // free-space M, damping applied around it
+    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x, d_tmp);
+    rbl_launch_apply_M(c->stream, P, false, d_tmp, d_r, nbl, 0, nbl, d_y, (double *)c->d_part.p, js,
+                       c->tune_variant, c->d_err);
+    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_y, d_y);
+  }
+}
+
+static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out)
+{
+  const int64_t n = 3 * nbl;
+  const int maxit = c->lanczos_max_iter;
+  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  int js = 1, rc;
+  const size_t pb = rbl_apply_M_part_bytes(nbl, nbl, c->n_cu, c->tune_jsplit, &js);
+  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
+  // workspace: V (n x (maxit+1)), u, tmp, prev-estimate, dot scratch
+  const size_t vbytes = sizeof(double) * (size_t)n;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 3 + sizeof(double) * 2048))) return rc;
+  double *V = (double *)c->d_tmp.p;
+  double *u = (double *)c->d_tmp2.p, *tmp = u + n, *coef_dev = tmp + n /* n doubles, reused */;
+  double *dots = coef_dev + n;
+  double h2[2];
+  auto dot2 = [&](const double *x, const double *y, const double *z) -> int {
+    rbl_launch_dot2(c->stream, x, y, z, n, dots);
+    RBL_HIP(c, hipMemcpyAsync(h2, dots, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    return RBL_OK;
+  };
+  if ((rc = dot2(d_W, d_W, nullptr))) return rc;
+  const double wnorm = std::sqrt(h2[0]);
+  if (!(wnorm > 0.0)) { RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream)); return RBL_OK; }
+  rbl_launch_axpby(c->stream, n, 1.0 / wnorm, d_W, 0.0, nullptr, V);
+  std::vector<double> alpha, beta, y_prev, y_cur;
+  int m = 0;
+  double resid = 1.0;
+  for (int it = 0; it < maxit; ++it) {
+    double *v = V + (size_t)it * n;
+    apply_A_dev(c, P, d_r, nbl, v, u, tmp, js);
+    if (it > 0) rbl_launch_axpby(c->stream, n, 1.0, u, -beta[it - 1], V + (size_t)(it - 1) * n, u);
+    if ((rc = dot2(v, u, nullptr))) return rc;
+    const double al = h2[0];
+    rbl_launch_axpby(c->stream, n, 1.0, u, -al, v, u);
+    if ((rc = dot2(u, u, nullptr))) return rc;
+    const double be = std::sqrt(h2[0]);
+    alpha.push_back(al);
+    m = it + 1;
+    // y = wnorm * T^{1/2} e1 in the Krylov basis
+    std::vector<double> d(alpha), e(beta), Z;
+    if (!tridiag_ql(d, e, Z, m)) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: tridiagonal eigensolve failed");
+    y_cur.assign(m, 0.0);
+    double dmax = 0.0;
+    for (int k = 0; k < m; ++k) dmax = std::max(dmax, std::fabs(d[k]));
+    for (int k = 0; k < m; ++k) {
+      if (d[k] < 0.0) {
+        if (d[k] < -1e-10 * dmax) return rbl_fail(c, RBL_ERR_NOT_SPD, "Lanczos: operator is not positive semi-definite");
+        d[k] = 0.0;
+      }
+      const double sk = std::sqrt(d[k]) * Z[k];  // Z[0*m + k] = first component of eigvec k
+      for (int p = 0; p < m; ++p) y_cur[p] += Z[(size_t)p * m + k] * sk;
+    }
+    for (int p = 0; p < m; ++p) y_cur[p] *= wnorm;
+    if (it > 0) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
+      double dn = 0.0, yn = 0.0;
+      for (int p = 0; p < m; ++p) {
+        const double yp = p < (int)y_prev.size() ? y_prev[p] : 0.0;
+        dn += (y_cur[p] - yp) * (y_cur[p] - yp);
+        yn += y_cur[p] * y_cur[p];
+      }
+      resid = std::sqrt(dn / yn);
+    }
+    y_prev = y_cur;
+    if (resid < c->lanczos_tol || !(be > 1e-300) || it + 1 == maxit) break;
+    beta.push_back(be);
+    rbl_launch_axpby(c->stream, n, 1.0 / be, u, 0.0, nullptr, V + (size_t)(it + 1) * n);
+  }
+  c->lanczos_iters = m;
+  c->lanczos_resid = resid;
+  // d_out = V[:, :m] y
+  RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream));
+  for (int p = 0; p < m; ++p)
+    rbl_launch_axpby(c->stream, n, y_cur[p], V + (size_t)p * n, 1.0, d_out, d_out);
+  return RBL_OK;
+}
+
+static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, int method, double *d_out)
+{
+  const int64_t n = 3 * nbl;
+  int rc;
+  if (method == RBL_MHALF_LANCZOS) return mhalf_lanczos_dev(c, d_r, nbl, d_W, d_out);
+  if (method != RBL_MHALF_CHOLESKY) return rbl_fail(c, RBL_ERR_ARG, "M_half_W: unknown method");
+  const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
+  if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp, rbl_trmv_part_bytes(n)))) return rc;
+  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  rbl_launch_build_M(c->stream, P, c->S.wall, true, d_r, nbl, (double *)c->d_mat.p, c->d_err);  // :667-669
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, nullptr, 0);   // :670-671
+  if (rc) return rbl_fail(c, rc, "cholesky launch failed");
+  rbl_launch_trmv_lower(c->stream, (const double *)c->d_mat.p, n, d_W, d_out, (double *)c->d_tmp.p);  // :672
+  return RBL_OK;
+}
+
+extern "C" {
+
+int rbl_M_half_W_dev(rbl_ctx *c, const double *d_r, int64_t n_blobs, const double *d_W, int method,
+                     double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n_blobs <= 0) return rbl_fail(c, RBL_ERR_SIZE, "M_half_W_dev: n_blobs must be positive");
+  return mhalf_dev(c, d_r, n_blobs, d_W, method, d_out);
+}
+
+int rbl_M_half_W_r(rbl_ctx *c, const double *r, int64_t n3, const double *W, uint64_t seed, int method,
+                   double *out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if (n3 <= 0 || n3 % 3 != 0) return rbl_fail(c, RBL_ERR_SIZE, "r_vecs must have length 3N");
+  if ((rc = rbl_dev_init(c))) return rc;
+  const size_t vb = sizeof(double) * (size_t)n3;
+  if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_W, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_U, vb))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
+  if (W) RBL_HIP(c, hipMemcpyAsync(c->d_W.p, W, vb, hipMemcpyHostToDevice, c->stream));
+  else rbl_launch_normal(c->stream, seed, 0, n3, (double *)c->d_W.p);  // replaces rand_vector :730-741
+  if ((rc = mhalf_dev(c, (const double *)c->d_r.p, n3 / 3, (const double *)c->d_W.p, method, (double *)c->d_U.p))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+int rbl_M_half_W(rbl_ctx *c, const double *W, uint64_t seed, int method, double *out)
+{
+  int rc = need_config(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  const int64_t n3 = (int64_t)3 * c->S.N_bod * c->S.N_blb;  // :663
+  const size_t vb = sizeof(double) * (size_t)n3;
+  if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_W, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_U, vb))) return rc;
+  if ((rc = positions_dev(c, 0, c->S.N_bod, (double *)c->d_r.p))) return rc;  // multi_body_pos :662
+  if (W) RBL_HIP(c, hipMemcpyAsync(c->d_W.p, W, vb, hipMemcpyHostToDevice, c->stream));
+  else rbl_launch_normal(c->stream, seed, 0, n3, (double *)c->d_W.p);
+  if ((rc = mhalf_dev(c, (const double *)c->d_r.p, n3 / 3, (const double *)c->d_W.p, method, (double *)c->d_U.p))) return rc;
+  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+int rbl_debug_pair_blocks(rbl_ctx *c, const double *ri, const double *rj, const int32_t *ii,
+                          const int32_t *jj, int64_t n, int wall, int mode, double *out9)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n <= 0) return RBL_OK;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp, sizeof(double) * 6 * (size_t)n + sizeof(int32_t) * 2 * (size_t)n))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp2, sizeof(double) * 9 * (size_t)n))) return rc;
+  double *dri = (double *)c->d_tmp.p, *drj = dri + 3 * n;
+  int32_t *dii = (int32_t *)(drj + 3 * n), *djj = dii + n;
+  RBL_HIP(c, hipMemcpyAsync(dri, ri, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(drj, rj, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(dii, ii, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(djj, jj, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  rbl_launch_pair_blocks(c->stream, rbl_make_params(c->S.a, c->S.eta), wall != 0, mode, dri, drj, dii,
+                         djj, n, (double *)c->d_tmp2.p, c->d_err);
+  RBL_HIP(c, hipMemcpyAsync(out9, c->d_tmp2.p, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, c->stream));
+  return finish_and_check(c);
+}
+
+// ============================================================================
+// 3. device-pointer API
+// ============================================================================
+int rbl_set_stream(rbl_ctx *c, void *s)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  c->stream = (hipStream_t)s;
+  return RBL_OK;
+}
+
+int rbl_apply_M_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs,
+                    int64_t row_begin, int64_t row_end, double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n_blobs <= 0 || row_begin < 0 || row_end > n_blobs || row_begin > row_end)
+    return rbl_fail(c, RBL_ERR_SIZE, "apply_M_dev: row range out of bounds");
+  int js = 1;
+  const size_t pb = rbl_apply_M_part_bytes(n_blobs, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);
+  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
+  rbl_launch_apply_M(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs,
+                     row_begin, row_end, d_out, (double *)c->d_part.p, js, c->tune_variant, c->d_err);
+  return RBL_OK;
+}
+
+int rbl_rotne_prager_tensor_dev(rbl_ctx *c, const double *d_r, int64_t n_blobs, int scale_damp,
+                                double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  rbl_launch_build_M(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, scale_damp != 0, d_r,
+                     n_blobs, d_out, c->d_err);
+  return RBL_OK;
+}
+
+int rbl_cholesky_lower_dev(rbl_ctx *c, double *d_M, int64_t n, int zero_upper)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  rc = rbl_launch_cholesky(c->stream, d_M, n, zero_upper != 0, c->d_err, nullptr, 0);
+  return rc ? rbl_fail(c, rc, "cholesky launch failed") : RBL_OK;
+}
+
+int rbl_trmv_lower_dev(rbl_ctx *c, const double *d_L, int64_t n, const double *d_W, double *d_out)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp, rbl_trmv_part_bytes(n)))) return rc;
+  rbl_launch_trmv_lower(c->stream, d_L, n, d_W, d_out, (double *)c->d_tmp.p);
+  return RBL_OK;
+}
+
+int rbl_sync_check(rbl_ctx *c)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  return finish_and_check(c);
+}
+
+int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
+{
+  if (!c) return RBL_ERR_ARG;
+  c->tune_jsplit = jsplit; c->tune_variant = variant;
+  return RBL_OK;
+}
+
+}  // extern "C"

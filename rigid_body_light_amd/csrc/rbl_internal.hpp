@@ -1,0 +1,125 @@
+// rbl_internal.hpp -- private declarations shared by the librbl translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rbl.h"
+#include "rbl_pair.hpp"
+
+// ----------------------------------------------------------------------------
+// Host-side rigid-body state: the O(N_bod) bookkeeping of CManyBodies
+// (reference c_rigid_obj.cpp:144-168 members).  Plain C++, no Eigen.
+// ----------------------------------------------------------------------------
+struct RblBodyState {
+  double a = 0, dt = 0, kBT = 0, eta = 0;
+  bool wall = false;          // PC_wall   :147
+  bool block_pc = false;      // block_diag_PC :148
+  double M_scale = 1.0;       // :149,194
+  bool pc_set = false;        // PC_mat_Set :151
+  bool cfg_set = false;       // :157
+  bool params_set = false;    // :166
+  bool K_set = false;
+  int N_bod = 0, N_blb = 0;
+  std::vector<double> ref_cfg;  // N_blb x 3 row-major, mean removed (:188)
+  std::vector<double> X;        // 3 N_bod
+  std::vector<double> Q;        // 4 N_bod, scalar-first, unit
+  // K is stored implicitly as the body-frame-rotated lever arms r_k = R(Q_b) c_k
+  std::vector<double> lever;    // 3 N   (r_k - X_b), :374
+  std::vector<double> KTKinv;   // 36 N_bod  (6x6 row-major per body), :302-326
+  // preconditioner caches (:152-154)
+  std::vector<double> invM_diag;   // 9 N      (3x3 row-major per blob) when !block_pc
+  std::vector<double> invM_block;  // N_bod * (3N_blb)^2 row-major      when block_pc
+  std::vector<double> Ninv_chol;   // 36 N_bod  lower Cholesky of K^T invM K blocks
+};
+
+void rbl_quat_to_rot(const double *q, double *R9);
+int rbl_body_set_K(RblBodyState &S, std::string &err);
+void rbl_body_K_x_U(const RblBodyState &S, const double *U, double *out);
+void rbl_body_KT_x_Lam(const RblBodyState &S, const double *lam, double *out);
+void rbl_body_Kinv_x_V(const RblBodyState &S, const double *V, double *out);
+void rbl_body_KTinv_x_F(const RblBodyState &S, const double *F, double *out);
+void rbl_body_update_X_Q(const RblBodyState &S, const double *U, std::vector<double> &Xo,
+                         std::vector<double> &Qo);
+int rbl_body_apply_PC(RblBodyState &S, const double *in, double *out, std::string &err);
+int rbl_chol6(double *A);  // in-place lower Cholesky of a 6x6 row-major block
+int rbl_inv_spd_or_lu(double *A, int n, double *work);  // in-place general inverse (row-major)
+
+// ----------------------------------------------------------------------------
+// Device buffers + context
+// ----------------------------------------------------------------------------
+struct RblDevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+struct rbl_ctx {
+  RblBodyState S;
+  std::string last_error;
+  // device
+  bool dev_ready = false;
+  int device = -1;
+  int n_cu = 0;
+  hipStream_t stream = nullptr;
+  RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2;
+  unsigned *d_err = nullptr;
+  unsigned *h_err = nullptr;  // pinned
+  // tuning
+  int tune_jsplit = 0;
+  int tune_variant = 0;
+  // lanczos
+  int lanczos_max_iter = 100;
+  double lanczos_tol = 1e-10;
+  int lanczos_iters = 0;
+  double lanczos_resid = 0.0;
+};
+
+RblParams rbl_make_params(double a, double eta);
+int rbl_dev_init(rbl_ctx *c);
+int rbl_dev_reserve(rbl_ctx *c, RblDevBuf &b, size_t bytes);
+int rbl_fail(rbl_ctx *c, int code, const std::string &msg);
+int rbl_hip_fail(rbl_ctx *c, hipError_t e, const char *what);
+int rbl_flags_to_status(rbl_ctx *c, unsigned flags);
+
+#define RBL_HIP(c, call)                                   \
+  do {                                                     \
+    hipError_t e__ = (call);                               \
+    if (e__ != hipSuccess) return rbl_hip_fail(c, e__, #call); \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// Kernel launchers (rbl_kernels.hip).  All enqueue on `st`, none synchronise.
+// ----------------------------------------------------------------------------
+size_t rbl_apply_M_part_bytes(int64_t n_blobs, int64_t nrows, int n_cu, int jsplit_override,
+                              int *jsplit_out);
+void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                        const double *d_r, int64_t n_blobs, int64_t row_begin,
+                        int64_t row_end, double *d_out, double *d_part, int jsplit,
+                        int variant, unsigned *d_err);
+void rbl_launch_blob_positions(hipStream_t st, const double *d_X, const double *d_Q,
+                               const double *d_cfg, int N_blb, int body_begin, int body_end,
+                               double *d_out);
+void rbl_launch_build_M(hipStream_t st, const RblParams &P, bool wall, bool scale_damp,
+                        const double *d_r, int64_t n_blobs, double *d_M, unsigned *d_err);
+void rbl_launch_pair_blocks(hipStream_t st, const RblParams &P, bool wall, int mode,
+                            const double *d_ri, const double *d_rj, const int32_t *d_ii,
+                            const int32_t *d_jj, int64_t n, double *d_out9, unsigned *d_err);
+void rbl_launch_normal(hipStream_t st, uint64_t seed, uint64_t offset, int64_t n, double *d_out);
+
+// dense linear algebra (rbl_dense.hip)
+int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
+                        double *d_work, size_t work_bytes);
+size_t rbl_cholesky_work_bytes(int64_t n);
+void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
+                           double *d_out, double *d_part);
+size_t rbl_trmv_part_bytes(int64_t n);
+
+// small vector kernels (rbl_kernels.hip) used by Lanczos
+void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const double *z,
+                     int64_t n, double *d_out2);  // out[0]=x.y out[1]=x.z (z may be null)
+void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,
+                      const double *y, double *out);
+void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
+                              int64_t n_blobs, const double *in, double *out);

@@ -1,0 +1,490 @@
+// rbl_kernels.hip -- hand-written gfx950 kernels of the blob-mobility hot path.
+//
+//   k_apply_M<WALL>      matrix-free  U = [B] M [B] F        (reference :641-659 + :413-459)
+//                        fp64-VALU bound; j-blob tiles staged in LDS, every lane of a
+//                        wavefront owns one i-blob and sweeps the tile by LDS broadcast.
+//   k_reduce_parts       sums the j-split partial slabs, applies 1/(8 pi eta a) and B_i
+//   k_build_M<WALL>      dense column-major assembly (reference :413-459), HBM-write
+//                        bound; reference-order arithmetic -> bit-identical entries
+//   k_blob_positions     r_k = R(Q_b) c_k + X_b           (reference :257-293)
+//   k_pair_blocks        test hook: independent 3x3 blocks
+//   k_normal             counter-based N(0,1) generator (replaces clock-seeded :730-741)
+//   small BLAS-1 helpers for Lanczos
+#include "rbl_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int TB = 256;  // threads per block = j-tile length
+
+struct __attribute__((aligned(16))) JBlob {
+  double x, y, z, fx, fy, fz;  // 48 B: three 16-B LDS broadcasts per j
+};
+
+__device__ __forceinline__ double damp_of(const RblParams &P, double z)
+{
+  return (z >= P.a) ? 1.0 : z / P.a;  // c_rigid_obj.cpp:629-633
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-free matvec.  grid = (i-tiles, jsplit).  Block (bx,by) owns rows
+// row_begin + bx*TB .. and columns [by*jchunk, (by+1)*jchunk).
+// jsplit == 1 : writes final U (scaled, damped) to out[3*(i-row_begin)]
+// jsplit  > 1 : writes raw partial sums to part[by][3*(i-row_begin)]
+// ---------------------------------------------------------------------------
+template <bool WALL, bool SELF>
+__device__ __forceinline__ void sweep_tile(const RblParams &P, const JBlob *sj, double xi,
+                                           double yi, double zi, int self_jj, double &ux,
+                                           double &uy, double &uz, unsigned &flags)
+{
+#pragma unroll 4
+  for (int jj = 0; jj < TB; ++jj) {
+    const JBlob b = sj[jj];
+    rbl_pair_accum<WALL, SELF>(P, xi, yi, zi, b.x, b.y, b.z, b.fx, b.fy, b.fz,
+                               SELF && (jj == self_jj), ux, uy, uz, flags);
+  }
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
+                                                const double *__restrict__ F,
+                                                double *__restrict__ out,
+                                                double *__restrict__ part, long N,
+                                                long row_begin, long row_end, long jchunk,
+                                                int jsplit, RblParams P, unsigned *err)
+{
+  __shared__ JBlob sj[TB];
+  const int t = threadIdx.x;
+  const long i_tile0 = row_begin + (long)blockIdx.x * TB;
+  const long i = i_tile0 + t;
+  const bool valid = i < row_end;
+  const long ic = valid ? i : row_end - 1;
+  const double xi = r[3 * ic], yi = r[3 * ic + 1], zi = r[3 * ic + 2];
+  unsigned flags = 0;
+  if (WALL && zi < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+
+  const long j_begin = (long)blockIdx.y * jchunk;
+  const long j_end = (j_begin + jchunk < N) ? j_begin + jchunk : N;
+  double ux = 0.0, uy = 0.0, uz = 0.0;
+
+  for (long j0 = j_begin; j0 < j_end; j0 += TB) {
+    // ---- stage one j-tile (positions + damped forces) into LDS -------------
+    const long j = j0 + t;
+    JBlob b;
+    if (j < j_end) {
+      b.x = r[3 * j]; b.y = r[3 * j + 1]; b.z = r[3 * j + 2];
+      double d = 1.0;
+      if (WALL) {
+        if (b.z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+        d = damp_of(P, b.z);
+      }
+      b.fx = d * F[3 * j]; b.fy = d * F[3 * j + 1]; b.fz = d * F[3 * j + 2];
+    } else {  // padding: zero force, far away, above the wall
+      b.x = 1.0e15; b.y = 1.0e15; b.z = 1.0; b.fx = 0.0; b.fy = 0.0; b.fz = 0.0;
+    }
+    __syncthreads();  // previous tile fully consumed
+    sj[t] = b;
+    __syncthreads();
+    // ---- sweep: does this tile contain any of the block's own rows? --------
+    const bool diag = (j0 < i_tile0 + TB) && (j0 + TB > i_tile0);  // block-uniform
+    if (diag) {
+      const long sjj = i - j0;  // index of i itself inside the tile (may be out of range)
+      const int self_jj = (valid && sjj >= 0 && sjj < TB) ? (int)sjj : -1;
+      sweep_tile<WALL, true>(P, sj, xi, yi, zi, self_jj, ux, uy, uz, flags);
+    } else {
+      sweep_tile<WALL, false>(P, sj, xi, yi, zi, -1, ux, uy, uz, flags);
+    }
+  }
+
+  if (valid) {
+    const long o = 3 * (i - row_begin);
+    if (jsplit == 1) {
+      const double sc = WALL ? P.nf * damp_of(P, zi) : P.nf;
+      out[o] = sc * ux; out[o + 1] = sc * uy; out[o + 2] = sc * uz;
+      if (!(isfinite(ux) && isfinite(uy) && isfinite(uz))) flags |= RBL_FLAG_NONFINITE;
+    } else {
+      double *p = part + (size_t)blockIdx.y * (size_t)(3 * (row_end - row_begin)) + o;
+      p[0] = ux; p[1] = uy; p[2] = uz;
+    }
+  } else {
+    flags &= ~RBL_FLAG_OVERLAP;  // clamped duplicate row: ignore its pair checks
+  }
+  if (flags) atomicOr(err, flags);
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__ part,
+                                                      const double *__restrict__ r,
+                                                      double *__restrict__ out, long row_begin,
+                                                      long nrows, int jsplit, RblParams P,
+                                                      unsigned *err)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over 3*nrows
+  if (idx >= 3 * nrows) return;
+  double s = 0.0;
+  for (int k = 0; k < jsplit; ++k) s += part[(size_t)k * (size_t)(3 * nrows) + idx];
+  double sc = P.nf;
+  if (WALL) sc *= damp_of(P, r[3 * (row_begin + idx / 3) + 2]);
+  out[idx] = sc * s;
+  if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+}
+
+// ---------------------------------------------------------------------------
+// Dense assembly, column-major n3 x n3 (ld = n3).  Block = 256 consecutive i
+// (768 consecutive rows) x JB consecutive j (3*JB columns).  Each 3x3 block is
+// computed with the reference's (min,max) roles and transposed when i > j, so
+// the matrix equals the reference's entry for entry.  Columns are written from
+// LDS as contiguous 8-B-per-lane runs.
+// ---------------------------------------------------------------------------
+constexpr int JB = 16;
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void k_build_M(const double *__restrict__ r,
+                                                 double *__restrict__ M, long N,
+                                                 int scale_damp, RblParams P, unsigned *err)
+{
+  __shared__ double col[3][768];
+  const int t = threadIdx.x;
+  const long i0 = (long)blockIdx.x * 256;
+  const long i = i0 + t;
+  const bool valid = i < N;
+  const long ic = valid ? i : N - 1;
+  const long n3 = 3 * N;
+  const double xi = r[3 * ic], yi = r[3 * ic + 1], zi = r[3 * ic + 2];
+  const double di = scale_damp ? damp_of(P, zi) : 1.0;
+  const long nrow_blk = ((N - i0) < 256 ? (N - i0) : 256) * 3;
+  unsigned flags = 0;
+  const long jb0 = (long)blockIdx.y * JB;
+  for (int jj = 0; jj < JB; ++jj) {
+    const long j = jb0 + jj;
+    if (j >= N) break;  // block-uniform
+    const double xj = r[3 * j], yj = r[3 * j + 1], zj = r[3 * j + 2];
+    double b[9];
+    const bool self = (ic == j);
+    if (ic <= j) {
+      rbl_block_ref(P, WALL, xi, yi, zi, xj, yj, zj, self, b, flags);
+    } else {  // stored block is (j,i); ours is its transpose (c_rigid_obj.cpp:451)
+      double bt[9];
+      rbl_block_ref(P, WALL, xj, yj, zj, xi, yi, zi, false, bt, flags);
+      b[0] = bt[0]; b[1] = bt[3]; b[2] = bt[6];
+      b[3] = bt[1]; b[4] = bt[4]; b[5] = bt[7];
+      b[6] = bt[2]; b[7] = bt[5]; b[8] = bt[8];
+    }
+    const double dj = scale_damp ? damp_of(P, zj) : 1.0;
+    {
+#pragma clang fp contract(off)
+      for (int k = 0; k < 9; ++k) {
+        double v = b[k] * P.nf;                   // Mob *= norm_fact  (:456)
+        if (scale_damp) v = (di * v) * dj;        // B * Mob * B       (:669)
+        b[k] = v;
+      }
+    }
+    __syncthreads();
+    for (int q = 0; q < 3; ++q)
+      for (int p = 0; p < 3; ++p) col[q][3 * t + p] = b[3 * p + q];
+    __syncthreads();
+    for (int q = 0; q < 3; ++q) {
+      double *dst = M + (size_t)(3 * j + q) * (size_t)n3 + (size_t)(3 * i0);
+      for (int e = t; e < nrow_blk; e += 256) dst[e] = col[q][e];
+    }
+  }
+  if (!valid) flags &= ~RBL_FLAG_OVERLAP;
+  if (flags) atomicOr(err, flags);
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_blob_positions(const double *__restrict__ X, const double *__restrict__ Q,
+                                 const double *__restrict__ cfg, int N_blb, int body_begin,
+                                 long n_out_blobs, double *__restrict__ out)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_out_blobs) return;
+  const int b = body_begin + (int)(idx / N_blb);
+  const int k = (int)(idx % N_blb);
+  const double w = Q[4 * b], x = Q[4 * b + 1], y = Q[4 * b + 2], z = Q[4 * b + 3];
+  // unit quaternion -> rotation (same expansion Eigen uses; reference :258)
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double c0 = cfg[3 * k], c1 = cfg[3 * k + 1], c2 = cfg[3 * k + 2];
+  {
+#pragma clang fp contract(off)
+    out[3 * idx] = c0 * (1 - (tyy + tzz)) + c1 * (txy - twz) + c2 * (txz + twy) + X[3 * b];
+    out[3 * idx + 1] = c0 * (txy + twz) + c1 * (1 - (txx + tzz)) + c2 * (tyz - twx) + X[3 * b + 1];
+    out[3 * idx + 2] = c0 * (txz - twy) + c1 * (tyz + twx) + c2 * (1 - (txx + tyy)) + X[3 * b + 2];
+  }
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_pair_blocks(const double *__restrict__ ri, const double *__restrict__ rj,
+                              const int32_t *__restrict__ ii, const int32_t *__restrict__ jj,
+                              long n, int wall, int mode, RblParams P, double *__restrict__ out,
+                              unsigned *err)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  unsigned flags = 0;
+  const double xi = ri[3 * k], yi = ri[3 * k + 1], zi = ri[3 * k + 2];
+  const double xj = rj[3 * k], yj = rj[3 * k + 1], zj = rj[3 * k + 2];
+  const int i = ii[k], j = jj[k];
+  double b[9];
+  if (mode == 0) {
+    if (i <= j) {
+      rbl_block_ref(P, wall != 0, xi, yi, zi, xj, yj, zj, i == j, b, flags);
+    } else {
+      double bt[9];
+      rbl_block_ref(P, wall != 0, xj, yj, zj, xi, yi, zi, false, bt, flags);
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) b[3 * p + q] = bt[3 * q + p];
+    }
+  } else {
+    // fast path: columns of the block are its action on unit forces
+    for (int c = 0; c < 3; ++c) {
+      double ux = 0, uy = 0, uz = 0;
+      const double fx = c == 0, fy = c == 1, fz = c == 2;
+      if (wall)
+        rbl_pair_accum<true, true>(P, xi, yi, zi, xj, yj, zj, fx, fy, fz, i == j, ux, uy, uz, flags);
+      else
+        rbl_pair_accum<false, true>(P, xi, yi, zi, xj, yj, zj, fx, fy, fz, i == j, ux, uy, uz, flags);
+      b[c] = ux; b[3 + c] = uy; b[6 + c] = uz;
+    }
+    if (wall && (zi < 0.0 || zj < 0.0)) flags |= RBL_FLAG_BELOW_WALL;
+  }
+  for (int e = 0; e < 9; ++e) out[9 * k + e] = b[e] * P.nf;
+  if (flags) atomicOr(err, flags);
+}
+
+// ---------------------------------------------------------------------------
+// Counter-based normal generator: Philox-4x32-10 -> Box-Muller, two doubles
+// from each 128-bit block.  Reproducible for (seed, offset) on any grid.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void k_normal(uint64_t seed, uint64_t offset, long n, double *__restrict__ out)
+{
+  const long pair = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one pair of outputs
+  if (2 * pair >= n) return;
+  const uint64_t ctr = offset + (uint64_t)pair;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x52424C31u /* "RBL1" */, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t a = ((uint64_t)c[0] << 32) | c[1];
+  const uint64_t b = ((uint64_t)c[2] << 32) | c[3];
+  const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);  // (0,1)
+  const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincos(6.283185307179586476925 * u2, &sn, &cs);
+  out[2 * pair] = rad * cs;
+  if (2 * pair + 1 < n) out[2 * pair + 1] = rad * sn;
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1 helpers (Lanczos): deterministic two-stage reductions.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dot2_partial(const double *__restrict__ x,
+                                                      const double *__restrict__ y,
+                                                      const double *__restrict__ z, long n,
+                                                      double *__restrict__ part)
+{
+  __shared__ double s0[256], s1[256];
+  double a = 0.0, b = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double xv = x[i];
+    a = __builtin_fma(xv, y[i], a);
+    if (z) b = __builtin_fma(xv, z[i], b);
+  }
+  s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s0[threadIdx.x] += s0[threadIdx.x + s]; s1[threadIdx.x] += s1[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0[0]; part[2 * blockIdx.x + 1] = s1[0]; }
+}
+
+__global__ __launch_bounds__(256) void k_dot2_final(const double *__restrict__ part, int nblk,
+                                                    double *__restrict__ out2)
+{
+  __shared__ double s0[256], s1[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+  s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s0[threadIdx.x] += s0[threadIdx.x + s]; s1[threadIdx.x] += s1[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = s0[0]; out2[1] = s1[0]; }
+}
+
+__global__ void k_axpby(long n, double a, const double *__restrict__ x, double b,
+                        const double *__restrict__ y, double *__restrict__ out)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+
+__global__ void k_scale_by_damp(RblParams P, const double *__restrict__ r, long n_blobs,
+                                const double *__restrict__ in, double *__restrict__ out)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * n_blobs) out[i] = damp_of(P, r[3 * (i / 3) + 2]) * in[i];
+}
+
+}  // namespace
+
+// =============================================================================
+// launchers
+// =============================================================================
+RblParams rbl_make_params(double a, double eta)
+{
+  RblParams P;
+  P.a = a;
+  P.inv_a = 1.0 / a;
+  P.nf = 1.0 / (8.0 * M_PI * eta * a);
+  P.four_a2 = 4.0 * a * a;
+  P.tiny2 = (1e-12 * a) * (1e-12 * a);
+  P.c_near_A = -0.375 / a;
+  P.c_near_B = 0.125 / a;
+  return P;
+}
+
+static int choose_jsplit(int64_t n_blobs, int64_t nrows, int n_cu, int override_)
+{
+  const int64_t itiles = (nrows + TB - 1) / TB;
+  const int64_t jtiles = (n_blobs + TB - 1) / TB;
+  int64_t js;
+  if (override_ > 0) {
+    js = override_;
+  } else {
+    // aim for ~8 rounds of (4 blocks per CU) so the tail round costs < ~6 %
+    const int64_t target = (int64_t)(n_cu > 0 ? n_cu : 256) * 4 * 8;
+    js = (target + itiles - 1) / itiles;
+  }
+  if (js > jtiles) js = jtiles;
+  if (js < 1) js = 1;
+  return (int)js;
+}
+
+size_t rbl_apply_M_part_bytes(int64_t n_blobs, int64_t nrows, int n_cu, int jsplit_override,
+                              int *jsplit_out)
+{
+  const int js = choose_jsplit(n_blobs, nrows, n_cu, jsplit_override);
+  if (jsplit_out) *jsplit_out = js;
+  return js > 1 ? (size_t)js * (size_t)(3 * nrows) * sizeof(double) : 0;
+}
+
+void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                        const double *d_r, int64_t n_blobs, int64_t row_begin,
+                        int64_t row_end, double *d_out, double *d_part, int jsplit,
+                        int /*variant*/, unsigned *d_err)
+{
+  const int64_t nrows = row_end - row_begin;
+  if (nrows <= 0 || n_blobs <= 0) return;
+  const int64_t itiles = (nrows + TB - 1) / TB;
+  const int64_t jtiles = (n_blobs + TB - 1) / TB;
+  const int64_t jchunk = ((jtiles + jsplit - 1) / jsplit) * TB;
+  // jsplit may shrink when the chunks are rounded up to whole tiles
+  const int js_eff = (int)((n_blobs + jchunk - 1) / jchunk);
+  dim3 grid((unsigned)itiles, (unsigned)js_eff), block(TB);
+  if (wall)
+    hipLaunchKernelGGL(k_apply_M<true>, grid, block, 0, st, d_r, d_F, d_out, d_part,
+                       (long)n_blobs, (long)row_begin, (long)row_end, (long)jchunk, js_eff, P, d_err);
+  else
+    hipLaunchKernelGGL(k_apply_M<false>, grid, block, 0, st, d_r, d_F, d_out, d_part,
+                       (long)n_blobs, (long)row_begin, (long)row_end, (long)jchunk, js_eff, P, d_err);
+  if (js_eff > 1) {
+    const int64_t n = 3 * nrows;
+    dim3 g2((unsigned)((n + 255) / 256)), b2(256);
+    if (wall)
+      hipLaunchKernelGGL(k_reduce_parts<true>, g2, b2, 0, st, d_part, d_r, d_out,
+                         (long)row_begin, (long)nrows, js_eff, P, d_err);
+    else
+      hipLaunchKernelGGL(k_reduce_parts<false>, g2, b2, 0, st, d_part, d_r, d_out,
+                         (long)row_begin, (long)nrows, js_eff, P, d_err);
+  }
+}
+
+void rbl_launch_blob_positions(hipStream_t st, const double *d_X, const double *d_Q,
+                               const double *d_cfg, int N_blb, int body_begin, int body_end,
+                               double *d_out)
+{
+  const long n = (long)(body_end - body_begin) * N_blb;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_blob_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_X,
+                     d_Q, d_cfg, N_blb, body_begin, n, d_out);
+}
+
+void rbl_launch_build_M(hipStream_t st, const RblParams &P, bool wall, bool scale_damp,
+                        const double *d_r, int64_t n_blobs, double *d_M, unsigned *d_err)
+{
+  if (n_blobs <= 0) return;
+  dim3 grid((unsigned)((n_blobs + 255) / 256), (unsigned)((n_blobs + JB - 1) / JB)), block(256);
+  if (wall)
+    hipLaunchKernelGGL(k_build_M<true>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
+                       scale_damp ? 1 : 0, P, d_err);
+  else
+    hipLaunchKernelGGL(k_build_M<false>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
+                       scale_damp ? 1 : 0, P, d_err);
+}
+
+void rbl_launch_pair_blocks(hipStream_t st, const RblParams &P, bool wall, int mode,
+                            const double *d_ri, const double *d_rj, const int32_t *d_ii,
+                            const int32_t *d_jj, int64_t n, double *d_out9, unsigned *d_err)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pair_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_ri, d_rj,
+                     d_ii, d_jj, (long)n, wall ? 1 : 0, mode, P, d_out9, d_err);
+}
+
+void rbl_launch_normal(hipStream_t st, uint64_t seed, uint64_t offset, int64_t n, double *d_out)
+{
+  if (n <= 0) return;
+  const long pairs = (n + 1) / 2;
+  hipLaunchKernelGGL(k_normal, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, seed,
+                     offset, (long)n, d_out);
+}
+
+// d_out2 must have room for 2 + 2*DOT_BLOCKS doubles: [0..1] result, rest scratch
+static constexpr int DOT_BLOCKS = 512;
+void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const double *z,
+                     int64_t n, double *d_out2)
+{
+  int nblk = (int)std::min<int64_t>(DOT_BLOCKS, (n + 255) / 256);
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(k_dot2_partial, dim3(nblk), dim3(256), 0, st, x, y, z, (long)n, d_out2 + 2);
+  hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, d_out2 + 2, nblk, d_out2);
+}
+
+void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,
+                      const double *y, double *out)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, a, x,
+                     b, y, out);
+}
+
+void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
+                              int64_t n_blobs, const double *in, double *out)
+{
+  const int64_t n = 3 * n_blobs;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_scale_by_damp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, d_r,
+                     (long)n_blobs, in, out);
+}

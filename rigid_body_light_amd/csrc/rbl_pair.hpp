@@ -1,0 +1,259 @@
+// rbl_pair.hpp -- device pair arithmetic for the blob mobility (gfx950, fp64).
+//
+// Two formulations of the same physics:
+//
+//  * rbl_block_ref():   the 3x3 block exactly as the reference assembles it
+//    (c_rigid_obj.cpp:31-142 and :432-447): same expressions, IEEE division and
+//    sqrt, FMA contraction OFF -> entries come out bit-identical to the CPU
+//    oracle.  Used by the dense-build kernel, which is HBM-write bound, so the
+//    extra ALU work is free.
+//
+//  * rbl_pair_accum():  matrix-free  U_i += M_ij F_j  in "vector form"
+//        M F = A F + Bc (r.F) r  +  f1 F + (f2 (e.F) + f3 Fz) e + (f4 (e.F) + f5 Fz) z^
+//    with ONE v_rsq_f64 + a 3rd-order Newton step per distance, no division, and
+//    h_hat eliminated algebraically ( h_hat ez = z_j/R, (1-h_hat) ez = z_i/R ).
+//    Used by the matvec kernels, which are fp64-VALU bound.  Agrees with the
+//    reference to ~1e-15 relative per pair (tests pin <=1e-12 on apply_M).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define RBL_FLAG_OVERLAP 1
+#define RBL_FLAG_BELOW_WALL 2
+#define RBL_FLAG_NONFINITE 4
+#define RBL_FLAG_NOT_SPD 8
+
+struct RblParams {
+  double a;        // blob radius
+  double inv_a;    // 1/a
+  double nf;       // 1/(8 pi eta a)            c_rigid_obj.cpp:415
+  double four_a2;  // (2a)^2, far/overlap switch c_rigid_obj.cpp:62
+  double tiny2;    // (1e-12 a)^2, overlap abort c_rigid_obj.cpp:53
+  double c_near_A; // -(3/8)/a   : 4/3 (1 - 9/32 r/a) = 4/3 + c_near_A r
+  double c_near_B; // (1/8)/a    : 4/3 * 3/32 (a/r) / a^2 = c_near_B / r
+};
+
+// ---------------------------------------------------------------------------
+// 1/sqrt(x), full double precision: v_rsq_f64 seed + one 3rd-order correction.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double rbl_rsqrt(double x)
+{
+  double y = __builtin_amdgcn_rsq(x);
+  double h = x * y;
+  double e = __builtin_fma(-h, y, 1.0);            // 1 - x y^2
+  double p = __builtin_fma(e, 0.375, 0.5);         // 1/2 + 3/8 e
+  double ye = y * e;
+  y = __builtin_fma(ye, p, y);                     // y (1 + e/2 + 3 e^2/8)
+  // second (cheap, 2nd-order) polish: seeds are ~2^-26..2^-29 accurate, after
+  // the cubic step the error is already < 2^-70; one more FMA pair guards the
+  // last bit against the seed being worse on some inputs.
+  h = x * y;
+  e = __builtin_fma(-h, y, 1.0);
+  y = __builtin_fma(y * 0.5, e, y);
+  return y;
+}
+
+// ---------------------------------------------------------------------------
+// Fast matrix-free accumulation of one ordered pair (i <- j).
+//   dx,dy,dz = r_i - r_j ;  zi, zj heights ; (Fx,Fy,Fz) = (damped) force on j
+//   SELF: compile-time "this j-tile may contain i" (index-equality self term)
+// Accumulates UNSCALED (units 1/(8 pi eta a)) into ux,uy,uz.
+// ---------------------------------------------------------------------------
+template <bool WALL, bool SELF>
+__device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, double yi,
+                                               double zi, double xj, double yj, double zj,
+                                               double Fx, double Fy, double Fz, bool is_self,
+                                               double &ux, double &uy, double &uz,
+                                               unsigned &flags)
+{
+  const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+  const double q = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, q);
+
+  // ---- free-space RPY (c_rigid_obj.cpp:48-79) in physical units ----------
+  const double invr = rbl_rsqrt(r2);
+  const double invr2 = invr * invr;
+  const double s = P.a * invr;                       // a/r
+  const double t = s * s;                            // (a/r)^2
+  // far:  A = (a/r)(1 + 2/3 (a/r)^2),  Bc = (a/r)(1 - 2 (a/r)^2)/r^2
+  const double A_far = __builtin_fma(s * t, 2.0 / 3.0, s);
+  const double B_far = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
+  // overlap: A = 4/3 - 3/8 r/a,  Bc = (1/8) / (a r)
+  const double rr = r2 * invr;                       // r
+  const double A_near = __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
+  const double B_near = invr * P.c_near_B;
+  const bool far = r2 >= P.four_a2;
+  double A = far ? A_far : A_near;
+  double Bc = far ? B_far : B_near;
+  if (SELF) {                                        // index equality, :40-46
+    A = is_self ? 4.0 / 3.0 : A;
+    Bc = is_self ? 0.0 : Bc;
+    if (!is_self && r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
+  } else {
+    if (r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
+  }
+  const double q2 = __builtin_fma(dy, Fy, dx * Fx);
+  const double rF = __builtin_fma(dz, Fz, q2);
+  const double tB = Bc * rF;
+
+  if (!WALL) {
+    ux = __builtin_fma(A, Fx, __builtin_fma(tB, dx, ux));
+    uy = __builtin_fma(A, Fy, __builtin_fma(tB, dy, uy));
+    uz = __builtin_fma(A, Fz, __builtin_fma(tB, dz, uz));
+    return;
+  }
+
+  // ---- single-wall correction (c_rigid_obj.cpp:98-140), ordered pair, h = z_j
+  const double Rz = zi + zj;                         // (rz + 2 z_j)
+  const double R2 = __builtin_fma(Rz, Rz, q);
+  const double invR = rbl_rsqrt(R2);
+  const double w = P.a * invR;                       // 1/R^ (dimensionless)
+  const double ez = Rz * invR;
+  const double w2 = w * w;
+  const double w3 = w2 * w;
+  const double w5 = w3 * w2;
+  const double ez2 = ez * ez;
+  const double g = zj * invR;                        // h_hat * ez
+  const double k = zi * invR;                        // (1 - h_hat) * ez
+  const double gk = g * k;                           // h_hat (1-h_hat) ez^2
+  const double p3 = __builtin_fma(-3.0, ez2, 1.0);
+  const double p5 = __builtin_fma(-5.0, ez2, 1.0);
+  const double p7 = __builtin_fma(-7.0, ez2, 1.0);
+  const double p5w3 = p5 * w3;
+  // fact1 = -(1+2gk) w - 2/3 (1-3ez2) w^3 + 2/3 (1-5ez2) w^5
+  double f1 = __builtin_fma(-2.0, gk, -1.0) * w;
+  f1 = __builtin_fma(p3 * w3, -2.0 / 3.0, f1);
+  f1 = __builtin_fma(p5 * w5, 2.0 / 3.0, f1);
+  // fact2 = -(1-6gk) w + 2 (1-5ez2) w^3 - 10/3 (1-7ez2) w^5
+  double f2 = __builtin_fma(6.0, gk, -1.0) * w;
+  f2 = __builtin_fma(p5w3, 2.0, f2);
+  f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
+  // fact3 = 2 g w (1 - 6 k ez) + ez ( -4 (1-5ez2) w^3 + 20/3 (2-7ez2) w^5 )
+  const double gw = g * w;
+  const double ezw5 = ez * w5;
+  double f3 = (gw + gw) * __builtin_fma(-6.0 * k, ez, 1.0);
+  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
+  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
+  // fact4 = 2 g w - 20/3 ez w^5
+  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw + gw);
+  // fact5 = -4 g (g w) - 4 ez2 w^3 - 4/3 (2 - 15 ez2) w^5
+  double f5 = -4.0 * (g * gw);
+  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
+  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
+
+  double cF, cE, cZ;   // coefficients of F, of (dx,dy,Rz), of z^
+  if (SELF && is_self) {
+    // self wall term (:98-104): diag only, args (0,0,2h; h = z_i/a)
+    const double iz = P.a / zi;                      // 1/h  (true division kept: rare path)
+    const double iz3 = iz * iz * iz;
+    const double iz5 = iz3 * iz * iz;
+    const double dpar = -(9.0 * iz - 2.0 * iz3 + iz5) / 12.0;
+    const double dper = -(9.0 * iz - 4.0 * iz3 + iz5) / 6.0;
+    ux = __builtin_fma(A + dpar, Fx, ux);
+    uy = __builtin_fma(A + dpar, Fy, uy);
+    uz = __builtin_fma(A + dper, Fz, uz);
+    return;
+  }
+  const double eF = __builtin_fma(Rz, Fz, q2) * invR; // e . F
+  cF = A + f1;
+  cE = __builtin_fma(f2, eF, f3 * Fz) * invR;        // multiplies (dx,dy,Rz)
+  cZ = __builtin_fma(f4, eF, f5 * Fz);
+  const double cxy = tB + cE;
+  ux = __builtin_fma(cF, Fx, __builtin_fma(cxy, dx, ux));
+  uy = __builtin_fma(cF, Fy, __builtin_fma(cxy, dy, uy));
+  uz = __builtin_fma(cF, Fz, __builtin_fma(tB, dz, __builtin_fma(cE, Rz, uz + cZ)));
+}
+
+// ---------------------------------------------------------------------------
+// Reference-order block (bit-compatible with the oracle).  b: row-major 3x3,
+// NOT yet scaled by nf.  lo/hi are the (i<=j) roles of c_rigid_obj.cpp:430-447.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ void rbl_rpy_ref(double rx, double ry, double rz, bool self,
+                                            double inv_a, double *o, unsigned &flags)
+{
+  const double four3 = 4.0 / 3.0;
+  if (self) {
+    o[0] = four3; o[1] = 0.0; o[2] = 0.0; o[3] = four3; o[4] = 0.0; o[5] = four3;
+    return;
+  }
+  rx = rx * inv_a; ry = ry * inv_a; rz = rz * inv_a;
+  const double r2 = rx * rx + ry * ry + rz * rz;
+  const double r = __builtin_sqrt(r2);
+  if (r < 1e-12) flags |= RBL_FLAG_OVERLAP;
+  const double invr = 1.0 / r;
+  const double invr2 = invr * invr;
+  if (r >= 2.0) {
+    const double c1 = 1.0 + 2.0 / (3.0 * r2);
+    const double c2 = (1.0 - 2.0 * invr2) * invr2;
+    o[0] = (c1 + c2 * rx * rx) * invr;
+    o[1] = (c2 * rx * ry) * invr;
+    o[2] = (c2 * rx * rz) * invr;
+    o[3] = (c1 + c2 * ry * ry) * invr;
+    o[4] = (c2 * ry * rz) * invr;
+    o[5] = (c1 + c2 * rz * rz) * invr;
+  } else {
+    const double c1 = four3 * (1.0 - 0.28125 * r);
+    const double c2 = four3 * 0.09375 * invr;
+    o[0] = c1 + c2 * rx * rx;
+    o[1] = c2 * rx * ry;
+    o[2] = c2 * rx * rz;
+    o[3] = c1 + c2 * ry * ry;
+    o[4] = c2 * ry * rz;
+    o[5] = c1 + c2 * rz * rz;
+  }
+}
+
+__device__ __forceinline__ void rbl_wall_ref(double rx, double ry, double rz, double *M,
+                                             bool self, double hj, unsigned &flags)
+{
+  if (hj < 0.0) { flags |= RBL_FLAG_BELOW_WALL; }
+  if (self) {
+    const double iz = 1.0 / hj;
+    const double iz3 = iz * iz * iz;
+    const double iz5 = iz3 * iz * iz;
+    M[0] += -(9 * iz - 2 * iz3 + iz5) / 12.0;
+    M[4] += -(9 * iz - 2 * iz3 + iz5) / 12.0;
+    M[8] += -(9 * iz - 4 * iz3 + iz5) / 6.0;
+    return;
+  }
+  const double hh = hj / rz;
+  const double iR = 1.0 / __builtin_sqrt(rx * rx + ry * ry + rz * rz);
+  const double ex = rx * iR, ey = ry * iR, ez = rz * iR;
+  const double iR3 = iR * iR * iR;
+  const double iR5 = iR3 * iR * iR;
+  const double f1 = -(3 * (1 + 2 * hh * (1 - hh) * ez * ez) * iR +
+                      2 * (1 - 3 * ez * ez) * iR3 - 2 * (1 - 5 * ez * ez) * iR5) / 3.0;
+  const double f2 = -(3 * (1 - 6 * hh * (1 - hh) * ez * ez) * iR -
+                      6 * (1 - 5 * ez * ez) * iR3 + 10 * (1 - 7 * ez * ez) * iR5) / 3.0;
+  const double f3 = ez *
+                    (3 * hh * (1 - 6 * (1 - hh) * ez * ez) * iR -
+                     6 * (1 - 5 * ez * ez) * iR3 + 10 * (2 - 7 * ez * ez) * iR5) *
+                    2.0 / 3.0;
+  const double f4 = ez * (3 * hh * iR - 10 * iR5) * 2.0 / 3.0;
+  const double f5 = -(3 * hh * hh * ez * ez * iR + 3 * ez * ez * iR3 +
+                      (2 - 15 * ez * ez) * iR5) * 4.0 / 3.0;
+  M[0] += f1 + f2 * ex * ex;
+  M[1] += f2 * ex * ey;
+  M[2] += f2 * ex * ez + f3 * ex;
+  M[3] += f2 * ey * ex;
+  M[4] += f1 + f2 * ey * ey;
+  M[5] += f2 * ey * ez + f3 * ey;
+  M[6] += f2 * ez * ex + f4 * ex;
+  M[7] += f2 * ez * ey + f4 * ey;
+  M[8] += f1 + f2 * ez * ez + f3 * ez + f4 * ez + f5;
+}
+
+// block for the ordered roles (lo <= hi):  r_lo - r_hi,  h = z_hi / a
+__device__ __forceinline__ void rbl_block_ref(const RblParams &P, bool wall, double xl,
+                                              double yl, double zl, double xh, double yh,
+                                              double zh, bool self, double *b, unsigned &flags)
+{
+  const double rx = xl - xh, ry = yl - yh, rz = zl - zh;
+  double s[6];
+  rbl_rpy_ref(rx, ry, rz, self, P.inv_a, s, flags);
+  b[0] = s[0]; b[1] = s[1]; b[2] = s[2];
+  b[3] = s[1]; b[4] = s[3]; b[5] = s[4];
+  b[6] = s[2]; b[7] = s[4]; b[8] = s[5];
+  if (wall) rbl_wall_ref(rx / P.a, ry / P.a, (rz + 2 * zh) / P.a, b, self, zh / P.a, flags);
+}
+#pragma clang fp contract(fast)

@@ -1,0 +1,81 @@
+"""Body-sharded multi-GPU apply_M: one process per GPU,
+bodies split contiguously by body index, ONE exchange step -- an all-gather of
+blob positions (once per configuration) and of the force vector (once per
+matvec) over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests).  Output rows are independent, so there is no reduction.
+
+The per-rank compute is the HIP kernel (DeviceContext.apply_M on the rank's row
+slice).  `row_apply` exists so the CPU gloo test can check the partition /
+exchange logic with the oracle standing in for the kernel; the product never
+sets it.
+"""
+import torch
+import torch.distributed as dist
+
+
+def body_partition(n_bodies, world_size):
+    """Contiguous split, sizes differ by at most one: -> list of (begin, end)."""
+    base, rem = divmod(n_bodies, world_size)
+    out, b = [], 0
+    for r in range(world_size):
+        e = b + base + (1 if r < rem else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+class ShardedMobility:
+    def __init__(self, n_bodies, blobs_per_body, group=None, device=None, ctx=None, row_apply=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_bodies, self.nblb = n_bodies, blobs_per_body
+        self.parts = body_partition(n_bodies, self.world)
+        self.b0, self.b1 = self.parts[self.rank]
+        self.row0, self.row1 = self.b0 * blobs_per_body, self.b1 * blobs_per_body
+        self.n_blobs = n_bodies * blobs_per_body
+        self.max_rows = max(e - b for b, e in self.parts) * blobs_per_body
+        self.device = device if device is not None else torch.device("cpu")
+        self.ctx = ctx
+        self.row_apply = row_apply
+        if ctx is None and row_apply is None:
+            raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
+        self.r_full = None
+
+    # -- exchange -----------------------------------------------------------
+    def all_gather_rows(self, local):
+        """local: (rows_local*3,) -> (n_blobs*3,) in body order.  Shards are padded to the
+        largest shard so a single all_gather_into_tensor moves everything."""
+        if self.world == 1:
+            return local.clone()
+        pad = torch.zeros(self.max_rows * 3, dtype=local.dtype, device=local.device)
+        pad[: local.numel()] = local
+        buf = torch.empty(self.world * self.max_rows * 3, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, pad, group=self.group)
+        if all((e - b) * self.nblb == self.max_rows for b, e in self.parts):
+            return buf
+        chunks = [buf[r * self.max_rows * 3: r * self.max_rows * 3 + (e - b) * self.nblb * 3]
+                  for r, (b, e) in enumerate(self.parts)]
+        return torch.cat(chunks)
+
+    def set_positions_local(self, r_local):
+        """r_local: this rank's blob positions (rows_local*3,).  One all-gather per configuration."""
+        self.r_full = self.all_gather_rows(r_local.contiguous())
+        return self.r_full
+
+    # -- matvec ---------------------------------------------------------------
+    def apply_M_local(self, F_local, gather_output=False):
+        """F_local: this rank's slice of the force vector.  Returns this rank's slice of
+        U = M F (or the full vector if gather_output)."""
+        F_full = self.all_gather_rows(F_local.contiguous())
+        U_local = self.apply_M_rows(F_full)
+        return self.all_gather_rows(U_local) if gather_output else U_local
+
+    def apply_M_rows(self, F_full):
+        nrows = self.row1 - self.row0
+        if self.row_apply is not None:
+            return self.row_apply(F_full, self.r_full, self.row0, self.row1)
+        out = torch.empty(nrows * 3, dtype=torch.float64, device=self.device)
+        self.ctx.apply_M(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.row0, self.row1,
+                         out.data_ptr())
+        return out

@@ -1,0 +1,44 @@
+"""The C-ABI library loads and exports every symbol include/rbl.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rbl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbl_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ctypes.CDLL(os.path.join(ROOT, "rigid_body_light_amd", "librbl.so"))
+    names = declared_symbols()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_context_lifecycle_and_loud_failure_without_device():
+    import torch
+    lib = ctypes.CDLL(os.path.join(ROOT, "rigid_body_light_amd", "librbl.so"))
+    lib.rbl_create.restype = ctypes.c_void_p
+    lib.rbl_destroy.argtypes = [ctypes.c_void_p]
+    lib.rbl_last_error.restype = ctypes.c_char_p
+    lib.rbl_last_error.argtypes = [ctypes.c_void_p]
+    lib.rbl_precision.restype = ctypes.c_char_p
+    assert lib.rbl_precision() == b"double"
+    h = lib.rbl_create()
+    assert h
+    lib.rbl_apply_M.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
+    buf = (ctypes.c_double * 6)(*([0.0] * 6))
+    rc = lib.rbl_apply_M(h, buf, buf, 6, buf)
+    assert rc == 7 and b"setParameters" in lib.rbl_last_error(h)     # RBL_ERR_STATE
+    if torch.cuda.device_count() == 0:
+        lib.rbl_set_parameters.argtypes = [ctypes.c_void_p] + [ctypes.c_double] * 4 + [ctypes.c_void_p, ctypes.c_int]
+        cfg = (ctypes.c_double * 6)(0, 0, 1, 0, 0, -1)
+        assert lib.rbl_set_parameters(h, 1.0, 0.1, 1.0, 1.0, cfg, 2) == 0
+        rc = lib.rbl_apply_M(h, buf, buf, 6, buf)
+        assert rc == 5 and b"no CPU fallback" in lib.rbl_last_error(h)  # RBL_ERR_NO_DEVICE
+    lib.rbl_destroy(h)

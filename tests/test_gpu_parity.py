@@ -1,0 +1,367 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI (pybind11 shim / ctypes), against the CPU oracle on the same seeded inputs, against
+the golden fixture of the reference's compiled pair kernels, and -- at the full
+BASELINE.json sizes -- through size-independent properties.
+
+Tolerances (fp64, stated per SURVEY.md section 8c):
+  pair blocks, reference-order arithmetic ........ bit-exact vs golden / oracle
+  pair blocks, fast matvec arithmetic ............ <= 2e-14 relative to the block norm
+  apply_M vs oracle .............................. relative L2 <= 1e-12
+  dense build vs oracle .......................... bit-exact
+  Cholesky factor / L W vs oracle ................ relative <= 1e-10 / 1e-9
+  Lanczos M^{1/2} W vs eigh square root .......... relative L2 <= 1e-7 (tol 1e-9 set)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import create_solver, random_positions
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def unhex(v):
+    return np.array([float.fromhex(x) for x in v])
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+
+def solver(a, eta, wall, cfg=None):
+    from rigid_body_light_amd import RigidBody, load_structure
+    if cfg is None:
+        cfg = load_structure(12)[1]
+    return RigidBody(cfg, np.array([[0.0, 0.0, 50.0]]), np.array([[1.0, 0, 0, 0]]), a, eta, 0.01, wall_PC=wall)
+
+
+# ---------------------------------------------------------------------------------
+# pair kernels vs the reference's own compiled kernels (golden fixture)
+# ---------------------------------------------------------------------------------
+def test_pair_blocks_vs_reference_golden():
+    with open(os.path.join(HERE, "golden", "pair_kernels.json")) as f:
+        g = json.load(f)
+    # free-space cases grouped by inv_a
+    by_a = {}
+    for c in g["rpy"]:
+        by_a.setdefault(c["inv_a"], []).append(c)
+    for inv_a_hex, cases in by_a.items():
+        a = 1.0 / float.fromhex(inv_a_hex)
+        eta = 1.0 / (8.0 * np.pi * a)       # nf = 1/(8 pi eta a) = 1 -> raw blocks
+        rb = solver(a, eta, False)
+        ri = np.array([unhex(c["r"]) for c in cases]); rj = np.zeros_like(ri)
+        ii = np.array([c["i"] for c in cases], dtype=np.int32); jj = np.array([c["j"] for c in cases], dtype=np.int32)
+        ref = np.array([unhex(c["out6"]) for c in cases])
+        ref9 = ref[:, [0, 1, 2, 1, 3, 4, 2, 4, 5]].reshape(-1, 3, 3)
+        nf = 1.0 / (8.0 * np.pi * eta * a)
+        exact = rb.cb.pair_blocks(ri, rj, ii, jj, False, 0)
+        # nf is not exactly 1.0 in floating point: compare after the same scaling
+        assert np.array_equal(exact, ref9 * nf)
+        fast = rb.cb.pair_blocks(ri, rj, ii, jj, False, 1)
+        scale = np.linalg.norm(ref9, axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(fast - ref9 * nf) / scale) < 2e-14
+
+
+def test_wall_blocks_vs_oracle_roles(orc):
+    """Full wall-corrected blocks, both index orders (i<j and i>j -> transposed roles)."""
+    rng = np.random.default_rng(21)
+    n = 4000
+    a, eta = 0.41642068, 1.3
+    ri = rng.uniform(-3, 3, (n, 3)); rj = rng.uniform(-3, 3, (n, 3))
+    ri[:, 2] = rng.uniform(0.05, 4, n); rj[:, 2] = rng.uniform(0.05, 4, n)
+    ii = rng.integers(0, 50, n).astype(np.int32); jj = rng.integers(0, 50, n).astype(np.int32)
+    same = ii == jj
+    rj[same] = ri[same]
+    rb = solver(a, eta, True)
+    ref = np.zeros((n, 3, 3))
+    for k in range(n):
+        if ii[k] <= jj[k]:
+            ref[k] = orc.pair_block(ri[k], rj[k], int(ii[k]), int(jj[k]), a, eta, True)
+        else:
+            ref[k] = orc.pair_block(rj[k], ri[k], int(jj[k]), int(ii[k]), a, eta, True).T
+    exact = rb.cb.pair_blocks(ri, rj, ii, jj, True, 0)
+    assert np.array_equal(exact, ref)                                  # bit-exact
+    fast = rb.cb.pair_blocks(ri, rj, ii, jj, True, 1)
+    # the fast path evaluates ordered pairs with h = z_j (no role swap): equal up to rounding
+    scale = np.linalg.norm(ref, axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(fast - ref) / scale) < 5e-13
+
+
+# ---------------------------------------------------------------------------------
+# apply_M vs the oracle (reference c_rigid_obj.cpp:641-659)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("wall", [False, True])
+def test_apply_M_cfg1_vs_oracle_dense(orc, wall):
+    """BASELINE cfg 1: 10 bodies x shell_N_12 -- literal dense oracle."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(10, 12, wall)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    F = np.random.default_rng(2).standard_normal(r.size)
+    U = rb.apply_M(F, r)
+    Uo = orc.apply_M(F, r, c["a"], c["eta"], wall, mode="dense")
+    assert U.shape == (360,)
+    assert rel(U, Uo) < 1e-12
+
+
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("nb,nblb", [(7, 162), (3, 642)])
+def test_apply_M_midsize_vs_oracle(orc, wall, nb, nblb):
+    """ragged sizes (N not a multiple of the 256 tile), j-split path, damping zone."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(nb, nblb, wall)
+    if wall:
+        c["X"][0, 2] = 1.0 + 0.5 * c["a"]      # one body dips into the damp zone z < a
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    F = np.random.default_rng(2).standard_normal(r.size)
+    Uo = orc.apply_M(F, r, c["a"], c["eta"], wall, mode="matfree")
+    for js in (0, 1, 3):
+        rb.cb.set_tuning(js, 0)
+        assert rel(rb.apply_M(F, r), Uo) < 1e-12
+
+
+def test_apply_M_cfg2_size_vs_oracle_rows(orc):
+    """BASELINE cfg 2 size (50 x shell_N_162 = 8100 blobs): oracle on a row sample."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(50, 162, False)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"])
+    r = rb.get_blob_positions()
+    F = np.random.default_rng(2).standard_normal(r.size)
+    U = rb.apply_M(F, r).reshape(-1, 3)
+    for (b, e) in ((0, 64), (4000, 4064), (8036, 8100)):
+        Uo = orc.apply_M_rows(F, r, b, e, c["a"], c["eta"], False, nthreads=8)
+        assert rel(U[b:e].ravel(), Uo) < 1e-12
+
+
+def test_apply_M_interface_behaviour():
+    """Mirror of reference tests/test_interface.py:149-177 and tests/test_wall.py."""
+    X, Q = random_positions(2, seed=30)
+    cb = create_solver(X, Q)
+    F = np.random.default_rng(31).standard_normal(72)
+    pos = cb.get_blob_positions()
+    assert pos.shape == (24, 3)
+    res = cb.apply_M(F, pos)
+    assert res.shape == (72,) and np.linalg.norm(res) > 0
+    F2 = np.concatenate((F, np.random.default_rng(32).standard_normal(3)))     # extra blob
+    pos2 = np.concatenate((pos, np.random.default_rng(33).uniform(1.0, 5.0, (1, 3))))
+    res2 = cb.apply_M(F2, pos2)
+    assert res2.shape == (75,) and np.linalg.norm(res2) > 0
+    out = cb.apply_saddle(np.random.default_rng(34).standard_normal(72 + 12))
+    assert out.shape == (84,) and np.linalg.norm(out) > 0
+    # float32 inputs accepted (tests/test_precision.py)
+    r32 = cb.apply_M(F.astype(np.float32), pos.astype(np.float32))
+    assert rel(r32, res) < 1e-5
+
+
+def test_saddle_numeric(orc, shell12):
+    from oracle import oracle as onp
+    X, Q = random_positions(3, seed=35)
+    cb = create_solver(X, Q)
+    x = np.random.default_rng(36).standard_normal(108 + 18)
+    out = cb.apply_saddle(x)
+    cfg = onp.remove_mean(shell12); Qn = onp.normalize_quats(Q)
+    K = onp.K_matrix(X, Qn, cfg)
+    r = orc.multi_body_pos(X, Q, cfg)
+    ref = np.concatenate([orc.apply_M(x[:108], r, 1.0, 1.0, False) - K @ x[108:], K.T @ x[:108]])
+    assert rel(out, ref) < 1e-12
+
+
+def test_wall_above_and_under():
+    cb = create_solver(np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0, 0, 0]]), wall_PC=True)  # test_wall.py:7-21
+    vec = np.random.default_rng(40).standard_normal(42)
+    assert np.linalg.norm(cb.apply_PC(vec)) > 0
+    assert np.linalg.norm(cb.apply_saddle(vec)) > 0
+    assert np.linalg.norm(cb.apply_M(vec[:36], cb.get_blob_positions())) > 0
+    cb = create_solver(np.array([[0.0, 0.0, 0.0]]), np.array([[1.0, 0, 0, 0]]), wall_PC=True)  # :24-38
+    for fn in (lambda: cb.apply_saddle(vec), lambda: cb.apply_PC(vec),
+               lambda: cb.apply_M(vec[:36], cb.get_blob_positions())):
+        with pytest.raises(RuntimeError, match="below the wall"):
+            fn()
+    # and the object is still usable afterwards (error word is cleared)
+    cb2 = create_solver(np.array([[0.0, 0.0, 3.0]]), np.array([[1.0, 0, 0, 0]]), wall_PC=True)
+    assert np.isfinite(cb2.apply_M(vec[:36], cb2.get_blob_positions())).all()
+
+
+def test_overlapping_blobs_raise_not_exit():
+    cb = create_solver(np.array([[0.0, 0.0, 5.0]]), np.array([[1.0, 0, 0, 0]]))
+    pos = np.zeros((3, 3)); pos[2] = [4, 0, 0]           # blobs 0 and 1 coincide
+    with pytest.raises(RuntimeError, match="OVERLAPPING"):
+        cb.apply_M(np.ones(9), pos)
+
+
+def test_blob_positions_bit_exact(orc, shell12):
+    from scipy.spatial.transform import Rotation
+    X, Q = random_positions(5, seed=41)
+    cb = create_solver(X, Q)
+    pos = cb.get_blob_positions()
+    assert pos.shape == (60, 3)
+    ref = orc.multi_body_pos(X, Q, shell12 - shell12.mean(axis=0)).reshape(-1, 3)
+    assert np.array_equal(pos, ref)
+    for i in range(5):                                   # reference tests/test_interface.py:55-73
+        ri = Rotation.from_quat(Q[i], scalar_first=True).apply(shell12) + X[i]
+        assert np.allclose(pos[12 * i:12 * i + 12], ri, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------
+# dense path: build, Cholesky, M_half_W (reference c_rigid_obj.cpp:413-459, 661-675)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("wall", [False, True])
+def test_dense_build_bit_exact(orc, wall):
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(5, 42, wall)        # 210 blobs: ragged vs the 256 tile and the 16-column groups
+    if wall:
+        c["X"][0, 2] = 1.0 + 0.5 * c["a"]
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    M = rb.dense_mobility(r)
+    Mo = orc.rotne_prager_tensor(r, c["a"], c["eta"], wall)
+    assert M.shape == (630, 630) and np.array_equal(M, Mo)
+    Md = rb.dense_mobility(r, scale_damp=True)
+    B = orc.damp(r, c["a"])
+    assert np.array_equal(Md, (B[:, None] * Mo) * B[None, :])
+
+
+@pytest.mark.parametrize("n", [8, 33, 360, 1000, 2307])
+def test_cholesky_vs_oracle(orc, n):
+    rng = np.random.default_rng(50 + n)
+    A = rng.standard_normal((n, n + 5))
+    M = A @ A.T + n * np.eye(n)
+    cb = create_solver(*random_positions(1, seed=1))
+    L = cb.cb.cholesky_lower(M)
+    Lo = orc.cholesky_lower(M)
+    assert np.array_equal(np.triu(L, 1), np.zeros((n, n)))
+    assert np.max(np.abs(L - Lo)) / np.max(np.abs(Lo)) < 1e-10
+    assert rel(L @ L.T, M) < 1e-13
+    with pytest.raises(RuntimeError, match="positive definite"):
+        Mb = M.copy(); Mb[n // 2, n // 2] = -1.0
+        cb.cb.cholesky_lower(Mb)
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_M_half_W_cholesky_vs_oracle(orc, wall):
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(10, 12, wall)
+    if not wall:
+        c["X"][:, 2] += 0.9 - c["X"][:, 2].min()   # free-space mobility, blobs in the damp zone (B always applied)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    W = np.random.default_rng(3).standard_normal(r.size)
+    out = rb.M_half_W(W)
+    ref = orc.M_half_W(r, c["a"], c["eta"], wall, W)
+    assert rel(out, ref) < 1e-9
+    # device-generated noise: reproducible, N(0,1)
+    o1 = rb.M_half_W(seed=5); o2 = rb.M_half_W(seed=5); o3 = rb.M_half_W(seed=6)
+    assert np.array_equal(o1, o2) and not np.array_equal(o1, o3)
+
+
+def test_M_half_W_lanczos_vs_dense_sqrt(orc):
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(10, 12, True)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=True)
+    rb.cb.set_lanczos(200, 1e-9)
+    r = rb.get_blob_positions()
+    W = np.random.default_rng(3).standard_normal(r.size)
+    out = rb.M_half_W(W, method="lanczos")
+    B = orc.damp(r, c["a"])
+    M = (B[:, None] * orc.rotne_prager_tensor(r, c["a"], c["eta"], True)) * B[None, :]
+    lam, V = np.linalg.eigh(M)
+    ref = V @ (np.sqrt(lam) * (V.T @ W))
+    it, res = rb.cb.lanczos_report()
+    assert 2 <= it <= 200 and res < 1e-9
+    assert rel(out, ref) < 1e-7
+
+
+def test_device_noise_covariance():
+    """<(L W)(L W)^T> -> B M B with device-generated W (pattern of reference Test_Mhalf :895-915)."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(2, 12, False)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"])
+    r = rb.get_blob_positions()
+    M = rb.dense_mobility(r, scale_damp=True)
+    S = np.zeros_like(M)
+    n = 4000
+    for s in range(n):
+        v = rb.M_half_W(seed=1000 + s)
+        S += np.outer(v, v)
+    # sampling error of a Wishart mean: ~ sqrt((tr M)^2 + |M|_F^2) / (sqrt(n) |M|_F)
+    bound = 2.0 * np.sqrt(np.trace(M) ** 2 + np.linalg.norm(M) ** 2) / (np.sqrt(n) * np.linalg.norm(M))
+    assert np.linalg.norm(S / n - M) / np.linalg.norm(M) < bound
+
+
+# ---------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties (no oracle run is feasible)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,nblb,wall", [(50, 162, False), (200, 642, True)])
+def test_full_size_properties(orc, nb, nblb, wall):
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
+    y = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
+
+    def M(v):
+        out = torch.empty_like(v)
+        ctx.apply_M(v.data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())
+        return out
+
+    Mx, My = M(x), M(y)
+    Mxy = M(2.0 * x - 3.0 * y)
+    ctx.sync_check()
+    assert float(torch.linalg.norm(Mxy - (2.0 * Mx - 3.0 * My)) / torch.linalg.norm(Mxy)) < 1e-12   # linearity
+    sym = abs(float(torch.dot(y, Mx) - torch.dot(x, My))) / abs(float(torch.dot(y, Mx)))
+    assert sym < 1e-10                                                                               # symmetry
+    assert float(torch.dot(x, Mx)) > 0                                                               # positivity
+    # row-sharded calls reproduce the full product exactly (what the multi-GPU path relies on)
+    cuts = [0, N // 8 + 5, N // 2, N]
+    parts = []
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        o = torch.empty(3 * (e - b), dtype=torch.float64, device=dev)
+        ctx.apply_M(x.data_ptr(), r.data_ptr(), N, b, e, o.data_ptr())
+        parts.append(o)
+    ctx.sync_check()
+    assert float(torch.linalg.norm(torch.cat(parts) - Mx) / torch.linalg.norm(Mx)) < 1e-13
+    # oracle spot check on a few rows of the full-size problem
+    rh = r.cpu().numpy(); xh = x.cpu().numpy()
+    b = N // 3
+    Uo = orc.apply_M_rows(xh, rh, b, b + 16, c["a"], c["eta"], wall, nthreads=8)
+    assert rel(Mx.cpu().numpy()[3 * b:3 * b + 48], Uo) < 1e-11
+
+
+def test_cholesky_cfg2_size_property():
+    """BASELINE cfg 2 size (n = 24 300): dense B M B, in-place Cholesky, L L^T x == M x."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    c = make_config(50, 162, False)
+    N = 50 * 162; n = 3 * N
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], False, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, 50, r.data_ptr())
+    Mat = torch.empty(n * n, dtype=torch.float64, device=dev)
+    ctx.build_M(r.data_ptr(), N, True, Mat.data_ptr())
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal(n)).to(dev)
+    Mx = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, Mx.data_ptr())   # z >> a here: B = I
+    ctx.cholesky(Mat.data_ptr(), n, zero_upper=True)
+    ctx.sync_check()
+    L = Mat.view(n, n).t()            # column-major storage viewed as a row-major transpose
+    LLtx = L @ (L.t() @ x)
+    assert float(torch.linalg.norm(LLtx - Mx) / torch.linalg.norm(Mx)) < 1e-11
+    out = torch.empty_like(x)
+    ctx.trmv_lower(Mat.data_ptr(), n, x.data_ptr(), out.data_ptr())
+    ctx.sync_check()
+    assert float(torch.linalg.norm(out - L @ x) / torch.linalg.norm(out)) < 1e-13

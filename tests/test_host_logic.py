@@ -1,0 +1,159 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute):
+the behaviour checks of reference tests/test_interface.py + tests/test_precision.py
+that do not touch the mobility, plus numeric checks of K, K^T, K^-1, apply_PC (diagonal
+PC) and evolve against the numpy restatement in oracle/oracle.py."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from conftest import create_solver, random_positions
+from oracle import oracle as onp
+
+
+def test_import_surface():
+    from Rigid import RigidBody, c_rigid                       # reference tests/test_import.py
+    assert c_rigid.CManyBodies.precision == "double"
+    for name in ("getConfig", "setParameters", "setBlkPC", "setWallPC", "set_K_mats", "K_x_U",
+                 "KT_x_Lam", "multi_body_pos", "apply_PC", "setConfig", "get_K", "get_Kinv",
+                 "evolve_X_Q", "apply_M"):                      # c_rigid_obj.cpp:1002-1023
+        assert hasattr(c_rigid.CManyBodies, name)
+    for name in ("get_config", "set_config", "get_blob_positions", "KT_dot", "K_dot", "apply_PC",
+                 "apply_saddle", "apply_M", "get_K", "get_Kinv", "evolve_rigid_bodies"):
+        assert hasattr(RigidBody, name)
+
+
+def test_create(shell12):                                      # tests/test_interface.py:8-23
+    from rigid_body_light_amd import RigidBody
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((10, 3)); Q = rng.standard_normal((10, 4))
+    RigidBody(shell12, X, Q, 1.0, 1.0, dt=0.01)
+    RigidBody(shell12, X, Q, 1.0, 1.0, dt=0.01, wall_PC=True)
+    RigidBody(shell12, X, Q, 1.0, 1.0, dt=0.01, block_PC=True)
+    with pytest.raises(RuntimeError):
+        RigidBody(shell12.flatten()[:-1], X, Q, 1.0, 1.0, dt=0.01)
+
+
+def test_config_roundtrip_and_shapes():                        # :26-38
+    rng = np.random.default_rng(1)
+    X0 = rng.random((10, 3)); Q0 = rng.random((10, 4))
+    cb = create_solver(X0, Q0)
+    cb.set_config(X0, Q0)
+    X, Q = cb.get_config()
+    assert np.allclose(X, X0)
+    assert np.allclose(Q, Rotation.from_quat(Q0).as_quat())    # normalised
+    assert X.shape == (10, 3) and Q.shape == (10, 4)
+    cb2 = create_solver(X0.flatten(), Q0.flatten())            # flat in -> flat out (src/Rigid.py:54)
+    assert cb2.get_config()[0].shape == (30,)
+    assert cb2.K_dot(np.ones(60)).shape == (360,)
+
+
+def test_bad_config():                                         # :41-52
+    rng = np.random.default_rng(2)
+    X0 = rng.random((10, 3)); Q0 = rng.random((10, 4))
+    cb = create_solver(X0, Q0)
+    with pytest.raises(RuntimeError):
+        cb.set_config(X0, Q0[:9])
+    with pytest.raises(RuntimeError):
+        cb.set_config(X0[:9], Q0)
+
+
+def test_inputs_not_mutated(shell12):
+    cfg = shell12 + 0.3                                        # non-zero mean: reference removes it in place
+    cfg0 = cfg.copy()
+    X, Q = random_positions(3, seed=3)
+    cb = create_solver(X, Q, rigid_config=cfg)
+    U = np.ones(18); U0 = U.copy()
+    cb.evolve_rigid_bodies(U)
+    assert np.array_equal(cfg, cfg0) and np.array_equal(U, U0)
+
+
+@pytest.mark.parametrize("precision", [np.float32, np.float64])   # tests/test_precision.py:7-25
+def test_K_ops_numeric(shell12, precision):
+    n = 5
+    X, Q = random_positions(n, seed=4)
+    Xp = X.astype(precision); Qp = Q.astype(precision)
+    cb = create_solver(Xp, Qp)
+    cfg = onp.remove_mean(shell12)
+    Qn = onp.normalize_quats(Qp)
+    K = onp.K_matrix(Xp, Qn, cfg)
+    U = np.random.default_rng(5).standard_normal(6 * n).astype(precision)
+    lam = np.random.default_rng(6).standard_normal(3 * 12 * n).astype(precision)
+    ku = cb.K_dot(U); ktl = cb.KT_dot(lam)
+    assert ku.shape == (n * 12, 3) and ktl.shape == (2 * n, 3)     # :76-109
+    np.testing.assert_allclose(ku.ravel(), K @ U.astype(np.float64), atol=1e-13)
+    np.testing.assert_allclose(ktl.ravel(), K.T @ lam.astype(np.float64), atol=1e-12)
+    with pytest.raises(RuntimeError):
+        cb.K_dot(np.zeros(6 * n - 3))
+    with pytest.raises(RuntimeError):
+        cb.KT_dot(np.zeros(3 * 12 * n - 5))
+
+
+def test_get_K_Kinv(shell12):                                  # :112-122 + numeric
+    n = 3
+    X, Q = random_positions(n, seed=7)
+    cb = create_solver(X, Q)
+    cfg = onp.remove_mean(shell12); Qn = onp.normalize_quats(Q)
+    K = cb.get_K(); Ki = cb.get_Kinv()
+    assert K.shape == (3 * 12 * n, 6 * n) and Ki.shape == (6 * n, 3 * 12 * n)
+    np.testing.assert_allclose(K.toarray(), onp.K_matrix(X, Qn, cfg), atol=1e-14)
+    np.testing.assert_allclose(Ki.toarray(), onp.Kinv_matrix(X, Qn, cfg), atol=1e-12)
+    np.testing.assert_allclose((Ki @ K).toarray(), np.eye(6 * n), atol=1e-12)   # pseudo-inverse
+
+
+def test_apply_PC_diag_numeric(orc, shell12):                  # :125-147, (block_PC=False) cases
+    n = 3
+    for wall in (False, True):
+        X, Q = random_positions(n, wall=wall, seed=8)
+        X[:, 2] += 1.0 if wall else 0.0
+        cb = create_solver(X, Q, wall_PC=wall)
+        size = 3 * 12 * n + 6 * n
+        b = np.random.default_rng(9).standard_normal(size)
+        out = cb.apply_PC(b)
+        assert out.shape == (size,) and np.linalg.norm(out) > 0
+        ref = onp.apply_PC(orc, b, X, onp.normalize_quats(Q), onp.remove_mean(shell12), 1.0, 1.0, wall, False)
+        np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-11)
+        with pytest.raises(RuntimeError):
+            cb.apply_PC(np.zeros(size - 4))
+
+
+def test_apply_PC_under_wall_raises():                         # tests/test_wall.py:33-36
+    cb = create_solver(np.array([[0.0, 0.0, 0.0]]), np.array([[1.0, 0, 0, 0]]), wall_PC=True)
+    with pytest.raises(RuntimeError, match="below the wall"):
+        cb.apply_PC(np.ones(42))
+
+
+def test_evolve_numeric(shell12):                              # :199-211 + numeric
+    n = 3
+    X, Q = random_positions(n, seed=10)
+    cb = create_solver(X, Q, dt=0.37)
+    U = np.random.default_rng(11).standard_normal(6 * n)
+    cb.evolve_rigid_bodies(U)
+    Xn, Qn = cb.get_config()
+    assert np.linalg.norm(Xn - X) > 0 and np.linalg.norm(Qn - Q) > 0
+    Xr, Qr = onp.evolve(X, onp.normalize_quats(Q), U, 0.37)
+    np.testing.assert_allclose(Xn, Xr, atol=1e-14)
+    np.testing.assert_allclose(Qn, Qr, atol=1e-14)
+    # K follows the new configuration (set_K_mats inside evolve, :876)
+    np.testing.assert_allclose(cb.get_K().toarray(), onp.K_matrix(Xr, Qr, onp.remove_mean(shell12)), atol=1e-13)
+    with pytest.raises(RuntimeError):
+        cb.evolve_rigid_bodies(np.zeros(6 * n - 1))
+
+
+def test_size_errors_without_gpu():
+    X, Q = random_positions(2, seed=12)
+    cb = create_solver(X, Q)
+    F = np.ones(72)
+    with pytest.raises(RuntimeError):
+        cb.apply_M(F[:-4], np.ones(72))                         # :158-163
+    with pytest.raises(RuntimeError):
+        cb.apply_M(F[:-1], np.ones(71))
+    with pytest.raises(RuntimeError):
+        cb.apply_saddle(np.ones(72 + 12 - 2))                   # :192-196
+
+
+def test_dimer_is_singular_error_not_exit():
+    # reference exit()s on singular K^T K (c_rigid_obj.cpp:313-316); we raise
+    cfg = np.array([[0, 0, -0.5], [0, 0, 0.5]])
+    from rigid_body_light_amd import RigidBody
+    with pytest.raises(RuntimeError, match="singular"):
+        RigidBody(cfg, np.zeros((1, 3)), np.array([[1.0, 0, 0, 0]]), 1.0, 1.0, 0.1)
