@@ -12,6 +12,16 @@ device is present.
 """
 import os as _os
 
+# PyTorch wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, soname
+# libamdhip64.so.7).  A process must hold exactly ONE HIP runtime: if librbl.so pulled in
+# /opt/rocm's copy first, torch could no longer see the GPU.  Importing torch first makes
+# its runtime the one librbl's NEEDED libamdhip64.so.7 resolves to.  (A pure C/C++ user of
+# librbl.so without torch simply gets the system runtime.)
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:  # torch is plumbing (device memory / streams / distributed), not required
+    _torch = None
+
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 
 try:

@@ -4,6 +4,11 @@ owner of device memory and streams; the pointers handed over are raw HIP pointer
 import ctypes as C
 import os
 
+try:  # one HIP runtime per process: torch's bundled copy must be loaded first (see __init__.py)
+    import torch as _torch  # noqa: F401
+except ImportError:
+    _torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 

@@ -340,7 +340,7 @@ def test_full_size_properties(orc, nb, nblb, wall):
 
 
 def test_cholesky_cfg2_size_property():
-    """BASELINE cfg 2 size (n = 24 300): dense B M B, in-place Cholesky, L L^T x == M x."""
+    """BASELINE cfg 2 size (n = 24 300): dense M, in-place Cholesky, L L^T x == M x."""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
@@ -352,10 +352,10 @@ def test_cholesky_cfg2_size_property():
     r = torch.empty(n, dtype=torch.float64, device=dev)
     ctx.blob_positions(0, 50, r.data_ptr())
     Mat = torch.empty(n * n, dtype=torch.float64, device=dev)
-    ctx.build_M(r.data_ptr(), N, True, Mat.data_ptr())
+    ctx.build_M(r.data_ptr(), N, False, Mat.data_ptr())
     x = torch.from_numpy(np.random.default_rng(4).standard_normal(n)).to(dev)
     Mx = torch.empty_like(x)
-    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, Mx.data_ptr())   # z >> a here: B = I
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, Mx.data_ptr())   # matrix-free product of the same M
     ctx.cholesky(Mat.data_ptr(), n, zero_upper=True)
     ctx.sync_check()
     L = Mat.view(n, n).t()            # column-major storage viewed as a row-major transpose
