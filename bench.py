@@ -53,7 +53,12 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
     N = nb * nblb
     F = np.random.default_rng(2).standard_normal(3 * N)
     out = {}
-    for label, nthreads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = min(ncores, int(os.environ.get("RBL_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+    for label, nthreads in (("1core", 1), ("allcores", ncores)):
         rows = 4 * nthreads
         t0 = time.perf_counter(); orc.apply_M_rows(F, r, 0, rows, c["a"], c["eta"], wall, nthreads); t1 = time.perf_counter()
         per_row = (t1 - t0) / rows
