@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg (0 = skip)")
     ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="0 heuristic, 1 ordered-rows kernel, 2 symmetric kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,8 +108,8 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=stream.cuda_stream)
     ctx.set_config(c["X"], c["Q"])
-    if args.jsplit:
-        ctx.set_tuning(args.jsplit, 0)
+    if args.jsplit or args.variant:
+        ctx.set_tuning(args.jsplit, args.variant)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
     nrows = sm.row1 - sm.row0
 

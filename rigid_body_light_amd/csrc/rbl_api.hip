@@ -99,6 +99,32 @@ static int finish_and_check(rbl_ctx *c)
   return rbl_flags_to_status(c, *c->h_err);
 }
 
+// Enqueue rows [row_begin,row_end) of U = [B] M [B] F on the context stream, choosing the
+// kernel variant: 1 = symmetric (unordered pairs, needs the full row range), 0 = ordered rows.
+// tune_variant: 0 = heuristic, 1 = force ordered, 2 = force symmetric.
+static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
+                           int64_t row_begin, int64_t row_end, double *d_out)
+{
+  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  const bool full = (row_begin == 0 && row_end == nbl);
+  bool sym = full && nbl >= 4096;
+  if (c->tune_variant == 1) sym = false;
+  if (c->tune_variant == 2) sym = full;
+  int rc;
+  if (sym) {
+    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1)))) return rc;
+    rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
+                           c->d_err);
+  } else {
+    int js = 1;
+    const size_t pb = rbl_apply_M_part_bytes(nbl, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);
+    if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
+    rbl_launch_apply_M(c->stream, P, wall, d_F, d_r, nbl, row_begin, row_end, d_out, (double *)c->d_part.p,
+                       js, 0, c->d_err);
+  }
+  return RBL_OK;
+}
+
 extern "C" {
 
 // ============================================================================
@@ -272,19 +298,15 @@ static int apply_M_host(rbl_ctx *c, const double *F, const double *r, int64_t n3
   rc = rbl_dev_init(c); if (rc) return rc;
   const int64_t nbl = n3 / 3;
   const size_t vb = sizeof(double) * (size_t)n3;
-  int js = 1;
-  const size_t pb = rbl_apply_M_part_bytes(nbl, nbl, c->n_cu, c->tune_jsplit, &js);
   if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_F, vb * nrhs))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_U, vb * nrhs))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
   RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
   RBL_HIP(c, hipMemcpyAsync(c->d_F.p, F, vb * nrhs, hipMemcpyHostToDevice, c->stream));
-  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   for (int k = 0; k < nrhs; ++k)
-    rbl_launch_apply_M(c->stream, P, c->S.wall, (const double *)c->d_F.p + (size_t)k * n3,
-                       (const double *)c->d_r.p, nbl, 0, nbl, (double *)c->d_U.p + (size_t)k * n3,
-                       (double *)c->d_part.p, js, c->tune_variant, c->d_err);
+    if ((rc = apply_M_enqueue(c, c->S.wall, (const double *)c->d_F.p + (size_t)k * n3, (const double *)c->d_r.p,
+                              nbl, 0, nbl, (double *)c->d_U.p + (size_t)k * n3)))
+      return rc;
   RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb * nrhs, hipMemcpyDeviceToHost, c->stream));
   return finish_and_check(c);
 }
@@ -555,18 +577,14 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 //   LANCZOS : Krylov approximation of the symmetric square root with the
 //             matrix-free matvec (no O(n^2) memory).
 // ---------------------------------------------------------------------------
-static void apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
-                        const double *d_x, double *d_y, double *d_tmp, int js)
+static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
+                       const double *d_x, double *d_y, double *d_tmp)
 {
-  if (c->S.wall) {  // kernel applies B M B itself
-    rbl_launch_apply_M(c->stream, P, true, d_x, d_r, nbl, 0, nbl, d_y, (double *)c->d_part.p, js,
-                       c->tune_variant, c->d_err);
-  } else {          // free-space M, damping applied around it
-    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x, d_tmp);
-    rbl_launch_apply_M(c->stream, P, false, d_tmp, d_r, nbl, 0, nbl, d_y, (double *)c->d_part.p, js,
-                       c->tune_variant, c->d_err);
-    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_y, d_y);
-  }
+  if (c->S.wall) return apply_M_enqueue(c, true, d_x, d_r, nbl, 0, nbl, d_y);  // kernel applies B M B itself
+  rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x, d_tmp);                 // free-space M, damping around it
+  int rc = apply_M_enqueue(c, false, d_tmp, d_r, nbl, 0, nbl, d_y);
+  rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_y, d_y);
+  return rc;
 }
 
 static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out)
@@ -574,9 +592,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   const int64_t n = 3 * nbl;
   const int maxit = c->lanczos_max_iter;
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
-  int js = 1, rc;
-  const size_t pb = rbl_apply_M_part_bytes(nbl, nbl, c->n_cu, c->tune_jsplit, &js);
-  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
+  int rc;
   // workspace: V (n x (maxit+1)), u, tmp, prev-estimate, dot scratch
   const size_t vbytes = sizeof(double) * (size_t)n;
   if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1)))) return rc;
@@ -600,7 +616,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   double resid = 1.0;
   for (int it = 0; it < maxit; ++it) {
     double *v = V + (size_t)it * n;
-    apply_A_dev(c, P, d_r, nbl, v, u, tmp, js);
+    if ((rc = apply_A_dev(c, P, d_r, nbl, v, u, tmp))) return rc;
     if (it > 0) rbl_launch_axpby(c->stream, n, 1.0, u, -beta[it - 1], V + (size_t)(it - 1) * n, u);
     if ((rc = dot2(v, u, nullptr))) return rc;
     const double al = h2[0];
@@ -748,12 +764,7 @@ int rbl_apply_M_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_
   if ((rc = rbl_dev_init(c))) return rc;
   if (n_blobs <= 0 || row_begin < 0 || row_end > n_blobs || row_begin > row_end)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_dev: row range out of bounds");
-  int js = 1;
-  const size_t pb = rbl_apply_M_part_bytes(n_blobs, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);
-  if ((rc = rbl_dev_reserve(c, c->d_part, pb))) return rc;
-  rbl_launch_apply_M(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs,
-                     row_begin, row_end, d_out, (double *)c->d_part.p, js, c->tune_variant, c->d_err);
-  return RBL_OK;
+  return apply_M_enqueue(c, c->S.wall, d_F, d_r, n_blobs, row_begin, row_end, d_out);
 }
 
 int rbl_rotne_prager_tensor_dev(rbl_ctx *c, const double *d_r, int64_t n_blobs, int scale_damp,

@@ -131,6 +131,125 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__
   if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
 }
 
+
+// ---------------------------------------------------------------------------
+// Symmetric matrix-free matvec (variant 1): every UNORDERED pair is evaluated once.
+// Work unit = one wavefront = (I-tile of 64 rows) x (chunk of C column tiles, J >= I).
+//   J == I : ordered sweep with the index-equality self term (broadcast LDS reads)
+//   J  > I : "systolic" sweep -- at step s lane l pairs its row i with column
+//            j = (l+s)&63, so the 64 lanes always touch 64 DIFFERENT j: j-data is read
+//            from LDS conflict-free and M_ji F_i is added to the j accumulator in LDS
+//            with ds_add_f64 (one lane per address per step -> deterministic order).
+// Row sums go to slabI[chunk][i], column sums to slabJ[I-row][j]; k_reduce_sym adds
+// them in a fixed order (no global atomics -> bitwise reproducible).
+// (i_first, i_step) selects the I-tiles of this launch (multi-GPU: I % world == rank).
+// ---------------------------------------------------------------------------
+constexpr int TS = 64;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+template <bool WALL>
+__global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r,
+                                                    const double *__restrict__ F,
+                                                    double *__restrict__ slabI,
+                                                    double *__restrict__ slabJ, long N, int T,
+                                                    int C, int i_first, int i_step, RblParams P,
+                                                    unsigned *err)
+{
+  __shared__ double2_t sP0[TS], sP1[TS], sP2[TS];  // (x,y) (z,fx) (fy,fz) of the j tile
+  __shared__ double sU[3][TS];                      // M_ji F_i sums for the j tile
+  const int lane = threadIdx.x;
+  const int I = i_first + (int)blockIdx.x * i_step;
+  const int c = blockIdx.y;
+  if (I >= T) return;
+  int J0 = c * C;
+  const int J1 = (J0 + C < T) ? J0 + C : T;
+  if (J0 < I) J0 = I;
+  if (J0 >= J1) return;
+  const long Npad = (long)T * TS;
+  unsigned flags = 0;
+
+  auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
+    if (idx < N) {
+      x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
+      double d = 1.0;
+      if (WALL) {
+        if (z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+        d = damp_of(P, z);
+      }
+      fx = d * F[3 * idx]; fy = d * F[3 * idx + 1]; fz = d * F[3 * idx + 2];
+    } else {  // padding blob: zero force, far from everything (and from every other pad)
+      x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0; fx = 0.0; fy = 0.0; fz = 0.0;
+    }
+  };
+
+  const long i = (long)I * TS + lane;
+  double xi, yi, zi, Fix, Fiy, Fiz;
+  load_blob(i, xi, yi, zi, Fix, Fiy, Fiz);
+  double uix = 0.0, uiy = 0.0, uiz = 0.0;
+
+  for (int J = J0; J < J1; ++J) {
+    const long j = (long)J * TS + lane;
+    double xj, yj, zj, Fjx, Fjy, Fjz;
+    load_blob(j, xj, yj, zj, Fjx, Fjy, Fjz);
+    __syncthreads();
+    sP0[lane] = (double2_t){xj, yj};
+    sP1[lane] = (double2_t){zj, Fjx};
+    sP2[lane] = (double2_t){Fjy, Fjz};
+    sU[0][lane] = 0.0; sU[1][lane] = 0.0; sU[2][lane] = 0.0;
+    __syncthreads();
+    if (J == I) {
+#pragma unroll 4
+      for (int jj = 0; jj < TS; ++jj) {
+        const double2_t a = sP0[jj], b = sP1[jj], d = sP2[jj];
+        rbl_pair_accum<WALL, true>(P, xi, yi, zi, a.x, a.y, b.x, b.y, d.x, d.y, jj == lane, uix, uiy,
+                                   uiz, flags);
+      }
+    } else {
+#pragma unroll 2
+      for (int s = 0; s < TS; ++s) {
+        const int jj = (lane + s) & (TS - 1);
+        const double2_t a = sP0[jj], b = sP1[jj], d = sP2[jj];
+        double vx, vy, vz;
+        rbl_pair_sym<WALL>(P, xi, yi, zi, Fix, Fiy, Fiz, a.x, a.y, b.x, b.y, d.x, d.y, uix, uiy, uiz,
+                           vx, vy, vz, flags);
+        __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+      double *p = slabJ + ((size_t)blockIdx.x * (size_t)Npad + (size_t)j) * 3;
+      p[0] = sU[0][lane]; p[1] = sU[1][lane]; p[2] = sU[2][lane];
+    }
+  }
+  double *p = slabI + ((size_t)c * (size_t)Npad + (size_t)i) * 3;
+  p[0] = uix; p[1] = uiy; p[2] = uiz;
+  if (flags) atomicOr(err, flags);
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void k_reduce_sym(const double *__restrict__ slabI,
+                                                    const double *__restrict__ slabJ,
+                                                    const double *__restrict__ r,
+                                                    double *__restrict__ out, long N, int T, int C,
+                                                    int nch, int i_first, int i_step, RblParams P,
+                                                    unsigned *err)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over 3*N
+  if (idx >= 3 * N) return;
+  const long j = idx / 3;
+  const int J = (int)(j / TS);
+  const size_t Npad3 = (size_t)T * TS * 3;
+  double s = 0.0;
+  if (J >= i_first && (J - i_first) % i_step == 0)       // this launch owned row tile J
+    for (int c = J / C; c < nch; ++c) s += slabI[(size_t)c * Npad3 + idx];
+  int k = 0;
+  for (int I = i_first; I < J; I += i_step, ++k) s += slabJ[(size_t)k * Npad3 + idx];
+  double sc = P.nf;
+  if (WALL) sc *= damp_of(P, r[3 * j + 2]);
+  out[idx] = sc * s;
+  if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+}
+
 // ---------------------------------------------------------------------------
 // Dense assembly, column-major n3 x n3 (ld = n3).  Block = 256 consecutive i
 // (768 consecutive rows) x JB consecutive j (3*JB columns).  Each 3x3 block is
@@ -418,6 +537,52 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
     else
       hipLaunchKernelGGL(k_reduce_parts<false>, g2, b2, 0, st, d_part, d_r, d_out,
                          (long)row_begin, (long)nrows, js_eff, P, d_err);
+  }
+}
+
+// ---- symmetric variant ------------------------------------------------------
+static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *C, int *nch, int *nrowsI)
+{
+  const int t = (int)((n_blobs + TS - 1) / TS);
+  const int rowsI = (t + i_step - 1) / i_step;
+  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 8 rounds of wave-units; a unit holds <= C tiles
+  const double pairs = 0.5 * (double)rowsI * (double)t;
+  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 8.0;
+  int c = (int)(pairs / target_units);
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
+  *T = t; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
+}
+
+size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step)
+{
+  int T, C, nch, rowsI;
+  sym_geometry(n_blobs, n_cu, i_step, &T, &C, &nch, &rowsI);
+  return ((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * sizeof(double);
+}
+
+void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                            const double *d_r, int64_t n_blobs, int i_first, int i_step,
+                            double *d_out, double *d_work, int n_cu, unsigned *d_err)
+{
+  if (n_blobs <= 0) return;
+  int T, C, nch, rowsI;
+  sym_geometry(n_blobs, n_cu, i_step, &T, &C, &nch, &rowsI);
+  double *slabI = d_work;
+  double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3;
+  dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
+  const int64_t n = 3 * n_blobs;
+  dim3 g2((unsigned)((n + 255) / 256)), b2(256);
+  if (wall) {
+    hipLaunchKernelGGL(k_apply_M_sym<true>, grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T,
+                       C, i_first, i_step, P, d_err);
+    hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C,
+                       nch, i_first, i_step, P, d_err);
+  } else {
+    hipLaunchKernelGGL(k_apply_M_sym<false>, grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T,
+                       C, i_first, i_step, P, d_err);
+    hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C,
+                       nch, i_first, i_step, P, d_err);
   }
 }
 

@@ -119,8 +119,8 @@ def test_apply_M_midsize_vs_oracle(orc, wall, nb, nblb):
     r = rb.get_blob_positions()
     F = np.random.default_rng(2).standard_normal(r.size)
     Uo = orc.apply_M(F, r, c["a"], c["eta"], wall, mode="matfree")
-    for js in (0, 1, 3):
-        rb.cb.set_tuning(js, 0)
+    for js, variant in ((0, 1), (1, 1), (3, 1), (0, 2), (0, 0)):   # ordered kernel (j-splits), symmetric kernel, heuristic
+        rb.cb.set_tuning(js, variant)
         assert rel(rb.apply_M(F, r), Uo) < 1e-12
 
 
@@ -131,10 +131,14 @@ def test_apply_M_cfg2_size_vs_oracle_rows(orc):
     rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"])
     r = rb.get_blob_positions()
     F = np.random.default_rng(2).standard_normal(r.size)
-    U = rb.apply_M(F, r).reshape(-1, 3)
-    for (b, e) in ((0, 64), (4000, 4064), (8036, 8100)):
-        Uo = orc.apply_M_rows(F, r, b, e, c["a"], c["eta"], False, nthreads=8)
-        assert rel(U[b:e].ravel(), Uo) < 1e-12
+    for variant in (1, 2):
+        rb.cb.set_tuning(0, variant)
+        U = rb.apply_M(F, r).reshape(-1, 3)
+        for (b, e) in ((0, 64), (4000, 4064), (8036, 8100)):
+            Uo = orc.apply_M_rows(F, r, b, e, c["a"], c["eta"], False, nthreads=8)
+            assert rel(U[b:e].ravel(), Uo) < 1e-12
+    # the symmetric kernel sums in a fixed order: bitwise reproducible
+    assert np.array_equal(rb.apply_M(F, r), rb.apply_M(F, r))
 
 
 def test_apply_M_interface_behaviour():
