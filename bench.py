@@ -119,16 +119,24 @@ def main():
     U_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    use_sym = args.variant != 1     # symmetric kernel (each unordered pair once) unless the ordered kernel is forced
+    U_part = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
+
     def step(k=None):
-        # a8: this rank's blob positions from (X,Q); one exchange; this rank's rows of U = B M B F
+        # a8: this rank's blob positions from (X,Q); one exchange; then this rank's share of U = B M B F
         ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
         r_full = sm.set_positions_local(r_local) if world > 1 else r_local
         F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
         if k is not None:
             ev[k][0].record(stream)
-        ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
+        if use_sym:   # unordered tile pairs with I % world == rank -> partial full-length U -> all-reduce
+            ctx.apply_M_sym(F_full.data_ptr(), r_full.data_ptr(), N, rank, world, U_part.data_ptr())
+        else:         # ordered pairs, this rank's rows, no reduction
+            ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
         if k is not None:
             ev[k][1].record(stream)
+        if use_sym and world > 1:
+            dist.all_reduce(U_part, op=dist.ReduceOp.SUM)
 
     def barrier():
         if world > 1:
@@ -155,7 +163,9 @@ def main():
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        pairs_per_launch = float(nrows) * float(N)               # ordered pairs one launch (this rank) evaluates
+        # ordered-pair equivalents one launch (this rank) covers: its rows x all columns, or its
+        # 1/world share of the unordered tile pairs (each standing for two ordered pairs)
+        pairs_per_launch = float(N) * float(N) / world if use_sym else float(nrows) * float(N)
         flops_alg = FLOPS_PER_PAIR[wall] * pairs_per_launch
         achieved = flops_alg / (kern_ms * 1e-3) / 1e12
         line = {
@@ -175,9 +185,10 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 200 bodies x shell_N_642 blobs, wall-corrected mobility"
                                    if args.config == "cfg3" else args.config,
                        "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
-                       "parallelism": "body-sharded x%d, all-gather(pos,F)" % world},
+                       "parallelism": ("tile-pair-sharded x%d, all-gather(pos,F) + all-reduce(U)" if use_sym else
+                                       "body-row-sharded x%d, all-gather(pos,F)") % world},
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
-            "roofline": {"bound": "fp64-valu", "kernel": "k_apply_M<%s>" % ("true" if wall else "false"),
+            "roofline": {"bound": "fp64-valu", "kernel": "%s<%s>" % ("k_apply_M_sym" if use_sym else "k_apply_M", "true" if wall else "false"),
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
                          "kernel_ms": kern_ms,

@@ -165,6 +165,14 @@ int rbl_set_stream(rbl_ctx *ctx, void *hip_stream);
 int rbl_apply_M_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
                     int64_t row_begin, int64_t row_end, double *d_out);
 
+/* Symmetric-kernel shard of apply_M for multi-GPU strong scaling: this call evaluates the
+ * unordered blob-tile pairs {I,J}, J >= I, whose row tile I satisfies I % i_step == i_first
+ * (tiles of 64 blobs) and writes the PARTIAL sum of U = [B] M [B] F over all 3*n_blobs entries
+ * to d_out; the sum of the i_step partial vectors (an all-reduce) is the full product.
+ * i_first = 0, i_step = 1 is the whole product. */
+int rbl_apply_M_sym_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
+                        int i_first, int i_step, double *d_out);
+
 /* blob positions of bodies [body_begin, body_end) into d_out
  * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */
 int rbl_blob_positions_dev(rbl_ctx *ctx, int body_begin, int body_end, double *d_out);

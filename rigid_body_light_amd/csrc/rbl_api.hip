@@ -138,7 +138,7 @@ void rbl_destroy(rbl_ctx *c)
   if (c->dev_ready) {
     hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
-                         &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2};
+                         &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol};
     for (RblDevBuf *b : bufs)
       if (b->p) hipFree(b->p);
     if (c->d_err) hipFree(c->d_err);
@@ -499,7 +499,8 @@ int rbl_cholesky_lower(rbl_ctx *c, double *M, int64_t n)
   const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
   RBL_HIP(c, hipMemcpyAsync(c->d_mat.p, M, mb, hipMemcpyHostToDevice, c->stream));
-  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, nullptr, 0);
+  if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
   RBL_HIP(c, hipMemcpyAsync(M, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
   return finish_and_check(c);
@@ -674,7 +675,8 @@ static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d
   if ((rc = rbl_dev_reserve(c, c->d_tmp, rbl_trmv_part_bytes(n)))) return rc;
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   rbl_launch_build_M(c->stream, P, c->S.wall, true, d_r, nbl, (double *)c->d_mat.p, c->d_err);  // :667-669
-  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, nullptr, 0);   // :670-671
+  if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);   // :670-671
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
   rbl_launch_trmv_lower(c->stream, (const double *)c->d_mat.p, n, d_W, d_out, (double *)c->d_tmp.p);  // :672
   return RBL_OK;
@@ -767,6 +769,19 @@ int rbl_apply_M_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_
   return apply_M_enqueue(c, c->S.wall, d_F, d_r, n_blobs, row_begin, row_end, d_out);
 }
 
+int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int i_first,
+                        int i_step, double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step)
+    return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_dev: need n_blobs > 0 and 0 <= i_first < i_step");
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step)))) return rc;
+  rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs, i_first,
+                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err);
+  return RBL_OK;
+}
+
 int rbl_rotne_prager_tensor_dev(rbl_ctx *c, const double *d_r, int64_t n_blobs, int scale_damp,
                                 double *d_out)
 {
@@ -781,7 +796,8 @@ int rbl_cholesky_lower_dev(rbl_ctx *c, double *d_M, int64_t n, int zero_upper)
 {
   if (!c) return RBL_ERR_ARG;
   int rc = rbl_dev_init(c); if (rc) return rc;
-  rc = rbl_launch_cholesky(c->stream, d_M, n, zero_upper != 0, c->d_err, nullptr, 0);
+  if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
+  rc = rbl_launch_cholesky(c->stream, d_M, n, zero_upper != 0, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);
   return rc ? rbl_fail(c, rc, "cholesky launch failed") : RBL_OK;
 }
 

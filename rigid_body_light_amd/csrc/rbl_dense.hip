@@ -6,8 +6,9 @@
 // Storage: column-major n x n, ld = n, 64-bit indexing (cfg 5 has 2.36e10 entries).
 //
 // Blocking: outer panels of NB columns; inside a panel, IB-wide steps of
-//   potf2 (one workgroup, LDS) -> trsm (row per lane, L_kk in LDS) -> rank-IB update
-//   of the rest of the panel; then ONE rank-NB MFMA update of the trailing matrix.
+//   potf2 (ONE wavefront, rows in registers, v_readlane broadcasts; also emits L_kk^-1)
+//   -> trsm as an MFMA product with L_kk^-1 -> rank-IB MFMA update of the rest of the
+//   panel; then ONE rank-NB MFMA update of the trailing matrix (LDS-tiled, double-buffered).
 // Only the lower triangle is referenced/updated (tiles strictly above the diagonal
 // are skipped; diagonal tiles are updated whole).
 #include "rbl_internal.hpp"
@@ -19,84 +20,149 @@ constexpr int NB = 256;   // outer panel width (K of the trailing MFMA update)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---- potf2: factor the IB x IB diagonal block at (k,k) -------------------------
-__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, long n, long k, int nb,
-                                               unsigned *err)
+// cross-lane broadcast of a double from a compile-time lane (v_readlane_b32 x2 -> SGPRs)
+__device__ __forceinline__ double bcast_lane(double v, int src)
 {
-  __shared__ double s[IB][IB + 1];
-  const int t = threadIdx.x;
-  for (int e = t; e < IB * IB; e += 256) {
-    const int i = e % IB, j = e / IB;
-    s[i][j] = (i < nb && j < nb) ? A[(size_t)(k + j) * n + (k + i)] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  for (int c = 0; c < nb; ++c) {
-    const double d = s[c][c];
-    if (!(d > 0.0)) {
-      if (t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
-      return;  // uniform: every thread reads the same s[c][c]
-    }
-    const double sd = sqrt(d);
-    __syncthreads();
-    if (t == 0) s[c][c] = sd;
-    if (t > c && t < nb) s[t][c] = s[t][c] / sd;
-    __syncthreads();
-    for (int e = t; e < IB * IB; e += 256) {
-      const int i = e % IB, j = e / IB;
-      if (j > c && i >= j && i < nb) s[i][j] -= s[i][c] * s[j][c];
-    }
-    __syncthreads();
-  }
-  for (int e = t; e < IB * IB; e += 256) {
-    const int i = e % IB, j = e / IB;
-    if (i < nb && j < nb && i >= j) A[(size_t)(k + j) * n + (k + i)] = s[i][j];
-  }
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
 
-// ---- trsm: rows below the diagonal block:  X <- X L_kk^{-T} ----------------------
-__global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, long n, long k, int nb)
+// ---- potf2: one wavefront factors the IB x IB diagonal block at (k,k) in registers ----
+// lane r holds row r of the block; column c's pivot and multipliers are broadcast with
+// v_readlane (no LDS, no barriers).  The same wave then inverts L (lane c solves
+// L y = e_c) and writes Linv (IB x IB, row-major [c][m]) for the MFMA triangular solve.
+__global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
+                                              double *__restrict__ Linv, unsigned *err)
 {
-  __shared__ double L[IB][IB + 1];
-  const int t = threadIdx.x;
-  for (int e = t; e < IB * IB; e += 256) {
-    const int i = e % IB, j = e / IB;
-    L[i][j] = (i < nb && j < nb && i >= j) ? A[(size_t)(k + j) * n + (k + i)] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  const long row = k + nb + (long)blockIdx.x * 256 + t;
-  if (row >= n) return;
-  double x[IB];
+  const int l = threadIdx.x;
+  double a[IB];
 #pragma unroll
-  for (int c = 0; c < IB; ++c) x[c] = (c < nb) ? A[(size_t)(k + c) * n + row] : 0.0;
+  for (int j = 0; j < IB; ++j)
+    a[j] = (l < nb && j < nb && j <= l) ? A[(size_t)(k + j) * n + (k + l)] : ((l == j) ? 1.0 : 0.0);
+  bool bad = false;
 #pragma unroll
   for (int c = 0; c < IB; ++c) {
-    double v = x[c];
+    const double d = bcast_lane(a[c], c);
+    if (!(d > 0.0)) bad = true;
+    const double sd = sqrt(d);
+    const double inv = 1.0 / sd;
+    a[c] = (l == c) ? sd : a[c] * inv;   // rows above the diagonal hold 0 already
 #pragma unroll
-    for (int m = 0; m < c; ++m) v = __builtin_fma(-x[m], L[c][m], v);
-    x[c] = v / L[c][c];
+    for (int j = c + 1; j < IB; ++j) {
+      const double ljc = bcast_lane(a[c], j);          // L[j][c]
+      a[j] = (l >= j) ? __builtin_fma(-a[c], ljc, a[j]) : a[j];
+    }
+  }
+  if (bad) {
+    if (l == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
   }
 #pragma unroll
-  for (int c = 0; c < IB; ++c)
-    if (c < nb) A[(size_t)(k + c) * n + row] = x[c];
+  for (int j = 0; j < IB; ++j)
+    if (l < nb && j < nb && j <= l) A[(size_t)(k + j) * n + (k + l)] = a[j];
+  // ---- Linv: lane c computes column c of L^{-1} by forward substitution ----------------
+  double y[IB];
+#pragma unroll
+  for (int r = 0; r < IB; ++r) {
+    double s = (r == l) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < r; ++m) s = __builtin_fma(-bcast_lane(a[m], r), y[m], s);   // L[r][m]
+    y[r] = s / bcast_lane(a[r], r);
+  }
+  if (l < IB) {
+#pragma unroll
+    for (int r = 0; r < IB; ++r) Linv[r * IB + l] = y[r];   // Linv[r][c=l]
+  }
 }
 
-// ---- rank-K update on the matrix cores -----------------------------------------
-//   C[i][j] -= sum_{k in [k0,k0+K)} A[i][k] A[j][k]     i in [r0,n), j in [r0,c1), i-tile >= j-tile
-// Workgroup = 4 waves (2x2), 128x128 tile; wave = 64x64 = 4x4 MFMA tiles of 16x16.
-// The MFMA computes the TRANSPOSED tile (A-operand from the j rows, B-operand from the
-// i rows) so that, in the C/D layout row=(lane>>4)+4v, col=lane&15, a lane's 16-lane
-// group touches 16 consecutive ROWS of one column of C: 128-B runs in column-major C.
-__global__ __launch_bounds__(256) void k_syrk_mfma(double *__restrict__ A, long n, long r0,
-                                                   long c1, long k0, int K)
+// ---- trsm on the matrix cores: rows below the diagonal block, X <- X L_kk^{-T} = X Linv^T --
+// wave = 64 rows x 32 columns; computes the transposed tile D'[c][i] = sum_m Linv[c][m] A[i][m]
+// so that the stores are 128-B runs along the rows of column-major A.  In place: a wave reads
+// all 32 columns of its 64 rows before it writes them.
+__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long n, long k, int nb,
+                                                   const double *__restrict__ Linv)
 {
-  const int bi = blockIdx.x, bj = blockIdx.y;
-  if (bi < bj) return;  // strictly-upper tile
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long i0 = r0 + (long)bi * 128 + (wave & 1) * 64;
-  const long j0 = r0 + (long)bj * 128 + (wave >> 1) * 64;
-  if (i0 >= n || j0 >= c1) return;
-  if (i0 + 63 < j0) return;  // wave tile strictly above the diagonal
   const int l15 = lane & 15, l4 = lane >> 4;
+  const long i0 = k + nb + ((long)blockIdx.x * 4 + wave) * 64;
+  if (i0 >= n) return;
+  double4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  long irow[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { long ir = i0 + 16 * q + l15; irow[q] = ir < n ? ir : n - 1; }
+#pragma unroll
+  for (int ks = 0; ks < IB / 4; ++ks) {
+    const int m = 4 * ks + l4;
+    const bool mv = m < nb;
+    const long col = mv ? (k + m) : k;
+    double bv[4], av[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const double v = A[(size_t)col * (size_t)n + irow[q]]; bv[q] = mv ? v : 0.0; }
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) av[tc] = Linv[(16 * tc + l15) * IB + m];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+        acc[tc][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tc], bv[ti], acc[tc][ti], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long row = i0 + 16 * ti + l15;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int cc = 16 * tc + l4 + 4 * v;
+        if (row < n && cc < nb) A[(size_t)(k + cc) * (size_t)n + row] = acc[tc][ti][v];
+      }
+    }
+}
+
+// ---- rank-K update on the matrix cores ---------------------------------------------------
+//   C[i][j] -= sum_{k in [k0,k0+K)} A[i][k] A[j][k]     i in [r0,n), j in [r0,c1), i-tile >= j-tile
+// Workgroup = 4 waves (2x2) on a 128x128 tile; wave = 64x64 = 4x4 MFMA tiles of 16x16x4.
+// The two 128 x KC panel slabs (i rows, j rows) are staged global -> registers -> LDS, double
+// buffered: the loads of stage s+1 are in flight while the 64 MFMAs of stage s run; one
+// barrier per stage.  LDS column stride 144 doubles (= 32 banks mod 64) keeps the 16-lane x
+// 4-column fragment reads conflict-free.  The MFMA computes the TRANSPOSED tile (A-operand
+// from the j rows, B-operand from the i rows) so a lane group stores 16 consecutive ROWS of one
+// column of C: 128-B runs in column-major C.  K must be a multiple of KC.
+constexpr int KC = 16;
+constexpr int LDP = 144;
+
+__global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, long n, long r0,
+                                                      long c1, long k0, int K)
+{
+  __shared__ double sI[2][KC * LDP];
+  __shared__ double sJ[2][KC * LDP];
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  if (bi < bj) return;  // strictly-upper block tile (block-uniform)
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63;
+  const int wi = wave & 1, wj = wave >> 1;
+  const long bi0 = r0 + (long)bi * 128, bj0 = r0 + (long)bj * 128;
+  if (bj0 >= c1) return;  // block-uniform
+  const long i0 = bi0 + wi * 64, j0 = bj0 + wj * 64;
+  const bool active = (i0 < n) && (j0 < c1) && !(i0 + 63 < j0);  // wave tile holds lower-triangle entries
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // loader: thread -> row (t & 127), column group (t >> 7) * 8 .. +7 of the KC-wide slab
+  const int lrow = t & 127, lcg = (t >> 7) * 8;
+  long gi = bi0 + lrow; if (gi >= n) gi = n - 1;
+  long gj = bj0 + lrow; if (gj >= n) gj = n - 1;
+  const double *pI = A + (size_t)(k0 + lcg) * (size_t)n + gi;
+  const double *pJ = A + (size_t)(k0 + lcg) * (size_t)n + gj;
+  double rI[8], rJ[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * n]; rJ[q] = pJ[(size_t)q * n]; }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { sI[0][(lcg + q) * LDP + lrow] = rI[q]; sJ[0][(lcg + q) * LDP + lrow] = rJ[q]; }
+  __syncthreads();
 
   double4_t acc[4][4];  // [tj][ti]
 #pragma unroll
@@ -104,24 +170,36 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(double *__restrict__ A, long 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  long irow[4], jrow[4];
+  const int nst = K / KC;
+  for (int s = 0; s < nst; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nst) {
+      pI += (size_t)KC * n; pJ += (size_t)KC * n;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    long ir = i0 + 16 * q + l15; irow[q] = ir < n ? ir : n - 1;
-    long jr = j0 + 16 * q + l15; jrow[q] = jr < n ? jr : n - 1;
+      for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * n]; rJ[q] = pJ[(size_t)q * n]; }
+    }
+    if (active) {
+      const double *fi = &sI[cur][l4 * LDP + wi * 64 + l15];
+      const double *fj = &sJ[cur][l4 * LDP + wj * 64 + l15];
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = fj[ks * 4 * LDP + 16 * q]; bv[q] = fi[ks * 4 * LDP + 16 * q]; }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti)
+            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nst) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { sI[cur ^ 1][(lcg + q) * LDP + lrow] = rI[q]; sJ[cur ^ 1][(lcg + q) * LDP + lrow] = rJ[q]; }
+    }
+    __syncthreads();
   }
-  const double *base = A + (size_t)(k0 + l4) * (size_t)n;
-  for (int kk = 0; kk < K; kk += 4) {
-    const double *colp = base + (size_t)kk * (size_t)n;
-    double av[4], bv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { av[q] = colp[jrow[q]]; bv[q] = colp[irow[q]]; }
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-        acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
-  }
+  if (!active) return;
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -188,32 +266,34 @@ __global__ void k_trmv_reduce(const double *__restrict__ part, long n, int nchun
 
 }  // namespace
 
-size_t rbl_cholesky_work_bytes(int64_t) { return 0; }
+size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * IB * IB; }
 
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
-                        double *, size_t)
+                        double *d_work, size_t work_bytes)
 {
+  if (!d_work || work_bytes < sizeof(double) * IB * IB) return RBL_ERR_ARG;
+  double *Linv = d_work;
   for (int64_t k = 0; k < n; k += NB) {
     const int64_t pw = (n - k < NB) ? (n - k) : NB;  // panel width
     const int64_t pend = k + pw;
     for (int64_t kk = k; kk < pend; kk += IB) {
       const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
-      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), 0, st, d_M, (long)n, (long)kk, nb, d_err);
+      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Linv, d_err);
       const int64_t rows = n - (kk + nb);
       if (rows > 0) {
-        hipLaunchKernelGGL(k_trsm, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_M,
-                           (long)n, (long)kk, nb);
+        hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_M,
+                           (long)n, (long)kk, nb, Linv);
         // rank-nb update of the rest of THIS panel: rows >= kk+nb, cols [kk+nb, pend)
         const int64_t r0 = kk + nb;
         if (r0 < pend) {
-          if (nb % 4 != 0) return RBL_ERR_SIZE;  // cannot happen: n3 multiple of 3, handled below
+          if (nb != IB) return RBL_ERR_SIZE;  // cannot happen: a short step is always the last of its panel
           dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128));
           hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0,
                              (long)pend, (long)kk, nb);
         }
       }
     }
-    if (pend < n) {  // trailing update with the whole panel, K = pw
+    if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
       dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((n - pend + 127) / 128));
       hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n,
                          (long)k, (int)pw);

@@ -63,7 +63,7 @@ struct rbl_ctx {
   int device = -1;
   int n_cu = 0;
   hipStream_t stream = nullptr;
-  RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2;
+  RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   // tuning

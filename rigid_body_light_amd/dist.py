@@ -2,7 +2,14 @@
 bodies split contiguously by body index, ONE exchange step -- an all-gather of
 blob positions (once per configuration) and of the force vector (once per
 matvec) over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in CPU tests).  Output rows are independent, so there is no reduction.
+"gloo" in CPU tests).
+
+Two per-rank work splits:
+  rows      (apply_M_local)     rank owns its bodies' rows, ordered-pair kernel, no reduction;
+  symmetric (apply_M_allreduce) rank owns the unordered blob-tile pairs {I,J>=I} with
+            I % world == rank (interleaved -> balanced triangle), symmetric kernel (each
+            unordered pair once, ~1.5x less arithmetic), then ONE all-reduce of the 24 N-byte
+            partial U.
 
 The per-rank compute is the HIP kernel (DeviceContext.apply_M on the rank's row
 slice).  `row_apply` exists so the CPU gloo test can check the partition /
@@ -25,7 +32,7 @@ def body_partition(n_bodies, world_size):
 
 
 class ShardedMobility:
-    def __init__(self, n_bodies, blobs_per_body, group=None, device=None, ctx=None, row_apply=None):
+    def __init__(self, n_bodies, blobs_per_body, group=None, device=None, ctx=None, row_apply=None, sym_apply=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -38,6 +45,7 @@ class ShardedMobility:
         self.device = device if device is not None else torch.device("cpu")
         self.ctx = ctx
         self.row_apply = row_apply
+        self.sym_apply = sym_apply
         if ctx is None and row_apply is None:
             raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
         self.r_full = None
@@ -70,6 +78,21 @@ class ShardedMobility:
         F_full = self.all_gather_rows(F_local.contiguous())
         U_local = self.apply_M_rows(F_full)
         return self.all_gather_rows(U_local) if gather_output else U_local
+
+    def apply_M_allreduce(self, F_local):
+        """Symmetric-kernel sharding: every rank evaluates the unordered tile pairs whose row
+        tile I satisfies I % world == rank and produces a PARTIAL full-length U; one
+        all-reduce (sum) completes it.  Returns the full U on every rank."""
+        F_full = self.all_gather_rows(F_local.contiguous())
+        if self.sym_apply is not None:
+            part = self.sym_apply(F_full, self.r_full, self.rank, self.world)
+        else:
+            part = torch.empty(self.n_blobs * 3, dtype=torch.float64, device=self.device)
+            self.ctx.apply_M_sym(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.rank, self.world,
+                                 part.data_ptr())
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        return part
 
     def apply_M_rows(self, F_full):
         nrows = self.row1 - self.row0

@@ -33,30 +33,48 @@ def _worker(rank, world, port, n_bodies, wall, ret):
         def row_apply(F_full, r_full, r0, r1):
             return torch.from_numpy(orc.apply_M_rows(F_full.numpy(), r_full.numpy(), r0, r1, a, eta, wall))
 
-        sm = ShardedMobility(n_bodies, 12, row_apply=row_apply)
+        def sym_apply(F_full, r_full, first, step):
+            # semantics of rbl_apply_M_sym_dev: unordered 64-blob tile pairs {I, J>=I}, I % step == first
+            rr, FF = r_full.numpy(), F_full.numpy()
+            B = orc.damp(rr, a) if wall else np.ones(rr.size)
+            M = (B[:, None] * orc.rotne_prager_tensor(rr, a, eta, wall)) * B[None, :]
+            n = rr.size // 3; T = (n + 63) // 64
+            part = np.zeros(3 * n)
+            for I in range(first, T, step):
+                ri = slice(192 * I, min(192 * (I + 1), 3 * n))
+                for J in range(I, T):
+                    cj = slice(192 * J, min(192 * (J + 1), 3 * n))
+                    part[ri] += M[ri, cj] @ FF[cj]
+                    if J > I:
+                        part[cj] += M[cj, ri] @ FF[ri]
+            return torch.from_numpy(part)
+
+        sm = ShardedMobility(n_bodies, 12, row_apply=row_apply, sym_apply=sym_apply)
         # each rank computes ONLY its own bodies' blob positions (a8) ...
         r_local = torch.from_numpy(orc.multi_body_pos(c["X"][sm.b0:sm.b1], c["Q"][sm.b0:sm.b1], cfg))
         r_full = sm.set_positions_local(r_local)                      # ... one all-gather per configuration
         F = np.random.default_rng(2).standard_normal(3 * 12 * n_bodies)
         U_local = sm.apply_M_local(torch.from_numpy(F[3 * sm.row0:3 * sm.row1]))
         U_full = sm.apply_M_local(torch.from_numpy(F[3 * sm.row0:3 * sm.row1]), gather_output=True)
+        U_sym = sm.apply_M_allreduce(torch.from_numpy(F[3 * sm.row0:3 * sm.row1]))
         if rank == 0:
             r_ref = orc.multi_body_pos(c["X"], c["Q"], cfg)
             U_ref = orc.apply_M(F, r_ref, a, eta, wall, mode="dense")
             ret["pos_ok"] = bool(np.array_equal(r_full.numpy(), r_ref))
             ret["err_full"] = float(np.abs(U_full.numpy() - U_ref).max() / np.abs(U_ref).max())
             ret["err_local"] = float(np.abs(U_local.numpy() - U_ref[3 * sm.row0:3 * sm.row1]).max() / np.abs(U_ref).max())
+            ret["err_sym"] = float(np.abs(U_sym.numpy() - U_ref).max() / np.abs(U_ref).max())
             ret["parts"] = sm.parts
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_bodies,wall", [(6, False), (7, True)])   # 7: uneven shards (4 + 3)
+@pytest.mark.parametrize("n_bodies,wall", [(6, False), (7, True), (30, True)])   # 7: uneven shards; 30: 6 tiles
 def test_two_rank_body_sharded_apply_M(n_bodies, wall):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), n_bodies, wall, ret), nprocs=2, join=True)
     assert ret["pos_ok"]
-    assert ret["err_full"] < 1e-13 and ret["err_local"] < 1e-13
+    assert ret["err_full"] < 1e-13 and ret["err_local"] < 1e-13 and ret["err_sym"] < 1e-13
     assert ret["parts"][0][0] == 0 and ret["parts"][-1][1] == n_bodies
 
 

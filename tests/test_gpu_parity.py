@@ -336,6 +336,14 @@ def test_full_size_properties(orc, nb, nblb, wall):
         parts.append(o)
     ctx.sync_check()
     assert float(torch.linalg.norm(torch.cat(parts) - Mx) / torch.linalg.norm(Mx)) < 1e-13
+    # symmetric-kernel shards (multi-GPU split I % step == first): partial sums add up to M x
+    acc = torch.zeros_like(x)
+    for first in range(3):
+        p = torch.empty_like(x)
+        ctx.apply_M_sym(x.data_ptr(), r.data_ptr(), N, first, 3, p.data_ptr())
+        acc += p
+    ctx.sync_check()
+    assert float(torch.linalg.norm(acc - Mx) / torch.linalg.norm(Mx)) < 1e-13
     # oracle spot check on a few rows of the full-size problem
     rh = r.cpu().numpy(); xh = x.cpu().numpy()
     b = N // 3
