@@ -52,6 +52,16 @@ int rbl_dev_init(rbl_ctx *c)
   RBL_HIP(c, hipMalloc((void **)&c->d_err, sizeof(unsigned)));
   RBL_HIP(c, hipHostMalloc((void **)&c->h_err, sizeof(unsigned), hipHostMallocDefault));
   RBL_HIP(c, hipMemset(c->d_err, 0, sizeof(unsigned)));
+  // auxiliary stream + events for the Cholesky lookahead (optional: failure just disables it)
+  if (hipStreamCreateWithFlags(&c->chol_aux.stream, hipStreamNonBlocking) == hipSuccess) {
+    for (int i = 0; i < 3; ++i)
+      if (hipEventCreateWithFlags(&c->chol_aux.ev[i], hipEventDisableTiming) != hipSuccess) {
+        c->chol_aux.stream = nullptr;
+        break;
+      }
+  } else {
+    c->chol_aux.stream = nullptr;
+  }
   c->dev_ready = true;
   return RBL_OK;
 }
@@ -141,6 +151,12 @@ void rbl_destroy(rbl_ctx *c)
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol};
     for (RblDevBuf *b : bufs)
       if (b->p) hipFree(b->p);
+    if (c->chol_aux.stream) {
+      (void)hipStreamSynchronize(c->chol_aux.stream);
+      for (int i = 0; i < 3; ++i)
+        if (c->chol_aux.ev[i]) (void)hipEventDestroy(c->chol_aux.ev[i]);
+      (void)hipStreamDestroy(c->chol_aux.stream);
+    }
     if (c->d_err) hipFree(c->d_err);
     if (c->h_err) hipHostFree(c->h_err);
   }
@@ -500,7 +516,7 @@ int rbl_cholesky_lower(rbl_ctx *c, double *M, int64_t n)
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
   RBL_HIP(c, hipMemcpyAsync(c->d_mat.p, M, mb, hipMemcpyHostToDevice, c->stream));
   if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
-  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes, &c->chol_aux);
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
   RBL_HIP(c, hipMemcpyAsync(M, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
   return finish_and_check(c);
@@ -676,7 +692,7 @@ static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   rbl_launch_build_M(c->stream, P, c->S.wall, true, d_r, nbl, (double *)c->d_mat.p, c->d_err);  // :667-669
   if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
-  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);   // :670-671
+  rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes, &c->chol_aux);   // :670-671
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
   rbl_launch_trmv_lower(c->stream, (const double *)c->d_mat.p, n, d_W, d_out, (double *)c->d_tmp.p);  // :672
   return RBL_OK;
@@ -797,7 +813,7 @@ int rbl_cholesky_lower_dev(rbl_ctx *c, double *d_M, int64_t n, int zero_upper)
   if (!c) return RBL_ERR_ARG;
   int rc = rbl_dev_init(c); if (rc) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
-  rc = rbl_launch_cholesky(c->stream, d_M, n, zero_upper != 0, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes);
+  rc = rbl_launch_cholesky(c->stream, d_M, n, zero_upper != 0, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes, &c->chol_aux);
   return rc ? rbl_fail(c, rc, "cholesky launch failed") : RBL_OK;
 }
 

@@ -20,58 +20,73 @@ constexpr int NB = 256;   // outer panel width (K of the trailing MFMA update)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// cross-lane broadcast of a double from a compile-time lane (v_readlane_b32 x2 -> SGPRs)
-__device__ __forceinline__ double bcast_lane(double v, int src)
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
-// ---- potf2: one wavefront factors the IB x IB diagonal block at (k,k) in registers ----
-// lane r holds row r of the block; column c's pivot and multipliers are broadcast with
-// v_readlane (no LDS, no barriers).  The same wave then inverts L (lane c solves
-// L y = e_c) and writes Linv (IB x IB, row-major [c][m]) for the MFMA triangular solve.
+// ---- potf2: one wavefront factors the IB x IB diagonal block at (k,k) ------------------
+// The block lives in LDS; a single wavefront needs no barriers (its LDS operations execute
+// in program order).  Column step c: pivot by v_rsq_f64 + Newton (no sqrt/div chain), scale
+// the column, then the 64 lanes update the trailing lower triangle (lane = row, two column
+// parities).  The same wave then inverts L by forward substitution (lane = column of
+// L^-1) and writes Linv (IB x IB, row-major [c][m]) for the MFMA triangular solve.
 __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
                                               double *__restrict__ Linv, unsigned *err)
 {
-  const int l = threadIdx.x;
-  double a[IB];
-#pragma unroll
-  for (int j = 0; j < IB; ++j)
-    a[j] = (l < nb && j < nb && j <= l) ? A[(size_t)(k + j) * n + (k + l)] : ((l == j) ? 1.0 : 0.0);
+  __shared__ double S[IB][IB + 1];
+  __shared__ double Y[IB][IB + 1];
+  __shared__ double dinv[IB];
+  const int t = threadIdx.x;
+  const int i = t & (IB - 1), par = t >> 5;
+  for (int e = t; e < IB * IB; e += 64) {
+    const int r = e & (IB - 1), c = e >> 5;  // consecutive lanes -> consecutive rows of a column
+    S[r][c] = (r < nb && c < nb && c <= r) ? A[(size_t)(k + c) * n + (k + r)] : ((r == c) ? 1.0 : 0.0);
+  }
   bool bad = false;
-#pragma unroll
   for (int c = 0; c < IB; ++c) {
-    const double d = bcast_lane(a[c], c);
-    if (!(d > 0.0)) bad = true;
-    const double sd = sqrt(d);
-    const double inv = 1.0 / sd;
-    a[c] = (l == c) ? sd : a[c] * inv;   // rows above the diagonal hold 0 already
+    const double d = S[c][c];
+    bad = bad || !(d > 0.0);
+    const double inv = rbl_rsqrt(d);
+    const double lic = (i == c) ? d * inv : S[i][c] * inv;   // L[i][c]  (rows i < c hold 0)
+    if (par == 0) S[i][c] = lic;
+    if (t == 0) dinv[c] = inv;
+    // batch: all reads of this column step first, then the FMAs, then the writes (a plain
+    // read-modify-write loop would serialise on possible LDS aliasing: ~150 cycles/entry)
+    double lj[IB / 2], sij[IB / 2];
 #pragma unroll
-    for (int j = c + 1; j < IB; ++j) {
-      const double ljc = bcast_lane(a[c], j);          // L[j][c]
-      a[j] = (l >= j) ? __builtin_fma(-a[c], ljc, a[j]) : a[j];
+    for (int q = 0; q < IB / 2; ++q) {
+      const int j = c + 1 + par + 2 * q;
+      const int jj = j < IB ? j : IB - 1;
+      lj[q] = S[jj][c];
+      sij[q] = S[i][jj];
+    }
+#pragma unroll
+    for (int q = 0; q < IB / 2; ++q) {
+      const int j = c + 1 + par + 2 * q;
+      if (j < IB && i >= j) S[i][j] = __builtin_fma(-lic, lj[q], sij[q]);
     }
   }
-  if (bad) {
-    if (l == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+  if (bad && t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+  for (int e = t; e < IB * IB; e += 64) {
+    const int r = e & (IB - 1), c = e >> 5;
+    if (r < nb && c < nb && c <= r) A[(size_t)(k + c) * n + (k + r)] = S[r][c];
   }
+  // ---- Linv: lane c (both half-waves compute the same thing) solves L y = e_c ------------
+  // right-looking substitution with the unknowns in registers (static indices) and the
+  // rows of L broadcast from LDS: no LDS round trip on the dependency chain.
+  double x[IB];
 #pragma unroll
-  for (int j = 0; j < IB; ++j)
-    if (l < nb && j < nb && j <= l) A[(size_t)(k + j) * n + (k + l)] = a[j];
-  // ---- Linv: lane c computes column c of L^{-1} by forward substitution ----------------
-  double y[IB];
+  for (int r = 0; r < IB; ++r) x[r] = (r == i) ? 1.0 : 0.0;
 #pragma unroll
-  for (int r = 0; r < IB; ++r) {
-    double s = (r == l) ? 1.0 : 0.0;
+  for (int m = 0; m < IB; ++m) {
+    const double ym = x[m] * dinv[m];
+    x[m] = ym;
 #pragma unroll
-    for (int m = 0; m < r; ++m) s = __builtin_fma(-bcast_lane(a[m], r), y[m], s);   // L[r][m]
-    y[r] = s / bcast_lane(a[r], r);
+    for (int r = m + 1; r < IB; ++r) x[r] = __builtin_fma(-S[r][m], ym, x[r]);
   }
-  if (l < IB) {
+  if (par == 0) {
 #pragma unroll
-    for (int r = 0; r < IB; ++r) Linv[r * IB + l] = y[r];   // Linv[r][c=l]
+    for (int r = 0; r < IB; ++r) Y[r][i] = x[r];
+  }
+  for (int e = t; e < IB * IB; e += 64) {
+    const int c = e & (IB - 1), r = e >> 5;
+    Linv[r * IB + c] = Y[r][c];
   }
 }
 
@@ -268,14 +283,31 @@ __global__ void k_trmv_reduce(const double *__restrict__ part, long n, int nchun
 
 size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * IB * IB; }
 
+// Panel p is factored on the caller's stream while the big trailing update R_{p-1} of the
+// previous panel still runs on the auxiliary stream (one-panel lookahead):
+//   main: [wait L_{p-1}] factor panel p, record P_p
+//   aux : wait P_p ; L_p = update of the NEXT panel's columns, record L_p ; R_p = the rest
+// R_{p-1} touches only columns >= k_p + NB, the panel only its own NB columns, so the two
+// never write the same entries; same-column updates stay ordered on the aux stream.
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
-                        double *d_work, size_t work_bytes)
+                        double *d_work, size_t work_bytes, const RblCholAux *aux)
 {
   if (!d_work || work_bytes < sizeof(double) * IB * IB) return RBL_ERR_ARG;
   double *Linv = d_work;
+  const bool look = aux && aux->stream && n > 4 * NB;
+  hipStream_t sb = look ? aux->stream : st;
+  if (look) {
+    if (hipEventRecord(aux->ev[2], st) != hipSuccess) return RBL_ERR_HIP;
+    if (hipStreamWaitEvent(sb, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
+  }
+  bool pending_L = false;
   for (int64_t k = 0; k < n; k += NB) {
     const int64_t pw = (n - k < NB) ? (n - k) : NB;  // panel width
     const int64_t pend = k + pw;
+    if (look && pending_L) {
+      if (hipStreamWaitEvent(st, aux->ev[1], 0) != hipSuccess) return RBL_ERR_HIP;
+      pending_L = false;
+    }
     for (int64_t kk = k; kk < pend; kk += IB) {
       const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
       hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Linv, d_err);
@@ -294,10 +326,30 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       }
     }
     if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
-      dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((n - pend + 127) / 128));
-      hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n,
-                         (long)k, (int)pw);
+      if (look) {
+        if (hipEventRecord(aux->ev[0], st) != hipSuccess) return RBL_ERR_HIP;
+        if (hipStreamWaitEvent(sb, aux->ev[0], 0) != hipSuccess) return RBL_ERR_HIP;
+      }
+      const int64_t lend = (pend + NB < n) ? pend + NB : n;   // L_p: the next panel's columns
+      {
+        dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((lend - pend + 127) / 128));
+        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)pend, (long)lend,
+                           (long)k, (int)pw);
+      }
+      if (look) {
+        if (hipEventRecord(aux->ev[1], sb) != hipSuccess) return RBL_ERR_HIP;
+        pending_L = true;
+      }
+      if (lend < n) {                                          // R_p: everything right of it
+        dim3 grid((unsigned)((n - lend + 127) / 128), (unsigned)((n - lend + 127) / 128));
+        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)lend, (long)n,
+                           (long)k, (int)pw);
+      }
     }
+  }
+  if (look) {
+    if (hipEventRecord(aux->ev[2], sb) != hipSuccess) return RBL_ERR_HIP;
+    if (hipStreamWaitEvent(st, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
   }
   if (zero_upper)
     hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)n, (unsigned)((n + 255) / 256)), dim3(256), 0,

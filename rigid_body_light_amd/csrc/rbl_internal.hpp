@@ -55,6 +55,11 @@ struct RblDevBuf {
   size_t bytes = 0;
 };
 
+struct RblCholAux {        // second stream + events for the one-panel lookahead
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
 struct rbl_ctx {
   RblBodyState S;
   std::string last_error;
@@ -66,6 +71,7 @@ struct rbl_ctx {
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
+  RblCholAux chol_aux;
   // tuning
   int tune_jsplit = 0;
   int tune_variant = 0;
@@ -114,7 +120,7 @@ void rbl_launch_normal(hipStream_t st, uint64_t seed, uint64_t offset, int64_t n
 
 // dense linear algebra (rbl_dense.hip)
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
-                        double *d_work, size_t work_bytes);
+                        double *d_work, size_t work_bytes, const RblCholAux *aux);
 size_t rbl_cholesky_work_bytes(int64_t n);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
                            double *d_out, double *d_part);
