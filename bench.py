@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per cpu_baseline leg (0 = skip)")
     ap.add_argument("--jsplit", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0, help="0 heuristic, 1 ordered-rows kernel, 2 symmetric kernel")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path with several ranks on ONE GPU)")
+    ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,11 +95,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)     # several ranks may share a GPU only in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
@@ -135,10 +143,11 @@ def main():
             ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
         if k is not None:
             ev[k][1].record(stream)
-        if use_sym and world > 1:
-            dist.all_reduce(U_part, op=dist.ReduceOp.SUM)
+        if use_sym:
+            sm.all_reduce_sum(U_part)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -160,6 +169,18 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item()); kern_ms = float(kern_ms.item())
+
+    check = None
+    if args.check:   # parity of what was just timed: oracle on a row sample (rank 0 rows / full vector)
+        from oracle import Oracle
+        orc = Oracle()
+        cfg0 = c["cfg"] - c["cfg"].mean(axis=0)
+        r_ref = orc.multi_body_pos(c["X"], c["Q"], cfg0)
+        b0 = sm.row0 + (nrows // 2)
+        Uo = orc.apply_M_rows(F_full_host, r_ref, b0, b0 + 8, c["a"], c["eta"], wall, nthreads=8)
+        got = (U_part[3 * b0:3 * b0 + 24] if use_sym else U_local[3 * (b0 - sm.row0):3 * (b0 - sm.row0) + 24]).cpu().numpy()
+        check = float(np.linalg.norm(got - Uo) / np.linalg.norm(Uo))
+        assert check < 1e-11, "rank %d: parity vs oracle failed: %g" % (rank, check)
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -194,6 +215,8 @@ def main():
                          "kernel_ms": kern_ms,
                          "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch)},
         }
+        if check is not None:
+            line["check_rel_err_vs_oracle"] = check
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]

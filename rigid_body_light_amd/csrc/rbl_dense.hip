@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int IB = 32;    // inner step width
-constexpr int NB = 256;   // outer panel width (K of the trailing MFMA update)
+constexpr int NB = 512;   // outer panel width (K of the trailing MFMA update)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 

@@ -49,6 +49,10 @@ class ShardedMobility:
         if ctx is None and row_apply is None:
             raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
         self.r_full = None
+        # CPU-staged collectives when the process group cannot move device tensors (gloo rehearsal
+        # of the multi-rank path on a single GPU); RCCL ("nccl") moves device buffers directly.
+        self.stage_cpu = bool(dist.is_initialized() and dist.get_backend(group) == "gloo"
+                              and self.device.type == "cuda")
 
     # -- exchange -----------------------------------------------------------
     def all_gather_rows(self, local):
@@ -58,8 +62,13 @@ class ShardedMobility:
             return local.clone()
         pad = torch.zeros(self.max_rows * 3, dtype=local.dtype, device=local.device)
         pad[: local.numel()] = local
-        buf = torch.empty(self.world * self.max_rows * 3, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(buf, pad, group=self.group)
+        if self.stage_cpu:
+            hbuf = torch.empty(self.world * self.max_rows * 3, dtype=local.dtype)
+            dist.all_gather_into_tensor(hbuf, pad.cpu(), group=self.group)
+            buf = hbuf.to(local.device)
+        else:
+            buf = torch.empty(self.world * self.max_rows * 3, dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(buf, pad, group=self.group)
         if all((e - b) * self.nblb == self.max_rows for b, e in self.parts):
             return buf
         chunks = [buf[r * self.max_rows * 3: r * self.max_rows * 3 + (e - b) * self.nblb * 3]
@@ -90,8 +99,16 @@ class ShardedMobility:
             part = torch.empty(self.n_blobs * 3, dtype=torch.float64, device=self.device)
             self.ctx.apply_M_sym(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.rank, self.world,
                                  part.data_ptr())
+        return self.all_reduce_sum(part)
+
+    def all_reduce_sum(self, part):
         if self.world > 1:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+            if self.stage_cpu:
+                h = part.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                part.copy_(h)
+            else:
+                dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         return part
 
     def apply_M_rows(self, F_full):
