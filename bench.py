@@ -211,7 +211,10 @@ def main():
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
             "roofline": {"bound": "fp64-valu", "kernel": "%s<%s>" % ("k_apply_M_sym" if use_sym else "k_apply_M", "true" if wall else "false"),
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_TFLOPS,
+                         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
+                         # gfx950 correction + WRITE_SIZE, KB -> B): profiles/r01_bench_cfg3_sym_pmc_summary.txt
+                         "traffic": (2 * 90600.6e3 + 3.07085e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
                          "kernel_ms": kern_ms,
                          "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch)},
         }

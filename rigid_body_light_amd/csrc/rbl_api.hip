@@ -117,7 +117,7 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
 {
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   const bool full = (row_begin == 0 && row_end == nbl);
-  bool sym = full && nbl >= 4096;
+  bool sym = full;   // measured faster at every size, N = 120 ... 128 400 (profiles/r01_apply_M_all_configs.md)
   if (c->tune_variant == 1) sym = false;
   if (c->tune_variant == 2) sym = full;
   int rc;
