@@ -165,6 +165,11 @@ int rbl_set_stream(rbl_ctx *ctx, void *hip_stream);
 int rbl_apply_M_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
                     int64_t row_begin, int64_t row_end, double *d_out);
 
+/* apply_M for nrhs right-hand sides resident on the device (d_F, d_out column-major
+ * 3*n_blobs x nrhs).  Four or more vectors run on the fp64 matrix cores, 16 per pass. */
+int rbl_apply_M_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
+                          int nrhs, double *d_out);
+
 /* Symmetric-kernel shard of apply_M for multi-GPU strong scaling: this call evaluates the
  * unordered blob-tile pairs {I,J}, J >= I, whose row tile I satisfies I % i_step == i_first
  * (tiles of 64 blobs) and writes the PARTIAL sum of U = [B] M [B] F over all 3*n_blobs entries

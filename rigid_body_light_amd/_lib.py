@@ -30,6 +30,7 @@ def lib():
         L.rbl_set_config.argtypes = [vp, vp, vp, C.c_int]
         L.rbl_set_stream.argtypes = [vp, vp]
         L.rbl_apply_M_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+        L.rbl_apply_M_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, vp]
         L.rbl_apply_M_sym_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
         L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
         L.rbl_rotne_prager_tensor_dev.argtypes = [vp, vp, i64, C.c_int, vp]
@@ -81,6 +82,10 @@ class DeviceContext:
     def apply_M(self, dF, dr, n_blobs, row_begin, row_end, dout):
         """dF, dr, dout: integer device addresses (tensor.data_ptr())."""
         self._chk(self.L.rbl_apply_M_dev(self.h, dF, dr, n_blobs, row_begin, row_end, dout))
+
+    def apply_M_multi(self, dF, dr, n_blobs, nrhs, dout):
+        """nrhs vectors, column-major (3 n_blobs) x nrhs; >= 4 go through the fp64-MFMA kernel."""
+        self._chk(self.L.rbl_apply_M_multi_dev(self.h, dF, dr, n_blobs, nrhs, dout))
 
     def apply_M_sym(self, dF, dr, n_blobs, i_first, i_step, dout):
         """partial product over the tile rows I % i_step == i_first (sum over ranks = full U)."""

@@ -135,6 +135,32 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   return RBL_OK;
 }
 
+// nrhs right-hand sides, column-major n3 x nrhs on the device.  >= 4 vectors go through the
+// fp64-MFMA kernel in passes of 16; fewer are cheaper one by one on the symmetric kernel.
+// tune_variant 3 forces the MFMA kernel, 1/2 force the single-RHS kernels.
+static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
+                                 int nrhs, double *d_out)
+{
+  const int64_t n3 = 3 * nbl;
+  bool mfma = nrhs >= 4;
+  if (c->tune_variant == 3) mfma = true;
+  if (c->tune_variant == 1 || c->tune_variant == 2) mfma = false;
+  int rc;
+  if (!mfma) {
+    for (int k = 0; k < nrhs; ++k)
+      if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
+    return RBL_OK;
+  }
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_mrhs_bytes(nbl, c->n_cu)))) return rc;
+  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  for (int k = 0; k < nrhs; k += 16) {
+    const int nb = (nrhs - k < 16) ? nrhs - k : 16;
+    rbl_launch_apply_M_mrhs(c->stream, P, wall, d_F + (size_t)k * n3, d_r, nbl, nb, d_out + (size_t)k * n3,
+                            (double *)c->d_part.p, c->n_cu, c->d_err);
+  }
+  return RBL_OK;
+}
+
 extern "C" {
 
 // ============================================================================
@@ -319,10 +345,9 @@ static int apply_M_host(rbl_ctx *c, const double *F, const double *r, int64_t n3
   if ((rc = rbl_dev_reserve(c, c->d_U, vb * nrhs))) return rc;
   RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
   RBL_HIP(c, hipMemcpyAsync(c->d_F.p, F, vb * nrhs, hipMemcpyHostToDevice, c->stream));
-  for (int k = 0; k < nrhs; ++k)
-    if ((rc = apply_M_enqueue(c, c->S.wall, (const double *)c->d_F.p + (size_t)k * n3, (const double *)c->d_r.p,
-                              nbl, 0, nbl, (double *)c->d_U.p + (size_t)k * n3)))
-      return rc;
+  if ((rc = apply_M_multi_enqueue(c, c->S.wall, (const double *)c->d_F.p, (const double *)c->d_r.p, nbl, nrhs,
+                                  (double *)c->d_U.p)))
+    return rc;
   RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb * nrhs, hipMemcpyDeviceToHost, c->stream));
   return finish_and_check(c);
 }
@@ -783,6 +808,15 @@ int rbl_apply_M_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_
   if (n_blobs <= 0 || row_begin < 0 || row_end > n_blobs || row_begin > row_end)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_dev: row range out of bounds");
   return apply_M_enqueue(c, c->S.wall, d_F, d_r, n_blobs, row_begin, row_end, d_out);
+}
+
+int rbl_apply_M_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int nrhs,
+                          double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n_blobs <= 0 || nrhs < 1) return rbl_fail(c, RBL_ERR_SIZE, "apply_M_multi_dev: need n_blobs > 0, nrhs >= 1");
+  return apply_M_multi_enqueue(c, c->S.wall, d_F, d_r, n_blobs, nrhs, d_out);
 }
 
 int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int i_first,

@@ -250,6 +250,133 @@ __global__ __launch_bounds__(256) void k_reduce_sym(const double *__restrict__ s
   if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
 }
 
+
+// ---------------------------------------------------------------------------
+// Multi-RHS matvec on the fp64 matrix cores: up to 16 right-hand sides per pass.
+// A wavefront owns 16 rows i; per step every lane evaluates ONE ordered pair
+// (i = i0 + (lane&15), j = j0 + 4 s + (lane>>4)) -- exactly the A-operand layout of
+// v_mfma_f64_16x16x4 (A[m = lane&15][k = lane>>4]) -- builds its 3x3 block on the VALU
+// and feeds the nine entries to nine MFMAs
+//        D_a[i][n] += M_ij[a][b] * F_b[j][n]        a,b in {x,y,z}, n = RHS index,
+// whose B-operands F_b[j = lane>>4][n = lane&15] are the packed forces.  The pair
+// coefficients cost ~100 VALU instructions per lane-step, the nine MFMAs 9 x 2048 flop:
+// the kernel is matrix-core bound and 16 vectors cost ~2-3x one single-RHS product.
+// Layouts: Fp[j][b][16] (damped, zero padded), Up[split][i][a][16] (raw sums).
+// ---------------------------------------------------------------------------
+typedef double double4m_t __attribute__((ext_vector_type(4)));
+constexpr int MR = 16;      // RHS per pass = MFMA N dimension
+constexpr int MTJ = 256;    // j tile staged in LDS (positions only)
+
+template <bool WALL, bool SELF>
+__device__ __forceinline__ void mrhs_tile(const RblParams &P, const double *sx, const double *sy,
+                                          const double *sz, const double *__restrict__ Fp, long j0,
+                                          long i, double xi, double yi, double zi, int l15, int l4,
+                                          double4m_t &dx_, double4m_t &dy_, double4m_t &dz_,
+                                          unsigned &flags)
+{
+  const double *fp = Fp + ((size_t)(j0 + l4) * 3) * MR + l15;
+#pragma unroll 2
+  for (int s = 0; s < MTJ / 4; ++s) {
+    const int jj = 4 * s + l4;
+    const double f0 = fp[0], f1 = fp[MR], f2 = fp[2 * MR];
+    fp += (size_t)4 * 3 * MR;
+    double m[9];
+    rbl_pair_block_fast<WALL, SELF>(P, xi, yi, zi, sx[jj], sy[jj], sz[jj], SELF && (j0 + jj == i), m, flags);
+    dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], f0, dx_, 0, 0, 0);
+    dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], f1, dx_, 0, 0, 0);
+    dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], f2, dx_, 0, 0, 0);
+    dy_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[3], f0, dy_, 0, 0, 0);
+    dy_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[4], f1, dy_, 0, 0, 0);
+    dy_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[5], f2, dy_, 0, 0, 0);
+    dz_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[6], f0, dz_, 0, 0, 0);
+    dz_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[7], f1, dz_, 0, 0, 0);
+    dz_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[8], f2, dz_, 0, 0, 0);
+  }
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__ r,
+                                                      const double *__restrict__ Fp,
+                                                      double *__restrict__ Up, long N, long Npad,
+                                                      long jchunk, RblParams P, unsigned *err)
+{
+  __shared__ double sx[MTJ], sy[MTJ], sz[MTJ];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long i_blk0 = (long)blockIdx.x * 64;
+  const long i = i_blk0 + wave * 16 + l15;
+  const long ic = i < N ? i : N - 1;
+  const double xi = r[3 * ic], yi = r[3 * ic + 1], zi = r[3 * ic + 2];
+  unsigned flags = 0;
+  const long j_begin = (long)blockIdx.y * jchunk;
+  const long j_end = (j_begin + jchunk < Npad) ? j_begin + jchunk : Npad;
+  double4m_t ax = {0, 0, 0, 0}, ay = {0, 0, 0, 0}, az = {0, 0, 0, 0};
+  for (long j0 = j_begin; j0 < j_end; j0 += MTJ) {
+    const long j = j0 + t;
+    double x, y, z;
+    if (j < N) {
+      x = r[3 * j]; y = r[3 * j + 1]; z = r[3 * j + 2];
+      if (WALL && z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+    } else {  // padding (its packed forces are zero)
+      x = 1.0e15 * (double)(2 + (j - N)); y = 0.0; z = 1.0;
+    }
+    __syncthreads();
+    sx[t] = x; sy[t] = y; sz[t] = z;
+    __syncthreads();
+    const bool diag = (j0 < i_blk0 + 64) && (j0 + MTJ > i_blk0);  // block-uniform
+    if (diag)
+      mrhs_tile<WALL, true>(P, sx, sy, sz, Fp, j0, i < N ? i : -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+    else
+      mrhs_tile<WALL, false>(P, sx, sy, sz, Fp, j0, -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+  }
+  // D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4 v, col = lane & 15
+  double *up = Up + (size_t)blockIdx.y * (size_t)Npad * 3 * MR;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const long io = i_blk0 + wave * 16 + l4 + 4 * v;
+    if (io < N) {
+      double *p = up + ((size_t)io * 3) * MR + l15;
+      p[0] = ax[v]; p[MR] = ay[v]; p[2 * MR] = az[v];
+    }
+  }
+  if (i >= N) flags &= ~RBL_FLAG_OVERLAP;
+  if (flags) atomicOr(err, flags);
+}
+
+// pack nrhs column-major RHS (n3 x nrhs) into Fp[j][b][16], damped, zero padded
+template <bool WALL>
+__global__ void k_pack_rhs(const double *__restrict__ F, const double *__restrict__ r, long N, long Npad,
+                           int nrhs, RblParams P, double *__restrict__ Fp)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over Npad*3*16
+  if (idx >= Npad * 3 * MR) return;
+  const int n = (int)(idx % MR);
+  const long jb = idx / MR;  // j*3 + b
+  const long j = jb / 3;
+  double v = 0.0;
+  if (j < N && n < nrhs) {
+    v = F[(size_t)n * (size_t)(3 * N) + jb];
+    if (WALL) v *= damp_of(P, r[3 * j + 2]);
+  }
+  Fp[idx] = v;
+}
+
+template <bool WALL>
+__global__ void k_unpack_rhs(const double *__restrict__ Up, const double *__restrict__ r, long N, long Npad,
+                             int nrhs, int nsplit, RblParams P, double *__restrict__ out, unsigned *err)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*3*nrhs, ia fastest
+  if (idx >= 3 * N * nrhs) return;
+  const long ia = idx % (3 * N);
+  const int n = (int)(idx / (3 * N));
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += Up[(size_t)k * (size_t)Npad * 3 * MR + (size_t)ia * MR + n];
+  double sc = P.nf;
+  if (WALL) sc *= damp_of(P, r[3 * (ia / 3) + 2]);
+  out[idx] = sc * s;
+  if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+}
+
 // ---------------------------------------------------------------------------
 // Dense assembly, column-major n3 x n3 (ld = n3).  Block = 256 consecutive i
 // (768 consecutive rows) x JB consecutive j (3*JB columns).  Each 3x3 block is
@@ -583,6 +710,49 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
                        C, i_first, i_step, P, d_err);
     hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C,
                        nch, i_first, i_step, P, d_err);
+  }
+}
+
+// ---- multi-RHS (MFMA) variant ---------------------------------------------------
+static void mrhs_geometry(int64_t n_blobs, int n_cu, int64_t *Npad, int *nsplit, int64_t *jchunk)
+{
+  const int64_t np = ((n_blobs + MTJ - 1) / MTJ) * MTJ;
+  const int64_t iblocks = (n_blobs + 63) / 64;
+  const int64_t jtiles = np / MTJ;
+  int64_t js = ((int64_t)(n_cu > 0 ? n_cu : 256) * 4 * 4 + iblocks - 1) / iblocks;  // ~4 rounds of 4 blocks/CU
+  if (js > jtiles) js = jtiles;
+  if (js < 1) js = 1;
+  const int64_t jc = ((jtiles + js - 1) / js) * MTJ;
+  *Npad = np; *jchunk = jc; *nsplit = (int)((np + jc - 1) / jc);
+}
+
+size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu)
+{
+  int64_t np, jc; int ns;
+  mrhs_geometry(n_blobs, n_cu, &np, &ns, &jc);
+  return (size_t)np * 3 * MR * sizeof(double) * (size_t)(1 + ns);
+}
+
+// d_F, d_out: column-major n3 x nrhs (nrhs <= 16).  d_work from rbl_apply_M_mrhs_bytes.
+void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                             const double *d_r, int64_t n_blobs, int nrhs, double *d_out,
+                             double *d_work, int n_cu, unsigned *d_err)
+{
+  if (n_blobs <= 0 || nrhs <= 0) return;
+  int64_t np, jc; int ns;
+  mrhs_geometry(n_blobs, n_cu, &np, &ns, &jc);
+  double *Fp = d_work, *Up = d_work + (size_t)np * 3 * MR;
+  const int64_t npk = np * 3 * MR, nun = 3 * n_blobs * nrhs;
+  dim3 gp((unsigned)((npk + 255) / 256)), gu((unsigned)((nun + 255) / 256)), b(256);
+  dim3 grid((unsigned)((n_blobs + 63) / 64), (unsigned)ns);
+  if (wall) {
+    hipLaunchKernelGGL(k_pack_rhs<true>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp);
+    hipLaunchKernelGGL(k_apply_M_mrhs<true>, grid, b, 0, st, d_r, Fp, Up, (long)n_blobs, (long)np, (long)jc, P, d_err);
+    hipLaunchKernelGGL(k_unpack_rhs<true>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err);
+  } else {
+    hipLaunchKernelGGL(k_pack_rhs<false>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp);
+    hipLaunchKernelGGL(k_apply_M_mrhs<false>, grid, b, 0, st, d_r, Fp, Up, (long)n_blobs, (long)np, (long)jc, P, d_err);
+    hipLaunchKernelGGL(k_unpack_rhs<false>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err);
   }
 }
 

@@ -268,6 +268,102 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
 }
 
 // ---------------------------------------------------------------------------
+// Full 3x3 block of one ORDERED pair (i <- j, h = z_j) from the fast coefficient
+// arithmetic, row-major m[9], unscaled.  Used by the multi-RHS kernel, where the
+// block is the A-operand of fp64 MFMAs:  M = cF I + Bc d d^T + f2 e e^T + f3 e z^T
+// + f4 z e^T + f5 z z^T.
+// ---------------------------------------------------------------------------
+template <bool WALL, bool SELF>
+__device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double xi, double yi,
+                                                    double zi, double xj, double yj, double zj,
+                                                    bool is_self, double *m, unsigned &flags)
+{
+  const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+  const double q = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, q);
+  const double invr = rbl_rsqrt(r2);
+  const double invr2 = invr * invr;
+  const double s = P.a * invr;
+  const double t = s * s;
+  double A = __builtin_fma(s * t, 2.0 / 3.0, s);
+  double Bc = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
+  if (__builtin_expect(__any(r2 < P.four_a2), 0)) {
+    const double rr = r2 * invr;
+    const bool far = r2 >= P.four_a2;
+    A = far ? A : __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
+    Bc = far ? Bc : invr * P.c_near_B;
+    if (r2 < P.tiny2 && !(SELF && is_self)) flags |= RBL_FLAG_OVERLAP;
+  }
+  if (SELF) {
+    A = is_self ? 4.0 / 3.0 : A;
+    Bc = is_self ? 0.0 : Bc;
+  }
+  const double Bdx = Bc * dx, Bdy = Bc * dy, Bdz = Bc * dz;
+  if (!WALL) {
+    m[0] = __builtin_fma(Bdx, dx, A); m[1] = Bdx * dy; m[2] = Bdx * dz;
+    m[3] = m[1]; m[4] = __builtin_fma(Bdy, dy, A); m[5] = Bdy * dz;
+    m[6] = m[2]; m[7] = m[5]; m[8] = __builtin_fma(Bdz, dz, A);
+    return;
+  }
+  const double Rz = zi + zj;
+  const double R2 = __builtin_fma(Rz, Rz, q);
+  const double invR = rbl_rsqrt(R2);
+  const double w = P.a * invR;
+  const double ez = Rz * invR;
+  const double w2 = w * w;
+  const double w3 = w2 * w;
+  const double w5 = w3 * w2;
+  const double ez2 = ez * ez;
+  const double g = zj * invR;
+  const double k = zi * invR;
+  const double gk = g * k;
+  const double p3 = __builtin_fma(-3.0, ez2, 1.0);
+  const double p5 = __builtin_fma(-5.0, ez2, 1.0);
+  const double p7 = __builtin_fma(-7.0, ez2, 1.0);
+  const double p5w3 = p5 * w3;
+  double f1 = __builtin_fma(-2.0, gk, -1.0) * w;
+  f1 = __builtin_fma(p3 * w3, -2.0 / 3.0, f1);
+  f1 = __builtin_fma(p5 * w5, 2.0 / 3.0, f1);
+  double f2 = __builtin_fma(6.0, gk, -1.0) * w;
+  f2 = __builtin_fma(p5w3, 2.0, f2);
+  f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
+  const double gw2 = 2.0 * (g * w);
+  const double ezw5 = ez * w5;
+  double f3 = gw2 * __builtin_fma(-6.0 * k, ez, 1.0);
+  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
+  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
+  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw2);
+  double f5 = -2.0 * (g * gw2);
+  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
+  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
+  if (SELF && is_self) {  // self wall term (:98-104): diagonal only
+    const double iz = P.a / zi;
+    const double iz3 = iz * iz * iz;
+    const double iz5 = iz3 * iz * iz;
+    const double dpar = -(9.0 * iz - 2.0 * iz3 + iz5) / 12.0;
+    const double dper = -(9.0 * iz - 4.0 * iz3 + iz5) / 6.0;
+    m[0] = A + dpar; m[1] = 0.0; m[2] = 0.0;
+    m[3] = 0.0; m[4] = A + dpar; m[5] = 0.0;
+    m[6] = 0.0; m[7] = 0.0; m[8] = A + dper;
+    return;
+  }
+  const double cF = A + f1;
+  const double Ex = dx * invR, Ey = dy * invR;
+  const double f2x = f2 * Ex, f2y = f2 * Ey, f2z = f2 * ez;
+  const double cxz = __builtin_fma(Bdx, dz, f2x * ez);
+  const double cyz = __builtin_fma(Bdy, dz, f2y * ez);
+  m[0] = __builtin_fma(Bdx, dx, __builtin_fma(f2x, Ex, cF));
+  m[1] = __builtin_fma(Bdx, dy, f2x * Ey);
+  m[2] = __builtin_fma(f3, Ex, cxz);
+  m[3] = m[1];
+  m[4] = __builtin_fma(Bdy, dy, __builtin_fma(f2y, Ey, cF));
+  m[5] = __builtin_fma(f3, Ey, cyz);
+  m[6] = __builtin_fma(f4, Ex, cxz);
+  m[7] = __builtin_fma(f4, Ey, cyz);
+  m[8] = __builtin_fma(Bdz, dz, __builtin_fma(f2z, ez, cF)) + __builtin_fma(f3 + f4, ez, f5);
+}
+
+// ---------------------------------------------------------------------------
 // Reference-order block (bit-compatible with the oracle).  b: row-major 3x3,
 // NOT yet scaled by nf.  lo/hi are the (i<=j) roles of c_rigid_obj.cpp:430-447.
 // ---------------------------------------------------------------------------

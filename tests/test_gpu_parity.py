@@ -141,6 +141,26 @@ def test_apply_M_cfg2_size_vs_oracle_rows(orc):
     assert np.array_equal(rb.apply_M(F, r), rb.apply_M(F, r))
 
 
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("nrhs", [1, 5, 16, 19])
+def test_apply_M_multi_mfma_vs_oracle(orc, wall, nrhs):
+    """Multi-RHS product (fp64-MFMA kernel for >= 4 vectors, 16 per pass) against the oracle."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(4, 162, wall)          # 648 blobs: ragged vs the 64-row blocks and 256-column tiles
+    if wall:
+        c["X"][0, 2] = 1.0 + 0.5 * c["a"]
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    F = np.random.default_rng(7).standard_normal((nrhs, r.size))
+    U = rb.apply_M_multi(F, r)
+    assert U.shape == (nrhs, r.size)
+    for k in range(nrhs):
+        assert rel(U[k], orc.apply_M(F[k], r, c["a"], c["eta"], wall, mode="matfree")) < 1e-12
+    rb.cb.set_tuning(0, 3)                 # force the MFMA kernel even for few vectors
+    U3 = rb.apply_M_multi(F, r)
+    assert rel(U3, U) < 1e-13
+
+
 def test_apply_M_interface_behaviour():
     """Mirror of reference tests/test_interface.py:149-177 and tests/test_wall.py."""
     X, Q = random_positions(2, seed=30)
@@ -344,6 +364,15 @@ def test_full_size_properties(orc, nb, nblb, wall):
         acc += p
     ctx.sync_check()
     assert float(torch.linalg.norm(acc - Mx) / torch.linalg.norm(Mx)) < 1e-13
+    # 16 right-hand sides through the MFMA kernel == 16 single products (linearity across kernels)
+    if nb == 50:
+        X16 = torch.from_numpy(rng.standard_normal((16, 3 * N))).to(dev)
+        X16[0] = x; X16[1] = y
+        O16 = torch.empty_like(X16)
+        ctx.apply_M_multi(X16.data_ptr(), r.data_ptr(), N, 16, O16.data_ptr())
+        ctx.sync_check()
+        assert float(torch.linalg.norm(O16[0] - Mx) / torch.linalg.norm(Mx)) < 1e-13
+        assert float(torch.linalg.norm(O16[1] - My) / torch.linalg.norm(My)) < 1e-13
     # oracle spot check on a few rows of the full-size problem
     rh = r.cpu().numpy(); xh = x.cpu().numpy()
     b = N // 3

@@ -36,4 +36,19 @@ for name, nb, nblb, wall in (("cfg1 10x12 free", 10, 12, False), ("cfg1 10x12 wa
         t = (time.perf_counter() - t0) / reps
         fl = (204.0 if wall else 59.0) * N * N
         print("| %s | %d | %s | %.4f | %.1f | %.2f |" % (name, N, vname, t * 1e3, 18.0 * N * N / t / 1e9, fl / t / 1e12), flush=True)
+    if N >= 8000:   # 16 right-hand sides on the fp64 matrix cores
+        F16 = torch.from_numpy(np.random.default_rng(5).standard_normal((16, 3 * N))).to(dev)
+        U16 = torch.empty_like(F16)
+        ctx.set_tuning(0, 0)
+        for _ in range(2):
+            ctx.apply_M_multi(F16.data_ptr(), r.data_ptr(), N, 16, U16.data_ptr())
+        ctx.sync_check()
+        reps = 20 if N < 10000 else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.apply_M_multi(F16.data_ptr(), r.data_ptr(), N, 16, U16.data_ptr())
+        ctx.sync_check()
+        t = (time.perf_counter() - t0) / reps
+        print("| %s | %d | 16-RHS MFMA | %.4f (= %.4f per vector) | %.1f | MFMA %.2f TFLOP/s |" % (
+            name, N, t * 1e3, t * 1e3 / 16, 16 * 18.0 * N * N / t / 1e9, 16 * 18.0 * N * N / t / 1e12), flush=True)
     ctx.close()
