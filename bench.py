@@ -76,6 +76,36 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
     return out
 
 
+def timestep_mode(args, dev):
+    """1 step = one deterministic time step, everything resident on ONE GPU."""
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import DeterministicStepper
+    nb, nblb, wall = CONFIGS[args.config]
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    stp = DeterministicStepper(ctx, nb, nblb, dev)
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    iters = 20
+    res = []
+    for _ in range(args.warmup):
+        stp.step(Fb, iters)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res.append(stp.step(Fb, iters)[1])
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    sec = (t1 - t0) / args.steps
+    print(json.dumps({
+        "metric": "timesteps/sec (deterministic fixed-work step: %d GMRES iterations = %d apply_M + PC + K ops + evolve), "
+                  "%d x shell_N_%d, %s, fp64" % (iters, iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
+        "value": 1.0 / sec, "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
+        "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual_after_%d_iters" % iters: res[-1]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +117,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 heuristic, 1 ordered-rows kernel, 2 symmetric kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on ONE GPU)")
+    ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep"],
+                    help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
+                         "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")
     args = ap.parse_args()
 
@@ -110,6 +143,8 @@ def main():
     from rigid_body_light_amd._lib import DeviceContext
     from rigid_body_light_amd.dist import ShardedMobility
 
+    if args.mode == "timestep":
+        return timestep_mode(args, dev)
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb

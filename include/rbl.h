@@ -196,6 +196,17 @@ int rbl_trmv_lower_dev(rbl_ctx *ctx, const double *d_L, int64_t n, const double 
 int rbl_M_half_W_dev(rbl_ctx *ctx, const double *d_r, int64_t n_blobs, const double *d_W,
                      int method, double *d_out);
 
+/* ---- device-resident rigid-body operators: a Krylov iteration without host round trips ----
+ * rbl_sync_bodies_dev uploads (X, Q, ref_cfg) and computes lever arms + blob positions on the
+ * GPU; the functions below call it themselves when the configuration has changed.
+ * Vectors: U/F 6*N_bod, lambda/slip 3*N, saddle/PC vectors 3*N + 6*N_bod (reference layout). */
+int rbl_sync_bodies_dev(rbl_ctx *ctx);
+int rbl_positions_dev(rbl_ctx *ctx, const double **d_pos, int64_t *n_blobs);  /* multi_body_pos, resident */
+int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /* K_x_U    :404 */
+int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */
+int rbl_apply_PC_dev(rbl_ctx *ctx, const double *d_in, double *d_out);        /* apply_PC :589, diagonal PC */
+int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /* src/Rigid.py:73-80 */
+
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);
 

@@ -30,6 +30,15 @@ def lib():
         L.rbl_set_config.argtypes = [vp, vp, vp, C.c_int]
         L.rbl_set_stream.argtypes = [vp, vp]
         L.rbl_apply_M_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+        L.rbl_sync_bodies_dev.argtypes = [vp]
+        L.rbl_positions_dev.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(i64)]
+        L.rbl_K_x_U_dev.argtypes = [vp, vp, vp]
+        L.rbl_KT_x_Lam_dev.argtypes = [vp, vp, vp]
+        L.rbl_apply_PC_dev.argtypes = [vp, vp, vp]
+        L.rbl_apply_saddle_dev.argtypes = [vp, vp, vp]
+        L.rbl_evolve_X_Q.argtypes = [vp, vp]
+        L.rbl_get_config.argtypes = [vp, vp, vp]
+        L.rbl_set_blk_pc.argtypes = [vp, C.c_int]
         L.rbl_apply_M_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, vp]
         L.rbl_apply_M_sym_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
         L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -82,6 +91,35 @@ class DeviceContext:
     def apply_M(self, dF, dr, n_blobs, row_begin, row_end, dout):
         """dF, dr, dout: integer device addresses (tensor.data_ptr())."""
         self._chk(self.L.rbl_apply_M_dev(self.h, dF, dr, n_blobs, row_begin, row_end, dout))
+
+    # -- device-resident rigid-body operators (own configuration) ----------------------
+    def positions_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.rbl_positions_dev(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def K_x_U(self, dU, dout):
+        self._chk(self.L.rbl_K_x_U_dev(self.h, dU, dout))
+
+    def KT_x_Lam(self, dlam, dout):
+        self._chk(self.L.rbl_KT_x_Lam_dev(self.h, dlam, dout))
+
+    def apply_PC(self, din, dout):
+        self._chk(self.L.rbl_apply_PC_dev(self.h, din, dout))
+
+    def apply_saddle(self, dx, dout):
+        self._chk(self.L.rbl_apply_saddle_dev(self.h, dx, dout))
+
+    def evolve(self, U_host):
+        import numpy as np
+        U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
+        self._chk(self.L.rbl_evolve_X_Q(self.h, U.ctypes.data))
+
+    def get_config(self, n_bodies):
+        import numpy as np
+        X = np.zeros(3 * n_bodies); Q = np.zeros(4 * n_bodies)
+        self._chk(self.L.rbl_get_config(self.h, X.ctypes.data, Q.ctypes.data))
+        return X.reshape(-1, 3), Q.reshape(-1, 4)
 
     def apply_M_multi(self, dF, dr, n_blobs, nrhs, dout):
         """nrhs vectors, column-major (3 n_blobs) x nrhs; >= 4 go through the fp64-MFMA kernel."""

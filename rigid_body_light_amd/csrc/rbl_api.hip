@@ -172,19 +172,20 @@ void rbl_destroy(rbl_ctx *c)
 {
   if (!c) return;
   if (c->dev_ready) {
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
-                         &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol};
+                         &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad};
     for (RblDevBuf *b : bufs)
-      if (b->p) hipFree(b->p);
+      if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
       (void)hipStreamSynchronize(c->chol_aux.stream);
       for (int i = 0; i < 3; ++i)
         if (c->chol_aux.ev[i]) (void)hipEventDestroy(c->chol_aux.ev[i]);
       (void)hipStreamDestroy(c->chol_aux.stream);
     }
-    if (c->d_err) hipFree(c->d_err);
-    if (c->h_err) hipHostFree(c->h_err);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->h_err) (void)hipHostFree(c->h_err);
   }
   delete c;
 }
@@ -209,11 +210,12 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   S.N_blb = N_blb;
   S.params_set = true;
   S.M_scale = 1.0;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false;
   return RBL_OK;
 }
 
 int rbl_set_blk_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.block_pc = v != 0; return RBL_OK; }
-int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; return RBL_OK; }
+int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; c->dev_pc_valid = false; return RBL_OK; }
 
 int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
 {
@@ -229,6 +231,7 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
   }
   S.cfg_set = true;
   S.K_set = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false;
   // NOTE the reference does NOT reset PC_mat_Set here (SURVEY.md 8b "state quirks");
   // a stale preconditioner after set_config is a trap, so we do invalidate it.
   S.pc_set = false;
@@ -510,6 +513,7 @@ int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
   rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
   S.X.swap(Xo);
   S.Q.swap(Qo);
+  c->dev_bodies_valid = false; c->dev_pc_valid = false;
   rc = rbl_body_set_K(S, c->last_error);                          // :876
   S.pc_set = false;                                               // :877
   return rc;
@@ -871,6 +875,92 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
   if (!c) return RBL_ERR_ARG;
   c->tune_jsplit = jsplit; c->tune_variant = variant;
+  return RBL_OK;
+}
+
+}  // extern "C"
+
+// ---- device-resident body state + geometric operators ------------
+static int sync_bodies(rbl_ctx *c)
+{
+  int rc = need_config(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (c->dev_bodies_valid) return RBL_OK;
+  RblBodyState &S = c->S;
+  const size_t N = (size_t)S.N_bod * S.N_blb;
+  if ((rc = rbl_dev_reserve(c, c->d_XQ, sizeof(double) * 7 * (size_t)S.N_bod))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_cfg, sizeof(double) * 3 * (size_t)S.N_blb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_lever, sizeof(double) * 3 * N))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_pos, sizeof(double) * 3 * N))) return rc;
+  double *dX = (double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
+  RBL_HIP(c, hipMemcpyAsync(dX, S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(dQ, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
+  rbl_launch_body_geom(c->stream, dX, dQ, (const double *)c->d_cfg.p, S.N_blb, (int64_t)N, (double *)c->d_lever.p,
+                       (double *)c->d_pos.p);
+  RBL_HIP(c, hipStreamSynchronize(c->stream));  // host vectors are pageable
+  c->dev_bodies_valid = true;
+  c->dev_pc_valid = false;
+  return RBL_OK;
+}
+
+extern "C" {
+
+int rbl_sync_bodies_dev(rbl_ctx *c) { return sync_bodies(c); }
+
+int rbl_positions_dev(rbl_ctx *c, const double **d_pos, int64_t *n_blobs)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (d_pos) *d_pos = (const double *)c->d_pos.p;
+  if (n_blobs) *n_blobs = (int64_t)c->S.N_bod * c->S.N_blb;
+  return RBL_OK;
+}
+
+int rbl_K_x_U_dev(rbl_ctx *c, const double *d_U, double *d_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, d_U, c->S.N_blb, (int64_t)c->S.N_bod * c->S.N_blb, d_out,
+                   nullptr, 0.0);
+  return RBL_OK;
+}
+
+int rbl_KT_x_Lam_dev(rbl_ctx *c, const double *d_lam, double *d_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, d_lam, c->S.N_blb, c->S.N_bod, d_out);
+  return RBL_OK;
+}
+
+int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (c->S.block_pc)
+    return rbl_fail(c, RBL_ERR_STATE, "apply_PC_dev: the block-diagonal preconditioner is host-only (use rbl_apply_PC)");
+  const RblBodyState &S = c->S;
+  if (!c->dev_pc_valid) {
+    const size_t N = (size_t)S.N_bod * S.N_blb;
+    if ((rc = rbl_dev_reserve(c, c->d_invM2, sizeof(double) * 2 * N))) return rc;
+    if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
+    rbl_launch_pc_diag_build(c->stream, rbl_make_params(S.a, S.eta), S.wall, (const double *)c->d_lever.p,
+                             (const double *)c->d_pos.p, S.N_blb, S.N_bod, (double *)c->d_invM2.p, (double *)c->d_NL.p,
+                             c->d_err);
+    c->dev_pc_valid = true;
+  }
+  rbl_launch_pc_diag_apply(c->stream, (const double *)c->d_lever.p, (const double *)c->d_invM2.p, (const double *)c->d_NL.p,
+                           S.N_blb, S.N_bod, d_in, d_out);
+  return RBL_OK;
+}
+
+// [M lambda - K U ; K^T lambda] on the object's own configuration (src/Rigid.py:73-80)
+int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3))) return rc;
+  if ((rc = apply_M_enqueue(c, S.wall, d_x, (const double *)c->d_pos.p, N, 0, N, (double *)c->d_sad.p))) return rc;
+  rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, d_out, (const double *)c->d_sad.p, -1.0);
+  rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, d_x, S.N_blb, S.N_bod, d_out + n3);
   return RBL_OK;
 }
 

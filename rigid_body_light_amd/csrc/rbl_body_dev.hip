@@ -1,0 +1,256 @@
+// rbl_body_dev.hip -- device versions of the per-body geometric operators around the hot path
+// (SURVEY.md section 8f rows N1/N2): K U, K^T lambda (reference c_rigid_obj.cpp:328-410), the
+// diagonal preconditioner apply_PC (:489-543, :589-616) and the saddle-operator epilogue
+// (src/Rigid.py:73-80).  They exist so that a Krylov iteration needs no host round trip:
+// everything a GMRES step touches stays in HBM.  All are O(N) and latency-bound; one
+// workgroup per rigid body, deterministic LDS tree reductions (no atomics).
+#include "rbl_internal.hpp"
+
+namespace {
+
+constexpr int BT = 256;
+
+__device__ __forceinline__ void quat_rot(const double *q, double *R)
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// lever arms l_k = R(Q_b) c_k (:374) and positions r_k = l_k + X_b (:257-265)
+__global__ void k_body_geom(const double *__restrict__ X, const double *__restrict__ Q,
+                            const double *__restrict__ cfg, int N_blb, long N,
+                            double *__restrict__ lever, double *__restrict__ pos)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N) return;
+  const int b = (int)(idx / N_blb), k = (int)(idx % N_blb);
+  double R[9];
+  quat_rot(Q + 4 * b, R);
+  const double c0 = cfg[3 * k], c1 = cfg[3 * k + 1], c2 = cfg[3 * k + 2];
+  {
+#pragma clang fp contract(off)
+    const double l0 = c0 * R[0] + c1 * R[1] + c2 * R[2];
+    const double l1 = c0 * R[3] + c1 * R[4] + c2 * R[5];
+    const double l2 = c0 * R[6] + c1 * R[7] + c2 * R[8];
+    lever[3 * idx] = l0; lever[3 * idx + 1] = l1; lever[3 * idx + 2] = l2;
+    pos[3 * idx] = l0 + X[3 * b]; pos[3 * idx + 1] = l1 + X[3 * b + 1]; pos[3 * idx + 2] = l2 + X[3 * b + 2];
+  }
+}
+
+// out_k = U_b + Omega_b x l_k     (:368-383, :404)
+__global__ void k_K_x_U(const double *__restrict__ lever, const double *__restrict__ U, int N_blb,
+                        long N, double *__restrict__ out, const double *__restrict__ sub, double alpha)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N) return;
+  const int b = (int)(idx / N_blb);
+  const double *u = U + 6 * b, *om = u + 3, *l = lever + 3 * idx;
+  const double k0 = u[0] + l[2] * om[1] - l[1] * om[2];
+  const double k1 = u[1] + l[0] * om[2] - l[2] * om[0];
+  const double k2 = u[2] + l[1] * om[0] - l[0] * om[1];
+  if (sub) {  // out = sub + alpha * K U   (saddle epilogue: slip = M lambda - K U)
+    out[3 * idx] = sub[3 * idx] + alpha * k0; out[3 * idx + 1] = sub[3 * idx + 1] + alpha * k1;
+    out[3 * idx + 2] = sub[3 * idx + 2] + alpha * k2;
+  } else {
+    out[3 * idx] = k0; out[3 * idx + 1] = k1; out[3 * idx + 2] = k2;
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double (*s)[BT], int t)
+{
+#pragma unroll
+  for (int q = 0; q < NV; ++q) s[q][t] = v[q];
+  __syncthreads();
+  for (int st = BT / 2; st > 0; st >>= 1) {
+    if (t < st) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) s[q][t] += s[q][t + st];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = s[q][0];
+  __syncthreads();
+}
+
+// F_b = sum lambda_k, T_b = sum l_k x lambda_k   (:410); one workgroup per body
+__global__ __launch_bounds__(BT) void k_KT_x_Lam(const double *__restrict__ lever,
+                                                 const double *__restrict__ lam, int N_blb,
+                                                 double *__restrict__ out)
+{
+  __shared__ double s[6][BT];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double f[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = t; k < N_blb; k += BT) {
+    const size_t idx = 3 * ((size_t)b * N_blb + k);
+    const double *l = lever + idx, *v = lam + idx;
+    f[0] += v[0]; f[1] += v[1]; f[2] += v[2];
+    f[3] += l[1] * v[2] - l[2] * v[1];
+    f[4] += l[2] * v[0] - l[0] * v[2];
+    f[5] += l[0] * v[1] - l[1] * v[0];
+  }
+  block_reduce<6>(f, s, t);
+  if (t < 6) out[6 * b + t] = f[t];
+}
+
+// diag_invM (:489-543) + Ninv = K^T invM K per body and its Cholesky (:593-594, :554-567)
+template <bool WALL>
+__global__ __launch_bounds__(BT) void k_pc_diag_build(const double *__restrict__ lever,
+                                                      const double *__restrict__ pos, int N_blb,
+                                                      RblParams P, double *__restrict__ invM2,
+                                                      double *__restrict__ NL, unsigned *err)
+{
+  __shared__ double s[21][BT];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double scale = 1.0 / P.nf;  // 8 pi eta a
+  double acc[21];
+#pragma unroll
+  for (int q = 0; q < 21; ++q) acc[q] = 0.0;
+  for (int k = t; k < N_blb; k += BT) {
+    const size_t i = (size_t)b * N_blb + k;
+    double dxx = 4.0 / 3.0, dzz = 4.0 / 3.0;
+    if (WALL) {  // self wall term (:98-104), h = z/a
+      const double h = pos[3 * i + 2] / P.a;
+      if (h < 0.0) atomicOr(err, (unsigned)RBL_FLAG_BELOW_WALL);
+      const double iz = 1.0 / h, iz3 = iz * iz * iz, iz5 = iz3 * iz * iz;
+      dxx += -(9 * iz - 2 * iz3 + iz5) / 12.0;
+      dzz += -(9 * iz - 4 * iz3 + iz5) / 6.0;
+    }
+    const double px = scale / dxx, pz = scale / dzz;  // invM = diag(px, px, pz)
+    invM2[2 * i] = px; invM2[2 * i + 1] = pz;
+    const double lx = lever[3 * i], ly = lever[3 * i + 1], lz = lever[3 * i + 2];
+    // K_k = [I | G], G = [[0, lz, -ly], [-lz, 0, lx], [ly, -lx, 0]];  D = diag(px,px,pz)
+    const double Kk[3][6] = {{1, 0, 0, 0, lz, -ly}, {0, 1, 0, -lz, 0, lx}, {0, 0, 1, ly, -lx, 0}};
+    const double D[3] = {px, px, pz};
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        acc[q] += Kk[0][r] * D[0] * Kk[0][c] + Kk[1][r] * D[1] * Kk[1][c] + Kk[2][r] * D[2] * Kk[2][c];
+        ++q;
+      }
+  }
+  block_reduce<21>(acc, s, t);
+  if (t == 0) {  // 6x6 lower Cholesky, row-major L
+    double L[36];
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c <= r; ++c) { L[6 * r + c] = acc[q]; if (c < r) L[6 * c + r] = 0.0; ++q; }
+    bool ok = true;
+    for (int j = 0; j < 6; ++j) {
+      double d = L[6 * j + j];
+      for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+      if (!(d > 0.0)) ok = false;
+      d = sqrt(d);
+      L[6 * j + j] = d;
+      for (int i = j + 1; i < 6; ++i) {
+        double v = L[6 * i + j];
+        for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+        L[6 * i + j] = v / d;
+      }
+    }
+    if (!ok) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+    for (int e = 0; e < 36; ++e) NL[36 * (size_t)b + e] = L[e];
+  }
+}
+
+// apply_PC (:589-616) with the diagonal invM: one workgroup per body
+__global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__ lever,
+                                                      const double *__restrict__ invM2,
+                                                      const double *__restrict__ NL, int N_blb,
+                                                      long n3, const double *__restrict__ in,
+                                                      double *__restrict__ out)
+{
+  __shared__ double s[6][BT];
+  __shared__ double Ush[6];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double *slip = in, *F = in + n3;
+  double f[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = t; k < N_blb; k += BT) {  // K^T (invM slip)
+    const size_t i = (size_t)b * N_blb + k;
+    const double *l = lever + 3 * i;
+    const double v0 = invM2[2 * i] * slip[3 * i], v1 = invM2[2 * i] * slip[3 * i + 1],
+                 v2 = invM2[2 * i + 1] * slip[3 * i + 2];
+    f[0] += v0; f[1] += v1; f[2] += v2;
+    f[3] += l[1] * v2 - l[2] * v1;
+    f[4] += l[2] * v0 - l[0] * v2;
+    f[5] += l[0] * v1 - l[1] * v0;
+  }
+  block_reduce<6>(f, s, t);
+  if (t == 0) {  // U = Ninv^-1 (-F - K^T invM slip) through the 6x6 Cholesky factor (:601-608)
+    const double *L = NL + 36 * (size_t)b;
+    double y[6], u[6];
+    for (int p = 0; p < 6; ++p) {
+      double v = -F[6 * b + p] - f[p];
+      for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
+      y[p] = v / L[6 * p + p];
+    }
+    for (int p = 5; p >= 0; --p) {
+      double v = y[p];
+      for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
+      u[p] = v / L[6 * p + p];
+    }
+    for (int p = 0; p < 6; ++p) { Ush[p] = u[p]; out[n3 + 6 * b + p] = u[p]; }
+  }
+  __syncthreads();
+  const double u0 = Ush[0], u1 = Ush[1], u2 = Ush[2], o0 = Ush[3], o1 = Ush[4], o2 = Ush[5];
+  for (int k = t; k < N_blb; k += BT) {  // Lambda = invM (slip + K U)   (:610, M_scale = 1)
+    const size_t i = (size_t)b * N_blb + k;
+    const double *l = lever + 3 * i;
+    out[3 * i] = invM2[2 * i] * (slip[3 * i] + u0 + l[2] * o1 - l[1] * o2);
+    out[3 * i + 1] = invM2[2 * i] * (slip[3 * i + 1] + u1 + l[0] * o2 - l[2] * o0);
+    out[3 * i + 2] = invM2[2 * i + 1] * (slip[3 * i + 2] + u2 + l[1] * o0 - l[0] * o1);
+  }
+}
+
+}  // namespace
+
+void rbl_launch_body_geom(hipStream_t st, const double *dX, const double *dQ, const double *dcfg,
+                          int N_blb, int64_t N, double *d_lever, double *d_pos)
+{
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_body_geom, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, dX, dQ, dcfg, N_blb,
+                     (long)N, d_lever, d_pos);
+}
+
+void rbl_launch_K_x_U(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N,
+                      double *d_out, const double *d_sub, double alpha)
+{
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_K_x_U, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_lever, d_U, N_blb,
+                     (long)N, d_out, d_sub, alpha);
+}
+
+void rbl_launch_KT_x_Lam(hipStream_t st, const double *d_lever, const double *d_lam, int N_blb, int N_bod,
+                         double *d_out)
+{
+  if (N_bod <= 0) return;
+  hipLaunchKernelGGL(k_KT_x_Lam, dim3(N_bod), dim3(BT), 0, st, d_lever, d_lam, N_blb, d_out);
+}
+
+void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, const double *d_lever,
+                              const double *d_pos, int N_blb, int N_bod, double *d_invM2, double *d_NL,
+                              unsigned *d_err)
+{
+  if (N_bod <= 0) return;
+  if (wall)
+    hipLaunchKernelGGL(k_pc_diag_build<true>, dim3(N_bod), dim3(BT), 0, st, d_lever, d_pos, N_blb, P, d_invM2, d_NL, d_err);
+  else
+    hipLaunchKernelGGL(k_pc_diag_build<false>, dim3(N_bod), dim3(BT), 0, st, d_lever, d_pos, N_blb, P, d_invM2, d_NL, d_err);
+}
+
+void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
+                              int N_blb, int N_bod, const double *d_in, double *d_out)
+{
+  if (N_bod <= 0) return;
+  hipLaunchKernelGGL(k_pc_diag_apply, dim3(N_bod), dim3(BT), 0, st, d_lever, d_invM2, d_NL, N_blb,
+                     (long)3 * N_blb * N_bod, d_in, d_out);
+}

@@ -69,6 +69,8 @@ struct rbl_ctx {
   int n_cu = 0;
   hipStream_t stream = nullptr;
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
+  RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
+  bool dev_bodies_valid = false, dev_pc_valid = false;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   RblCholAux chol_aux;
@@ -137,3 +139,16 @@ void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, doub
                       const double *y, double *out);
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
                               int64_t n_blobs, const double *in, double *out);
+
+// per-body geometric operators on the device (rbl_body_dev.hip)
+void rbl_launch_body_geom(hipStream_t st, const double *dX, const double *dQ, const double *dcfg,
+                          int N_blb, int64_t N, double *d_lever, double *d_pos);
+void rbl_launch_K_x_U(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N,
+                      double *d_out, const double *d_sub, double alpha);
+void rbl_launch_KT_x_Lam(hipStream_t st, const double *d_lever, const double *d_lam, int N_blb, int N_bod,
+                         double *d_out);
+void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, const double *d_lever,
+                              const double *d_pos, int N_blb, int N_bod, double *d_invM2, double *d_NL,
+                              unsigned *d_err);
+void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
+                              int N_blb, int N_bod, const double *d_in, double *d_out);

@@ -1,0 +1,81 @@
+"""Time-step DRIVER on top of the operator surface -- the "external user code" of the reference
+(Krylov solver + time loop are NOT in the reference repo).  It defines what
+this project calls one deterministic time step:
+
+    positions -> right-preconditioned GMRES on  A = apply_saddle  with  P^-1 = apply_PC ,
+                 rhs = [0 ; -F_body]  ->  U  ->  evolve_rigid_bodies(U)
+
+All vectors stay on the GPU (torch tensors as plain device buffers); the operators are the HIP
+kernels behind include/rbl.h (rbl_apply_saddle_dev, rbl_apply_PC_dev).  The small Hessenberg
+least-squares problem is solved on the host once per solve.
+"""
+import numpy as np
+import torch
+
+
+def gmres_right_pc(apply_A, apply_Pinv, b, iters, rtol=None):
+    """Right-preconditioned GMRES(iters), no restart.  apply_A / apply_Pinv: tensor -> tensor.
+    Arnoldi with classical Gram-Schmidt applied twice (two GEMVs each, no host sync inside the
+    loop unless rtol is given).  Returns (x, number of iterations, relative residual estimate)."""
+    n = b.numel()
+    dev, dt = b.device, b.dtype
+    V = torch.zeros(iters + 1, n, dtype=dt, device=dev)
+    H = torch.zeros(iters + 1, iters, dtype=dt, device=dev)
+    beta = torch.linalg.norm(b)
+    V[0] = b / beta
+    m = iters
+    for j in range(iters):
+        w = apply_A(apply_Pinv(V[j]))
+        for _ in range(2):                       # CGS2
+            h = V[: j + 1] @ w
+            w = w - h @ V[: j + 1]
+            H[: j + 1, j] += h
+        hn = torch.linalg.norm(w)
+        H[j + 1, j] = hn
+        V[j + 1] = w / hn
+        if rtol is not None:                     # host check costs one sync per iteration
+            Hh = H[: j + 2, : j + 1].cpu().numpy()
+            e1 = np.zeros(j + 2); e1[0] = float(beta)
+            y, res, *_ = np.linalg.lstsq(Hh, e1, rcond=None)
+            r = np.linalg.norm(Hh @ y - e1) / float(beta)
+            if r < rtol:
+                m = j + 1
+                break
+    Hh = H[: m + 1, :m].cpu().numpy()
+    e1 = np.zeros(m + 1); e1[0] = float(beta)
+    y, *_ = np.linalg.lstsq(Hh, e1, rcond=None)
+    resid = float(np.linalg.norm(Hh @ y - e1) / float(beta))
+    z = torch.from_numpy(y).to(dev) @ V[:m]
+    return apply_Pinv(z), m, resid
+
+
+class DeterministicStepper:
+    """One deterministic time step per call (fixed-work: `iters` GMRES iterations = iters+1 apply_M)."""
+
+    def __init__(self, ctx, n_bodies, blobs_per_body, device):
+        self.ctx, self.nb, self.nblb, self.dev = ctx, n_bodies, blobs_per_body, device
+        self.n3 = 3 * n_bodies * blobs_per_body
+        self.size = self.n3 + 6 * n_bodies
+
+    def _A(self, x):
+        out = torch.empty_like(x)
+        self.ctx.apply_saddle(x.data_ptr(), out.data_ptr())
+        return out
+
+    def _Pinv(self, x):
+        out = torch.empty_like(x)
+        self.ctx.apply_PC(x.contiguous().data_ptr(), out.data_ptr())
+        return out
+
+    def solve(self, F_body, iters=20, rtol=None):
+        """Solve the saddle system for rhs = [0 ; -F_body]; returns (lambda, U, iterations, residual)."""
+        b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
+        b[self.n3:] = -torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
+        x, m, resid = gmres_right_pc(self._A, self._Pinv, b, iters, rtol)
+        return x[: self.n3], x[self.n3:], m, resid
+
+    def step(self, F_body, iters=20, rtol=None):
+        lam, U, m, resid = self.solve(F_body, iters, rtol)
+        self.ctx.evolve(U.cpu().numpy())          # O(N_bod) host update, then K/positions rebuilt on the GPU
+        self.ctx.sync_check()
+        return m, resid

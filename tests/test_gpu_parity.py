@@ -406,3 +406,79 @@ def test_cholesky_cfg2_size_property():
     ctx.trmv_lower(Mat.data_ptr(), n, x.data_ptr(), out.data_ptr())
     ctx.sync_check()
     assert float(torch.linalg.norm(out - L @ x) / torch.linalg.norm(out)) < 1e-13
+
+
+# ---------------------------------------------------------------------------------
+# device-resident rigid-body operators (rows N1/N2) and the time-step driver
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("wall", [False, True])
+def test_device_body_operators_vs_host_and_oracle(orc, shell12, wall):
+    import torch
+    from oracle import oracle as onp
+    from rigid_body_light_amd._lib import DeviceContext
+    nb = 7
+    X, Q = random_positions(nb, wall=wall, seed=60)
+    if wall:
+        X[:, 2] += 1.0
+    a, eta = 0.9, 1.2
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=0.1, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    cfg = onp.remove_mean(shell12); Qn = onp.normalize_quats(Q)
+    K = onp.K_matrix(X, Qn, cfg)
+    n3 = 3 * 12 * nb
+    rng = np.random.default_rng(61)
+    U = rng.standard_normal(6 * nb); lam = rng.standard_normal(n3); x = rng.standard_normal(n3 + 6 * nb)
+    dU, dl, dx = (torch.from_numpy(v).to(dev) for v in (U, lam, x))
+    o1 = torch.empty(n3, dtype=torch.float64, device=dev); ctx.K_x_U(dU.data_ptr(), o1.data_ptr())
+    o2 = torch.empty(6 * nb, dtype=torch.float64, device=dev); ctx.KT_x_Lam(dl.data_ptr(), o2.data_ptr())
+    o3 = torch.empty_like(dx); ctx.apply_PC(dx.data_ptr(), o3.data_ptr())
+    o4 = torch.empty_like(dx); ctx.apply_saddle(dx.data_ptr(), o4.data_ptr())
+    p, n = ctx.positions_ptr()
+    ctx.sync_check()
+    assert n == 12 * nb
+    np.testing.assert_allclose(o1.cpu().numpy(), K @ U, atol=1e-13)
+    np.testing.assert_allclose(o2.cpu().numpy(), K.T @ lam, atol=1e-12)
+    ref_pc = onp.apply_PC(orc, x, X, Qn, cfg, a, eta, wall, False)
+    assert rel(o3.cpu().numpy(), ref_pc) < 1e-12
+    r = orc.multi_body_pos(X, Q, cfg)
+    ref_sad = np.concatenate([orc.apply_M(x[:n3], r, a, eta, wall) - K @ x[n3:], K.T @ x[:n3]])
+    assert rel(o4.cpu().numpy(), ref_sad) < 1e-12
+    # after an evolve the device state follows the host state
+    ctx.evolve(rng.standard_normal(6 * nb) * 0.05)
+    Xn, Qq = ctx.get_config(nb)
+    ctx.K_x_U(dU.data_ptr(), o1.data_ptr()); ctx.sync_check()
+    np.testing.assert_allclose(o1.cpu().numpy(), onp.K_matrix(Xn, Qq, cfg) @ U, atol=1e-13)
+
+
+def test_gmres_timestep_small(orc, shell12):
+    """Deterministic step: GMRES on the device operators reproduces the dense saddle solve."""
+    import torch
+    from oracle import oracle as onp
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import DeterministicStepper
+    nb = 5
+    X, Q = random_positions(nb, wall=True, seed=70)
+    X[:, 2] += 1.5
+    a, eta = 1.0, 1.0
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(a, eta, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    st = DeterministicStepper(ctx, nb, 12, dev)
+    Fb = np.tile([0, 0, -1.0, 0, 0, 0], nb)
+    lam, U, m, resid = st.solve(Fb, iters=60, rtol=1e-10)
+    assert resid < 1e-10 and m <= 60
+    cfg = onp.remove_mean(shell12); Qn = onp.normalize_quats(Q)
+    K = onp.K_matrix(X, Qn, cfg)
+    r = orc.multi_body_pos(X, Q, cfg)
+    B = orc.damp(r, a)
+    M = (B[:, None] * orc.rotne_prager_tensor(r, a, eta, True)) * B[None, :]
+    n3 = 36 * nb
+    A = np.block([[M, -K], [K.T, np.zeros((6 * nb, 6 * nb))]])
+    ref = np.linalg.solve(A, np.concatenate([np.zeros(n3), -Fb]))
+    assert rel(U.cpu().numpy(), ref[n3:]) < 1e-8
+    # bodies pushed towards the wall move down
+    assert (U.cpu().numpy().reshape(-1, 6)[:, 2] < 0).all() or (U.cpu().numpy().reshape(-1, 6)[:, 2] > 0).all()
+    X0 = ctx.get_config(nb)[0].copy()
+    st.step(Fb, iters=20)
+    assert np.linalg.norm(ctx.get_config(nb)[0] - X0) > 0
