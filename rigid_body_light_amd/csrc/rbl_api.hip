@@ -100,6 +100,47 @@ static int need_config(rbl_ctx *c)
   return RBL_OK;
 }
 
+
+// Host <-> device copies of the host-pointer API.  Caller arrays are pageable; both
+// hipMemcpy and hipMemcpyAsync then pin the caller's pages on the fly (measured ~20 ms for
+// a fresh 3 MB numpy array on this stack).  Large copies therefore go through the context's
+// own pinned staging buffer in 32 MB chunks (DMA + one CPU memcpy); small ones stay direct.
+static constexpr size_t RBL_STAGE_BYTES = 32u << 20;
+
+static int stage_ready(rbl_ctx *c)
+{
+  if (c->h_stage) return RBL_OK;
+  RBL_HIP(c, hipHostMalloc(&c->h_stage, RBL_STAGE_BYTES, hipHostMallocDefault));
+  return RBL_OK;
+}
+
+static int copy_h2d(rbl_ctx *c, void *dst, const void *src, size_t bytes)
+{
+  if (bytes <= (64u << 10)) { RBL_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RBL_OK; }
+  int rc = stage_ready(c); if (rc) return rc;
+  for (size_t off = 0; off < bytes; off += RBL_STAGE_BYTES) {
+    const size_t nb = (bytes - off < RBL_STAGE_BYTES) ? bytes - off : RBL_STAGE_BYTES;
+    RBL_HIP(c, hipStreamSynchronize(c->stream));   // staging buffer free again
+    std::memcpy(c->h_stage, (const char *)src + off, nb);
+    RBL_HIP(c, hipMemcpyAsync((char *)dst + off, c->h_stage, nb, hipMemcpyHostToDevice, c->stream));
+  }
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return RBL_OK;
+}
+
+static int copy_d2h(rbl_ctx *c, void *dst, const void *src, size_t bytes)
+{
+  if (bytes <= (64u << 10)) { RBL_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); return RBL_OK; }
+  int rc = stage_ready(c); if (rc) return rc;
+  for (size_t off = 0; off < bytes; off += RBL_STAGE_BYTES) {
+    const size_t nb = (bytes - off < RBL_STAGE_BYTES) ? bytes - off : RBL_STAGE_BYTES;
+    RBL_HIP(c, hipMemcpyAsync(c->h_stage, (const char *)src + off, nb, hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy((char *)dst + off, c->h_stage, nb);
+  }
+  return RBL_OK;
+}
+
 // read + clear the latched device flags (stream must be idle for h_err to be valid)
 static int finish_and_check(rbl_ctx *c)
 {
@@ -186,6 +227,7 @@ void rbl_destroy(rbl_ctx *c)
     }
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
   }
   delete c;
 }
@@ -330,7 +372,7 @@ int rbl_multi_body_pos(rbl_ctx *c, double *out)
   const size_t n3 = (size_t)3 * c->S.N_bod * c->S.N_blb;
   rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * n3); if (rc) return rc;
   rc = positions_dev(c, 0, c->S.N_bod, (double *)c->d_r.p); if (rc) return rc;
-  RBL_HIP(c, hipMemcpyAsync(out, c->d_r.p, sizeof(double) * n3, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, out, c->d_r.p, sizeof(double) * n3); if (rc__) return rc__; }
   RBL_HIP(c, hipStreamSynchronize(c->stream));
   return RBL_OK;
 }
@@ -346,12 +388,12 @@ static int apply_M_host(rbl_ctx *c, const double *F, const double *r, int64_t n3
   if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_F, vb * nrhs))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_U, vb * nrhs))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipMemcpyAsync(c->d_F.p, F, vb * nrhs, hipMemcpyHostToDevice, c->stream));
+  { int rc__ = copy_h2d(c, c->d_r.p, r, vb); if (rc__) return rc__; }
+  { int rc__ = copy_h2d(c, c->d_F.p, F, vb * nrhs); if (rc__) return rc__; }
   if ((rc = apply_M_multi_enqueue(c, c->S.wall, (const double *)c->d_F.p, (const double *)c->d_r.p, nbl, nrhs,
                                   (double *)c->d_U.p)))
     return rc;
-  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb * nrhs, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, out, c->d_U.p, vb * nrhs); if (rc__) return rc__; }
   return finish_and_check(c);
 }
 
@@ -408,8 +450,7 @@ static int build_block_invM(rbl_ctx *c)
     rbl_launch_build_M(c->stream, P, S.wall, false, (const double *)c->d_r.p + (size_t)b * m,
                        S.N_blb, (double *)c->d_mat.p + (size_t)b * msz, c->d_err);
   S.invM_block.resize(msz * S.N_bod);
-  RBL_HIP(c, hipMemcpyAsync(S.invM_block.data(), c->d_mat.p, sizeof(double) * msz * S.N_bod,
-                            hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, S.invM_block.data(), c->d_mat.p, sizeof(double) * msz * S.N_bod); if (rc__) return rc__; }
   if ((rc = finish_and_check(c))) return rc;
   for (int b = 0; b < S.N_bod; ++b)  // column-major copy of a symmetric-by-construction matrix
     if (rbl_inv_spd_or_lu(&S.invM_block[(size_t)b * msz], m, nullptr))
@@ -530,10 +571,10 @@ int rbl_rotne_prager_tensor(rbl_ctx *c, const double *r, int64_t n3, int scale_d
   const size_t mb = sizeof(double) * (size_t)n3 * (size_t)n3;
   if ((rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * n3))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, sizeof(double) * n3, hipMemcpyHostToDevice, c->stream));
+  { int rc__ = copy_h2d(c, c->d_r.p, r, sizeof(double) * n3); if (rc__) return rc__; }
   rbl_launch_build_M(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, scale_damp != 0,
                      (const double *)c->d_r.p, n3 / 3, (double *)c->d_mat.p, c->d_err);
-  RBL_HIP(c, hipMemcpyAsync(out, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, out, c->d_mat.p, mb); if (rc__) return rc__; }
   return finish_and_check(c);
 }
 
@@ -543,11 +584,11 @@ int rbl_cholesky_lower(rbl_ctx *c, double *M, int64_t n)
   int rc = rbl_dev_init(c); if (rc) return rc;
   const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(c->d_mat.p, M, mb, hipMemcpyHostToDevice, c->stream));
+  { int rc__ = copy_h2d(c, c->d_mat.p, M, mb); if (rc__) return rc__; }
   if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
   rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, true, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes, &c->chol_aux);
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
-  RBL_HIP(c, hipMemcpyAsync(M, c->d_mat.p, mb, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, M, c->d_mat.p, mb); if (rc__) return rc__; }
   return finish_and_check(c);
 }
 
@@ -748,11 +789,11 @@ int rbl_M_half_W_r(rbl_ctx *c, const double *r, int64_t n3, const double *W, uin
   if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_W, vb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_U, vb))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(c->d_r.p, r, vb, hipMemcpyHostToDevice, c->stream));
-  if (W) RBL_HIP(c, hipMemcpyAsync(c->d_W.p, W, vb, hipMemcpyHostToDevice, c->stream));
+  { int rc__ = copy_h2d(c, c->d_r.p, r, vb); if (rc__) return rc__; }
+  if (W) { int rc__ = copy_h2d(c, c->d_W.p, W, vb); if (rc__) return rc__; }
   else rbl_launch_normal(c->stream, seed, 0, n3, (double *)c->d_W.p);  // replaces rand_vector :730-741
   if ((rc = mhalf_dev(c, (const double *)c->d_r.p, n3 / 3, (const double *)c->d_W.p, method, (double *)c->d_U.p))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, out, c->d_U.p, vb); if (rc__) return rc__; }
   return finish_and_check(c);
 }
 
@@ -766,10 +807,10 @@ int rbl_M_half_W(rbl_ctx *c, const double *W, uint64_t seed, int method, double 
   if ((rc = rbl_dev_reserve(c, c->d_W, vb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_U, vb))) return rc;
   if ((rc = positions_dev(c, 0, c->S.N_bod, (double *)c->d_r.p))) return rc;  // multi_body_pos :662
-  if (W) RBL_HIP(c, hipMemcpyAsync(c->d_W.p, W, vb, hipMemcpyHostToDevice, c->stream));
+  if (W) { int rc__ = copy_h2d(c, c->d_W.p, W, vb); if (rc__) return rc__; }
   else rbl_launch_normal(c->stream, seed, 0, n3, (double *)c->d_W.p);
   if ((rc = mhalf_dev(c, (const double *)c->d_r.p, n3 / 3, (const double *)c->d_W.p, method, (double *)c->d_U.p))) return rc;
-  RBL_HIP(c, hipMemcpyAsync(out, c->d_U.p, vb, hipMemcpyDeviceToHost, c->stream));
+  { int rc__ = copy_d2h(c, out, c->d_U.p, vb); if (rc__) return rc__; }
   return finish_and_check(c);
 }
 

@@ -73,6 +73,7 @@ struct rbl_ctx {
   bool dev_bodies_valid = false, dev_pc_valid = false;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
+  void *h_stage = nullptr;    // pinned staging for large pageable host copies
   RblCholAux chol_aux;
   // tuning
   int tune_jsplit = 0;
