@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__
 constexpr int TS = 64;
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-template <bool WALL>
+template <bool WALL, int NI>
 __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r,
                                                     const double *__restrict__ F,
                                                     double *__restrict__ slabI,
@@ -155,15 +155,18 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
                                                     int C, int i_first, int i_step, RblParams P,
                                                     unsigned *err)
 {
+  // A lane owns NI rows (row "super-tile" I = tiles NI*I .. NI*I+NI-1): the j data read from
+  // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS];  // (x,y) (z,fx) (fy,fz) of the j tile
   __shared__ double sU[3][TS];                      // M_ji F_i sums for the j tile
   const int lane = threadIdx.x;
-  const int I = i_first + (int)blockIdx.x * i_step;
+  const int I = i_first + (int)blockIdx.x * i_step;  // super-tile index
   const int c = blockIdx.y;
-  if (I >= T) return;
+  const int It0 = NI * I;                            // first 64-row tile of this super-tile
+  if (It0 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
-  if (J0 < I) J0 = I;
+  if (J0 < It0) J0 = It0;
   if (J0 >= J1) return;
   const long Npad = (long)T * TS;
   unsigned flags = 0;
@@ -182,10 +185,12 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     }
   };
 
-  const long i = (long)I * TS + lane;
-  double xi, yi, zi, Fix, Fiy, Fiz;
-  load_blob(i, xi, yi, zi, Fix, Fiy, Fiz);
-  double uix = 0.0, uiy = 0.0, uiz = 0.0;
+  double xi[NI], yi[NI], zi[NI], Fix[NI], Fiy[NI], Fiz[NI], uix[NI], uiy[NI], uiz[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);
+    uix[a] = 0.0; uiy[a] = 0.0; uiz[a] = 0.0;
+  }
 
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
@@ -197,32 +202,57 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     sP2[lane] = (double2_t){Fjy, Fjz};
     sU[0][lane] = 0.0; sU[1][lane] = 0.0; sU[2][lane] = 0.0;
     __syncthreads();
-    if (J == I) {
-#pragma unroll 4
-      for (int jj = 0; jj < TS; ++jj) {
-        const double2_t a = sP0[jj], b = sP1[jj], d = sP2[jj];
-        rbl_pair_accum<WALL, true>(P, xi, yi, zi, a.x, a.y, b.x, b.y, d.x, d.y, jj == lane, uix, uiy,
-                                   uiz, flags);
-      }
-    } else {
+    if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
 #pragma unroll 2
       for (int s = 0; s < TS; ++s) {
         const int jj = (lane + s) & (TS - 1);
-        const double2_t a = sP0[jj], b = sP1[jj], d = sP2[jj];
-        double vx, vy, vz;
-        rbl_pair_sym<WALL>(P, xi, yi, zi, Fix, Fiy, Fiz, a.x, a.y, b.x, b.y, d.x, d.y, uix, uiy, uiz,
-                           vx, vy, vz, flags);
+        const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
+        double vx = 0.0, vy = 0.0, vz = 0.0;
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+          rbl_pair_sym<WALL>(P, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
+                             pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
         __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+    } else {              // J is one of the owned row tiles: per sub-tile diagonal / symmetric / skip
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        if (J == It0 + a) {
+#pragma unroll 4
+          for (int jj = 0; jj < TS; ++jj) {
+            const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
+            rbl_pair_accum<WALL, true>(P, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane,
+                                       uix[a], uiy[a], uiz[a], flags);
+          }
+        } else if (J > It0 + a) {
+          for (int s = 0; s < TS; ++s) {
+            const int jj = (lane + s) & (TS - 1);
+            const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
+            double vx = 0.0, vy = 0.0, vz = 0.0;
+            rbl_pair_sym<WALL>(P, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
+                               pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
+            __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    if (J > It0) {  // some owned row tile precedes J: column sums exist
       __syncthreads();
       double *p = slabJ + ((size_t)blockIdx.x * (size_t)Npad + (size_t)j) * 3;
       p[0] = sU[0][lane]; p[1] = sU[1][lane]; p[2] = sU[2][lane];
     }
   }
-  double *p = slabI + ((size_t)c * (size_t)Npad + (size_t)i) * 3;
-  p[0] = uix; p[1] = uiy; p[2] = uiz;
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    if (It0 + a < T) {
+      double *p = slabI + ((size_t)c * (size_t)Npad + (size_t)(It0 + a) * TS + lane) * 3;
+      p[0] = uix[a]; p[1] = uiy[a]; p[2] = uiz[a];
+    }
+  }
   if (flags) atomicOr(err, flags);
 }
 
@@ -231,25 +261,25 @@ __global__ __launch_bounds__(256) void k_reduce_sym(const double *__restrict__ s
                                                     const double *__restrict__ slabJ,
                                                     const double *__restrict__ r,
                                                     double *__restrict__ out, long N, int T, int C,
-                                                    int nch, int i_first, int i_step, RblParams P,
+                                                    int nch, int NI, int i_first, int i_step, RblParams P,
                                                     unsigned *err)
 {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over 3*N
   if (idx >= 3 * N) return;
   const long j = idx / 3;
   const int J = (int)(j / TS);
+  const int Is = J / NI;                                 // super-tile owning row tile J
   const size_t Npad3 = (size_t)T * TS * 3;
   double s = 0.0;
-  if (J >= i_first && (J - i_first) % i_step == 0)       // this launch owned row tile J
-    for (int c = J / C; c < nch; ++c) s += slabI[(size_t)c * Npad3 + idx];
+  if (Is >= i_first && (Is - i_first) % i_step == 0)     // this launch owned the rows of tile J
+    for (int c = (NI * Is) / C; c < nch; ++c) s += slabI[(size_t)c * Npad3 + idx];
   int k = 0;
-  for (int I = i_first; I < J; I += i_step, ++k) s += slabJ[(size_t)k * Npad3 + idx];
+  for (int I = i_first; NI * I < J; I += i_step, ++k) s += slabJ[(size_t)k * Npad3 + idx];
   double sc = P.nf;
   if (WALL) sc *= damp_of(P, r[3 * j + 2]);
   out[idx] = sc * s;
   if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
 }
-
 
 // ---------------------------------------------------------------------------
 // Multi-RHS matvec on the fp64 matrix cores: up to 16 right-hand sides per pass.
@@ -668,24 +698,42 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 }
 
 // ---- symmetric variant ------------------------------------------------------
-static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *C, int *nch, int *nrowsI)
+static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI)
 {
   const int t = (int)((n_blobs + TS - 1) / TS);
-  const int rowsI = (t + i_step - 1) / i_step;
-  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 8 rounds of wave-units; a unit holds <= C tiles
+  // 2 rows per lane once there is parallelism to spare: same speed on one GPU (the kernel is
+  // VALU-issue bound either way) but half the column-sum slab to write and re-read
+  const int ni = (t >= 128 * i_step) ? 2 : 1;
+  const int tsup = (t + ni - 1) / ni;                    // row super-tiles
+  const int rowsI = (tsup + i_step - 1) / i_step;
+  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 4 rounds of wave-units; a unit sweeps <= C column tiles
   const double pairs = 0.5 * (double)rowsI * (double)t;
-  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 8.0;
+  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 4.0;
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 64) c = 64;
-  *T = t; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
+  *T = t; *NI = ni; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
 }
 
 size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step)
 {
-  int T, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &C, &nch, &rowsI);
+  int T, NI, C, nch, rowsI;
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI);
   return ((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * sizeof(double);
+}
+
+template <bool WALL, int NI>
+static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
+                       int i_first, int i_step, double *d_out, double *slabI, double *slabJ, int T, int C, int nch,
+                       int rowsI, unsigned *d_err)
+{
+  dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
+  const int64_t n = 3 * n_blobs;
+  dim3 g2((unsigned)((n + 255) / 256)), b2(256);
+  hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
+                     i_first, i_step, P, d_err);
+  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C, nch, NI,
+                     i_first, i_step, P, d_err);
 }
 
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
@@ -693,23 +741,16 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
                             double *d_out, double *d_work, int n_cu, unsigned *d_err)
 {
   if (n_blobs <= 0) return;
-  int T, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &C, &nch, &rowsI);
+  int T, NI, C, nch, rowsI;
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI);
   double *slabI = d_work;
   double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3;
-  dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
-  const int64_t n = 3 * n_blobs;
-  dim3 g2((unsigned)((n + 255) / 256)), b2(256);
-  if (wall) {
-    hipLaunchKernelGGL(k_apply_M_sym<true>, grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T,
-                       C, i_first, i_step, P, d_err);
-    hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C,
-                       nch, i_first, i_step, P, d_err);
+  if (NI == 2) {
+    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
+    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
   } else {
-    hipLaunchKernelGGL(k_apply_M_sym<false>, grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T,
-                       C, i_first, i_step, P, d_err);
-    hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C,
-                       nch, i_first, i_step, P, d_err);
+    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
+    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
   }
 }
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
 // Symmetric pair (i != j): evaluates the scalar coefficients ONCE and applies the
 // block in both directions,
 //     U_i += M_ij F_j            (accumulated into uix,uiy,uiz)
-//     U_j  = M_ji F_i            (returned in ujx,ujy,ujz; caller adds it to j)
+//     U_j += M_ji F_i            (accumulated into ujx,ujy,ujz; caller adds it to j)
 // M_ji = M_ij^T holds exactly for the RPY part and, for the wall part, through the
 // role swap g <-> k (h = z_i instead of z_j): fact1, fact2, the e_z-part of fact3
 // and the h-free part of fact5 are shared.  ~127 fp64 ops per unordered pair vs
@@ -203,9 +203,9 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
     uix = __builtin_fma(A, Fjx, __builtin_fma(tBj, dx, uix));
     uiy = __builtin_fma(A, Fjy, __builtin_fma(tBj, dy, uiy));
     uiz = __builtin_fma(A, Fjz, __builtin_fma(tBj, dz, uiz));
-    ujx = __builtin_fma(A, Fix, tBi * dx);
-    ujy = __builtin_fma(A, Fiy, tBi * dy);
-    ujz = __builtin_fma(A, Fiz, tBi * dz);
+    ujx = __builtin_fma(A, Fix, __builtin_fma(tBi, dx, ujx));
+    ujy = __builtin_fma(A, Fiy, __builtin_fma(tBi, dy, ujy));
+    ujz = __builtin_fma(A, Fiz, __builtin_fma(tBi, dz, ujz));
     return;
   }
 
@@ -262,9 +262,9 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   uix = __builtin_fma(cF, Fjx, __builtin_fma(cxyj, dx, uix));
   uiy = __builtin_fma(cF, Fjy, __builtin_fma(cxyj, dy, uiy));
   uiz = __builtin_fma(cF, Fjz, __builtin_fma(tBj, dz, __builtin_fma(cEj, Rz, uiz + cZj)));
-  ujx = __builtin_fma(cF, Fix, cxyi * dx);
-  ujy = __builtin_fma(cF, Fiy, cxyi * dy);
-  ujz = __builtin_fma(cF, Fiz, __builtin_fma(tBi, dz, __builtin_fma(cEi, Rz, cZi)));
+  ujx = __builtin_fma(cF, Fix, __builtin_fma(cxyi, dx, ujx));
+  ujy = __builtin_fma(cF, Fiy, __builtin_fma(cxyi, dy, ujy));
+  ujz = __builtin_fma(cF, Fiz, __builtin_fma(tBi, dz, __builtin_fma(cEi, Rz, ujz + cZi)));
 }
 
 // ---------------------------------------------------------------------------
