@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep"],
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
+    ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps at N=1 (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")
     args = ap.parse_args()
 
@@ -255,6 +256,21 @@ def main():
         }
         if check is not None:
             line["check_rel_err_vs_oracle"] = check
+        if world == 1 and args.timestep_steps > 0:
+            # the reference has no time-step driver; ours (SURVEY.md 8d "fixed-work" step, krylov.py):
+            # 20 right-preconditioned GMRES iterations on apply_saddle (= 21 apply_M + diag PC + K ops) + evolve
+            from rigid_body_light_amd.krylov import DeterministicStepper
+            stp = DeterministicStepper(ctx, nb, nblb, dev)
+            Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+            stp.step(Fb, 20)
+            torch.cuda.synchronize(); ts0 = time.perf_counter()
+            for _ in range(args.timestep_steps):
+                m_it, res_it = stp.step(Fb, 20)
+            torch.cuda.synchronize(); ts = (time.perf_counter() - ts0) / args.timestep_steps
+            line["timestep"] = {"timesteps_per_sec": 1.0 / ts, "ms_per_timestep": ts * 1e3, "apply_M_per_timestep": 21,
+                                "definition": "deterministic fixed-work step: 20 GMRES iterations on the saddle operator "
+                                              "(diagonal PC) + evolve, all operators on the GPU",
+                                "gmres_residual": res_it, "steps_timed": args.timestep_steps}
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]

@@ -161,6 +161,32 @@ def test_apply_M_multi_mfma_vs_oracle(orc, wall, nrhs):
     assert rel(U3, U) < 1e-13
 
 
+def test_single_blob_analytic_and_edge_sizes(orc):
+    """N = 1 (isolated blob, Faxen wall expansions of SURVEY.md 8c), N = 2, N = 65 (tile + 1)."""
+    a, eta = 0.7, 1.3
+    F = np.array([0.3, -1.0, 2.0])
+    rb = solver(a, eta, False)
+    np.testing.assert_allclose(rb.apply_M(F, np.array([0.0, 0.0, 5.0])), F / (6 * np.pi * eta * a), rtol=1e-15)
+    rbw = solver(a, eta, True)
+    for h in (1.2, 2.0, 7.5):
+        par = 1 - 9 / 16 / h + 1 / 8 / h ** 3 - 1 / 16 / h ** 5
+        per = 1 - 9 / 8 / h + 1 / 2 / h ** 3 - 1 / 8 / h ** 5
+        np.testing.assert_allclose(rbw.apply_M(F, np.array([0.0, 0.0, h * a])),
+                                   F * np.array([par, par, per]) / (6 * np.pi * eta * a), rtol=1e-13)
+    rng = np.random.default_rng(8)
+    for n in (2, 63, 64, 65, 129):
+        r = rng.uniform(0, 6, (n, 3)) * np.array([1, 1, 0.5]) + np.array([0, 0, 0.8])
+        Fn = rng.standard_normal(3 * n)
+        for obj, wall in ((rb, False), (rbw, True)):
+            for variant in (1, 2):
+                obj.cb.set_tuning(0, variant)
+                assert rel(obj.apply_M(Fn, r), orc.apply_M(Fn, r, a, eta, wall, mode="dense")) < 1e-12
+    with pytest.raises(RuntimeError):
+        rb.cb.apply_M(np.zeros(0), np.zeros(0))            # empty input is a size error, not a crash
+    with pytest.raises(RuntimeError):
+        rb.cb.apply_M(np.zeros(4), np.zeros(4))            # not a multiple of 3
+
+
 def test_apply_M_interface_behaviour():
     """Mirror of reference tests/test_interface.py:149-177 and tests/test_wall.py."""
     X, Q = random_positions(2, seed=30)
