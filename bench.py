@@ -106,6 +106,60 @@ def timestep_mode(args, dev):
         "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual_after_%d_iters" % iters: res[-1]}), flush=True)
 
 
+def brownian_mode(args, dev, world, rank):
+    """BASELINE cfg 4: wall-corrected + Brownian on N GPUs.  1 step = one Brownian increment M^{1/2} W by
+    Lanczos (tol 1e-3) on the tile-pair-sharded product (all-gather once, one all-reduce per iteration)."""
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.dist import ShardedMobility
+    from rigid_body_light_amd.krylov import lanczos_mhalf
+    nb, nblb, wall = CONFIGS[args.config]
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
+    r_local = torch.empty(3 * (sm.row1 - sm.row0), dtype=torch.float64, device=dev)
+    ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
+    sm.set_positions_local(r_local)
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(3 * N)).to(dev)   # identical on every rank
+
+    def A(v):    # wall=True: the kernel applies B M B; vectors are replicated, only this product communicates
+        part = torch.empty(3 * N, dtype=torch.float64, device=dev)
+        ctx.apply_M_sym(v.contiguous().data_ptr(), sm.r_full.data_ptr(), N, rank, world, part.data_ptr())
+        return sm.all_reduce_sum(part)
+
+    its = 0
+    for _ in range(args.warmup):
+        lanczos_mhalf(A, W, 100, 1e-3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y, its, ch = lanczos_mhalf(A, W, 100, 1e-3)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    sec = torch.tensor([(time.perf_counter() - t0) / args.steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+    ctx.sync_check()
+    if rank == 0:
+        sec = float(sec.item())
+        print(json.dumps({
+            "metric": "Brownian increments/sec (M^{1/2} W by Lanczos to 1e-3, %d iterations), %d x shell_N_%d, %s, fp64"
+                      % (its, nb, nblb, "wall-corrected" if wall else "free-space"),
+            "value": 1.0 / sec, "unit": "increments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": "BASELINE.json configs[3]" if args.config == "cfg3" else args.config,
+                                            "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
+                                            "parallelism": "tile-pair-sharded x%d, all-reduce(U) per Lanczos iteration" % world},
+            "lanczos_iterations": its, "mf_gflops": its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +171,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 heuristic, 1 ordered-rows kernel, 2 symmetric kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on ONE GPU)")
-    ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep"],
+    ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep", "brownian"],
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
     ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps at N=1 (0 = skip)")
@@ -146,6 +200,8 @@ def main():
 
     if args.mode == "timestep":
         return timestep_mode(args, dev)
+    if args.mode == "brownian":
+        return brownian_mode(args, dev, world, rank)
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb

@@ -79,3 +79,43 @@ class DeterministicStepper:
         self.ctx.evolve(U.cpu().numpy())          # O(N_bod) host update, then K/positions rebuilt on the GPU
         self.ctx.sync_check()
         return m, resid
+
+
+def lanczos_mhalf(apply_A, W, max_iter=100, tol=1e-3, check_every=1):
+    """Matrix-free M^{1/2} W by Lanczos (same algorithm as librbl's rbl_M_half_W(..., LANCZOS), written
+    on torch vectors so the operator can be the multi-GPU sharded product: with the symmetric
+    sharding every rank holds the full vectors, the recurrences are replicated and only `apply_A`
+    communicates).  apply_A: tensor -> tensor computing (B M B) v.  Returns (y, iterations, change)."""
+    n = W.numel()
+    V = torch.empty(max_iter + 1, n, dtype=W.dtype, device=W.device)
+    wnorm = float(torch.linalg.norm(W))
+    if wnorm == 0.0:
+        return torch.zeros_like(W), 0, 0.0
+    V[0] = W / wnorm
+    alpha, beta = [], []
+    y_prev, y_cur, change, m = None, None, 1.0, 0
+    for it in range(max_iter):
+        u = apply_A(V[it])
+        if it > 0:
+            u = u - beta[-1] * V[it - 1]
+        al = float(torch.dot(V[it], u))
+        u = u - al * V[it]
+        be = float(torch.linalg.norm(u))
+        alpha.append(al)
+        m = it + 1
+        if m % check_every == 0 or it + 1 == max_iter:
+            T = np.diag(alpha) + np.diag(beta, 1) + np.diag(beta, -1)
+            lam, Z = np.linalg.eigh(T)
+            y_cur = wnorm * (Z @ (np.sqrt(np.clip(lam, 0.0, None)) * Z[0]))
+            if y_prev is not None:
+                yp = np.zeros(m); yp[: y_prev.size] = y_prev
+                change = float(np.linalg.norm(y_cur - yp) / np.linalg.norm(y_cur))
+            y_prev = y_cur
+            if change < tol:
+                break
+        if be < 1e-300 or it + 1 == max_iter:
+            break
+        beta.append(be)
+        V[it + 1] = u / be
+    out = torch.from_numpy(y_cur).to(W.device) @ V[:m]
+    return out, m, change

@@ -508,3 +508,36 @@ def test_gmres_timestep_small(orc, shell12):
     X0 = ctx.get_config(nb)[0].copy()
     st.step(Fb, iters=20)
     assert np.linalg.norm(ctx.get_config(nb)[0] - X0) > 0
+
+
+def test_torch_lanczos_matches_library_lanczos():
+    """krylov.lanczos_mhalf (the form used with the multi-GPU sharded product) == librbl's Lanczos."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import lanczos_mhalf
+    c = make_config(6, 162, True)
+    N = 6 * 162
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], True, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, 6, r.data_ptr())
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(3 * N)).to(dev)
+
+    def A(v):
+        out = torch.empty_like(v)
+        ctx.apply_M(v.contiguous().data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())   # wall=True: B M B
+        return out
+
+    y, m, ch = lanczos_mhalf(A, W, max_iter=150, tol=1e-8)
+    ctx.set_lanczos(150, 1e-8)
+    ref = torch.empty_like(W)
+    ctx.M_half_W(r.data_ptr(), N, W.data_ptr(), "lanczos", ref.data_ptr())
+    ctx.sync_check()
+    it, res = ctx.lanczos_report()
+    assert abs(m - it) <= 1
+    assert float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)) < 1e-7
+    # (M^{1/2})^2 = M :  apply the square root twice
+    y2, _, _ = lanczos_mhalf(A, y, max_iter=150, tol=1e-9)
+    assert float(torch.linalg.norm(y2 - A(W)) / torch.linalg.norm(y2)) < 1e-5
