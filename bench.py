@@ -85,25 +85,32 @@ def timestep_mode(args, dev):
     c = make_config(nb, nblb, wall)
     N = nb * nblb
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    if args.pc == "block":
+        from rigid_body_light_amd._lib import lib
+        lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
     stp = DeterministicStepper(ctx, nb, nblb, dev)
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
-    iters = 20
-    res = []
+    iters = 20 if args.rtol <= 0 else 200
+    rtol = args.rtol if args.rtol > 0 else None
+    res, used = [], []
     for _ in range(args.warmup):
-        stp.step(Fb, iters)
+        stp.step(Fb, iters, rtol)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
-        res.append(stp.step(Fb, iters)[1])
+        m_used, r_last = stp.step(Fb, iters, rtol)
+        res.append(r_last); used.append(m_used)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     sec = (t1 - t0) / args.steps
+    iters = int(round(sum(used) / len(used)))
     print(json.dumps({
-        "metric": "timesteps/sec (deterministic fixed-work step: %d GMRES iterations = %d apply_M + PC + K ops + evolve), "
-                  "%d x shell_N_%d, %s, fp64" % (iters, iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
+        "metric": "timesteps/sec (deterministic step: %d GMRES iterations (%s, %s PC) = %d apply_M + PC + K ops + evolve), "
+                  "%d x shell_N_%d, %s, fp64" % (iters, "fixed work" if rtol is None else "converged to %g" % rtol, args.pc,
+                                                 iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
         "value": 1.0 / sec, "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
-        "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual_after_%d_iters" % iters: res[-1]}), flush=True)
+        "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used}), flush=True)
 
 
 def brownian_mode(args, dev, world, rank):
@@ -175,6 +182,9 @@ def main():
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
     ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps at N=1 (0 = skip)")
+    ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
+    ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
+                    "instead of the fixed 20 iterations")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")
     args = ap.parse_args()
 

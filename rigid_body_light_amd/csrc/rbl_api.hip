@@ -216,7 +216,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -256,7 +256,7 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   return RBL_OK;
 }
 
-int rbl_set_blk_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.block_pc = v != 0; return RBL_OK; }
+int rbl_set_blk_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.block_pc = v != 0; c->S.pc_set = false; c->dev_pc_valid = false; return RBL_OK; }
 int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; c->dev_pc_valid = false; return RBL_OK; }
 
 int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
@@ -434,42 +434,24 @@ static int build_diag_invM(rbl_ctx *c)
   return RBL_OK;
 }
 
-// Block_diag_invM (:461-487): per-body dense mobility assembled on the GPU
-// (k_build_M on that body's blobs), inverted on the host.
-static int build_block_invM(rbl_ctx *c)
-{
-  RblBodyState &S = c->S;
-  int rc = rbl_dev_init(c); if (rc) return rc;
-  const int m = 3 * S.N_blb;
-  const size_t msz = (size_t)m * m;
-  if ((rc = rbl_dev_reserve(c, c->d_r, sizeof(double) * (size_t)m * S.N_bod))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_mat, sizeof(double) * msz * S.N_bod))) return rc;
-  if ((rc = positions_dev(c, 0, S.N_bod, (double *)c->d_r.p))) return rc;
-  const RblParams P = rbl_make_params(S.a, S.eta);
-  for (int b = 0; b < S.N_bod; ++b)
-    rbl_launch_build_M(c->stream, P, S.wall, false, (const double *)c->d_r.p + (size_t)b * m,
-                       S.N_blb, (double *)c->d_mat.p + (size_t)b * msz, c->d_err);
-  S.invM_block.resize(msz * S.N_bod);
-  { int rc__ = copy_d2h(c, S.invM_block.data(), c->d_mat.p, sizeof(double) * msz * S.N_bod); if (rc__) return rc__; }
-  if ((rc = finish_and_check(c))) return rc;
-  for (int b = 0; b < S.N_bod; ++b)  // column-major copy of a symmetric-by-construction matrix
-    if (rbl_inv_spd_or_lu(&S.invM_block[(size_t)b * msz], m, nullptr))
-      return rbl_fail(c, RBL_ERR_SINGULAR, "per-body mobility block is singular");
-  // the device matrix was column-major; inverse of the transpose = transpose of the
-  // inverse, and apply_invM reads row-major -> transpose once
-  for (int b = 0; b < S.N_bod; ++b) {
-    double *A = &S.invM_block[(size_t)b * msz];
-    for (int p = 0; p < m; ++p)
-      for (int q = p + 1; q < m; ++q) std::swap(A[(size_t)p * m + q], A[(size_t)q * m + p]);
-  }
-  return RBL_OK;
-}
+int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out);
 
 int rbl_apply_PC(rbl_ctx *c, const double *in, double *out)
 {
   int rc = need_K(c); if (rc) return rc;
+  if (c->S.block_pc) {
+    // Block_diag_invM (:461-487) lives on the GPU: batched per-body Cholesky + substitution
+    if ((rc = rbl_dev_init(c))) return rc;
+    const size_t nv = (size_t)3 * c->S.N_bod * c->S.N_blb + (size_t)6 * c->S.N_bod;
+    if ((rc = rbl_dev_reserve(c, c->d_tmp, sizeof(double) * 2 * nv))) return rc;
+    double *din = (double *)c->d_tmp.p, *dout = din + nv;
+    if ((rc = copy_h2d(c, din, in, sizeof(double) * nv))) return rc;
+    if ((rc = rbl_apply_PC_dev(c, din, dout))) return rc;
+    if ((rc = copy_d2h(c, out, dout, sizeof(double) * nv))) return rc;
+    return finish_and_check(c);
+  }
   if (!c->S.pc_set) {
-    rc = c->S.block_pc ? build_block_invM(c) : build_diag_invM(c);
+    rc = build_diag_invM(c);
     if (rc) return rc;
   }
   rc = rbl_body_apply_PC(c->S, in, out, c->last_error);
@@ -972,12 +954,61 @@ int rbl_KT_x_Lam_dev(rbl_ctx *c, const double *d_lam, double *d_out)
   return RBL_OK;
 }
 
+// Block_diag_invM on the device (:461-487): per-body dense mobility (batched k_build_M), batched
+// in-place Cholesky on the matrix cores, then invM_b v = (L L^T)^-1 v by k_block_solve.
+static int pc_block_build(rbl_ctx *c)
+{
+  const RblBodyState &S = c->S;
+  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  int rc;
+  if ((rc = rbl_dev_reserve(c, c->d_blkL, sizeof(double) * (size_t)msz * S.N_bod))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_blkLinv, rbl_cholesky_batched_work_bytes(m, S.N_bod)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
+  const RblParams P = rbl_make_params(S.a, S.eta);
+  rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p, S.N_blb, S.N_bod, (double *)c->d_blkL.p,
+                             msz, c->d_err);
+  rc = rbl_launch_cholesky_batched(c->stream, (double *)c->d_blkL.p, m, S.N_bod, msz, c->d_err, (double *)c->d_blkLinv.p);
+  if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
+  // Ninv_b = K_b^T invM_b K_b, column by column (bodies do not couple), then its 6x6 Cholesky
+  double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *cols = w2 + n3, *Uunit = cols + 36 * (size_t)S.N_bod;
+  for (int cc = 0; cc < 6; ++cc) {
+    rbl_launch_unit_U(c->stream, S.N_bod, cc, Uunit);
+    rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Uunit, S.N_blb, N, w1, nullptr, 0.0);
+    if ((rc = rbl_launch_block_solve(c->stream, (const double *)c->d_blkL.p, m, S.N_bod, msz, (const double *)c->d_blkLinv.p,
+                                     w1, w2, m)))
+      return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
+    rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, w2, S.N_blb, S.N_bod, cols + (size_t)cc * 6 * S.N_bod);
+  }
+  rbl_launch_pc_block_ninv(c->stream, cols, S.N_bod, (double *)c->d_NL.p, c->d_err);
+  return RBL_OK;
+}
+
+static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
+{
+  const RblBodyState &S = c->S;
+  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *f6 = w2 + n3 + 36 * (size_t)S.N_bod + 6 * (size_t)S.N_bod;
+  const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p, *lev = (const double *)c->d_lever.p;
+  int rc;
+  if ((rc = rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, d_in, w1, m))) return rc;      // invM slip
+  rbl_launch_KT_x_Lam(c->stream, lev, w1, S.N_blb, S.N_bod, f6);                                     // K^T (invM slip)
+  rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p, d_in + n3, f6, S.N_bod, d_out + n3); // U  (:601-608)
+  rbl_launch_K_x_U(c->stream, lev, d_out + n3, S.N_blb, N, w2, d_in, 1.0);                           // slip + K U
+  return rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, w2, d_out, m);                    // Lambda (:610)
+}
+
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
 {
   int rc = sync_bodies(c); if (rc) return rc;
-  if (c->S.block_pc)
-    return rbl_fail(c, RBL_ERR_STATE, "apply_PC_dev: the block-diagonal preconditioner is host-only (use rbl_apply_PC)");
   const RblBodyState &S = c->S;
+  if (S.block_pc) {
+    if (!c->dev_pc_valid) {
+      if ((rc = pc_block_build(c))) return rc;
+      c->dev_pc_valid = true;
+    }
+    return pc_block_apply(c, d_in, d_out);
+  }
   if (!c->dev_pc_valid) {
     const size_t N = (size_t)S.N_bod * S.N_blb;
     if ((rc = rbl_dev_reserve(c, c->d_invM2, sizeof(double) * 2 * N))) return rc;

@@ -211,7 +211,80 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
   }
 }
 
+// block-diagonal PC: assemble Ninv_b = K_b^T invM_b K_b from its six columns and factor it (6x6)
+__global__ void k_pc_block_ninv(const double *__restrict__ cols /* [6][6*N_bod]: column c of every body */,
+                                int N_bod, double *__restrict__ NL, unsigned *err)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N_bod) return;
+  double L[36];
+  for (int c = 0; c < 6; ++c)
+    for (int p = 0; p < 6; ++p) L[6 * p + c] = cols[(size_t)c * 6 * N_bod + 6 * b + p];
+  bool ok = true;
+  for (int j = 0; j < 6; ++j) {
+    double d = L[6 * j + j];
+    for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+    if (!(d > 0.0)) ok = false;
+    d = sqrt(d);
+    L[6 * j + j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = L[6 * i + j];
+      for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = v / d;
+    }
+    for (int i = 0; i < j; ++i) L[6 * i + j] = 0.0;
+  }
+  if (!ok) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+  for (int e = 0; e < 36; ++e) NL[36 * (size_t)b + e] = L[e];
+}
+
+// U_b = Ninv_b^-1 (-F_b - f_b) through the 6x6 Cholesky factor (:601-608); also copies U to out
+__global__ void k_pc_block_mid(const double *__restrict__ NL, const double *__restrict__ F,
+                               const double *__restrict__ f, int N_bod, double *__restrict__ U)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N_bod) return;
+  const double *L = NL + 36 * (size_t)b;
+  double y[6], u[6];
+  for (int p = 0; p < 6; ++p) {
+    double v = -F[6 * b + p] - f[6 * b + p];
+    for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
+    y[p] = v / L[6 * p + p];
+  }
+  for (int p = 5; p >= 0; --p) {
+    double v = y[p];
+    for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
+    u[p] = v / L[6 * p + p];
+  }
+  for (int p = 0; p < 6; ++p) U[6 * b + p] = u[p];
+}
+
+__global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * N_bod) U[i] = (i % 6 == c) ? 1.0 : 0.0;
+}
+
 }  // namespace
+
+void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err)
+{
+  if (N_bod <= 0) return;
+  hipLaunchKernelGGL(k_pc_block_ninv, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_cols, N_bod, d_NL, d_err);
+}
+
+void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
+                             double *d_U)
+{
+  if (N_bod <= 0) return;
+  hipLaunchKernelGGL(k_pc_block_mid, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_NL, d_F, d_f, N_bod, d_U);
+}
+
+void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)
+{
+  if (N_bod <= 0) return;
+  hipLaunchKernelGGL(k_unit_U, dim3((6 * N_bod + 255) / 256), dim3(256), 0, st, N_bod, c, d_U);
+}
 
 void rbl_launch_body_geom(hipStream_t st, const double *dX, const double *dQ, const double *dcfg,
                           int N_blb, int64_t N, double *d_lever, double *d_pos)

@@ -27,8 +27,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // parities).  The same wave then inverts L by forward substitution (lane = column of
 // L^-1) and writes Linv (IB x IB, row-major [c][m]) for the MFMA triangular solve.
 __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
-                                              double *__restrict__ Linv, unsigned *err)
+                                              double *__restrict__ Linv, unsigned *err, long strideA,
+                                              long strideL)
 {
+  A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
+  Linv += (size_t)blockIdx.z * (size_t)strideL;
   __shared__ double S[IB][IB + 1];
   __shared__ double Y[IB][IB + 1];
   __shared__ double dinv[IB];
@@ -95,8 +98,11 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
 // so that the stores are 128-B runs along the rows of column-major A.  In place: a wave reads
 // all 32 columns of its 64 rows before it writes them.
 __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long n, long k, int nb,
-                                                   const double *__restrict__ Linv)
+                                                   const double *__restrict__ Linv, long strideA,
+                                                   long strideL)
 {
+  A += (size_t)blockIdx.z * (size_t)strideA;
+  Linv += (size_t)blockIdx.z * (size_t)strideL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, l4 = lane >> 4;
   const long i0 = k + nb + ((long)blockIdx.x * 4 + wave) * 64;
@@ -151,8 +157,9 @@ constexpr int KC = 16;
 constexpr int LDP = 144;
 
 __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, long n, long r0,
-                                                      long c1, long k0, int K)
+                                                      long c1, long k0, int K, long strideA)
 {
+  A += (size_t)blockIdx.z * (size_t)strideA;
   __shared__ double sI[2][KC * LDP];
   __shared__ double sJ[2][KC * LDP];
   const int bi = blockIdx.x, bj = blockIdx.y;
@@ -310,18 +317,18 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
     }
     for (int64_t kk = k; kk < pend; kk += IB) {
       const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
-      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Linv, d_err);
+      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Linv, d_err, 0L, 0L);
       const int64_t rows = n - (kk + nb);
       if (rows > 0) {
         hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_M,
-                           (long)n, (long)kk, nb, Linv);
+                           (long)n, (long)kk, nb, Linv, 0L, 0L);
         // rank-nb update of the rest of THIS panel: rows >= kk+nb, cols [kk+nb, pend)
         const int64_t r0 = kk + nb;
         if (r0 < pend) {
           if (nb != IB) return RBL_ERR_SIZE;  // cannot happen: a short step is always the last of its panel
           dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128));
           hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0,
-                             (long)pend, (long)kk, nb);
+                             (long)pend, (long)kk, nb, 0L);
         }
       }
     }
@@ -334,7 +341,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       {
         dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((lend - pend + 127) / 128));
         hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)pend, (long)lend,
-                           (long)k, (int)pw);
+                           (long)k, (int)pw, 0L);
       }
       if (look) {
         if (hipEventRecord(aux->ev[1], sb) != hipSuccess) return RBL_ERR_HIP;
@@ -343,7 +350,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       if (lend < n) {                                          // R_p: everything right of it
         dim3 grid((unsigned)((n - lend + 127) / 128), (unsigned)((n - lend + 127) / 128));
         hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)lend, (long)n,
-                           (long)k, (int)pw);
+                           (long)k, (int)pw, 0L);
       }
     }
   }
@@ -354,6 +361,121 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
   if (zero_upper)
     hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)n, (unsigned)((n + 255) / 256)), dim3(256), 0,
                        st, d_M, (long)n);
+  return RBL_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Batched variant for the block-diagonal preconditioner (reference Block_diag_invM, :461-487):
+// `batch` SPD matrices of order n (one per rigid body, n = 3 N_blb), stride strideA doubles.
+// Same kernels with blockIdx.z = matrix; plain right-looking IB-steps (the matrices are small, so
+// no outer panels / lookahead).  All diagonal-block inverses are KEPT: Linv[b][step][IB*IB] feed the
+// substitution kernel below.  K of the rank update is always IB, a multiple of KC.
+// ---------------------------------------------------------------------------------------------
+size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
+{
+  const int64_t nsteps = (n + IB - 1) / IB;
+  return sizeof(double) * (size_t)batch * (size_t)nsteps * IB * IB;
+}
+
+int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
+                                unsigned *d_err, double *d_Linv)
+{
+  const int64_t nsteps = (n + IB - 1) / IB;
+  const long strideL = (long)(nsteps * IB * IB);
+  int64_t step = 0;
+  for (int64_t kk = 0; kk < n; kk += IB, ++step) {
+    const int nb = (int)((n - kk < IB) ? (n - kk) : IB);
+    double *Lk = d_Linv + (size_t)step * IB * IB;
+    hipLaunchKernelGGL(k_potf2, dim3(1, 1, batch), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Lk, d_err,
+                       (long)strideA, strideL);
+    const int64_t rows = n - (kk + nb);
+    if (rows > 0) {
+      hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256), 1, batch), dim3(256), 0, st, d_M,
+                         (long)n, (long)kk, nb, Lk, (long)strideA, strideL);
+      const int64_t r0 = kk + nb;
+      dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((n - r0 + 127) / 128), batch);
+      hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0, (long)n, (long)kk, nb,
+                         (long)strideA);
+    }
+  }
+  return RBL_OK;
+}
+
+namespace {
+// x = (L L^T)^-1 v for every matrix of the batch: one workgroup per matrix, the vector lives in
+// LDS, L is streamed once per sweep.  Diagonal IB-blocks are applied through their stored
+// inverses (no sequential 32-step chains).
+//   forward :  t = Linv_kk y_k ; y_k = t ; y[rest] -= L[rest, k-block] t
+//   backward:  x_k = Linv_kk^T y_k ;        y[before] -= L[k-block, before]^T x_k
+constexpr int SOLVE_MAXN = 8192;   // 64 KB of LDS
+
+__global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ L, long n, long strideA,
+                                                     const double *__restrict__ Linv, long strideL,
+                                                     const double *__restrict__ in, double *__restrict__ out,
+                                                     long vec_stride)
+{
+  extern __shared__ double y[];                      // n doubles + IB scratch
+  double *tbuf = y + n;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double *Lb = L + (size_t)b * (size_t)strideA;
+  const double *Lib = Linv + (size_t)b * (size_t)strideL;
+  const double *v = in + (size_t)b * (size_t)vec_stride;
+  for (long e = t; e < n; e += 256) y[e] = v[e];
+  __syncthreads();
+  const int nsteps = (int)((n + IB - 1) / IB);
+  for (int s = 0; s < nsteps; ++s) {                 // ---- forward: L y' = v
+    const long k = (long)s * IB;
+    const int nb = (int)((n - k < IB) ? n - k : IB);
+    const double *Li = Lib + (size_t)s * IB * IB;
+    if (t < IB) {
+      double acc = 0.0;
+      if (t < nb)
+        for (int m = 0; m <= t; ++m) acc = __builtin_fma(Li[t * IB + m], y[k + m], acc);
+      tbuf[t] = acc;
+    }
+    __syncthreads();
+    if (t < nb) y[k + t] = tbuf[t];
+    for (long r = k + nb + t; r < n; r += 256) {
+      double acc = y[r];
+      const double *col = Lb + (size_t)k * (size_t)n + r;
+      for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[m], acc);
+      y[r] = acc;
+    }
+    __syncthreads();
+  }
+  for (int s = nsteps - 1; s >= 0; --s) {            // ---- backward: L^T x = y'
+    const long k = (long)s * IB;
+    const int nb = (int)((n - k < IB) ? n - k : IB);
+    const double *Li = Lib + (size_t)s * IB * IB;
+    if (t < IB) {
+      double acc = 0.0;
+      if (t < nb)
+        for (int m = t; m < nb; ++m) acc = __builtin_fma(Li[m * IB + t], y[k + m], acc);   // Linv^T
+      tbuf[t] = acc;
+    }
+    __syncthreads();
+    if (t < nb) y[k + t] = tbuf[t];
+    for (long c = t; c < k; c += 256) {              // columns before the block: y[c] -= sum_r L[k+r][c] x_r
+      double acc = y[c];
+      const double *row = Lb + (size_t)c * (size_t)n + k;
+      for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[m], acc);
+      y[c] = acc;
+    }
+    __syncthreads();
+  }
+  double *o = out + (size_t)b * (size_t)vec_stride;
+  for (long e = t; e < n; e += 256) o[e] = y[e];
+}
+}  // namespace
+
+int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
+                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride)
+{
+  if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
+  const int64_t nsteps = (n + IB - 1) / IB;
+  hipLaunchKernelGGL(k_block_solve, dim3(batch), dim3(256), sizeof(double) * (size_t)(n + IB), st, d_L, (long)n,
+                     (long)strideA, d_Linv, (long)(nsteps * IB * IB), d_in, d_out, (long)vec_stride);
   return RBL_OK;
 }
 

@@ -70,6 +70,7 @@ struct rbl_ctx {
   hipStream_t stream = nullptr;
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
+  RblDevBuf d_blkL, d_blkLinv, d_pcw;               // block-diagonal PC: per-body Cholesky factors + work
   bool dev_bodies_valid = false, dev_pc_valid = false;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
@@ -129,6 +130,11 @@ void rbl_launch_normal(hipStream_t st, uint64_t seed, uint64_t offset, int64_t n
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
                         double *d_work, size_t work_bytes, const RblCholAux *aux);
 size_t rbl_cholesky_work_bytes(int64_t n);
+size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch);
+int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
+                                unsigned *d_err, double *d_Linv);
+int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
+                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
                            double *d_out, double *d_part);
 size_t rbl_trmv_part_bytes(int64_t n);
@@ -153,3 +159,9 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
                               unsigned *d_err);
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
                               int N_blb, int N_bod, const double *d_in, double *d_out);
+void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err);
+void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
+                             double *d_U);
+void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
+void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
+                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

@@ -419,8 +419,11 @@ constexpr int JB = 16;
 template <bool WALL>
 __global__ __launch_bounds__(256) void k_build_M(const double *__restrict__ r,
                                                  double *__restrict__ M, long N,
-                                                 int scale_damp, RblParams P, unsigned *err)
+                                                 int scale_damp, RblParams P, unsigned *err,
+                                                 long strideR, long strideM)
 {
+  r += (size_t)blockIdx.z * (size_t)strideR;   // batched: one blob set / one matrix per blockIdx.z
+  M += (size_t)blockIdx.z * (size_t)strideM;
   __shared__ double col[3][768];
   const int t = threadIdx.x;
   const long i0 = (long)blockIdx.x * 256;
@@ -814,10 +817,24 @@ void rbl_launch_build_M(hipStream_t st, const RblParams &P, bool wall, bool scal
   dim3 grid((unsigned)((n_blobs + 255) / 256), (unsigned)((n_blobs + JB - 1) / JB)), block(256);
   if (wall)
     hipLaunchKernelGGL(k_build_M<true>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
-                       scale_damp ? 1 : 0, P, d_err);
+                       scale_damp ? 1 : 0, P, d_err, 0L, 0L);
   else
     hipLaunchKernelGGL(k_build_M<false>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
-                       scale_damp ? 1 : 0, P, d_err);
+                       scale_damp ? 1 : 0, P, d_err, 0L, 0L);
+}
+
+// `batch` independent blob sets of n_blobs each (one rigid body each), matrices strideM apart
+void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
+                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err)
+{
+  if (n_blobs <= 0 || batch <= 0) return;
+  dim3 grid((unsigned)((n_blobs + 255) / 256), (unsigned)((n_blobs + JB - 1) / JB), (unsigned)batch), block(256);
+  if (wall)
+    hipLaunchKernelGGL(k_build_M<true>, grid, block, 0, st, d_r, d_M, (long)n_blobs, 0, P, d_err,
+                       (long)(3 * n_blobs), (long)strideM);
+  else
+    hipLaunchKernelGGL(k_build_M<false>, grid, block, 0, st, d_r, d_M, (long)n_blobs, 0, P, d_err,
+                       (long)(3 * n_blobs), (long)strideM);
 }
 
 void rbl_launch_pair_blocks(hipStream_t st, const RblParams &P, bool wall, int mode,
