@@ -368,8 +368,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
 // ---------------------------------------------------------------------------------------------
 // Batched variant for the block-diagonal preconditioner (reference Block_diag_invM, :461-487):
 // `batch` SPD matrices of order n (one per rigid body, n = 3 N_blb), stride strideA doubles.
-// Same kernels with blockIdx.z = matrix; plain right-looking IB-steps (the matrices are small, so
-// no outer panels / lookahead).  All diagonal-block inverses are KEPT: Linv[b][step][IB*IB] feed the
+// Same kernels with blockIdx.z = matrix, outer panels of 256 columns, no lookahead.  All diagonal-block inverses are KEPT: Linv[b][step][IB*IB] feed the
 // substitution kernel below.  K of the rank update is always IB, a multiple of KC.
 // ---------------------------------------------------------------------------------------------
 size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
@@ -381,21 +380,32 @@ size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
 int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
                                 unsigned *d_err, double *d_Linv)
 {
+  constexpr int NBB = 256;   // outer panel of the batched factorisation: rank-256 trailing updates
   const int64_t nsteps = (n + IB - 1) / IB;
   const long strideL = (long)(nsteps * IB * IB);
-  int64_t step = 0;
-  for (int64_t kk = 0; kk < n; kk += IB, ++step) {
-    const int nb = (int)((n - kk < IB) ? (n - kk) : IB);
-    double *Lk = d_Linv + (size_t)step * IB * IB;
-    hipLaunchKernelGGL(k_potf2, dim3(1, 1, batch), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Lk, d_err,
-                       (long)strideA, strideL);
-    const int64_t rows = n - (kk + nb);
-    if (rows > 0) {
-      hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256), 1, batch), dim3(256), 0, st, d_M,
-                         (long)n, (long)kk, nb, Lk, (long)strideA, strideL);
-      const int64_t r0 = kk + nb;
-      dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((n - r0 + 127) / 128), batch);
-      hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0, (long)n, (long)kk, nb,
+  for (int64_t k = 0; k < n; k += NBB) {
+    const int64_t pw = (n - k < NBB) ? (n - k) : NBB;
+    const int64_t pend = k + pw;
+    for (int64_t kk = k; kk < pend; kk += IB) {
+      const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
+      double *Lk = d_Linv + (size_t)(kk / IB) * IB * IB;
+      hipLaunchKernelGGL(k_potf2, dim3(1, 1, batch), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Lk, d_err,
+                         (long)strideA, strideL);
+      const int64_t rows = n - (kk + nb);
+      if (rows > 0) {
+        hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256), 1, batch), dim3(256), 0, st, d_M,
+                           (long)n, (long)kk, nb, Lk, (long)strideA, strideL);
+        const int64_t r0 = kk + nb;
+        if (r0 < pend) {   // rest of this panel, K = IB
+          dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128), batch);
+          hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0, (long)pend, (long)kk, nb,
+                             (long)strideA);
+        }
+      }
+    }
+    if (pend < n) {        // trailing matrix, K = NBB (a short panel is the last one)
+      dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((n - pend + 127) / 128), batch);
+      hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n, (long)k, (int)pw,
                          (long)strideA);
     }
   }
@@ -436,11 +446,27 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
     }
     __syncthreads();
     if (t < nb) y[k + t] = tbuf[t];
-    for (long r = k + nb + t; r < n; r += 256) {
-      double acc = y[r];
-      const double *col = Lb + (size_t)k * (size_t)n + r;
-      for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[m], acc);
-      y[r] = acc;
+    if (nb == IB) {   // full block: 32 independent strided loads per row are issued back to back
+      for (long r = k + IB + t; r < n; r += 256) {
+        const double *col = Lb + (size_t)k * (size_t)n + r;
+        double lv[IB];
+#pragma unroll
+        for (int m = 0; m < IB; ++m) lv[m] = col[(size_t)m * n];
+        double a0 = y[r], a1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < IB; m += 2) {
+          a0 = __builtin_fma(-lv[m], tbuf[m], a0);
+          a1 = __builtin_fma(-lv[m + 1], tbuf[m + 1], a1);
+        }
+        y[r] = a0 + a1;
+      }
+    } else {
+      for (long r = k + nb + t; r < n; r += 256) {
+        double acc = y[r];
+        const double *col = Lb + (size_t)k * (size_t)n + r;
+        for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[m], acc);
+        y[r] = acc;
+      }
     }
     __syncthreads();
   }
@@ -456,11 +482,27 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
     }
     __syncthreads();
     if (t < nb) y[k + t] = tbuf[t];
-    for (long c = t; c < k; c += 256) {              // columns before the block: y[c] -= sum_r L[k+r][c] x_r
-      double acc = y[c];
-      const double *row = Lb + (size_t)c * (size_t)n + k;
-      for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[m], acc);
-      y[c] = acc;
+    if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r  (256 B contiguous per lane)
+      for (long c = t; c < k; c += 256) {
+        const double *row = Lb + (size_t)c * (size_t)n + k;
+        double lv[IB];
+#pragma unroll
+        for (int m = 0; m < IB; ++m) lv[m] = row[m];
+        double a0 = y[c], a1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < IB; m += 2) {
+          a0 = __builtin_fma(-lv[m], tbuf[m], a0);
+          a1 = __builtin_fma(-lv[m + 1], tbuf[m + 1], a1);
+        }
+        y[c] = a0 + a1;
+      }
+    } else {
+      for (long c = t; c < k; c += 256) {
+        double acc = y[c];
+        const double *row = Lb + (size_t)c * (size_t)n + k;
+        for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[m], acc);
+        y[c] = acc;
+      }
     }
     __syncthreads();
   }
