@@ -89,7 +89,7 @@ def timestep_mode(args, dev):
         from rigid_body_light_amd._lib import lib
         lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
-    stp = DeterministicStepper(ctx, nb, nblb, dev)
+    stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
     iters = 20 if args.rtol <= 0 else 200
     rtol = args.rtol if args.rtol > 0 else None
@@ -183,6 +183,7 @@ def main():
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
     ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps at N=1 (0 = skip)")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
+    ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")

@@ -201,6 +201,9 @@ int rbl_M_half_W_dev(rbl_ctx *ctx, const double *d_r, int64_t n_blobs, const dou
  * GPU; the functions below call it themselves when the configuration has changed.
  * Vectors: U/F 6*N_bod, lambda/slip 3*N, saddle/PC vectors 3*N + 6*N_bod (reference layout). */
 int rbl_sync_bodies_dev(rbl_ctx *ctx);
+/* uploads + workspace growth + preconditioner build for the current configuration, so that the
+ * operator calls below are launch-only afterwards (capturable in a hipGraph) */
+int rbl_prepare_dev(rbl_ctx *ctx);
 int rbl_positions_dev(rbl_ctx *ctx, const double **d_pos, int64_t *n_blobs);  /* multi_body_pos, resident */
 int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /* K_x_U    :404 */
 int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */

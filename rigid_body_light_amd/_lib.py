@@ -31,6 +31,7 @@ def lib():
         L.rbl_set_stream.argtypes = [vp, vp]
         L.rbl_apply_M_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp]
         L.rbl_sync_bodies_dev.argtypes = [vp]
+        L.rbl_prepare_dev.argtypes = [vp]
         L.rbl_positions_dev.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(i64)]
         L.rbl_K_x_U_dev.argtypes = [vp, vp, vp]
         L.rbl_KT_x_Lam_dev.argtypes = [vp, vp, vp]
@@ -97,6 +98,10 @@ class DeviceContext:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.L.rbl_positions_dev(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def prepare(self):
+        """uploads, workspace growth and PC build now -> later operator calls are launch-only"""
+        self._chk(self.L.rbl_prepare_dev(self.h))
 
     def K_x_U(self, dU, dout):
         self._chk(self.L.rbl_K_x_U_dev(self.h, dU, dout))

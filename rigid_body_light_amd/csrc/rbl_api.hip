@@ -1023,6 +1023,25 @@ int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
   return RBL_OK;
 }
 
+// Everything a solver iteration needs that is NOT a plain kernel launch (uploads, workspace
+// growth, preconditioner build) done now, so that the iteration itself -- apply_saddle_dev,
+// apply_PC_dev, K ops -- is launch-only and can be captured in a hipGraph.
+int rbl_prepare_dev(rbl_ctx *c)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(N, c->n_cu, 1)))) return rc;
+  if (!c->dev_pc_valid) {   // build the preconditioner eagerly (apply on a scratch vector)
+    const size_t nv = (size_t)n3 + 6 * (size_t)S.N_bod;
+    if ((rc = rbl_dev_reserve(c, c->d_tmp, sizeof(double) * 2 * nv))) return rc;
+    RBL_HIP(c, hipMemsetAsync(c->d_tmp.p, 0, sizeof(double) * 2 * nv, c->stream));
+    if ((rc = rbl_apply_PC_dev(c, (const double *)c->d_tmp.p, (double *)c->d_tmp.p + nv))) return rc;
+  }
+  return finish_and_check(c);
+}
+
 // [M lambda - K U ; K^T lambda] on the object's own configuration (src/Rigid.py:73-80)
 int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
 {

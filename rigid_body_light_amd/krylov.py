@@ -50,12 +50,19 @@ def gmres_right_pc(apply_A, apply_Pinv, b, iters, rtol=None):
 
 
 class DeterministicStepper:
-    """One deterministic time step per call (fixed-work: `iters` GMRES iterations = iters+1 apply_M)."""
+    """One deterministic time step per call (fixed-work: `iters` GMRES iterations = iters+1 apply_M).
 
-    def __init__(self, ctx, n_bodies, blobs_per_body, device):
+    use_graph=True captures the whole fixed-work solve (every HIP kernel of the operators and every
+    torch vector op of the Arnoldi process) in ONE hipGraph and replays it each step: the small
+    configurations are launch-bound (cfg 1: ~14 us of kernels per apply_M), a replay removes the
+    per-launch host cost.  The non-launch work (uploads, PC build) happens in ctx.prepare()."""
+
+    def __init__(self, ctx, n_bodies, blobs_per_body, device, use_graph=False):
         self.ctx, self.nb, self.nblb, self.dev = ctx, n_bodies, blobs_per_body, device
         self.n3 = 3 * n_bodies * blobs_per_body
         self.size = self.n3 + 6 * n_bodies
+        self.use_graph = use_graph
+        self._graph = None
 
     def _A(self, x):
         out = torch.empty_like(x)
@@ -67,12 +74,58 @@ class DeterministicStepper:
         self.ctx.apply_PC(x.contiguous().data_ptr(), out.data_ptr())
         return out
 
+    def _arnoldi(self, b, iters):
+        """sync-free part of GMRES: returns (V, H, beta) as device tensors"""
+        n = b.numel()
+        V = torch.zeros(iters + 1, n, dtype=b.dtype, device=b.device)
+        H = torch.zeros(iters + 1, iters, dtype=b.dtype, device=b.device)
+        beta = torch.linalg.norm(b)
+        V[0] = b / beta
+        for j in range(iters):
+            w = self._A(self._Pinv(V[j]))
+            for _ in range(2):
+                h = V[: j + 1] @ w
+                w = w - h @ V[: j + 1]
+                H[: j + 1, j] += h
+            hn = torch.linalg.norm(w)
+            H[j + 1, j] = hn
+            V[j + 1] = w / hn
+        return V, H, beta
+
+    def _finish(self, V, H, beta, iters):
+        Hh = H.cpu().numpy()
+        e1 = np.zeros(iters + 1); e1[0] = float(beta)
+        y, *_ = np.linalg.lstsq(Hh, e1, rcond=None)
+        resid = float(np.linalg.norm(Hh @ y - e1) / float(beta))
+        z = torch.from_numpy(y).to(self.dev) @ V[:iters]
+        return self._Pinv(z), resid
+
     def solve(self, F_body, iters=20, rtol=None):
         """Solve the saddle system for rhs = [0 ; -F_body]; returns (lambda, U, iterations, residual)."""
-        b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
-        b[self.n3:] = -torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
-        x, m, resid = gmres_right_pc(self._A, self._Pinv, b, iters, rtol)
-        return x[: self.n3], x[self.n3:], m, resid
+        Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
+        if rtol is not None or not self.use_graph:
+            b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
+            b[self.n3:] = -Fb
+            x, m, resid = gmres_right_pc(self._A, self._Pinv, b, iters, rtol)
+            return x[: self.n3], x[self.n3:], m, resid
+        self.ctx.prepare()
+        if self._graph is None or self._graph_iters != iters:
+            self._b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
+            self._b[self.n3:] = -Fb
+            self._arnoldi(self._b, min(iters, 2))               # eager warm-up: allocator + workspaces
+            torch.cuda.synchronize()
+            cap_stream = torch.cuda.Stream()
+            with torch.cuda.stream(cap_stream):
+                self.ctx.set_stream(cap_stream.cuda_stream)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap_stream):
+                    self._V, self._H, self._beta = self._arnoldi(self._b, iters)
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            self._graph, self._graph_iters = g, iters
+        self._b[self.n3:] = -Fb
+        self._graph.replay()
+        x, resid = self._finish(self._V, self._H, self._beta, iters)
+        return x[: self.n3], x[self.n3:], iters, resid
 
     def step(self, F_body, iters=20, rtol=None):
         lam, U, m, resid = self.solve(F_body, iters, rtol)
