@@ -76,11 +76,13 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
     return out
 
 
-def timestep_mode(args, dev):
-    """1 step = one deterministic time step, everything resident on ONE GPU."""
+def timestep_mode(args, dev, world=1, rank=0):
+    """1 step = one deterministic time step, all operators on the GPU(s); with N > 1 the mobility
+    product of every GMRES iteration is tile-pair sharded (one all-reduce per iteration)."""
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
-    from rigid_body_light_amd.krylov import DeterministicStepper
+    from rigid_body_light_amd.dist import ShardedMobility
+    from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb
@@ -89,28 +91,45 @@ def timestep_mode(args, dev):
         from rigid_body_light_amd._lib import lib
         lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
-    stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
+    if world > 1:
+        stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
+    else:
+        stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
     iters = 20 if args.rtol <= 0 else 200
     rtol = args.rtol if args.rtol > 0 else None
     res, used = [], []
     for _ in range(args.warmup):
         stp.step(Fb, iters, rtol)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
     for _ in range(args.steps):
         m_used, r_last = stp.step(Fb, iters, rtol)
         res.append(r_last); used.append(m_used)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    sec = (t1 - t0) / args.steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    sec_t = torch.tensor([(t1 - t0) / args.steps], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(sec_t, op=dist.ReduceOp.MAX)
+    sec = float(sec_t.item())
     iters = int(round(sum(used) / len(used)))
+    if world > 1 and rank != 0:
+        dist.destroy_process_group()
+        return
     print(json.dumps({
         "metric": "timesteps/sec (deterministic step: %d GMRES iterations (%s, %s PC) = %d apply_M + PC + K ops + evolve), "
                   "%d x shell_N_%d, %s, fp64" % (iters, "fixed work" if rtol is None else "converged to %g" % rtol, args.pc,
                                                  iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
-        "value": 1.0 / sec, "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": 1.0 / sec, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
         "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def brownian_mode(args, dev, world, rank):
@@ -181,7 +200,7 @@ def main():
     ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep", "brownian"],
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
-    ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps at N=1 (0 = skip)")
+    ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps (0 = skip)")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
@@ -210,7 +229,7 @@ def main():
     from rigid_body_light_amd.dist import ShardedMobility
 
     if args.mode == "timestep":
-        return timestep_mode(args, dev)
+        return timestep_mode(args, dev, world, rank)
     if args.mode == "brownian":
         return brownian_mode(args, dev, world, rank)
     nb, nblb, wall = CONFIGS[args.config]
@@ -285,6 +304,28 @@ def main():
         check = float(np.linalg.norm(got - Uo) / np.linalg.norm(Uo))
         assert check < 1e-11, "rank %d: parity vs oracle failed: %g" % (rank, check)
 
+    tstep = None
+    if args.timestep_steps > 0:
+        # the reference has no time-step driver; ours (SURVEY.md 8d "fixed-work" step, krylov.py): 20 right-
+        # preconditioned GMRES iterations on apply_saddle (= 21 apply_M + diagonal PC + K ops) + evolve.  With N > 1
+        # the mobility product of every iteration is tile-pair sharded (one all-reduce per iteration).
+        from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper
+        stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
+        Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+        stp.step(Fb, 20)
+        barrier(); ts0 = time.perf_counter()
+        for _ in range(args.timestep_steps):
+            m_it, res_it = stp.step(Fb, 20)
+        barrier()
+        tsv = torch.tensor([(time.perf_counter() - ts0) / args.timestep_steps], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tsv, op=dist.ReduceOp.MAX)
+        ts = float(tsv.item())
+        tstep = {"timesteps_per_sec": 1.0 / ts, "ms_per_timestep": ts * 1e3, "apply_M_per_timestep": 21,
+                 "definition": "deterministic fixed-work step: 20 GMRES iterations on the saddle operator (diagonal PC) "
+                               "+ evolve, all operators on the GPU(s)",
+                 "gmres_residual": res_it, "steps_timed": args.timestep_steps}
+
     if rank == 0:
         sec_per_step = elapsed / args.steps
         # ordered-pair equivalents one launch (this rank) covers: its rows x all columns, or its
@@ -323,21 +364,8 @@ def main():
         }
         if check is not None:
             line["check_rel_err_vs_oracle"] = check
-        if world == 1 and args.timestep_steps > 0:
-            # the reference has no time-step driver; ours (SURVEY.md 8d "fixed-work" step, krylov.py):
-            # 20 right-preconditioned GMRES iterations on apply_saddle (= 21 apply_M + diag PC + K ops) + evolve
-            from rigid_body_light_amd.krylov import DeterministicStepper
-            stp = DeterministicStepper(ctx, nb, nblb, dev)
-            Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
-            stp.step(Fb, 20)
-            torch.cuda.synchronize(); ts0 = time.perf_counter()
-            for _ in range(args.timestep_steps):
-                m_it, res_it = stp.step(Fb, 20)
-            torch.cuda.synchronize(); ts = (time.perf_counter() - ts0) / args.timestep_steps
-            line["timestep"] = {"timesteps_per_sec": 1.0 / ts, "ms_per_timestep": ts * 1e3, "apply_M_per_timestep": 21,
-                                "definition": "deterministic fixed-work step: 20 GMRES iterations on the saddle operator "
-                                              "(diagonal PC) + evolve, all operators on the GPU",
-                                "gmres_residual": res_it, "steps_timed": args.timestep_steps}
+        if tstep is not None:
+            line["timestep"] = tstep
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]

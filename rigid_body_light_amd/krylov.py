@@ -172,3 +172,39 @@ def lanczos_mhalf(apply_A, W, max_iter=100, tol=1e-3, check_every=1):
         V[it + 1] = u / be
     out = torch.from_numpy(y_cur).to(W.device) @ V[:m]
     return out, m, change
+
+
+class ShardedDeterministicStepper(DeterministicStepper):
+    """The same deterministic step on P GPUs (one process each): the mobility product inside the
+    saddle operator is tile-pair sharded (ShardedMobility.apply_M_allreduce: all-reduce of the
+    partial U), everything else -- K ops, preconditioner, Arnoldi vectors -- is O(N), replicated and
+    bitwise identical on every rank, so no other communication is needed."""
+
+    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device):
+        super().__init__(ctx, n_bodies, blobs_per_body, device, use_graph=False)
+        self.sm = sharded
+
+    def refresh_positions(self):
+        p, n = self.ctx.positions_ptr()                 # replicated body state -> full positions on this rank
+        self.sm.r_full = torch.empty(3 * n, dtype=torch.float64, device=self.dev)
+        self.ctx.blob_positions(0, self.nb, self.sm.r_full.data_ptr())
+
+    def _A(self, x):
+        n3 = self.n3
+        lam = x[:n3].contiguous()
+        part = torch.empty(n3, dtype=torch.float64, device=self.dev)
+        self.ctx.apply_M_sym(lam.data_ptr(), self.sm.r_full.data_ptr(), n3 // 3, self.sm.rank, self.sm.world, part.data_ptr())
+        Ml = self.sm.all_reduce_sum(part)
+        out = torch.empty_like(x)
+        ku = torch.empty(n3, dtype=torch.float64, device=self.dev)
+        U = x[n3:].contiguous()
+        self.ctx.K_x_U(U.data_ptr(), ku.data_ptr())
+        out[:n3] = Ml - ku
+        kt = torch.empty(6 * self.nb, dtype=torch.float64, device=self.dev)
+        self.ctx.KT_x_Lam(lam.data_ptr(), kt.data_ptr())
+        out[n3:] = kt
+        return out
+
+    def step(self, F_body, iters=20, rtol=None):
+        self.refresh_positions()
+        return super().step(F_body, iters, rtol)
