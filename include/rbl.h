@@ -81,7 +81,9 @@ int rbl_KT_x_Lam(rbl_ctx *ctx, const double *lambda, double *out);
 /* multi_body_pos() -> [3N], c_rigid_obj.cpp:295-300 (computed on the GPU) */
 int rbl_multi_body_pos(rbl_ctx *ctx, double *out);
 
-/* apply_PC(IN[3N+6Nb]) -> [3N+6Nb], c_rigid_obj.cpp:589-616 */
+/* apply_PC(IN[3N+6Nb]) -> [3N+6Nb], c_rigid_obj.cpp:589-616.  Diagonal PC (diag_invM :489): host
+ * arithmetic, O(N).  Block-diagonal PC (Block_diag_invM :461): GPU -- batched per-body mobility,
+ * batched Cholesky on the matrix cores, substitution instead of the reference's explicit inverse. */
 int rbl_apply_PC(rbl_ctx *ctx, const double *in, double *out);
 
 /* get_K() / get_Kinv(), c_rigid_obj.cpp:978-992: CSC arrays.  Call once with

@@ -196,72 +196,22 @@ int rbl_chol6(double *A)
   return RBL_OK;
 }
 
-// in-place inverse of a dense n x n row-major matrix (Gauss-Jordan, partial
-// pivoting) -- what Mob.inverse() does for the per-body blocks (:475).
-int rbl_inv_spd_or_lu(double *A, int n, double *work)
-{
-  std::vector<int> piv(n);
-  (void)work;
-  for (int c = 0; c < n; ++c) {
-    int p = c;
-    double best = std::fabs(A[(size_t)c * n + c]);
-    for (int r = c + 1; r < n; ++r) {
-      const double v = std::fabs(A[(size_t)r * n + c]);
-      if (v > best) { best = v; p = r; }
-    }
-    if (best == 0.0) return RBL_ERR_SINGULAR;
-    piv[c] = p;
-    if (p != c)
-      for (int k = 0; k < n; ++k) std::swap(A[(size_t)c * n + k], A[(size_t)p * n + k]);
-    const double ip = 1.0 / A[(size_t)c * n + c];
-    A[(size_t)c * n + c] = 1.0;
-    for (int k = 0; k < n; ++k) A[(size_t)c * n + k] *= ip;
-    for (int r = 0; r < n; ++r) {
-      if (r == c) continue;
-      const double f = A[(size_t)r * n + c];
-      if (f == 0.0) continue;
-      A[(size_t)r * n + c] = 0.0;
-      double *ar = &A[(size_t)r * n];
-      const double *ac = &A[(size_t)c * n];
-      for (int k = 0; k < n; ++k) ar[k] -= f * ac[k];
-    }
-  }
-  for (int c = n - 1; c >= 0; --c) {
-    const int p = piv[c];
-    if (p != c)
-      for (int r = 0; r < n; ++r) std::swap(A[(size_t)r * n + c], A[(size_t)r * n + p]);
-  }
-  return RBL_OK;
-}
-
 // invM * v for the cached preconditioner mobility inverse
 static void apply_invM(const RblBodyState &S, const double *v, double *out)
 {
+  // diagonal preconditioner only: the block-diagonal one lives on the GPU (rbl_api.hip)
   const int nb = S.N_bod, nl = S.N_blb;
-  if (!S.block_pc) {
-    for (size_t i = 0; i < (size_t)nb * nl; ++i) {
-      const double *B = &S.invM_diag[9 * i];
-      const double *x = v + 3 * i;
-      out[3 * i] = B[0] * x[0] + B[1] * x[1] + B[2] * x[2];
-      out[3 * i + 1] = B[3] * x[0] + B[4] * x[1] + B[5] * x[2];
-      out[3 * i + 2] = B[6] * x[0] + B[7] * x[1] + B[8] * x[2];
-    }
-  } else {
-    const int m = 3 * nl;
-    for (int b = 0; b < nb; ++b) {
-      const double *B = &S.invM_block[(size_t)b * m * m];
-      const double *x = v + (size_t)b * m;
-      for (int p = 0; p < m; ++p) {
-        double s = 0.0;
-        for (int q = 0; q < m; ++q) s += B[(size_t)p * m + q] * x[q];
-        out[(size_t)b * m + p] = s;
-      }
-    }
+  for (size_t i = 0; i < (size_t)nb * nl; ++i) {
+    const double *B = &S.invM_diag[9 * i];
+    const double *x = v + 3 * i;
+    out[3 * i] = B[0] * x[0] + B[1] * x[1] + B[2] * x[2];
+    out[3 * i + 1] = B[3] * x[0] + B[4] * x[1] + B[5] * x[2];
+    out[3 * i + 2] = B[6] * x[0] + B[7] * x[1] + B[8] * x[2];
   }
 }
 
-// apply_PC, c_rigid_obj.cpp:589-616.  The caller (rbl_api) fills invM_diag /
-// invM_block beforehand when !pc_set (diag_invM :489-543, Block_diag_invM :461-487).
+// apply_PC, c_rigid_obj.cpp:589-616, diagonal PC.  The caller (rbl_api) fills invM_diag
+// beforehand when !pc_set (diag_invM :489-543).
 int rbl_body_apply_PC(RblBodyState &S, const double *in, double *out, std::string &err)
 {
   const int nb = S.N_bod, nl = S.N_blb;

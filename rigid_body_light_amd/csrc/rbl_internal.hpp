@@ -31,7 +31,6 @@ struct RblBodyState {
   std::vector<double> KTKinv;   // 36 N_bod  (6x6 row-major per body), :302-326
   // preconditioner caches (:152-154)
   std::vector<double> invM_diag;   // 9 N      (3x3 row-major per blob) when !block_pc
-  std::vector<double> invM_block;  // N_bod * (3N_blb)^2 row-major      when block_pc
   std::vector<double> Ninv_chol;   // 36 N_bod  lower Cholesky of K^T invM K blocks
 };
 
@@ -45,7 +44,6 @@ void rbl_body_update_X_Q(const RblBodyState &S, const double *U, std::vector<dou
                          std::vector<double> &Qo);
 int rbl_body_apply_PC(RblBodyState &S, const double *in, double *out, std::string &err);
 int rbl_chol6(double *A);  // in-place lower Cholesky of a 6x6 row-major block
-int rbl_inv_spd_or_lu(double *A, int n, double *work);  // in-place general inverse (row-major)
 
 // ----------------------------------------------------------------------------
 // Device buffers + context

@@ -39,7 +39,22 @@ M = torch.empty(n * n, dtype=torch.float64, device=dev)
 tb = timed(lambda: ctx.build_M(r.data_ptr(), N, True, M.data_ptr()))
 tb = timed(lambda: ctx.build_M(r.data_ptr(), N, True, M.data_ptr()))
 print("build  n=%d: %.2f ms  %.1f GB/s write" % (n, tb * 1e3, 8.0 * n * n / tb / 1e9))
-tc = timed(lambda: ctx.cholesky(M.data_ptr(), n, False))
+verify = "--verify" in sys.argv
+if verify:
+    d0 = M[:: n + 1].clone()                       # diag(B M B) before the factorisation
+tc = timed(lambda: ctx.cholesky(M.data_ptr(), n, verify))
 print("chol   n=%d: %.2f ms  %.2f TFLOP/s" % (n, tc * 1e3, n ** 3 / 3.0 / tc / 1e12))
+if verify:                                         # diag(L L^T) == diag(M): n independent row checks
+    V = M.view(n, n)                               # V[a][b] = L[b][a]
+    acc = torch.zeros(n, dtype=torch.float64, device=dev)
+    for a0 in range(0, n, 2048):
+        acc += (V[a0:a0 + 2048] ** 2).sum(0)
+    err = float(((acc - d0).abs() / d0.abs()).max())
+    print("verify n=%d: max_i |sum_j L_ij^2 - M_ii| / M_ii = %.3e" % (n, err))
+    # and L W against a row-sampled reference  (L W)_i = sum_j L_ij W_j
+    tt0 = torch.empty_like(W); ctx.trmv_lower(M.data_ptr(), n, W.data_ptr(), tt0.data_ptr()); ctx.sync_check()
+    rows = torch.tensor([0, 1, n // 3, n // 2, n - 2, n - 1], device=dev)
+    ref = (V[:, rows] * W[:, None]).sum(0)
+    print("verify L*W on 6 rows: max rel err %.3e" % float(((tt0[rows] - ref).abs() / ref.abs()).max()))
 tt = timed(lambda: ctx.trmv_lower(M.data_ptr(), n, W.data_ptr(), out.data_ptr()), 3)
 print("trmv   n=%d: %.2f ms  %.1f GB/s read" % (n, tt * 1e3, 4.0 * n * n / tt / 1e9))
