@@ -252,7 +252,7 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   S.N_blb = N_blb;
   S.params_set = true;
   S.M_scale = 1.0;
-  c->dev_bodies_valid = false; c->dev_pc_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
   return RBL_OK;
 }
 
@@ -273,7 +273,7 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
   }
   S.cfg_set = true;
   S.K_set = false;
-  c->dev_bodies_valid = false; c->dev_pc_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
   // NOTE the reference does NOT reset PC_mat_Set here (SURVEY.md 8b "state quirks");
   // a stale preconditioner after set_config is a trap, so we do invalidate it.
   S.pc_set = false;
@@ -339,9 +339,11 @@ int rbl_KTinv_x_F(rbl_ctx *c, const double *F, double *out)
   return RBL_OK;
 }
 
-// upload X, Q, ref_cfg; positions of bodies [b0,b1) -> d_out
-static int positions_dev(rbl_ctx *c, int b0, int b1, double *d_out)
+// (X, Q, ref_cfg) resident on the device: uploaded once per configuration change (pageable host
+// vectors -> one synchronisation there), so the per-step position kernel is launch-only.
+static int ensure_xq_dev(rbl_ctx *c)
 {
+  if (c->dev_xq_valid) return RBL_OK;
   RblBodyState &S = c->S;
   int rc = rbl_dev_reserve(c, c->d_XQ, sizeof(double) * 7 * (size_t)S.N_bod); if (rc) return rc;
   rc = rbl_dev_reserve(c, c->d_cfg, sizeof(double) * 3 * (size_t)S.N_blb); if (rc) return rc;
@@ -349,6 +351,17 @@ static int positions_dev(rbl_ctx *c, int b0, int b1, double *d_out)
   RBL_HIP(c, hipMemcpyAsync(dX, S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
   RBL_HIP(c, hipMemcpyAsync(dQ, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
   RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  c->dev_xq_valid = true;
+  return RBL_OK;
+}
+
+// positions of bodies [b0,b1) -> d_out
+static int positions_dev(rbl_ctx *c, int b0, int b1, double *d_out)
+{
+  int rc = ensure_xq_dev(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const double *dX = (const double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
   rbl_launch_blob_positions(c->stream, dX, dQ, (const double *)c->d_cfg.p, S.N_blb, b0, b1, d_out);
   return RBL_OK;
 }
@@ -359,10 +372,7 @@ int rbl_blob_positions_dev(rbl_ctx *c, int body_begin, int body_end, double *d_o
   rc = rbl_dev_init(c); if (rc) return rc;
   if (body_begin < 0 || body_end > c->S.N_bod || body_begin > body_end)
     return rbl_fail(c, RBL_ERR_SIZE, "blob_positions_dev: body range out of bounds");
-  // the host vectors are pageable: make the async copies complete before they can change
-  rc = positions_dev(c, body_begin, body_end, d_out); if (rc) return rc;
-  RBL_HIP(c, hipStreamSynchronize(c->stream));
-  return RBL_OK;
+  return positions_dev(c, body_begin, body_end, d_out);
 }
 
 int rbl_multi_body_pos(rbl_ctx *c, double *out)
@@ -536,7 +546,7 @@ int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
   rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
   S.X.swap(Xo);
   S.Q.swap(Qo);
-  c->dev_bodies_valid = false; c->dev_pc_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
   rc = rbl_body_set_K(S, c->last_error);                          // :876
   S.pc_set = false;                                               // :877
   return rc;
@@ -911,17 +921,12 @@ static int sync_bodies(rbl_ctx *c)
   if (c->dev_bodies_valid) return RBL_OK;
   RblBodyState &S = c->S;
   const size_t N = (size_t)S.N_bod * S.N_blb;
-  if ((rc = rbl_dev_reserve(c, c->d_XQ, sizeof(double) * 7 * (size_t)S.N_bod))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_cfg, sizeof(double) * 3 * (size_t)S.N_blb))) return rc;
+  if ((rc = ensure_xq_dev(c))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_lever, sizeof(double) * 3 * N))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pos, sizeof(double) * 3 * N))) return rc;
-  double *dX = (double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
-  RBL_HIP(c, hipMemcpyAsync(dX, S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipMemcpyAsync(dQ, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
+  const double *dX = (const double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
   rbl_launch_body_geom(c->stream, dX, dQ, (const double *)c->d_cfg.p, S.N_blb, (int64_t)N, (double *)c->d_lever.p,
                        (double *)c->d_pos.p);
-  RBL_HIP(c, hipStreamSynchronize(c->stream));  // host vectors are pageable
   c->dev_bodies_valid = true;
   c->dev_pc_valid = false;
   return RBL_OK;

@@ -709,9 +709,11 @@ static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI,
   const int ni = (t >= 128 * i_step) ? 2 : 1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   const int rowsI = (tsup + i_step - 1) / i_step;
-  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 4 rounds of wave-units; a unit sweeps <= C column tiles
+  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 2 rounds of wave-units; a unit sweeps <= C column tiles.
+  // Longer chunks mean fewer row-sum slabs to write and re-read (the reduction is the only
+  // non-scaling part of a multi-GPU shard).
   const double pairs = 0.5 * (double)rowsI * (double)t;
-  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 4.0;
+  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 2.0;
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 64) c = 64;
