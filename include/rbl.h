@@ -134,6 +134,14 @@ int rbl_M_half_W(rbl_ctx *ctx, const double *W, uint64_t seed, int method, doubl
 int rbl_M_half_W_r(rbl_ctx *ctx, const double *r_vecs, int64_t n3, const double *W,
                    uint64_t seed, int method, double *out);
 
+/* M_RFD(), c_rigid_obj.cpp:769-796 (C++ only in the reference): random finite difference of the
+ * mobility, (1/delta)[M(q + delta/2 Kinv W) - M(q - delta/2 Kinv W)] W, out[3N].  W == NULL draws
+ * N(0,1) from `seed`.  The reference hard-codes delta = 1e-4. */
+int rbl_M_RFD(rbl_ctx *ctx, const double *W, uint64_t seed, double delta, double *out);
+
+/* KTinv_RFD(), c_rigid_obj.cpp:743-767: K^T (1/delta)[Kinv(q+)^T - Kinv(q-)^T] W, W[6Nb] -> out[6Nb] */
+int rbl_KTinv_RFD(rbl_ctx *ctx, const double *W, double delta, double *out);
+
 /* Lanczos controls / report (iterations used by the last call, last residual) */
 int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
 int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);

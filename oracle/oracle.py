@@ -297,3 +297,28 @@ def evolve(X, Qn, U, dt):
         Qn[j] = qq / np.linalg.norm(qq)
         X[j] += U[j, :3]
     return X, Qn
+
+
+def update_X_Q(X, Qn, U):
+    """update_X_Q, c_rigid_obj.cpp:691-710: U has displacement units (no dt)."""
+    return evolve(X, Qn, U, 1.0)
+
+
+def M_RFD(orc, W, X, Qn, ref_cfg, a, eta, wall, delta):
+    """c_rigid_obj.cpp:769-796 with the noise W injected."""
+    cfg = np.asarray(ref_cfg).reshape(-1, 3)
+    uom = Kinv_matrix(X, Qn, cfg) @ W
+    Xp, Qp = update_X_Q(X, Qn, 0.5 * delta * uom)
+    Xm, Qm = update_X_Q(X, Qn, -0.5 * delta * uom)
+    Mp = orc.apply_M(W, orc.multi_body_pos(Xp, Qp, cfg), a, eta, wall)
+    Mm = orc.apply_M(W, orc.multi_body_pos(Xm, Qm, cfg), a, eta, wall)
+    return (Mp - Mm) / delta
+
+
+def KTinv_RFD(W, X, Qn, ref_cfg, delta):
+    """c_rigid_obj.cpp:743-767."""
+    cfg = np.asarray(ref_cfg).reshape(-1, 3)
+    Xp, Qp = update_X_Q(X, Qn, 0.5 * delta * W)
+    Xm, Qm = update_X_Q(X, Qn, -0.5 * delta * W)
+    out = (Kinv_matrix(Xp, Qp, cfg).T @ W - Kinv_matrix(Xm, Qm, cfg).T @ W) / delta
+    return K_matrix(X, Qn, cfg).T @ out

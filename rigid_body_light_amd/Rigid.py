@@ -115,6 +115,21 @@ class RigidBody:
             W = W.flatten()
         return self.cb.M_half_W(W, seed, method)
 
+    def M_RFD(self, W=None, seed=0, delta=1.0e-4):
+        """Random finite difference of the mobility (reference c_rigid_obj.cpp:769-796, C++ only):
+        (1/delta)[M(q + delta/2 Kinv W) - M(q - delta/2 Kinv W)] W -- the thermal-drift term."""
+        if W is not None:
+            W = np.asarray(W)
+            self._check_input_size(lambda_vec=W)
+            W = W.flatten()
+        return self.cb.M_RFD(W, seed, delta)
+
+    def KTinv_RFD(self, W, delta=1.0e-4):
+        """reference c_rigid_obj.cpp:743-767 (C++ only); W has length 6*N_bodies."""
+        W = np.asarray(W)
+        self._check_input_size(U_vec=W)
+        return self.cb.KTinv_RFD(W.flatten(), delta)
+
     def apply_M_multi(self, forces, positions):
         forces = np.atleast_2d(np.asarray(forces))
         return self.cb.apply_M_multi(forces, np.asarray(positions).flatten())

@@ -185,6 +185,31 @@ struct CManyBodies {
     return out;
   }
 
+  darr M_RFD(py::object W, uint64_t seed, double delta)             // :769 (unbound in the reference)
+  {
+    darr out(n3());
+    int rc;
+    if (W.is_none()) {
+      py::gil_scoped_release rel;
+      rc = rbl_M_RFD(ctx, nullptr, seed, delta, out.mutable_data());
+    } else {
+      darr Wa = W.cast<darr>();
+      if (Wa.size() != n3()) throw std::runtime_error("M_RFD: W must have length 3*N_blobs");
+      py::gil_scoped_release rel;
+      rc = rbl_M_RFD(ctx, Wa.data(), seed, delta, out.mutable_data());
+    }
+    check(rc);
+    return out;
+  }
+
+  darr KTinv_RFD(darr W, double delta)                              // :743 (unbound in the reference)
+  {
+    if (W.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("KTinv_RFD: W must have length 6*N_bod");
+    darr out(6 * (py::ssize_t)n_bod());
+    check(rbl_KTinv_RFD(ctx, W.data(), delta, out.mutable_data()));
+    return out;
+  }
+
   py::tuple lanczos_report()
   {
     int it = 0; double res = 0;
@@ -261,6 +286,8 @@ PYBIND11_MODULE(c_rigid, m)
       .def("M_half_W", &CManyBodies::M_half_W, py::arg("W") = py::none(), py::arg("seed") = 0,
            py::arg("method") = "cholesky")
       .def("M_half_W_r", &CManyBodies::M_half_W_r, py::arg("r_vecs"), py::arg("W"), py::arg("method") = "cholesky")
+      .def("M_RFD", &CManyBodies::M_RFD, py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("delta") = 1.0e-4)
+      .def("KTinv_RFD", &CManyBodies::KTinv_RFD, py::arg("W"), py::arg("delta") = 1.0e-4)
       .def("lanczos_report", &CManyBodies::lanczos_report)
       .def("set_lanczos", &CManyBodies::set_lanczos, py::arg("max_iter"), py::arg("tol"))
       .def("rotne_prager_tensor", &CManyBodies::rotne_prager_tensor, py::arg("r_vecs"), py::arg("scale_damp") = false)

@@ -1061,3 +1061,71 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
 }
 
 }  // extern "C"
+
+// ---- random finite differences (reference C++-only members) ---------------
+extern "C" {
+
+// M_RFD(), c_rigid_obj.cpp:769-796:  (1/delta) [ M(q + delta/2 dq) - M(q - delta/2 dq) ] W  with
+// dq = Kinv W.  The two products run on the GPU at the two displaced configurations.
+int rbl_M_RFD(rbl_ctx *c, const double *W, uint64_t seed, double delta, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!(delta > 0.0)) return rbl_fail(c, RBL_ERR_ARG, "M_RFD: delta must be positive");
+  RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  const size_t vb = sizeof(double) * (size_t)n3;
+  if ((rc = rbl_dev_reserve(c, c->d_W, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_r, vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_U, 2 * vb))) return rc;
+  std::vector<double> Wh((size_t)n3);
+  if (W) {
+    std::memcpy(Wh.data(), W, vb);
+    if ((rc = copy_h2d(c, c->d_W.p, W, vb))) return rc;
+  } else {  // rand_vector (:730-741) replaced by the seeded device generator
+    rbl_launch_normal(c->stream, seed, 0, n3, (double *)c->d_W.p);
+    if ((rc = copy_d2h(c, Wh.data(), c->d_W.p, vb))) return rc;
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<double> uom((size_t)6 * S.N_bod), win((size_t)6 * S.N_bod), Xs, Qs;
+  rbl_body_Kinv_x_V(S, Wh.data(), uom.data());                        // UOM = Kinv W (:776)
+  const std::vector<double> X0 = S.X, Q0 = S.Q;
+  double *dM[2] = {(double *)c->d_U.p, (double *)c->d_U.p + n3};
+  for (int sgn = 0; sgn < 2; ++sgn) {                                 // q +- delta/2 dq (:783-788)
+    const double f = (sgn == 0 ? 0.5 : -0.5) * delta;
+    for (size_t i = 0; i < win.size(); ++i) win[i] = f * uom[i];
+    rbl_body_update_X_Q(S, win.data(), Xs, Qs);
+    S.X = Xs; S.Q = Qs; c->dev_xq_valid = false;                      // displaced configuration, temporarily
+    rc = positions_dev(c, 0, S.N_bod, (double *)c->d_r.p);
+    if (!rc) rc = apply_M_enqueue(c, S.wall, (const double *)c->d_W.p, (const double *)c->d_r.p, N, 0, N, dM[sgn]);
+    S.X = X0; S.Q = Q0; c->dev_xq_valid = false;
+    if (rc) return rc;
+  }
+  rbl_launch_axpby(c->stream, n3, 1.0 / delta, dM[0], -1.0 / delta, dM[1], dM[0]);   // :793
+  if ((rc = copy_d2h(c, out, dM[0], vb))) return rc;
+  return finish_and_check(c);
+}
+
+// KTinv_RFD(), c_rigid_obj.cpp:743-767:  K^T (1/delta) [ Kinv(q+)^T - Kinv(q-)^T ] W, W of length 6 N_bod
+int rbl_KTinv_RFD(rbl_ctx *c, const double *W, double delta, double *out)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if (!W || !(delta > 0.0)) return rbl_fail(c, RBL_ERR_ARG, "KTinv_RFD: need W and delta > 0");
+  const RblBodyState &S = c->S;
+  const size_t n3 = (size_t)3 * S.N_bod * S.N_blb;
+  std::vector<double> win((size_t)6 * S.N_bod), acc(n3, 0.0), tmp(n3);
+  for (int sgn = 0; sgn < 2; ++sgn) {
+    const double f = (sgn == 0 ? 0.5 : -0.5) * delta;
+    for (size_t i = 0; i < win.size(); ++i) win[i] = f * W[i];
+    RblBodyState T = S;                                              // displaced copy (:755-761)
+    rbl_body_update_X_Q(S, win.data(), T.X, T.Q);
+    if ((rc = rbl_body_set_K(T, c->last_error))) return rc;
+    rbl_body_KTinv_x_F(T, W, tmp.data());
+    const double w = (sgn == 0 ? 1.0 : -1.0) / delta;
+    for (size_t i = 0; i < n3; ++i) acc[i] += w * tmp[i];            // :763-764
+  }
+  rbl_body_KT_x_Lam(S, acc.data(), out);                             // :766
+  return RBL_OK;
+}
+
+}  // extern "C"

@@ -600,3 +600,23 @@ def test_graph_captured_solve_equals_eager(shell12):
     np.testing.assert_allclose(X1, X0, rtol=0, atol=1e-12)
     np.testing.assert_allclose(Q1, Q0, rtol=0, atol=1e-12)
     assert abs(r0 - r1) < 1e-9
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_M_RFD_vs_oracle(orc, shell12, wall):
+    """M_RFD (reference c_rigid_obj.cpp:769-796): two GPU products at displaced configurations."""
+    from oracle import oracle as onp
+    nb = 5
+    X, Q = random_positions(nb, wall=wall, seed=95)
+    if wall:
+        X[:, 2] += 1.2
+    cb = create_solver(X, Q, wall_PC=wall)
+    W = np.random.default_rng(96).standard_normal(36 * nb)
+    out = cb.M_RFD(W, delta=1e-4)
+    ref = onp.M_RFD(orc, W, X, onp.normalize_quats(Q), onp.remove_mean(shell12), 1.0, 1.0, wall, 1e-4)
+    # a difference quotient amplifies the 1e-15 product error by 1/delta
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 1e-7
+    # the configuration is left untouched and seeded noise is reproducible
+    X1, Q1 = cb.get_config()
+    assert np.allclose(X1, X)
+    assert np.array_equal(cb.M_RFD(seed=3), cb.M_RFD(seed=3))

@@ -157,3 +157,20 @@ def test_dimer_is_singular_error_not_exit():
     from rigid_body_light_amd import RigidBody
     with pytest.raises(RuntimeError, match="singular"):
         RigidBody(cfg, np.zeros((1, 3)), np.array([[1.0, 0, 0, 0]]), 1.0, 1.0, 0.1)
+
+
+def test_KTinv_RFD_numeric():
+    """reference c_rigid_obj.cpp:743-767 (host-only arithmetic) vs the numpy restatement.  An
+    irregular body: for the symmetric shells the quantity vanishes identically."""
+    n = 3
+    cfg = np.random.default_rng(5).uniform(-1, 1, (9, 3)) * np.array([2.0, 1.0, 0.5])
+    X, Q = random_positions(n, seed=20)
+    cb = create_solver(X, Q, rigid_config=cfg)
+    W = np.random.default_rng(21).standard_normal(6 * n)
+    for delta in (1e-2, 1e-4):
+        out = cb.KTinv_RFD(W, delta=delta)
+        ref = onp.KTinv_RFD(W, X, onp.normalize_quats(Q), onp.remove_mean(cfg), delta)
+        assert out.shape == (6 * n,) and np.abs(ref).max() > 0.1
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-14 / delta * 50)   # difference quotient: rounding / delta
+    with pytest.raises(RuntimeError):
+        cb.KTinv_RFD(W[:-1])
