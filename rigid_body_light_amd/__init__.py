@@ -32,7 +32,7 @@ except ImportError as _e:  # fail loudly: the product has no Python/CPU path
         "(run `python -m rigid_body_light_amd.build`): %s" % (_e,)
     ) from _e
 
-from .Rigid import RigidBody  # noqa: E402,F401
+from .rigid_body import RigidBody  # noqa: E402,F401
 from .synth import load_structure, make_config, STRUCT_DIR  # noqa: E402,F401
 
 __all__ = ["RigidBody", "c_rigid", "load_structure", "make_config", "STRUCT_DIR"]
