@@ -194,12 +194,11 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
     Bc = far ? Bc : B_near;
     if (r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
   }
-  const double q2j = __builtin_fma(dy, Fjy, dx * Fjx);
-  const double q2i = __builtin_fma(dy, Fiy, dx * Fix);
-  const double tBj = Bc * __builtin_fma(dz, Fjz, q2j);
-  const double tBi = Bc * __builtin_fma(dz, Fiz, q2i);
-
-  if (!WALL) {
+  if (!WALL) {   // free space: the vector form A F + Bc (d.F) d is cheaper than forming the block
+    const double q2j = __builtin_fma(dy, Fjy, dx * Fjx);
+    const double q2i = __builtin_fma(dy, Fiy, dx * Fix);
+    const double tBj = Bc * __builtin_fma(dz, Fjz, q2j);
+    const double tBi = Bc * __builtin_fma(dz, Fiz, q2i);
     uix = __builtin_fma(A, Fjx, __builtin_fma(tBj, dx, uix));
     uiy = __builtin_fma(A, Fjy, __builtin_fma(tBj, dy, uiy));
     uiz = __builtin_fma(A, Fjz, __builtin_fma(tBj, dz, uiz));
@@ -209,6 +208,8 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
     return;
   }
 
+  // Wall: coefficients for ONE direction (h = z_j), then the nine entries of M_ij explicitly;
+  // M_ji = M_ij^T exactly (fact3(h) + fact4(1-h) = -2 e_z fact2), so U_j += M_ij^T F_i reuses them.
   const double Rz = zi + zj;
   const double R2 = __builtin_fma(Rz, Rz, q);
   const double invR = rbl_rsqrt(R2);
@@ -218,8 +219,8 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   const double w3 = w2 * w;
   const double w5 = w3 * w2;
   const double ez2 = ez * ez;
-  const double g = zj * invR;
-  const double k = zi * invR;
+  const double g = zj * invR;                        // h_hat * ez
+  const double k = zi * invR;                        // (1 - h_hat) * ez
   const double gk = g * k;
   const double p3 = __builtin_fma(-3.0, ez2, 1.0);
   const double p5 = __builtin_fma(-5.0, ez2, 1.0);
@@ -231,40 +232,39 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   double f2 = __builtin_fma(6.0, gk, -1.0) * w;
   f2 = __builtin_fma(p5w3, 2.0, f2);
   f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
+  const double gw = g * w;
   const double ezw5 = ez * w5;
-  // shared pieces of fact3 / fact4 / fact5
-  double f3e = (ez * p5w3) * -4.0;
-  f3e = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3e);
-  const double f4e = ezw5 * (-20.0 / 3.0);
-  double f5c = (ez2 * w3) * -4.0;
-  f5c = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5c);
-  const double gw2 = 2.0 * (g * w), kw2 = 2.0 * (k * w);
-  const double sixez = -6.0 * ez;
-  // i <- j : h = z_j  (g plays h_hat*ez, k plays (1-h_hat)*ez)
-  const double f3j = __builtin_fma(gw2, __builtin_fma(sixez, k, 1.0), f3e);
-  const double f4j = gw2 + f4e;
-  const double f5j = __builtin_fma(-2.0 * g, gw2, f5c);
-  // j <- i : h = z_i  (roles of g and k swap)
-  const double f3i = __builtin_fma(kw2, __builtin_fma(sixez, g, 1.0), f3e);
-  const double f4i = kw2 + f4e;
-  const double f5i = __builtin_fma(-2.0 * k, kw2, f5c);
+  double f3 = gw * __builtin_fma(-12.0 * ez, k, 2.0);            // 2 g w (1 - 6 k ez)
+  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
+  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
+  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw + gw);   // 2 g w - 20/3 ez w^5
+  double f5 = (-4.0 * g) * gw;                                   // -4 g^2 w
+  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
+  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
+
   const double cF = A + f1;
-  const double RzFj = Rz * Fjz, RzFi = Rz * Fiz;
-  // e.F with e = (dx,dy,Rz)/R for i<-j and (-dx,-dy,Rz)/R for j<-i
-  const double eFj = (RzFj + q2j) * invR;
-  const double eFi = (RzFi - q2i) * invR;
-  const double cEj = __builtin_fma(f2, eFj, f3j * Fjz) * invR;
-  const double cEi = __builtin_fma(f2, eFi, f3i * Fiz) * invR;
-  const double cZj = __builtin_fma(f4j, eFj, f5j * Fjz);
-  const double cZi = __builtin_fma(f4i, eFi, f5i * Fiz);
-  const double cxyj = tBj + cEj;
-  const double cxyi = tBi - cEi;
-  uix = __builtin_fma(cF, Fjx, __builtin_fma(cxyj, dx, uix));
-  uiy = __builtin_fma(cF, Fjy, __builtin_fma(cxyj, dy, uiy));
-  uiz = __builtin_fma(cF, Fjz, __builtin_fma(tBj, dz, __builtin_fma(cEj, Rz, uiz + cZj)));
-  ujx = __builtin_fma(cF, Fix, __builtin_fma(cxyi, dx, ujx));
-  ujy = __builtin_fma(cF, Fiy, __builtin_fma(cxyi, dy, ujy));
-  ujz = __builtin_fma(cF, Fiz, __builtin_fma(tBi, dz, __builtin_fma(cEi, Rz, ujz + cZi)));
+  const double beta = __builtin_fma(f2, invR * invR, Bc);        // lateral dyad: (Bc + f2/R^2) d d^T
+  const double f2ez = f2 * ez;
+  const double Bdz = Bc * dz;
+  const double gxz = __builtin_fma(f2ez + f3, invR, Bdz);        // M_xz = dx gxz, M_yz = dy gxz
+  const double gzx = __builtin_fma(f2ez + f4, invR, Bdz);        // M_zx = dx gzx, M_zy = dy gzx
+  const double bx = beta * dx, by = beta * dy;
+  const double mxx = __builtin_fma(bx, dx, cF);
+  const double mxy = bx * dy;
+  const double myy = __builtin_fma(by, dy, cF);
+  const double mxz = dx * gxz, myz = dy * gxz;
+  const double mzx = dx * gzx, mzy = dy * gzx;
+  double mzz = __builtin_fma(Bdz, dz, cF);
+  mzz = __builtin_fma(f2ez, ez, mzz);
+  mzz = __builtin_fma(f3 + f4, ez, mzz) + f5;
+  // U_i += M F_j
+  uix = __builtin_fma(mxx, Fjx, __builtin_fma(mxy, Fjy, __builtin_fma(mxz, Fjz, uix)));
+  uiy = __builtin_fma(mxy, Fjx, __builtin_fma(myy, Fjy, __builtin_fma(myz, Fjz, uiy)));
+  uiz = __builtin_fma(mzx, Fjx, __builtin_fma(mzy, Fjy, __builtin_fma(mzz, Fjz, uiz)));
+  // U_j += M^T F_i
+  ujx = __builtin_fma(mxx, Fix, __builtin_fma(mxy, Fiy, __builtin_fma(mzx, Fiz, ujx)));
+  ujy = __builtin_fma(mxy, Fix, __builtin_fma(myy, Fiy, __builtin_fma(mzy, Fiz, ujy)));
+  ujz = __builtin_fma(mxz, Fix, __builtin_fma(myz, Fiy, __builtin_fma(mzz, Fiz, ujz)));
 }
 
 // ---------------------------------------------------------------------------
