@@ -29,7 +29,7 @@ try:
 except ImportError as _e:  # fail loudly: the product has no Python/CPU path
     raise ImportError(
         "rigid_body_light_amd: native extension c_rigid/librbl.so not built "
-        "(run `python -m rigid_body_light_amd.build`): %s" % (_e,)
+        "(run `python rigid_body_light_amd/build.py`): %s" % (_e,)
     ) from _e
 
 from .rigid_body import RigidBody  # noqa: E402,F401

@@ -18,7 +18,7 @@ def lib():
     if _LIB is None:
         path = os.path.join(_HERE, "librbl.so")
         if not os.path.exists(path):
-            raise ImportError("librbl.so not built; run `python -m rigid_body_light_amd.build`")
+            raise ImportError("librbl.so not built; run `python rigid_body_light_amd/build.py`")
         L = C.CDLL(path)
         vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
         L.rbl_create.restype = vp

@@ -4,7 +4,7 @@
   c_rigid.<abi>.so     g++ + pybind11               csrc/c_rigid.cpp  (links librbl.so, rpath $ORIGIN)
 
 Both land next to this file so they travel with the tree (gpurun snapshot) and are the
-files the Python package loads.  `python -m rigid_body_light_amd.build [--force]`.
+files the Python package loads.  `python rigid_body_light_amd/build.py [--force]`.
 """
 import os
 import subprocess
