@@ -53,7 +53,9 @@ int rbl_dev_init(rbl_ctx *c)
   RBL_HIP(c, hipHostMalloc((void **)&c->h_err, sizeof(unsigned), hipHostMallocDefault));
   RBL_HIP(c, hipMemset(c->d_err, 0, sizeof(unsigned)));
   // auxiliary stream + events for the Cholesky lookahead (optional: failure just disables it)
-  if (hipStreamCreateWithFlags(&c->chol_aux.stream, hipStreamNonBlocking) == hipSuccess) {
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
+  if (hipStreamCreateWithPriority(&c->chol_aux.stream, hipStreamNonBlocking, prio_hi) == hipSuccess) {
     for (int i = 0; i < 3; ++i)
       if (hipEventCreateWithFlags(&c->chol_aux.ev[i], hipEventDisableTiming) != hipSuccess) {
         c->chol_aux.stream = nullptr;

@@ -290,72 +290,74 @@ __global__ void k_trmv_reduce(const double *__restrict__ part, long n, int nchun
 
 size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * IB * IB; }
 
-// Panel p is factored on the caller's stream while the big trailing update R_{p-1} of the
-// previous panel still runs on the auxiliary stream (one-panel lookahead):
-//   main: [wait L_{p-1}] factor panel p, record P_p
-//   aux : wait P_p ; L_p = update of the NEXT panel's columns, record L_p ; R_p = the rest
+// Panel p is factored on the high-priority auxiliary stream while the big trailing update R_{p-1}
+// of the previous panel still runs on the caller's stream (one-panel lookahead):
+//   aux   : [wait L_{p-1}] factor panel p, record P_p
+//   caller: wait P_p ; L_p = update of the NEXT panel's columns, record L_p ; R_p = the rest
 // R_{p-1} touches only columns >= k_p + NB, the panel only its own NB columns, so the two
-// never write the same entries; same-column updates stay ordered on the aux stream.
+// never write the same entries; same-column updates stay ordered on the caller's stream.
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
                         double *d_work, size_t work_bytes, const RblCholAux *aux)
 {
   if (!d_work || work_bytes < sizeof(double) * IB * IB) return RBL_ERR_ARG;
   double *Linv = d_work;
   const bool look = aux && aux->stream && n > 4 * NB;
-  hipStream_t sb = look ? aux->stream : st;
+  // sp: panel stream (the HIGH-priority auxiliary stream, so the small latency-bound panel kernels
+  // are dispatched ahead of the remaining workgroups of the big update);  su: update stream (caller's)
+  hipStream_t sp = look ? aux->stream : st, su = st;
   if (look) {
     if (hipEventRecord(aux->ev[2], st) != hipSuccess) return RBL_ERR_HIP;
-    if (hipStreamWaitEvent(sb, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
+    if (hipStreamWaitEvent(sp, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
   }
   bool pending_L = false;
   for (int64_t k = 0; k < n; k += NB) {
     const int64_t pw = (n - k < NB) ? (n - k) : NB;  // panel width
     const int64_t pend = k + pw;
     if (look && pending_L) {
-      if (hipStreamWaitEvent(st, aux->ev[1], 0) != hipSuccess) return RBL_ERR_HIP;
+      if (hipStreamWaitEvent(sp, aux->ev[1], 0) != hipSuccess) return RBL_ERR_HIP;
       pending_L = false;
     }
     for (int64_t kk = k; kk < pend; kk += IB) {
       const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
-      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Linv, d_err, 0L, 0L);
+      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, sp, d_M, (long)n, (long)kk, nb, Linv, d_err, 0L, 0L);
       const int64_t rows = n - (kk + nb);
       if (rows > 0) {
-        hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_M,
+        hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, sp, d_M,
                            (long)n, (long)kk, nb, Linv, 0L, 0L);
         // rank-nb update of the rest of THIS panel: rows >= kk+nb, cols [kk+nb, pend)
         const int64_t r0 = kk + nb;
         if (r0 < pend) {
           if (nb != IB) return RBL_ERR_SIZE;  // cannot happen: a short step is always the last of its panel
           dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128));
-          hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0,
+          hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sp, d_M, (long)n, (long)r0,
                              (long)pend, (long)kk, nb, 0L);
         }
       }
     }
     if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
       if (look) {
-        if (hipEventRecord(aux->ev[0], st) != hipSuccess) return RBL_ERR_HIP;
-        if (hipStreamWaitEvent(sb, aux->ev[0], 0) != hipSuccess) return RBL_ERR_HIP;
+        if (hipEventRecord(aux->ev[0], sp) != hipSuccess) return RBL_ERR_HIP;
+        if (hipStreamWaitEvent(su, aux->ev[0], 0) != hipSuccess) return RBL_ERR_HIP;
       }
       const int64_t lend = (pend + NB < n) ? pend + NB : n;   // L_p: the next panel's columns
       {
         dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((lend - pend + 127) / 128));
-        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)pend, (long)lend,
+        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, su, d_M, (long)n, (long)pend, (long)lend,
                            (long)k, (int)pw, 0L);
       }
       if (look) {
-        if (hipEventRecord(aux->ev[1], sb) != hipSuccess) return RBL_ERR_HIP;
+        if (hipEventRecord(aux->ev[1], su) != hipSuccess) return RBL_ERR_HIP;
         pending_L = true;
       }
       if (lend < n) {                                          // R_p: everything right of it
         dim3 grid((unsigned)((n - lend + 127) / 128), (unsigned)((n - lend + 127) / 128));
-        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sb, d_M, (long)n, (long)lend, (long)n,
+        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, su, d_M, (long)n, (long)lend, (long)n,
                            (long)k, (int)pw, 0L);
       }
     }
   }
-  if (look) {
-    if (hipEventRecord(aux->ev[2], sb) != hipSuccess) return RBL_ERR_HIP;
+  if (look) {   // the last panel ran on sp
+    if (hipEventRecord(aux->ev[2], sp) != hipSuccess) return RBL_ERR_HIP;
     if (hipStreamWaitEvent(st, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
   }
   if (zero_upper)
