@@ -100,17 +100,18 @@ def test_get_K_Kinv(shell12):                                  # :112-122 + nume
     np.testing.assert_allclose((Ki @ K).toarray(), np.eye(6 * n), atol=1e-12)   # pseudo-inverse
 
 
-def test_apply_PC_diag_numeric(orc, shell12):                  # :125-147, (block_PC=False) cases
+@pytest.mark.parametrize("precision", [np.float32, np.float64])  # tests/test_precision.py:28-44
+def test_apply_PC_diag_numeric(orc, shell12, precision):       # :125-147, (block_PC=False) cases
     n = 3
     for wall in (False, True):
         X, Q = random_positions(n, wall=wall, seed=8)
         X[:, 2] += 1.0 if wall else 0.0
         cb = create_solver(X, Q, wall_PC=wall)
         size = 3 * 12 * n + 6 * n
-        b = np.random.default_rng(9).standard_normal(size)
+        b = np.random.default_rng(9).standard_normal(size).astype(precision)
         out = cb.apply_PC(b)
         assert out.shape == (size,) and np.linalg.norm(out) > 0
-        ref = onp.apply_PC(orc, b, X, onp.normalize_quats(Q), onp.remove_mean(shell12), 1.0, 1.0, wall, False)
+        ref = onp.apply_PC(orc, b.astype(np.float64), X, onp.normalize_quats(Q), onp.remove_mean(shell12), 1.0, 1.0, wall, False)
         np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-11)
         with pytest.raises(RuntimeError):
             cb.apply_PC(np.zeros(size - 4))
