@@ -161,6 +161,9 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   const bool full = (row_begin == 0 && row_end == nbl);
   bool sym = full;   // measured faster at every size, N = 120 ... 128 400 (profiles/r01_apply_M_all_configs.md)
+  // its row/column-sum slabs grow like N^2/128 * 24 B (1.7 GB at 128 400 blobs, ~100 GB at 10^6):
+  // beyond a budget the ordered kernel (O(N) workspace, ~1.6x the time) takes over
+  if (sym && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1) > c->sym_workspace_budget) sym = false;
   if (c->tune_variant == 1) sym = false;
   if (c->tune_variant == 2) sym = full;
   int rc;

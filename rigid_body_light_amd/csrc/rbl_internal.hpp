@@ -75,6 +75,7 @@ struct rbl_ctx {
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
   RblCholAux chol_aux;
   // tuning
+  size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
   int tune_jsplit = 0;
   int tune_variant = 0;
   // lanczos
