@@ -223,7 +223,9 @@ int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /*
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);
 
-/* override the matvec decomposition (0 = heuristic) -- tuning/test hook */
+/* tuning / test hook.  jsplit: j-split of the ordered kernel (0 = heuristic).  variant: 0 = heuristic
+ * (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 = force the ordered kernel,
+ * 2 = force the symmetric kernel, 3 = force the MFMA multi-RHS kernel. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

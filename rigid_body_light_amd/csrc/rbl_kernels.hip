@@ -1,15 +1,21 @@
 // rbl_kernels.hip -- hand-written gfx950 kernels of the blob-mobility hot path.
 //
-//   k_apply_M<WALL>      matrix-free  U = [B] M [B] F        (reference :641-659 + :413-459)
-//                        fp64-VALU bound; j-blob tiles staged in LDS, every lane of a
-//                        wavefront owns one i-blob and sweeps the tile by LDS broadcast.
-//   k_reduce_parts       sums the j-split partial slabs, applies 1/(8 pi eta a) and B_i
-//   k_build_M<WALL>      dense column-major assembly (reference :413-459), HBM-write
-//                        bound; reference-order arithmetic -> bit-identical entries
-//   k_blob_positions     r_k = R(Q_b) c_k + X_b           (reference :257-293)
-//   k_pair_blocks        test hook: independent 3x3 blocks
-//   k_normal             counter-based N(0,1) generator (replaces clock-seeded :730-741)
-//   small BLAS-1 helpers for Lanczos
+//   k_apply_M_sym<WALL,NI>  matrix-free U = [B] M [B] F, every UNORDERED pair once (default):
+//                           wave-private LDS tile, systolic lane<->column pairing, ds_add_f64
+//                           column sums, slabs reduced by k_reduce_sym   (reference :641-659,:413-459)
+//   k_apply_M<WALL>         the same product by ordered pairs for a ROW RANGE (row sharding,
+//                           very large N): j tiles staged in LDS, lane = row, LDS broadcast;
+//                           j-split partial slabs reduced by k_reduce_parts
+//   k_apply_M_mrhs<WALL>    16 right-hand sides: pair blocks on the VALU, nine v_mfma_f64_16x16x4
+//                           per step apply them (k_pack_rhs / k_unpack_rhs transpose the vectors)
+//   k_build_M<WALL>         dense column-major assembly (reference :413-459), HBM-write bound,
+//                           reference-order arithmetic -> bit-identical entries; batched over bodies
+//   k_blob_positions        r_k = R(Q_b) c_k + X_b                       (reference :257-293)
+//   k_pair_blocks           test hook: independent 3x3 blocks
+//   k_normal                counter-based N(0,1) generator (replaces clock-seeded :730-741)
+//   BLAS-1 helpers for Lanczos (deterministic two-stage reductions)
+// All fp64-VALU-bound kernels share the pair arithmetic of rbl_pair.hpp.  No float atomics on
+// global memory anywhere: every sum has a fixed order, results are bitwise reproducible.
 #include "rbl_internal.hpp"
 
 #include <algorithm>
