@@ -351,12 +351,17 @@ def test_full_size_properties(orc, nb, nblb, wall):
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
     c = make_config(nb, nblb, wall)
+    if wall:
+        c["X"][:7, 2] = 1.0 + 0.4 * c["a"]      # seven bodies dip into the damping zone 0 < z < a
     N = nb * nblb
     dev = torch.device("cuda:0")
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
     r = torch.empty(3 * N, dtype=torch.float64, device=dev)
     ctx.blob_positions(0, nb, r.data_ptr())
+    if wall:
+        zs = r.view(-1, 3)[:, 2]
+        assert float(zs.min()) > 0 and int((zs < c["a"]).sum()) > 50
     rng = np.random.default_rng(2)
     x = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
     y = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
@@ -401,9 +406,10 @@ def test_full_size_properties(orc, nb, nblb, wall):
         assert float(torch.linalg.norm(O16[1] - My) / torch.linalg.norm(My)) < 1e-13
     # oracle spot check on a few rows of the full-size problem
     rh = r.cpu().numpy(); xh = x.cpu().numpy()
-    b = N // 3
-    Uo = orc.apply_M_rows(xh, rh, b, b + 16, c["a"], c["eta"], wall, nthreads=8)
-    assert rel(Mx.cpu().numpy()[3 * b:3 * b + 48], Uo) < 1e-11
+    Mxh = Mx.cpu().numpy()
+    for b in (0, 300, N // 3, N - 16):          # rows of damped bodies, interior rows, the last (ragged) tile
+        Uo = orc.apply_M_rows(xh, rh, b, b + 16, c["a"], c["eta"], wall, nthreads=8)
+        assert rel(Mxh[3 * b:3 * b + 48], Uo) < 1e-11
 
 
 def test_cholesky_cfg2_size_property():
