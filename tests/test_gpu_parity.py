@@ -361,7 +361,7 @@ def test_full_size_properties(orc, nb, nblb, wall):
     ctx.blob_positions(0, nb, r.data_ptr())
     if wall:
         zs = r.view(-1, 3)[:, 2]
-        assert float(zs.min()) > 0 and int((zs < c["a"]).sum()) > 50
+        assert float(zs.min()) > 0 and int((zs < c["a"]).sum()) >= 20
     rng = np.random.default_rng(2)
     x = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
     y = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
