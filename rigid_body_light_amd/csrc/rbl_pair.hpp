@@ -182,9 +182,9 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   const double invr = rbl_rsqrt(r2);
   const double invr2 = invr * invr;
   const double s = P.a * invr;
-  const double t = s * s;
-  double A = __builtin_fma(s * t, 2.0 / 3.0, s);
-  double Bc = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
+  const double s3 = (s * s) * s;
+  double A = __builtin_fma(s3, 2.0 / 3.0, s);              // (a/r)(1 + 2/3 (a/r)^2)
+  double Bc = __builtin_fma(s3, -2.0, s) * invr2;          // (a/r)(1 - 2 (a/r)^2) / r^2
   if (__builtin_expect(__any(r2 < P.four_a2), 0)) {   // wave-uniform: overlap branch is rare
     const double rr = r2 * invr;
     const double A_near = __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
@@ -232,31 +232,31 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   double f2 = __builtin_fma(6.0, gk, -1.0) * w;
   f2 = __builtin_fma(p5w3, 2.0, f2);
   f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
-  const double gw = g * w;
-  const double ezw5 = ez * w5;
-  double f3 = gw * __builtin_fma(-12.0 * ez, k, 2.0);            // 2 g w (1 - 6 k ez)
-  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
-  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
-  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw + gw);   // 2 g w - 20/3 ez w^5
-  double f5 = (-4.0 * g) * gw;                                   // -4 g^2 w
+  // f2 ez + f3 = w (T0 - T1),  f2 ez + f4 = w (T0 + T1)  with  T0 = 2 g - ez,
+  // T1 = 6 g k ez + ez w^2 [(2 - 10 ez^2) + w^2 (-10 + 70/3 ez^2)]   (sum / difference of fact3, fact4)
+  const double T0 = __builtin_fma(2.0, g, -ez);
+  const double inner = __builtin_fma(w2, __builtin_fma(ez2, 70.0 / 3.0, -10.0), __builtin_fma(ez2, -10.0, 2.0));
+  const double T1 = __builtin_fma(6.0 * ez, gk, (ez * w2) * inner);
+  const double wi = w * invR;
+  // fact5 = -4 g^2 w - 4 ez^2 w^3 - 4/3 (2 - 15 ez^2) w^5
+  double f5 = (-4.0 * g) * (g * w);
   f5 = __builtin_fma(ez2 * w3, -4.0, f5);
   f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
 
   const double cF = A + f1;
   const double beta = __builtin_fma(f2, invR * invR, Bc);        // lateral dyad: (Bc + f2/R^2) d d^T
-  const double f2ez = f2 * ez;
   const double Bdz = Bc * dz;
-  const double gxz = __builtin_fma(f2ez + f3, invR, Bdz);        // M_xz = dx gxz, M_yz = dy gxz
-  const double gzx = __builtin_fma(f2ez + f4, invR, Bdz);        // M_zx = dx gzx, M_zy = dy gzx
+  const double gxz = __builtin_fma(T0 - T1, wi, Bdz);            // M_xz = dx gxz, M_yz = dy gxz
+  const double gzx = __builtin_fma(T0 + T1, wi, Bdz);            // M_zx = dx gzx, M_zy = dy gzx
+  // f2 ez^2 + (f3 + f4) ez  =  ez [ (f2 ez + f3) + (f2 ez + f4) ] - f2 ez^2  =  2 w ez T0 - f2 ez^2
+  const double zz = __builtin_fma((w + w) * ez, T0, -(f2 * ez2));
   const double bx = beta * dx, by = beta * dy;
   const double mxx = __builtin_fma(bx, dx, cF);
   const double mxy = bx * dy;
   const double myy = __builtin_fma(by, dy, cF);
   const double mxz = dx * gxz, myz = dy * gxz;
   const double mzx = dx * gzx, mzy = dy * gzx;
-  double mzz = __builtin_fma(Bdz, dz, cF);
-  mzz = __builtin_fma(f2ez, ez, mzz);
-  mzz = __builtin_fma(f3 + f4, ez, mzz) + f5;
+  const double mzz = __builtin_fma(Bdz, dz, cF) + (zz + f5);
   // U_i += M F_j
   uix = __builtin_fma(mxx, Fjx, __builtin_fma(mxy, Fjy, __builtin_fma(mxz, Fjz, uix)));
   uiy = __builtin_fma(mxy, Fjx, __builtin_fma(myy, Fjy, __builtin_fma(myz, Fjz, uiy)));
