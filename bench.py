@@ -138,7 +138,7 @@ def brownian_mode(args, dev, world, rank):
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
     from rigid_body_light_amd.dist import ShardedMobility
-    from rigid_body_light_amd.krylov import lanczos_mhalf
+    from rigid_body_light_amd.krylov import lanczos_mhalf, lanczos_mhalf_multi
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb
@@ -155,6 +155,31 @@ def brownian_mode(args, dev, world, rank):
         ctx.apply_M_sym(v.contiguous().data_ptr(), sm.r_full.data_ptr(), N, rank, world, part.data_ptr())
         return sm.all_reduce_sum(part)
 
+    if args.nvec > 1:   # k increments at once: every Lanczos iteration is one multi-vector product (MFMA for k >= 4)
+        if world != 1:
+            raise SystemExit("--nvec > 1 is a single-GPU mode")
+        Wk = torch.from_numpy(np.random.default_rng(3).standard_normal((args.nvec, 3 * N))).to(dev)
+
+        def Ak(Vk):
+            out = torch.empty_like(Vk)
+            ctx.apply_M_multi(Vk.data_ptr(), sm.r_full.data_ptr(), N, args.nvec, out.data_ptr())
+            return out
+
+        for _ in range(args.warmup):
+            lanczos_mhalf_multi(Ak, Wk, 100, 1e-3)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            Y, its, ch = lanczos_mhalf_multi(Ak, Wk, 100, 1e-3)
+        torch.cuda.synchronize(); sec = (time.perf_counter() - t0) / args.steps
+        ctx.sync_check()
+        print(json.dumps({
+            "metric": "Brownian increments/sec (%d independent M^{1/2} W by lock-step Lanczos to 1e-3, %d iterations, multi-RHS "
+                      "product on the fp64 matrix cores), %d x shell_N_%d, %s, fp64" % (args.nvec, its, nb, nblb, "wall-corrected, B M B" if wall else "free-space M without damping"),
+            "value": args.nvec / sec, "unit": "increments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": {"workload": args.config, "n_blobs": N, "wall": wall, "nvec": args.nvec},
+            "lanczos_iterations": its, "mf_gflops": args.nvec * its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
+        return
     its = 0
     for _ in range(args.warmup):
         lanczos_mhalf(A, W, 100, 1e-3)
@@ -201,6 +226,8 @@ def main():
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
     ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps (0 = skip)")
+    ap.add_argument("--nvec", type=int, default=1, help="--mode brownian: independent noise vectors advanced in lockstep "
+                    "(>= 4 uses the fp64-MFMA multi-RHS product; 1 GPU)")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "

@@ -208,3 +208,44 @@ class ShardedDeterministicStepper(DeterministicStepper):
     def step(self, F_body, iters=20, rtol=None):
         self.refresh_positions()
         return super().step(F_body, iters, rtol)
+
+
+def lanczos_mhalf_multi(apply_A_multi, W, max_iter=100, tol=1e-3):
+    """k independent Brownian increments M^{1/2} W_c at once: k Lanczos recurrences advanced in lockstep,
+    so that every iteration is ONE multi-vector product -- which librbl runs on the fp64 matrix
+    cores for k >= 4 (rbl_apply_M_multi_dev, 16 vectors per pass).  W: (k, n) tensor.
+    apply_A_multi: (k, n) -> (k, n) computing (B M B) v_c for every row.  Returns (Y (k,n), iterations, change)."""
+    k, n = W.shape
+    dev = W.device
+    V = torch.empty(max_iter + 1, k, n, dtype=W.dtype, device=dev)
+    wnorm = torch.linalg.norm(W, dim=1)
+    V[0] = W / wnorm[:, None]
+    alpha = np.zeros((max_iter, k)); beta = np.zeros((max_iter, k))
+    wn = wnorm.cpu().numpy()
+    y_prev = [None] * k
+    coef = None
+    change = np.ones(k)
+    m = 0
+    for it in range(max_iter):
+        U = apply_A_multi(V[it].contiguous())
+        if it > 0:
+            U = U - torch.from_numpy(beta[it - 1]).to(dev)[:, None] * V[it - 1]
+        al = (V[it] * U).sum(dim=1)
+        U = U - al[:, None] * V[it]
+        be = torch.linalg.norm(U, dim=1)
+        alpha[it] = al.cpu().numpy(); beta[it] = be.cpu().numpy()
+        m = it + 1
+        coef = np.zeros((k, m))
+        for c in range(k):
+            T = np.diag(alpha[:m, c]) + np.diag(beta[:m - 1, c], 1) + np.diag(beta[:m - 1, c], -1)
+            lam, Z = np.linalg.eigh(T)
+            coef[c] = wn[c] * (Z @ (np.sqrt(np.clip(lam, 0.0, None)) * Z[0]))
+            if y_prev[c] is not None:
+                yp = np.zeros(m); yp[: y_prev[c].size] = y_prev[c]
+                change[c] = np.linalg.norm(coef[c] - yp) / np.linalg.norm(coef[c])
+            y_prev[c] = coef[c]
+        if change.max() < tol or it + 1 == max_iter or beta[it].min() < 1e-300:
+            break
+        V[it + 1] = U / be[:, None]
+    Y = torch.einsum("ck,kcn->cn", torch.from_numpy(coef).to(dev), V[:m])
+    return Y, m, float(change.max())

@@ -3,7 +3,7 @@ operators standing in for the HIP ones (the driver is external-user code in refe
 import numpy as np
 import torch
 
-from rigid_body_light_amd.krylov import gmres_right_pc, lanczos_mhalf
+from rigid_body_light_amd.krylov import gmres_right_pc, lanczos_mhalf, lanczos_mhalf_multi
 
 
 def test_gmres_right_preconditioned_solves_spd_and_saddle_like_systems():
@@ -34,3 +34,15 @@ def test_lanczos_square_root():
     y, m, ch = lanczos_mhalf(lambda v: Mt @ v, torch.from_numpy(W), max_iter=80, tol=1e-12)
     np.testing.assert_allclose(y.numpy(), ref, rtol=1e-8, atol=1e-10)
     assert m <= 80
+
+
+def test_lanczos_multi_vector_lockstep():
+    rng = np.random.default_rng(2)
+    n, k = 70, 5
+    A0 = rng.standard_normal((n, n)); M = A0 @ A0.T / n + np.eye(n)
+    lam, V = np.linalg.eigh(M)
+    W = rng.standard_normal((k, n))
+    ref = (V @ (np.sqrt(lam)[:, None] * (V.T @ W.T))).T
+    Mt = torch.from_numpy(M)
+    Y, m, ch = lanczos_mhalf_multi(lambda X: X @ Mt, torch.from_numpy(W), max_iter=70, tol=1e-12)
+    np.testing.assert_allclose(Y.numpy(), ref, rtol=1e-8, atol=1e-10)
