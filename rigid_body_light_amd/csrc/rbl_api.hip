@@ -912,6 +912,7 @@ int rbl_sync_check(rbl_ctx *c)
 int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
   if (!c) return RBL_ERR_ARG;
+  rbl_set_sym_chunk_override(variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;
   return RBL_OK;
 }

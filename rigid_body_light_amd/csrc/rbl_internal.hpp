@@ -108,6 +108,7 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
                         int64_t row_end, double *d_out, double *d_part, int jsplit,
                         int variant, unsigned *d_err);
 size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step);
+void rbl_set_sym_chunk_override(int c);   // tuning hook: chunk length C of the symmetric kernel (0 = heuristic)
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
                             double *d_out, double *d_work, int n_cu, unsigned *d_err);

@@ -707,6 +707,9 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 }
 
 // ---- symmetric variant ------------------------------------------------------
+static int g_sym_chunk_override = 0;   // tuning hook (rbl_set_tuning jsplit with variant 2): forces C
+void rbl_set_sym_chunk_override(int c) { g_sym_chunk_override = c; }
+
 static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI)
 {
   const int t = (int)((n_blobs + TS - 1) / TS);
@@ -715,14 +718,16 @@ static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI,
   const int ni = (t >= 128 * i_step) ? 2 : 1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   const int rowsI = (tsup + i_step - 1) / i_step;
-  // ~ (4 waves/SIMD x 4 SIMD x CUs) x 2 rounds of wave-units; a unit sweeps <= C column tiles.
-  // Longer chunks mean fewer row-sum slabs to write and re-read (the reduction is the only
-  // non-scaling part of a multi-GPU shard).
+  // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
+  // wave-units balance the triangular work and hide tile-boundary latency; C = 4..16 is flat at
+  // 128 400 blobs (29.8-29.9 ms vs 30.8 at C = 64), C = 2 best at 8 100.  Aim for ~8 rounds of
+  // (4 waves/SIMD x 4 SIMD x CUs) units, capped at 16 tiles.
   const double pairs = 0.5 * (double)rowsI * (double)t;
-  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 2.0;
+  const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 8.0;
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
-  if (c > 64) c = 64;
+  if (c > 16) c = 16;
+  if (g_sym_chunk_override > 0) c = g_sym_chunk_override;
   *T = t; *NI = ni; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
 }
 
