@@ -52,7 +52,7 @@ def build(force=False, verbose_resources=False):
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
             cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-x", "hip",
-                   "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+                   "-Wall", "-Wno-unused-function"] + os.environ.get("RBL_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose_resources:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             jobs.append(cmd)

@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__
 // (i_first, i_step) selects the I-tiles of this launch (multi-GPU: I % world == rank).
 // ---------------------------------------------------------------------------
 constexpr int TS = 64;
+#ifndef RBL_SYM_UNROLL
+#define RBL_SYM_UNROLL 2
+#endif
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 template <bool WALL, int NI>
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     sU[0][lane] = 0.0; sU[1][lane] = 0.0; sU[2][lane] = 0.0;
     __syncthreads();
     if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
-#pragma unroll 2
+#pragma unroll RBL_SYM_UNROLL
       for (int s = 0; s < TS; ++s) {
         const int jj = (lane + s) & (TS - 1);
         const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
