@@ -17,7 +17,6 @@ namespace {
 
 constexpr int IB = 32;    // inner step width
 constexpr int NB = 512;   // outer panel width (K of the trailing MFMA update)
-constexpr int MB = 128;   // middle panel width (K of the update inside an outer panel)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -26,17 +25,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // in program order).  Column step c: pivot by v_rsq_f64 + Newton (no sqrt/div chain), scale
 // the column, then the 64 lanes update the trailing lower triangle (lane = row, two column
 // parities).  The same wave then inverts L by forward substitution (lane = column of
-// L^-1) and writes Linv (IB x IB, row-major [c][m]) for the MFMA triangular solve.
-__global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
-                                              double *__restrict__ Linv, unsigned *err, long strideA,
-                                              long strideL)
+// L^-1) and leaves Linv (IB x IB, row-major [c][m]) in Y for the MFMA triangular solve.
+// t = lane (0..63).  Returns true when a pivot was not positive.
+__device__ __forceinline__ bool potf2_wave(double *__restrict__ A, long n, long k, int nb,
+                                           double (*S)[IB + 1], double (*Y)[IB + 1], double *dinv, int t)
 {
-  A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
-  Linv += (size_t)blockIdx.z * (size_t)strideL;
-  __shared__ double S[IB][IB + 1];
-  __shared__ double Y[IB][IB + 1];
-  __shared__ double dinv[IB];
-  const int t = threadIdx.x;
   const int i = t & (IB - 1), par = t >> 5;
   for (int e = t; e < IB * IB; e += 64) {
     const int r = e & (IB - 1), c = e >> 5;  // consecutive lanes -> consecutive rows of a column
@@ -66,7 +59,6 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
       if (j < IB && i >= j) S[i][j] = __builtin_fma(-lic, lj[q], sij[q]);
     }
   }
-  if (bad && t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
   for (int e = t; e < IB * IB; e += 64) {
     const int r = e & (IB - 1), c = e >> 5;
     if (r < nb && c < nb && c <= r) A[(size_t)(k + c) * n + (k + r)] = S[r][c];
@@ -88,9 +80,136 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
 #pragma unroll
     for (int r = 0; r < IB; ++r) Y[r][i] = x[r];
   }
+  return bad;
+}
+
+__global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
+                                              double *__restrict__ Linv, unsigned *err, long strideA,
+                                              long strideL)
+{
+  A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
+  Linv += (size_t)blockIdx.z * (size_t)strideL;
+  __shared__ double S[IB][IB + 1];
+  __shared__ double Y[IB][IB + 1];
+  __shared__ double dinv[IB];
+  const int t = threadIdx.x;
+  const bool bad = potf2_wave(A, n, k, nb, S, Y, dinv, t);
+  if (bad && t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
   for (int e = t; e < IB * IB; e += 64) {
     const int c = e & (IB - 1), r = e >> 5;
     Linv[r * IB + c] = Y[r][c];
+  }
+}
+
+// ---- diagonal block of an outer panel: ONE workgroup factors the whole pw x pw block -----------
+// The right-looking IB-steps (potf2 -> trsm -> rank-IB update) of the block run inside one
+// 16-wave workgroup with __syncthreads() between phases instead of ~3 kernel launches per step:
+// on the critical path of the factorisation a launch boundary costs tens of microseconds (queueing
+// behind the big trailing update + write-back of dirtied lines), a workgroup barrier ~1 us.
+// The block (<= 2 MB) stays in L2/L1 of this CU; every phase's global stores are re-read only after
+// a workgroup barrier.  trsm and update are MFMA (transposed tiles, as in the other kernels).
+// Also writes every L_kk^-1 to LinvAll[step] for k_trsm_tall.
+__global__ __launch_bounds__(1024) void k_potrf_block(double *__restrict__ A, long ld, long k, int pw,
+                                                      double *__restrict__ LinvAll, unsigned *err)
+{
+  __shared__ double S[IB][IB + 1];
+  __shared__ double Y[IB][IB + 1];   // L_kk^-1, row-major [c][m]
+  __shared__ double dinv[IB];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long pend = k + pw;
+  const int nsteps = (pw + IB - 1) / IB;
+  for (int s = 0; s < nsteps; ++s) {
+    const long kk = k + (long)s * IB;
+    const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
+    const long rem0 = kk + nb;
+    if (wave == 0) {
+      const bool bad = potf2_wave(A, ld, kk, nb, S, Y, dinv, lane);
+      if (bad && lane == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+      for (int e = lane; e < IB * IB; e += 64) {
+        const int c = e & (IB - 1), r = e >> 5;
+        LinvAll[(size_t)s * IB * IB + r * IB + c] = Y[r][c];
+      }
+    }
+    __syncthreads();
+    if (rem0 >= pend) break;            // block-uniform: nothing below / right of this step
+    const int nrt = (int)((pend - rem0 + 31) / 32);   // 32-row tiles below the diagonal block
+    // ---- trsm: X = A[rows, kk:kk+32] * Linv^T, one 32-row tile per wave-iteration ------------
+    for (int g = wave; g < nrt; g += 16) {
+      const long i0 = rem0 + 32L * g;
+      long irow[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { long ir = i0 + 16 * q + l15; irow[q] = ir < pend ? ir : pend - 1; }
+      double4_t acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < IB / 4; ++ks) {
+        const int m = 4 * ks + l4;
+        const double *cp = A + (size_t)(kk + m) * (size_t)ld;
+        const double b0 = cp[irow[0]], b1 = cp[irow[1]];
+        const double a0 = Y[l15][m], a1 = Y[16 + l15][m];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const long row = i0 + 16 * ti + l15;
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (row < pend) A[(size_t)(kk + 16 * tc + l4 + 4 * v) * (size_t)ld + row] = acc[tc][ti][v];
+        }
+    }
+    __syncthreads();
+    // ---- rank-IB update of the rest of the block: lower 32x32 tiles dealt round-robin to waves --
+    int idx = 0;
+    for (int bi = 0; bi < nrt; ++bi)
+      for (int bj = 0; bj <= bi; ++bj, ++idx) {
+        if ((idx & 15) != wave) continue;
+        const long i0 = rem0 + 32L * bi, j0 = rem0 + 32L * bj;
+        long irow[2], jrow[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          long ir = i0 + 16 * q + l15; irow[q] = ir < pend ? ir : pend - 1;
+          long jr = j0 + 16 * q + l15; jrow[q] = jr < pend ? jr : pend - 1;
+        }
+        double4_t acc[2][2];   // [tj][ti]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < IB / 4; ++ks) {
+          const double *cp = A + (size_t)(kk + 4 * ks + l4) * (size_t)ld;
+          const double a0 = cp[jrow[0]], a1 = cp[jrow[1]];
+          const double b0 = cp[irow[0]], b1 = cp[irow[1]];
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            const long row = i0 + 16 * ti + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const long col = j0 + 16 * tj + l4 + 4 * v;
+              if (row < pend && col < pend) {
+                double *pp = A + (size_t)col * (size_t)ld + row;
+                *pp = *pp - acc[tj][ti][v];
+              }
+            }
+          }
+      }
+    __syncthreads();
   }
 }
 
@@ -98,9 +217,9 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
 // wave = 64 rows x 32 columns; computes the transposed tile D'[c][i] = sum_m Linv[c][m] A[i][m]
 // so that the stores are 128-B runs along the rows of column-major A.  In place: a wave reads
 // all 32 columns of its 64 rows before it writes them.
-__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long n, long k, int nb,
+__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long ld, long k, int nb,
                                                    const double *__restrict__ Linv, long strideA,
-                                                   long strideL)
+                                                   long strideL, long n /* rows < n are solved */)
 {
   A += (size_t)blockIdx.z * (size_t)strideA;
   Linv += (size_t)blockIdx.z * (size_t)strideL;
@@ -123,7 +242,7 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long 
     const long col = mv ? (k + m) : k;
     double bv[4], av[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const double v = A[(size_t)col * (size_t)n + irow[q]]; bv[q] = mv ? v : 0.0; }
+    for (int q = 0; q < 4; ++q) { const double v = A[(size_t)col * (size_t)ld + irow[q]]; bv[q] = mv ? v : 0.0; }
 #pragma unroll
     for (int tc = 0; tc < 2; ++tc) av[tc] = Linv[(16 * tc + l15) * IB + m];
 #pragma unroll
@@ -140,9 +259,87 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long 
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int cc = 16 * tc + l4 + 4 * v;
-        if (row < n && cc < nb) A[(size_t)(k + cc) * (size_t)n + row] = acc[tc][ti][v];
+        if (row < n && cc < nb) A[(size_t)(k + cc) * (size_t)ld + row] = acc[tc][ti][v];
       }
     }
+}
+
+// ---- tall panel solve: rows below an outer panel, ALL its IB-blocks in one launch -----------
+//   X = A21 L11^{-T}  for rows [r_begin, n) and the panel columns [k0, k0 + nblk*IB)
+// Left-looking per 32-column block j:  X_j = (A_j - sum_{m<j} X_m L_jm^T) L_jj^{-T}.
+// A wave owns 32 rows and walks the column blocks; everything is MFMA, transposed tiles
+// (D'[c][i]) as in k_trsm_mfma.  The fp64 C/D layout (row = (lane>>4) + 4v, col = lane&15) IS the
+// B-operand layout (k = lane>>4 (+4 ks), n = lane&15), so T = A_j - S goes from the accumulator
+// registers straight into the product with Linv_jj -- no LDS, no shuffles.  X_m written by this
+// workgroup is re-read (by other lanes) after a workgroup barrier (same CU -> same L1).
+// This replaces nblk x (k_trsm_mfma + rank-32 k_syrk_mfma) launches over the tall rows of the
+// right-looking panel: the latency-bound chain on the critical path only sees the NB x NB block.
+__global__ __launch_bounds__(256) void k_trsm_tall(double *__restrict__ A, long ld, long n, long k0,
+                                                   int nblk, long r_begin,
+                                                   const double *__restrict__ LinvAll)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long i0 = r_begin + ((long)blockIdx.x * 4 + wave) * 32;
+  long irow[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { long ir = i0 + 16 * q + l15; irow[q] = ir < n ? ir : n - 1; }
+  for (int j = 0; j < nblk; ++j) {
+    double4_t acc[2][2];  // [tc][ti]  S tile, transposed: rows = panel column c, cols = matrix row i
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const long cj = k0 + (long)j * IB;  // first column (and first L11 row) of block j
+    for (int m = 0; m < j; ++m) {
+      const double *colp = A + (size_t)(k0 + (long)m * IB + l4) * (size_t)ld;
+#pragma unroll
+      for (int ks = 0; ks < IB / 4; ++ks) {
+        const double *cp = colp + (size_t)(4 * ks) * (size_t)ld;
+        const double a0 = cp[cj + l15], a1 = cp[cj + 16 + l15];   // L_jm[c][kk]
+        const double b0 = cp[irow[0]], b1 = cp[irow[1]];          // X_m[i][kk]
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    // T = A_j - S in the accumulator layout: element (c = 16 tc + l4 + 4 v, i = 16 ti + l15)
+    double4_t T[2][2];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          T[tc][ti][v] = A[(size_t)(cj + 16 * tc + l4 + 4 * v) * (size_t)ld + irow[ti]] - acc[tc][ti][v];
+    // X_j^T = Linv_jj T : k-step ks uses accumulator register v = ks & 3 of tile tc = ks >> 2 as B operand
+    const double *Li = LinvAll + (size_t)j * IB * IB;
+    double4_t X[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) X[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < IB / 4; ++ks) {
+      const double a0 = Li[l15 * IB + 4 * ks + l4], a1 = Li[(16 + l15) * IB + 4 * ks + l4];
+      const double b0 = T[ks >> 2][0][ks & 3], b1 = T[ks >> 2][1][ks & 3];
+      X[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, X[0][0], 0, 0, 0);
+      X[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, X[0][1], 0, 0, 0);
+      X[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, X[1][0], 0, 0, 0);
+      X[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, X[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        const long row = i0 + 16 * ti + l15;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (row < n) A[(size_t)(cj + 16 * tc + l4 + 4 * v) * (size_t)ld + row] = X[tc][ti][v];
+      }
+    __syncthreads();  // X_j visible to every lane of the workgroup before block j+1 re-reads it
+  }
 }
 
 // ---- rank-K update on the matrix cores ---------------------------------------------------
@@ -157,8 +354,9 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long 
 constexpr int KC = 16;
 constexpr int LDP = 144;
 
-__global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, long n, long r0,
-                                                      long c1, long k0, int K, long strideA)
+__global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, long ld, long r0,
+                                                      long c1, long k0, int K, long strideA,
+                                                      long n /* rows < n are updated */)
 {
   A += (size_t)blockIdx.z * (size_t)strideA;
   __shared__ double sI[2][KC * LDP];
@@ -178,11 +376,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   const int lrow = t & 127, lcg = (t >> 7) * 8;
   long gi = bi0 + lrow; if (gi >= n) gi = n - 1;
   long gj = bj0 + lrow; if (gj >= n) gj = n - 1;
-  const double *pI = A + (size_t)(k0 + lcg) * (size_t)n + gi;
-  const double *pJ = A + (size_t)(k0 + lcg) * (size_t)n + gj;
+  const double *pI = A + (size_t)(k0 + lcg) * (size_t)ld + gi;
+  const double *pJ = A + (size_t)(k0 + lcg) * (size_t)ld + gj;
   double rI[8], rJ[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * n]; rJ[q] = pJ[(size_t)q * n]; }
+  for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * ld]; rJ[q] = pJ[(size_t)q * ld]; }
 #pragma unroll
   for (int q = 0; q < 8; ++q) { sI[0][(lcg + q) * LDP + lrow] = rI[q]; sJ[0][(lcg + q) * LDP + lrow] = rJ[q]; }
   __syncthreads();
@@ -197,9 +395,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   for (int s = 0; s < nst; ++s) {
     const int cur = s & 1;
     if (s + 1 < nst) {
-      pI += (size_t)KC * n; pJ += (size_t)KC * n;
+      pI += (size_t)KC * ld; pJ += (size_t)KC * ld;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * n]; rJ[q] = pJ[(size_t)q * n]; }
+      for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * ld]; rJ[q] = pJ[(size_t)q * ld]; }
     }
     if (active) {
       const double *fi = &sI[cur][l4 * LDP + wi * 64 + l15];
@@ -232,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
       for (int v = 0; v < 4; ++v) {
         const long col = j0 + 16 * tj + l4 + 4 * v;
         if (row < n && col < c1) {
-          double *p = A + (size_t)col * (size_t)n + row;
+          double *p = A + (size_t)col * (size_t)ld + row;
           *p = *p - acc[tj][ti][v];
         }
       }
@@ -289,7 +487,7 @@ __global__ void k_trmv_reduce(const double *__restrict__ part, long n, int nchun
 
 }  // namespace
 
-size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * IB * IB; }
+size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * (NB / IB) * IB * IB; }   // one L_kk^-1 per IB-step of a panel
 
 // Panel p is factored on the high-priority auxiliary stream while the big trailing update R_{p-1}
 // of the previous panel still runs on the caller's stream (one-panel lookahead):
@@ -300,7 +498,7 @@ size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * IB * IB; }
 int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper, unsigned *d_err,
                         double *d_work, size_t work_bytes, const RblCholAux *aux)
 {
-  if (!d_work || work_bytes < sizeof(double) * IB * IB) return RBL_ERR_ARG;
+  if (!d_work || work_bytes < sizeof(double) * (NB / IB) * IB * IB) return RBL_ERR_ARG;
   double *Linv = d_work;
   const bool look = aux && aux->stream && n > 4 * NB;
   // sp: panel stream (the HIGH-priority auxiliary stream, so the small latency-bound panel kernels
@@ -311,50 +509,34 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
     if (hipStreamWaitEvent(sp, aux->ev[2], 0) != hipSuccess) return RBL_ERR_HIP;
   }
   bool pending_L = false;
-  for (int64_t k = 0; k < n; k += NB) {
-    const int64_t pw = (n - k < NB) ? (n - k) : NB;  // panel width
+  // panel width: NB while the trailing matrix is large (its rank-NB update then hides the panel
+  // chain), NB/2 near the end where the panel chain itself is the critical path
+  auto width_at = [n](int64_t k0) -> int64_t {
+    const int64_t w = (n - k0 > 12288) ? NB : NB / 2;
+    return (n - k0 < w) ? (n - k0) : w;
+  };
+  for (int64_t k = 0; k < n;) {
+    const int64_t pw = width_at(k);  // panel width
     const int64_t pend = k + pw;
     if (look && pending_L) {
       if (hipStreamWaitEvent(sp, aux->ev[1], 0) != hipSuccess) return RBL_ERR_HIP;
       pending_L = false;
     }
-    // three-level blocking inside the outer panel: IB-steps only update the rest of their MB-wide
-    // middle panel (4x less data dirtied per step -> cheaper kernel boundaries on the critical path),
-    // each finished middle panel updates the rest of the outer panel with ONE rank-MB product
-    for (int64_t km = k; km < pend; km += MB) {
-      const int64_t mend = (km + MB < pend) ? km + MB : pend;
-      for (int64_t kk = km; kk < mend; kk += IB) {
-        const int nb = (int)((mend - kk < IB) ? (mend - kk) : IB);
-        hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, sp, d_M, (long)n, (long)kk, nb, Linv, d_err, 0L, 0L);
-        const int64_t rows = n - (kk + nb);
-        if (rows > 0) {
-          hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, sp, d_M,
-                             (long)n, (long)kk, nb, Linv, 0L, 0L);
-          const int64_t r0 = kk + nb;
-          if (r0 < mend) {   // rank-IB update of the rest of THIS middle panel
-            if (nb != IB) return RBL_ERR_SIZE;  // cannot happen: a short step is always the last one
-            dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((mend - r0 + 127) / 128));
-            hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sp, d_M, (long)n, (long)r0,
-                               (long)mend, (long)kk, nb, 0L);
-          }
-        }
-      }
-      if (mend < pend) {     // rank-MB update of the rest of the outer panel (mend - km == MB here)
-        dim3 grid((unsigned)((n - mend + 127) / 128), (unsigned)((pend - mend + 127) / 128));
-        hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, sp, d_M, (long)n, (long)mend, (long)pend,
-                           (long)km, (int)(mend - km), 0L);
-      }
-    }
+    // the NB x NB diagonal block: one 16-wave workgroup, barriers instead of launches
+    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(1024), 0, sp, d_M, (long)n, (long)k, (int)pw, Linv, d_err);
+    if (pend < n)            // rows below the block: X = A21 L11^-T, all NB/IB column blocks in one launch
+      hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128)), dim3(256), 0, sp, d_M, (long)n,
+                         (long)n, (long)k, (int)(pw / IB), (long)pend, Linv);
     if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
       if (look) {
         if (hipEventRecord(aux->ev[0], sp) != hipSuccess) return RBL_ERR_HIP;
         if (hipStreamWaitEvent(su, aux->ev[0], 0) != hipSuccess) return RBL_ERR_HIP;
       }
-      const int64_t lend = (pend + NB < n) ? pend + NB : n;   // L_p: the next panel's columns
+      const int64_t lend = pend + width_at(pend);               // L_p: the next panel's columns
       {
         dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((lend - pend + 127) / 128));
         hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, su, d_M, (long)n, (long)pend, (long)lend,
-                           (long)k, (int)pw, 0L);
+                           (long)k, (int)pw, 0L, (long)n);
       }
       if (look) {
         if (hipEventRecord(aux->ev[1], su) != hipSuccess) return RBL_ERR_HIP;
@@ -363,9 +545,10 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       if (lend < n) {                                          // R_p: everything right of it
         dim3 grid((unsigned)((n - lend + 127) / 128), (unsigned)((n - lend + 127) / 128));
         hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, su, d_M, (long)n, (long)lend, (long)n,
-                           (long)k, (int)pw, 0L);
+                           (long)k, (int)pw, 0L, (long)n);
       }
     }
+    k = pend;
   }
   if (look) {   // the last panel ran on sp
     if (hipEventRecord(aux->ev[2], sp) != hipSuccess) return RBL_ERR_HIP;
@@ -407,19 +590,19 @@ int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batc
       const int64_t rows = n - (kk + nb);
       if (rows > 0) {
         hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256), 1, batch), dim3(256), 0, st, d_M,
-                           (long)n, (long)kk, nb, Lk, (long)strideA, strideL);
+                           (long)n, (long)kk, nb, Lk, (long)strideA, strideL, (long)n);
         const int64_t r0 = kk + nb;
         if (r0 < pend) {   // rest of this panel, K = IB
           dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128), batch);
           hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0, (long)pend, (long)kk, nb,
-                             (long)strideA);
+                             (long)strideA, (long)n);
         }
       }
     }
     if (pend < n) {        // trailing matrix, K = NBB (a short panel is the last one)
       dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((n - pend + 127) / 128), batch);
       hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n, (long)k, (int)pw,
-                         (long)strideA);
+                         (long)strideA, (long)n);
     }
   }
   return RBL_OK;
