@@ -86,27 +86,47 @@ def timestep_mode(args, dev, world=1, rank=0):
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb
-    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    brownian = args.kBT > 1e-10
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=args.kBT,
+                        stream_ptr=torch.cuda.current_stream().cuda_stream)
     if args.pc == "block":
         from rigid_body_light_amd._lib import lib
         lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
-    if world > 1:
-        stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
-    else:
-        stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
-    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
     iters = 20 if args.rtol <= 0 else 200
     rtol = args.rtol if args.rtol > 0 else None
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    lanczos_its = None
+    if brownian:   # stochastic midpoint step: 2 M^{1/2}W + M_RFD + Kinv, then the saddle solve at q^{n+1/2}
+        from rigid_body_light_amd.krylov import BrownianStepper, ShardedBrownianStepper
+        method = 0 if args.mhalf == "cholesky" else 1
+        if world > 1 or args.sharded_driver:
+            if method == 0:
+                raise SystemExit("the sharded Brownian step uses the Lanczos square root")
+            bst = ShardedBrownianStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall,
+                                         args.kBT, c["dt"], lanczos_tol=1e-3)
+            stp_step = lambda k: bst.step(Fb, seed=k, iters=iters, rtol=rtol)
+            lanczos_its = lambda: list(bst.lanczos_iterations)
+        else:
+            ctx.set_lanczos(100, 1e-3)
+            bst = BrownianStepper(ctx, nb, nblb, dev)
+            stp_step = lambda k: bst.step(Fb, seed=k, method=method, iters=iters, rtol=rtol)
+            lanczos_its = (lambda: [ctx.lanczos_report()[0]]) if method == 1 else None
+    else:
+        if world > 1:
+            stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
+        else:
+            stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
+        stp_step = lambda k: stp.step(Fb, iters, rtol)
     res, used = [], []
-    for _ in range(args.warmup):
-        stp.step(Fb, iters, rtol)
+    for k in range(args.warmup):
+        stp_step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        m_used, r_last = stp.step(Fb, iters, rtol)
+    for k in range(args.steps):
+        m_used, r_last = stp_step(args.warmup + k)
         res.append(r_last); used.append(m_used)
     torch.cuda.synchronize()
     if world > 1:
@@ -120,14 +140,23 @@ def timestep_mode(args, dev, world=1, rank=0):
     if world > 1 and rank != 0:
         dist.destroy_process_group()
         return
+    kind = "deterministic step"
+    extra = {}
+    if brownian:
+        kind = ("stochastic midpoint step, kBT=%g: 2 M^{1/2}W (%s) + M_RFD (2 apply_M) + Kinv, then" % (args.kBT, args.mhalf))
+        n_prod = iters + 1 + 2
+        if lanczos_its is not None:
+            extra["lanczos_iterations_last_step"] = lanczos_its()
+            n_prod += sum(extra["lanczos_iterations_last_step"]) * (1 if len(extra["lanczos_iterations_last_step"]) > 1 else 2)
+        extra["apply_M_per_step"] = n_prod
     print(json.dumps({
-        "metric": "timesteps/sec (deterministic step: %d GMRES iterations (%s, %s PC) = %d apply_M + PC + K ops + evolve), "
-                  "%d x shell_N_%d, %s, fp64" % (iters, "fixed work" if rtol is None else "converged to %g" % rtol, args.pc,
+        "metric": "timesteps/sec (%s: %d GMRES iterations (%s, %s PC) = %d apply_M + PC + K ops + evolve), "
+                  "%d x shell_N_%d, %s, fp64" % (kind, iters, "fixed work" if rtol is None else "converged to %g" % rtol, args.pc,
                                                  iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
         "value": 1.0 / sec, "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
-        "mf_gflops": (iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used}), flush=True)
+        "mf_gflops": extra.get("apply_M_per_step", iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used, **extra}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -228,6 +257,9 @@ def main():
     ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps (0 = skip)")
     ap.add_argument("--nvec", type=int, default=1, help="--mode brownian: independent noise vectors advanced in lockstep "
                     "(>= 4 uses the fp64-MFMA multi-RHS product; 1 GPU)")
+    ap.add_argument("--kBT", type=float, default=0.0, help="--mode timestep: > 0 runs the stochastic midpoint (Brownian) step")
+    ap.add_argument("--mhalf", default="lanczos", choices=["lanczos", "cholesky"], help="square root used by the Brownian step")
+    ap.add_argument("--sharded-driver", action="store_true", help="use the multi-GPU Brownian driver also at N = 1")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "

@@ -142,6 +142,26 @@ int rbl_M_RFD(rbl_ctx *ctx, const double *W, uint64_t seed, double delta, double
 /* KTinv_RFD(), c_rigid_obj.cpp:743-767: K^T (1/delta)[Kinv(q+)^T - Kinv(q-)^T] W, W[6Nb] -> out[6Nb] */
 int rbl_KTinv_RFD(rbl_ctx *ctx, const double *W, double delta, double *out);
 
+/* update_X_Q(U), c_rigid_obj.cpp:798-863: the configuration displaced by U[6Nb] (translation and rotation
+ * vector per body, displacement units) -> X_out[3Nb], Q_out[4Nb] (scalar-first); nothing is committed. */
+int rbl_update_X_Q(rbl_ctx *ctx, const double *U, double *X_out, double *Q_out);
+
+/* RHS_and_Midpoint(Slip, Force), c_rigid_obj.cpp:917-976 (C++ only in the reference): right-hand side and
+ * predictor configuration of the stochastic midpoint step.
+ *   in : Slip[n3], Force[6Nb] (NOT modified -- the reference mutates its arguments, :963,972);
+ *        W = [W1 | W2 | W_rfd], 3*n3 standard normals, or NULL to draw them from `seed` (:730-741 seeds
+ *        from the clock); method = RBL_MHALF_*; split_rand as the reference member (:150, default 1);
+ *        delta = RFD step (the reference hard-codes 1e-4, :771)
+ *   out: RHS[n3 + 6Nb] = [ Slip - (kBT*M_RFD + BI) ; -Force ],
+ *        BI = c2 (M^1/2 W1 - M^1/2 W2), c1 = 2 sqrt(kBT/dt), c2 = sqrt(kBT/dt)   (split_rand)
+ *        BI = c2  M^1/2 W1,             c1 = c2 = sqrt(2 kBT/dt)                 (otherwise)
+ *        X_half[3Nb], Q_half[4Nb] = update_X_Q((dt/2) Kinv c1 M^1/2 W1)           (:955-959)
+ *   kBT <= 1e-10: RHS = [Slip ; -Force], X_half/Q_half = current configuration     (:967-970)
+ * With RBL_MHALF_CHOLESKY the dense factor is computed once and applied to W1 and W2. */
+int rbl_RHS_and_Midpoint(rbl_ctx *ctx, const double *Slip, const double *Force, const double *W,
+                         uint64_t seed, int method, int split_rand, double delta, double *RHS,
+                         double *X_half, double *Q_half);
+
 /* Lanczos controls / report (iterations used by the last call, last residual) */
 int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
 int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);
@@ -219,6 +239,11 @@ int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /*
 int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */
 int rbl_apply_PC_dev(rbl_ctx *ctx, const double *d_in, double *d_out);        /* apply_PC :589, diagonal PC */
 int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /* src/Rigid.py:73-80 */
+/* RHS_and_Midpoint on device vectors (d_Slip[n3], d_Force[6Nb], d_W[3 n3] or NULL, d_RHS[n3+6Nb]);
+ * X_half / Q_half are host arrays (O(N_bod)). */
+int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d_Force, const double *d_W,
+                             uint64_t seed, int method, int split_rand, double delta, double *d_RHS,
+                             double *X_half, double *Q_half);
 
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);

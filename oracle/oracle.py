@@ -322,3 +322,28 @@ def KTinv_RFD(W, X, Qn, ref_cfg, delta):
     Xm, Qm = update_X_Q(X, Qn, -0.5 * delta * W)
     out = (Kinv_matrix(Xp, Qp, cfg).T @ W - Kinv_matrix(Xm, Qm, cfg).T @ W) / delta
     return K_matrix(X, Qn, cfg).T @ out
+
+
+def RHS_and_Midpoint(orc, Slip, Force, W1, W2, W_rfd, X, Qn, ref_cfg, a, eta, wall, dt, kBT,
+                     split_rand=True, delta=1.0e-4):
+    """RHS_and_Midpoint, c_rigid_obj.cpp:917-976, with the three noise vectors injected (the reference
+    draws them clock-seeded, :730-741).  Returns (RHS, X_half, Q_half); the inputs are not modified."""
+    cfg = np.asarray(ref_cfg).reshape(-1, 3)
+    Slip = np.array(Slip, dtype=np.float64).reshape(-1)
+    Force = np.array(Force, dtype=np.float64).reshape(-1)
+    Xh, Qh = np.array(X, dtype=np.float64).reshape(-1, 3), np.array(Qn, dtype=np.float64).reshape(-1, 4)
+    if kBT > 1e-10:                                                     # :922
+        r = orc.multi_body_pos(X, Qn, cfg)
+        mw1 = orc.M_half_W(r, a, eta, wall, W1)                         # :927
+        mw2 = orc.M_half_W(r, a, eta, wall, W2) if split_rand else None  # :934-936
+        rfd = M_RFD(orc, W_rfd, X, Qn, cfg, a, eta, wall, delta)        # :940
+        if split_rand:                                                  # :945-948
+            c1, c2 = 2.0 * np.sqrt(kBT / dt), np.sqrt(kBT / dt)
+            BI = c2 * (mw1 - mw2)
+        else:                                                           # :950-953
+            c1 = c2 = np.sqrt(2.0 * kBT / dt)
+            BI = c2 * mw1
+        uom_half = (dt / 2.0) * (Kinv_matrix(X, Qn, cfg) @ (c1 * mw1))  # :955-956
+        Xh, Qh = update_X_Q(X, Qn, uom_half)                            # :958
+        Slip = Slip - (kBT * rfd + BI)                                  # :963
+    return np.concatenate([Slip, -Force]), Xh, Qh                       # :972-975

@@ -51,6 +51,9 @@ def lib():
         L.rbl_set_tuning.argtypes = [vp, C.c_int, C.c_int]
         L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
         L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
+        L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
+        L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
+        L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -119,6 +122,30 @@ class DeviceContext:
         import numpy as np
         U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_evolve_X_Q(self.h, U.ctypes.data))
+
+    def update_X_Q(self, U_host, n_bodies):
+        """configuration displaced by U (displacement units), not committed -> (X, Q)"""
+        import numpy as np
+        U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
+        X = np.zeros(3 * n_bodies); Q = np.zeros(4 * n_bodies)
+        self._chk(self.L.rbl_update_X_Q(self.h, U.ctypes.data, X.ctypes.data, Q.ctypes.data))
+        return X.reshape(-1, 3), Q.reshape(-1, 4)
+
+    def Kinv_x_V(self, V_host, n_bodies):
+        """K^-1 V (reference :406): V[3 N_blobs] host -> [6 N_bodies] host (O(N) host work)"""
+        import numpy as np
+        V = np.ascontiguousarray(V_host, dtype=np.float64).reshape(-1)
+        out = np.zeros(6 * n_bodies)
+        self._chk(self.L.rbl_Kinv_x_V(self.h, V.ctypes.data, out.ctypes.data))
+        return out
+
+    def RHS_and_Midpoint(self, dSlip, dForce, dW, seed, method, split_rand, delta, dRHS, n_bodies):
+        """device-vector form of the reference's RHS_and_Midpoint -> (X_half, Q_half) on the host"""
+        import numpy as np
+        X = np.zeros(3 * n_bodies); Q = np.zeros(4 * n_bodies)
+        self._chk(self.L.rbl_RHS_and_Midpoint_dev(self.h, dSlip, dForce, dW, seed, method, int(split_rand), delta,
+                                                  dRHS, X.ctypes.data, Q.ctypes.data))
+        return X.reshape(-1, 3), Q.reshape(-1, 4)
 
     def get_config(self, n_bodies):
         import numpy as np

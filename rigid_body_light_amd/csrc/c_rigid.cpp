@@ -210,6 +210,40 @@ struct CManyBodies {
     return out;
   }
 
+  py::tuple update_X_Q(darr U)                                      // :798 (unbound in the reference)
+  {
+    if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("update_X_Q: U must have length 6*N_bod");
+    darr X(3 * (py::ssize_t)n_bod()), Q(4 * (py::ssize_t)n_bod());
+    check(rbl_update_X_Q(ctx, U.data(), X.mutable_data(), Q.mutable_data()));
+    return py::make_tuple(X, Q);
+  }
+
+  // RHS_and_Midpoint(Slip, Force) :917 (unbound in the reference) -> (RHS, X_half, Q_half)
+  py::tuple RHS_and_Midpoint(darr Slip, darr Force, py::object W, uint64_t seed, const std::string &method,
+                             bool split_rand, double delta)
+  {
+    const py::ssize_t nb = n_bod();
+    if (Slip.size() != n3()) throw std::runtime_error("RHS_and_Midpoint: Slip must have length 3*N_blobs");
+    if (Force.size() != 6 * nb) throw std::runtime_error("RHS_and_Midpoint: Force must have length 6*N_bod");
+    const int m = method == "lanczos" ? RBL_MHALF_LANCZOS : RBL_MHALF_CHOLESKY;
+    darr RHS(n3() + 6 * nb), X(3 * nb), Q(4 * nb);
+    darr Wa;
+    const double *Wp = nullptr;
+    if (!W.is_none()) {
+      Wa = W.cast<darr>();
+      if (Wa.size() != 3 * n3()) throw std::runtime_error("RHS_and_Midpoint: W must have length 9*N_blobs (W1|W2|W_rfd)");
+      Wp = Wa.data();
+    }
+    int rc;
+    {
+      py::gil_scoped_release rel;
+      rc = rbl_RHS_and_Midpoint(ctx, Slip.data(), Force.data(), Wp, seed, m, split_rand ? 1 : 0, delta,
+                                RHS.mutable_data(), X.mutable_data(), Q.mutable_data());
+    }
+    check(rc);
+    return py::make_tuple(RHS, X, Q);
+  }
+
   py::tuple lanczos_report()
   {
     int it = 0; double res = 0;
@@ -288,6 +322,10 @@ PYBIND11_MODULE(c_rigid, m)
       .def("M_half_W_r", &CManyBodies::M_half_W_r, py::arg("r_vecs"), py::arg("W"), py::arg("method") = "cholesky")
       .def("M_RFD", &CManyBodies::M_RFD, py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("delta") = 1.0e-4)
       .def("KTinv_RFD", &CManyBodies::KTinv_RFD, py::arg("W"), py::arg("delta") = 1.0e-4)
+      .def("update_X_Q", &CManyBodies::update_X_Q, py::arg("U"))
+      .def("RHS_and_Midpoint", &CManyBodies::RHS_and_Midpoint, py::arg("Slip"), py::arg("Force"),
+           py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("method") = "cholesky",
+           py::arg("split_rand") = true, py::arg("delta") = 1.0e-4)
       .def("lanczos_report", &CManyBodies::lanczos_report)
       .def("set_lanczos", &CManyBodies::set_lanczos, py::arg("max_iter"), py::arg("tol"))
       .def("rotne_prager_tensor", &CManyBodies::rotne_prager_tensor, py::arg("r_vecs"), py::arg("scale_damp") = false)

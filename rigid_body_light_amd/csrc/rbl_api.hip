@@ -221,7 +221,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_bd, &c->d_bd2};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -747,11 +747,18 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   return RBL_OK;
 }
 
-static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, int method, double *d_out)
+// nvec noise vectors (columns of d_W, stride n) -> nvec increments.  The dense factorisation is done ONCE
+// for all of them (the reference calls M_half_W() once per vector, :927-936, and refactors each time).
+static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, int nvec, int method,
+                           double *d_out)
 {
   const int64_t n = 3 * nbl;
   int rc;
-  if (method == RBL_MHALF_LANCZOS) return mhalf_lanczos_dev(c, d_r, nbl, d_W, d_out);
+  if (method == RBL_MHALF_LANCZOS) {
+    for (int v = 0; v < nvec; ++v)
+      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n))) return rc;
+    return RBL_OK;
+  }
   if (method != RBL_MHALF_CHOLESKY) return rbl_fail(c, RBL_ERR_ARG, "M_half_W: unknown method");
   const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
@@ -761,8 +768,15 @@ static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d
   if ((rc = rbl_dev_reserve(c, c->d_chol, rbl_cholesky_work_bytes(n)))) return rc;
   rc = rbl_launch_cholesky(c->stream, (double *)c->d_mat.p, n, false, c->d_err, (double *)c->d_chol.p, c->d_chol.bytes, &c->chol_aux);   // :670-671
   if (rc) return rbl_fail(c, rc, "cholesky launch failed");
-  rbl_launch_trmv_lower(c->stream, (const double *)c->d_mat.p, n, d_W, d_out, (double *)c->d_tmp.p);  // :672
+  for (int v = 0; v < nvec; ++v)
+    rbl_launch_trmv_lower(c->stream, (const double *)c->d_mat.p, n, d_W + (size_t)v * n, d_out + (size_t)v * n,
+                          (double *)c->d_tmp.p);  // :672
   return RBL_OK;
+}
+
+static int mhalf_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, int method, double *d_out)
+{
+  return mhalf_dev_multi(c, d_r, nbl, d_W, 1, method, d_out);
 }
 
 extern "C" {
@@ -1071,8 +1085,33 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
 // ---- random finite differences (reference C++-only members) ---------------
 extern "C" {
 
-// M_RFD(), c_rigid_obj.cpp:769-796:  (1/delta) [ M(q + delta/2 dq) - M(q - delta/2 dq) ] W  with
-// dq = Kinv W.  The two products run on the GPU at the two displaced configurations.
+// core of M_RFD(), c_rigid_obj.cpp:776-794: d_out = (1/delta)[M(q + delta/2 dq) - M(q - delta/2 dq)] W with
+// dq = Kinv W.  Wh = host copy of W (Kinv is O(N) host work), d_r: n3 scratch, d_work: 2 n3 scratch.
+static int m_rfd_core(rbl_ctx *c, const double *d_W, const double *Wh, double delta, double *d_out,
+                      double *d_r, double *d_work)
+{
+  RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  std::vector<double> uom((size_t)6 * S.N_bod), win((size_t)6 * S.N_bod), Xs, Qs;
+  rbl_body_Kinv_x_V(S, Wh, uom.data());                               // UOM = Kinv W (:776)
+  const std::vector<double> X0 = S.X, Q0 = S.Q;
+  double *dM[2] = {d_work, d_work + n3};
+  int rc = RBL_OK;
+  for (int sgn = 0; sgn < 2; ++sgn) {                                 // q +- delta/2 dq (:783-788)
+    const double f = (sgn == 0 ? 0.5 : -0.5) * delta;
+    for (size_t i = 0; i < win.size(); ++i) win[i] = f * uom[i];
+    rbl_body_update_X_Q(S, win.data(), Xs, Qs);
+    S.X = Xs; S.Q = Qs; c->dev_xq_valid = false;                      // displaced configuration, temporarily
+    rc = positions_dev(c, 0, S.N_bod, d_r);
+    if (!rc) rc = apply_M_enqueue(c, S.wall, d_W, d_r, N, 0, N, dM[sgn]);   // :790-791
+    S.X = X0; S.Q = Q0; c->dev_xq_valid = false;
+    if (rc) return rc;
+  }
+  rbl_launch_axpby(c->stream, n3, 1.0 / delta, dM[0], -1.0 / delta, dM[1], d_out);   // :793
+  return RBL_OK;
+}
+
+// M_RFD(), c_rigid_obj.cpp:769-796.  The two products run on the GPU at the two displaced configurations.
 int rbl_M_RFD(rbl_ctx *c, const double *W, uint64_t seed, double delta, double *out)
 {
   int rc = need_K(c); if (rc) return rc;
@@ -1093,22 +1132,95 @@ int rbl_M_RFD(rbl_ctx *c, const double *W, uint64_t seed, double delta, double *
     if ((rc = copy_d2h(c, Wh.data(), c->d_W.p, vb))) return rc;
     RBL_HIP(c, hipStreamSynchronize(c->stream));
   }
-  std::vector<double> uom((size_t)6 * S.N_bod), win((size_t)6 * S.N_bod), Xs, Qs;
-  rbl_body_Kinv_x_V(S, Wh.data(), uom.data());                        // UOM = Kinv W (:776)
-  const std::vector<double> X0 = S.X, Q0 = S.Q;
-  double *dM[2] = {(double *)c->d_U.p, (double *)c->d_U.p + n3};
-  for (int sgn = 0; sgn < 2; ++sgn) {                                 // q +- delta/2 dq (:783-788)
-    const double f = (sgn == 0 ? 0.5 : -0.5) * delta;
-    for (size_t i = 0; i < win.size(); ++i) win[i] = f * uom[i];
-    rbl_body_update_X_Q(S, win.data(), Xs, Qs);
-    S.X = Xs; S.Q = Qs; c->dev_xq_valid = false;                      // displaced configuration, temporarily
-    rc = positions_dev(c, 0, S.N_bod, (double *)c->d_r.p);
-    if (!rc) rc = apply_M_enqueue(c, S.wall, (const double *)c->d_W.p, (const double *)c->d_r.p, N, 0, N, dM[sgn]);
-    S.X = X0; S.Q = Q0; c->dev_xq_valid = false;
-    if (rc) return rc;
+  double *dU = (double *)c->d_U.p;
+  if ((rc = m_rfd_core(c, (const double *)c->d_W.p, Wh.data(), delta, dU, (double *)c->d_r.p, dU))) return rc;
+  if ((rc = copy_d2h(c, out, dU, vb))) return rc;
+  return finish_and_check(c);
+}
+
+// update_X_Q(U), c_rigid_obj.cpp:798-863: the configuration displaced by U (displacement units: translation
+// and rotation vector per body), WITHOUT committing it.
+int rbl_update_X_Q(rbl_ctx *c, const double *U, double *X_out, double *Q_out)
+{
+  int rc = need_config(c); if (rc) return rc;
+  if (!U || !X_out || !Q_out) return rbl_fail(c, RBL_ERR_ARG, "update_X_Q: null argument");
+  std::vector<double> Xo, Qo;
+  rbl_body_update_X_Q(c->S, U, Xo, Qo);
+  std::memcpy(X_out, Xo.data(), sizeof(double) * Xo.size());
+  std::memcpy(Q_out, Qo.data(), sizeof(double) * Qo.size());
+  return RBL_OK;
+}
+
+// RHS_and_Midpoint(Slip, Force), c_rigid_obj.cpp:917-976 -- device-resident form.  d_W = [W1 | W2 | W_rfd]
+// (3 n3) or NULL (drawn from `seed`).  d_RHS = [Slip - (kBT M_RFD + BI) ; -Force]  (n3 + 6 N_bod).
+int rbl_RHS_and_Midpoint_dev(rbl_ctx *c, const double *d_Slip, const double *d_Force, const double *d_W,
+                             uint64_t seed, int method, int split_rand, double delta, double *d_RHS,
+                             double *X_half, double *Q_half)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!d_Slip || !d_Force || !d_RHS || !X_half || !Q_half) return rbl_fail(c, RBL_ERR_ARG, "RHS_and_Midpoint: null argument");
+  RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N, nb6 = (int64_t)6 * S.N_bod;
+  const size_t vb = sizeof(double) * (size_t)n3;
+  rbl_launch_axpby(c->stream, nb6, -1.0, d_Force, 0.0, nullptr, d_RHS + n3);          // Force *= -1 (:972)
+  if (!(S.kBT > 1e-10)) {                                                              // no Brownian terms (:967-970)
+    RBL_HIP(c, hipMemcpyAsync(d_RHS, d_Slip, vb, hipMemcpyDeviceToDevice, c->stream));
+    std::memcpy(X_half, S.X.data(), sizeof(double) * S.X.size());
+    std::memcpy(Q_half, S.Q.data(), sizeof(double) * S.Q.size());
+    return finish_and_check(c);
   }
-  rbl_launch_axpby(c->stream, n3, 1.0 / delta, dM[0], -1.0 / delta, dM[1], dM[0]);   // :793
-  if ((rc = copy_d2h(c, out, dM[0], vb))) return rc;
+  if (!(S.dt > 0.0) || !(delta > 0.0)) return rbl_fail(c, RBL_ERR_ARG, "RHS_and_Midpoint: dt and delta must be positive");
+  // workspace: [W1 | W2 | W_rfd] (when drawn here), M^{1/2}W1, M^{1/2}W2, M_RFD, positions, 2 scratch
+  if ((rc = rbl_dev_reserve(c, c->d_bd, 9 * vb))) return rc;
+  double *base = (double *)c->d_bd.p;
+  double *dWown = base, *dMW = base + 3 * n3 /* 2 vectors */, *dRFD = base + 5 * n3, *dr = base + 6 * n3,
+         *dwork = base + 7 * n3;
+  if (!d_W) {                                                                          // rand_vector (:730-741)
+    rbl_launch_normal(c->stream, seed, 0, 3 * n3, dWown);
+    d_W = dWown;
+  }
+  const int nvec = split_rand ? 2 : 1;
+  if ((rc = positions_dev(c, 0, S.N_bod, dr))) return rc;                              // multi_body_pos (:662)
+  if ((rc = mhalf_dev_multi(c, dr, N, d_W, nvec, method, dMW))) return rc;             // M_half_W1/2 (:927-936)
+  std::vector<double> Wh((size_t)n3), mw1((size_t)n3);
+  if ((rc = copy_d2h(c, Wh.data(), d_W + 2 * n3, vb))) return rc;
+  if ((rc = copy_d2h(c, mw1.data(), dMW, vb))) return rc;
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = m_rfd_core(c, d_W + 2 * n3, Wh.data(), delta, dRFD, dr, dwork))) return rc;  // M_RFD (:940)
+  const double c1 = split_rand ? 2.0 * std::sqrt(S.kBT / S.dt) : std::sqrt(2.0 * S.kBT / S.dt);   // :945-952
+  const double c2 = split_rand ? std::sqrt(S.kBT / S.dt) : std::sqrt(2.0 * S.kBT / S.dt);
+  // Slip -= kBT M_RFD + BI,  BI = c2 (M^{1/2}W1 - M^{1/2}W2)  or  c2 M^{1/2}W1   (:948,953,963)
+  rbl_launch_axpby(c->stream, n3, 1.0, d_Slip, -S.kBT, dRFD, d_RHS);
+  rbl_launch_axpby(c->stream, n3, 1.0, d_RHS, -c2, dMW, d_RHS);
+  if (split_rand) rbl_launch_axpby(c->stream, n3, 1.0, d_RHS, c2, dMW + n3, d_RHS);
+  // predictor: q^{n+1/2} = q^n displaced by (dt/2) Kinv (c1 M^{1/2}W1)   (:955-959)
+  std::vector<double> uom((size_t)nb6), Xo, Qo;
+  rbl_body_Kinv_x_V(S, mw1.data(), uom.data());
+  for (double &u : uom) u *= 0.5 * S.dt * c1;
+  rbl_body_update_X_Q(S, uom.data(), Xo, Qo);
+  std::memcpy(X_half, Xo.data(), sizeof(double) * Xo.size());
+  std::memcpy(Q_half, Qo.data(), sizeof(double) * Qo.size());
+  return finish_and_check(c);
+}
+
+// host-pointer form of the same
+int rbl_RHS_and_Midpoint(rbl_ctx *c, const double *Slip, const double *Force, const double *W, uint64_t seed,
+                         int method, int split_rand, double delta, double *RHS, double *X_half, double *Q_half)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!Slip || !Force || !RHS) return rbl_fail(c, RBL_ERR_ARG, "RHS_and_Midpoint: null argument");
+  const int64_t n3 = (int64_t)3 * c->S.N_bod * c->S.N_blb, nb6 = (int64_t)6 * c->S.N_bod;
+  const size_t vb = sizeof(double) * (size_t)n3, fb = sizeof(double) * (size_t)nb6;
+  if ((rc = rbl_dev_reserve(c, c->d_bd2, (W ? 4 : 1) * vb + 2 * (vb + fb)))) return rc;
+  double *dSlip = (double *)c->d_bd2.p, *dForce = dSlip + n3, *dRHS = dForce + nb6, *dW = dRHS + n3 + nb6;
+  if ((rc = copy_h2d(c, dSlip, Slip, vb))) return rc;
+  if ((rc = copy_h2d(c, dForce, Force, fb))) return rc;
+  if (W && (rc = copy_h2d(c, dW, W, 3 * vb))) return rc;
+  if ((rc = rbl_RHS_and_Midpoint_dev(c, dSlip, dForce, W ? dW : nullptr, seed, method, split_rand, delta, dRHS,
+                                     X_half, Q_half))) return rc;
+  if ((rc = copy_d2h(c, RHS, dRHS, vb + fb))) return rc;
   return finish_and_check(c);
 }
 

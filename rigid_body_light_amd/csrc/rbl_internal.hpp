@@ -69,6 +69,7 @@ struct rbl_ctx {
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw;               // block-diagonal PC: per-body Cholesky factors + work
+  RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned

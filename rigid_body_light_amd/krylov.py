@@ -210,6 +210,123 @@ class ShardedDeterministicStepper(DeterministicStepper):
         return super().step(F_body, iters, rtol)
 
 
+class BrownianStepper(DeterministicStepper):
+    """One stochastic (midpoint) time step, assembled from the pieces the reference leaves unassembled
+    (`RHS_and_Midpoint`, c_rigid_obj.cpp:917-976):
+
+      1. at q^n      : rhs = [slip - (kBT M_RFD + BI) ; -F_body]  and the predictor configuration
+                       q^{n+1/2} = q^n displaced by (dt/2) Kinv c1 M^{1/2} W1      (librbl: rbl_RHS_and_Midpoint_dev)
+      2. at q^{n+1/2}: right-preconditioned GMRES on the saddle operator -> [lambda ; U]
+      3.               q^{n+1} = q^n displaced by dt U                              (evolve_X_Q, :865-878)
+
+    Steps 2-3 are this driver's completion of the scheme (the reference computes q^{n+1/2} but never
+    uses it).  The context must have been created with dt > 0 and kBT; kBT <= 1e-10 reduces this to
+    the deterministic step.  method: 0 = dense Cholesky (the reference's M_half_W), 1 = Lanczos."""
+
+    def step(self, F_body, slip=None, W=None, seed=0, method=1, iters=20, rtol=None, split_rand=True,
+             delta=1.0e-4):
+        Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1).contiguous()
+        sl = (torch.zeros(self.n3, dtype=torch.float64, device=self.dev) if slip is None else
+              torch.as_tensor(slip, dtype=torch.float64, device=self.dev).reshape(-1).contiguous())
+        Wd = None if W is None else torch.as_tensor(W, dtype=torch.float64, device=self.dev).reshape(-1).contiguous()
+        if Wd is not None and Wd.numel() != 3 * self.n3:
+            raise ValueError("W must hold 3 noise vectors [W1 | W2 | W_rfd] of length 3*N_blobs each")
+        Xn, Qn = self.ctx.get_config(self.nb)
+        rhs = torch.empty(self.size, dtype=torch.float64, device=self.dev)
+        Xh, Qh = self.ctx.RHS_and_Midpoint(sl.data_ptr(), Fb.data_ptr(), None if Wd is None else Wd.data_ptr(),
+                                           seed, method, split_rand, delta, rhs.data_ptr(), self.nb)
+        self.ctx.set_config(Xh, Qh)                      # operators and preconditioner at the predictor configuration
+        x, m, resid = gmres_right_pc(self._A, self._Pinv, rhs, iters, rtol)
+        U = x[self.n3:].cpu().numpy()
+        self.ctx.set_config(Xn, Qn)                      # the update starts from q^n
+        self.ctx.evolve(U)
+        self.ctx.sync_check()
+        return m, resid
+
+
+class ShardedBrownianStepper(ShardedDeterministicStepper):
+    """The stochastic midpoint step of BrownianStepper on P GPUs (BASELINE.json configs[3]).  The right-hand
+    side of c_rigid_obj.cpp:917-976 is composed here from device vector operations so that every mobility
+    product -- the Lanczos iterations of the two M^{1/2} W, the two products of M_RFD, the GMRES iterations --
+    is the tile-pair-sharded one (one all-reduce each); all vectors and the O(N_bod) body state are
+    replicated and bitwise identical on every rank (the noise comes from a seeded device generator)."""
+
+    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device, a, wall, kBT, dt,
+                 lanczos_tol=1e-3, lanczos_max_iter=100):
+        super().__init__(ctx, sharded, n_bodies, blobs_per_body, device)
+        self.a, self.wall, self.kBT, self.dt = a, wall, kBT, dt
+        self.ltol, self.lmax = lanczos_tol, lanczos_max_iter
+        self.lanczos_iterations = []
+
+    def _product(self, r_full, v):
+        """apply_M (reference :641-659) on the sharded pairs: B M B with the wall term, plain M without"""
+        part = torch.empty(self.n3, dtype=torch.float64, device=self.dev)
+        self.ctx.apply_M_sym(v.contiguous().data_ptr(), r_full.data_ptr(), self.n3 // 3, self.sm.rank, self.sm.world,
+                             part.data_ptr())
+        return self.sm.all_reduce_sum(part)
+
+    def _positions_at(self, X, Q):
+        Xn, Qn = self.ctx.get_config(self.nb)
+        self.ctx.set_config(X, Q)
+        r = torch.empty(self.n3, dtype=torch.float64, device=self.dev)
+        self.ctx.blob_positions(0, self.nb, r.data_ptr())
+        self.ctx.set_config(Xn, Qn)
+        return r
+
+    def rhs_and_midpoint(self, slip, Fb, W, split_rand=True, delta=1.0e-4):
+        n3 = self.n3
+        Xn, Qn = self.ctx.get_config(self.nb)
+        r_n = self._positions_at(Xn, Qn)
+        if self.wall:                                     # M_half_W always damps (:668-669); the wall kernel does it itself
+            A = lambda v: self._product(r_n, v)
+        else:
+            z = r_n.view(-1, 3)[:, 2]
+            B = torch.where(z >= self.a, torch.ones_like(z), z / self.a).repeat_interleave(3)   # make_damp_mat :618-639
+            A = lambda v: B * self._product(r_n, B * v)
+        W1, W2, Wr = W[:n3], W[n3:2 * n3], W[2 * n3:]
+        self.lanczos_iterations = []
+        mw1, it1, _ = lanczos_mhalf(A, W1, self.lmax, self.ltol)                      # :927
+        self.lanczos_iterations.append(it1)
+        if split_rand:                                                                # :934-936
+            mw2, it2, _ = lanczos_mhalf(A, W2, self.lmax, self.ltol)
+            self.lanczos_iterations.append(it2)
+        uom = self.ctx.Kinv_x_V(Wr.cpu().numpy(), self.nb)                            # M_RFD :776-794
+        Mpm = [self._product(self._positions_at(*self.ctx.update_X_Q(sg * 0.5 * delta * uom, self.nb)), Wr)
+               for sg in (1.0, -1.0)]
+        rfd = (Mpm[0] - Mpm[1]) / delta
+        kd = self.kBT / self.dt
+        if split_rand:                                                                # :945-953
+            c1, c2 = 2.0 * np.sqrt(kd), np.sqrt(kd)
+            BI = c2 * (mw1 - mw2)
+        else:
+            c1 = c2 = np.sqrt(2.0 * kd)
+            BI = c2 * mw1
+        uom_half = 0.5 * self.dt * c1 * self.ctx.Kinv_x_V(mw1.cpu().numpy(), self.nb)   # :955-956
+        Xh, Qh = self.ctx.update_X_Q(uom_half, self.nb)                               # :958
+        rhs = torch.cat([slip - (self.kBT * rfd + BI), -Fb])                          # :963-975
+        return rhs, Xh, Qh
+
+    def step(self, F_body, slip=None, W=None, seed=0, iters=20, rtol=None, split_rand=True, delta=1.0e-4):
+        Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
+        sl = (torch.zeros(self.n3, dtype=torch.float64, device=self.dev) if slip is None else
+              torch.as_tensor(slip, dtype=torch.float64, device=self.dev).reshape(-1))
+        if W is None:                                     # same seed + same device type -> same numbers on every rank
+            g = torch.Generator(device=self.dev); g.manual_seed(int(seed))
+            W = torch.randn(3 * self.n3, dtype=torch.float64, device=self.dev, generator=g)
+        else:
+            W = torch.as_tensor(W, dtype=torch.float64, device=self.dev).reshape(-1)
+        Xn, Qn = self.ctx.get_config(self.nb)
+        rhs, Xh, Qh = self.rhs_and_midpoint(sl, Fb, W, split_rand, delta)
+        self.ctx.set_config(Xh, Qh)                       # solve at the predictor configuration
+        self.refresh_positions()
+        x, m, resid = gmres_right_pc(self._A, self._Pinv, rhs, iters, rtol)
+        U = x[self.n3:].cpu().numpy()
+        self.ctx.set_config(Xn, Qn)                       # update from q^n
+        self.ctx.evolve(U)
+        self.ctx.sync_check()
+        return m, resid
+
+
 def lanczos_mhalf_multi(apply_A_multi, W, max_iter=100, tol=1e-3):
     """k independent Brownian increments M^{1/2} W_c at once: k Lanczos recurrences advanced in lockstep,
     so that every iteration is ONE multi-vector product -- which librbl runs on the fp64 matrix

@@ -130,6 +130,19 @@ class RigidBody:
         """reference c_rigid_obj.cpp:743-767 (C++ only); W has length 6*N_bodies."""
         return self.cb.KTinv_RFD(self._require(W, "body"), delta)
 
+    def update_X_Q(self, U):
+        """configuration displaced by U (translation + rotation vector per body), NOT committed
+        (reference c_rigid_obj.cpp:798-863, C++ only) -> (X, Q) flat arrays."""
+        return self.cb.update_X_Q(self._require(U, "body"))
+
+    def RHS_and_Midpoint(self, slip, force, W=None, seed=0, method="cholesky", split_rand=True, delta=1.0e-4):
+        """Right-hand side and predictor configuration of the stochastic midpoint step (reference
+        c_rigid_obj.cpp:917-976, C++ only): ([slip - (kBT M_RFD + BI) ; -force], X_half, Q_half).
+        W = [W1 | W2 | W_rfd] (9*N_blobs numbers) or None for seeded device noise."""
+        W = None if W is None else np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(-1))
+        return self.cb.RHS_and_Midpoint(self._require(slip, "blob"), self._require(force, "body"), W, seed,
+                                        method, split_rand, delta)
+
     def apply_M_multi(self, forces, positions):
         """k right-hand sides at once, forces (k, 3N); k >= 4 runs on the fp64 matrix cores."""
         return self.cb.apply_M_multi(np.atleast_2d(np.asarray(forces)), np.asarray(positions).reshape(-1))

@@ -626,3 +626,132 @@ def test_M_RFD_vs_oracle(orc, shell12, wall):
     X1, Q1 = cb.get_config()
     assert np.allclose(X1, X)
     assert np.array_equal(cb.M_RFD(seed=3), cb.M_RFD(seed=3))
+
+
+def _brownian_case(shell12, wall, nb=4, seed=120):
+    X, Q = random_positions(nb, wall=wall, seed=seed)
+    if wall:
+        X[:, 2] += 1.4
+    n3 = 36 * nb
+    rng = np.random.default_rng(seed + 1)
+    return X, Q, rng.standard_normal(3 * n3), rng.standard_normal(n3) * 0.1, np.tile([0.3, 0, -1.0, 0, 0.2, 0], nb)
+
+
+@pytest.mark.parametrize("split_rand", [True, False])
+@pytest.mark.parametrize("wall", [False, True])
+def test_RHS_and_Midpoint_vs_oracle(orc, shell12, wall, split_rand):
+    """RHS_and_Midpoint (reference c_rigid_obj.cpp:917-976) with injected noise, Cholesky square root."""
+    import rigid_body_light_amd as rbl
+    from oracle import oracle as onp
+    nb = 4
+    X, Q, W, slip, force = _brownian_case(shell12, wall)
+    n3 = 36 * nb
+    dt, a, eta, kBT = 0.01, 1.0, 1.0, 1.0        # the wrapper passes kBT = 1 (src/Rigid.py:23)
+    cb = create_solver(X, Q, wall_PC=wall, dt=dt)
+    slip0, force0 = slip.copy(), force.copy()
+    rhs, Xh, Qh = cb.RHS_and_Midpoint(slip, force, W, method="cholesky", split_rand=split_rand)
+    assert np.array_equal(slip, slip0) and np.array_equal(force, force0)      # arguments untouched
+    Qn = onp.normalize_quats(Q)
+    ref, Xr, Qr = onp.RHS_and_Midpoint(orc, slip, force, W[:n3], W[n3:2 * n3], W[2 * n3:], X, Qn,
+                                       onp.remove_mean(shell12), a, eta, wall, dt, kBT, split_rand)
+    # the M_RFD difference quotient carries 1e-15/delta of product rounding
+    assert rel(rhs[:n3], ref[:n3]) < 1e-8
+    assert np.array_equal(rhs[n3:], -force)
+    np.testing.assert_allclose(Xh.reshape(-1, 3), Xr, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(Qh.reshape(-1, 4), Qr, rtol=0, atol=1e-11)
+    X1, Q1 = cb.get_config()
+    assert np.allclose(X1.reshape(-1, 3), X) and np.allclose(Q1.reshape(-1, 4), Qn)   # nothing committed
+    # update_X_Q on its own
+    U = np.random.default_rng(5).standard_normal(6 * nb) * 0.1
+    Xu, Qu = cb.update_X_Q(U)
+    Xo, Qo = onp.update_X_Q(X, Qn, U)
+    np.testing.assert_allclose(Xu.reshape(-1, 3), Xo, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(Qu.reshape(-1, 4), Qo, rtol=0, atol=1e-14)
+    # seeded device noise is reproducible; Lanczos gives a different square root of the same M:
+    r1 = cb.RHS_and_Midpoint(slip, force, seed=11)[0]
+    assert np.array_equal(r1, cb.RHS_and_Midpoint(slip, force, seed=11)[0])
+    assert not np.array_equal(r1, cb.RHS_and_Midpoint(slip, force, seed=12)[0])
+
+
+def test_RHS_and_Midpoint_zero_temperature(shell12):
+    """kBT <= 1e-10: no Brownian terms (reference :967-970) -> [slip ; -force], configuration unchanged."""
+    import rigid_body_light_amd as rbl
+    nb = 3
+    X, Q, W, slip, force = _brownian_case(shell12, False, nb=nb)
+    cm = rbl.c_rigid.CManyBodies()
+    cm.setParameters(1.0, 0.01, 0.0, 1.0, shell12)
+    cm.setConfig(X.reshape(-1), Q.reshape(-1))
+    cm.set_K_mats()
+    rhs, Xh, Qh = cm.RHS_and_Midpoint(slip, force)
+    assert np.array_equal(rhs, np.concatenate([slip, -force]))
+    assert np.array_equal(Xh, X.reshape(-1))
+    Xc, Qc = cm.getConfig()
+    assert np.array_equal(Qh, Qc)
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_brownian_step_vs_dense_numpy(orc, shell12, wall):
+    """krylov.BrownianStepper: RHS at q^n, saddle solve at q^{n+1/2}, update from q^n -- against the same
+    step assembled from the oracle's dense matrices."""
+    import torch
+    from oracle import oracle as onp
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import BrownianStepper
+    nb = 4
+    X, Q, W, slip, force = _brownian_case(shell12, wall, seed=130)
+    n3 = 36 * nb
+    dt, a, eta, kBT = 0.005, 1.0, 1.0, 0.02
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    st = BrownianStepper(ctx, nb, 12, dev)
+    m, resid = st.step(force, slip=slip, W=W, method=0, iters=80, rtol=1e-11)
+    assert resid < 1e-11
+    Xg, Qg = ctx.get_config(nb)
+    cfg = onp.remove_mean(shell12); Qn = onp.normalize_quats(Q)
+    rhs, Xh, Qh = onp.RHS_and_Midpoint(orc, slip, force, W[:n3], W[n3:2 * n3], W[2 * n3:], X, Qn, cfg, a, eta, wall,
+                                       dt, kBT, True)
+    K = onp.K_matrix(Xh, Qh, cfg)
+    r = orc.multi_body_pos(Xh, Qh, cfg)
+    M = orc.rotne_prager_tensor(r, a, eta, wall)
+    if wall:
+        B = orc.damp(r, a)
+        M = (B[:, None] * M) * B[None, :]
+    A = np.block([[M, -K], [K.T, np.zeros((6 * nb, 6 * nb))]])
+    U = np.linalg.solve(A, rhs)[n3:]
+    Xr, Qr = onp.evolve(X, Qn, U, dt)
+    np.testing.assert_allclose(Xg, Xr, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Qg, Qr, rtol=0, atol=1e-9)
+    assert np.linalg.norm(Xg - X) > 1e-4                     # the bodies did move
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_sharded_brownian_step_equals_library_step(shell12, wall):
+    """krylov.ShardedBrownianStepper (the multi-GPU composition; here world = 1) == BrownianStepper, both with
+    a tightly converged Lanczos square root (the symmetric root is unique, so they must agree)."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.dist import ShardedMobility
+    from rigid_body_light_amd.krylov import BrownianStepper, ShardedBrownianStepper
+    nb = 4
+    X, Q, W, slip, force = _brownian_case(shell12, wall, seed=140)
+    dt, a, eta, kBT = 0.005, 1.0, 1.0, 0.02
+    dev = torch.device("cuda:0")
+    out = []
+    for sharded in (False, True):
+        ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        if sharded:
+            st = ShardedBrownianStepper(ctx, ShardedMobility(nb, 12, device=dev, ctx=ctx), nb, 12, dev, a, wall, kBT, dt,
+                                        lanczos_tol=1e-12, lanczos_max_iter=144)
+            m, resid = st.step(force, slip=slip, W=W, iters=80, rtol=1e-11)
+            assert len(st.lanczos_iterations) == 2
+        else:
+            ctx.set_lanczos(144, 1e-12)
+            st = BrownianStepper(ctx, nb, 12, dev)
+            m, resid = st.step(force, slip=slip, W=W, method=1, iters=80, rtol=1e-11)
+        assert resid < 1e-11
+        out.append(ctx.get_config(nb))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-9)
+    assert np.linalg.norm(out[0][0] - X) > 1e-4
