@@ -671,79 +671,88 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
   return rc;
 }
 
+// coefficients of  |W| T_m^{1/2} e_1  in the Krylov basis (T_m = tridiag(alpha, beta))
+static int lanczos_coeffs(rbl_ctx *c, const std::vector<double> &alpha, const std::vector<double> &beta, int m,
+                          double wnorm, std::vector<double> &y)
+{
+  std::vector<double> d(alpha.begin(), alpha.begin() + m), e(beta.begin(), beta.begin() + (m - 1)), Z;
+  if (!tridiag_ql(d, e, Z, m)) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: tridiagonal eigensolve failed");
+  y.assign(m, 0.0);
+  double dmax = 0.0;
+  for (int k = 0; k < m; ++k) dmax = std::max(dmax, std::fabs(d[k]));
+  for (int k = 0; k < m; ++k) {
+    if (d[k] < 0.0) {
+      if (d[k] < -1e-10 * dmax) return rbl_fail(c, RBL_ERR_NOT_SPD, "Lanczos: operator is not positive semi-definite");
+      d[k] = 0.0;
+    }
+    const double sk = std::sqrt(d[k]) * Z[k];  // Z[0*m + k] = first component of eigvec k
+    for (int p = 0; p < m; ++p) y[p] += Z[(size_t)p * m + k] * sk;
+  }
+  for (int p = 0; p < m; ++p) y[p] *= wnorm;
+  return RBL_OK;
+}
+
+// The recurrence runs entirely on the device (rbl_launch_lanczos_step keeps alpha, beta there); the host
+// reads them back only to test convergence: every iteration when a product is expensive, every 4th when the
+// iteration is launch-bound (small systems), so the stream is not drained twice per iteration.
 static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out)
 {
   const int64_t n = 3 * nbl;
   const int maxit = c->lanczos_max_iter;
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   int rc;
-  // workspace: V (n x (maxit+1)), u, tmp, prev-estimate, dot scratch
+  // workspace: V (n x (maxit+1)) | u, tmp | alpha[maxit], beta[maxit], |W|, coef[maxit], partial sums
   const size_t vbytes = sizeof(double) * (size_t)n;
+  const size_t nsc = (size_t)3 * maxit + 1;
   if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1)))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 3 + sizeof(double) * 2048))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 2 + sizeof(double) * (nsc + rbl_lanczos_part_doubles())))) return rc;
   double *V = (double *)c->d_tmp.p;
-  double *u = (double *)c->d_tmp2.p, *tmp = u + n, *coef_dev = tmp + n /* n doubles, reused */;
-  double *dots = coef_dev + n;
-  double h2[2];
-  auto dot2 = [&](const double *x, const double *y, const double *z) -> int {
-    rbl_launch_dot2(c->stream, x, y, z, n, dots);
-    RBL_HIP(c, hipMemcpyAsync(h2, dots, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    RBL_HIP(c, hipStreamSynchronize(c->stream));
-    return RBL_OK;
-  };
-  if ((rc = dot2(d_W, d_W, nullptr))) return rc;
-  const double wnorm = std::sqrt(h2[0]);
-  if (!(wnorm > 0.0)) { RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream)); return RBL_OK; }
-  rbl_launch_axpby(c->stream, n, 1.0 / wnorm, d_W, 0.0, nullptr, V);
-  std::vector<double> alpha, beta, y_prev, y_cur;
+  double *u = (double *)c->d_tmp2.p, *tmp = u + n;
+  double *d_alpha = tmp + n, *d_beta = d_alpha + maxit, *d_wn = d_beta + maxit, *d_coef = d_wn + 1,
+         *d_part = d_coef + maxit;
+  rbl_launch_lanczos_init(c->stream, n, d_W, d_wn, V, d_part);
+  const int check_every = (nbl > 20000) ? 1 : 4;
+  std::vector<double> hs((size_t)2 * maxit + 1), alpha, beta, y_cur, y_prev;
   int m = 0;
-  double resid = 1.0;
-  for (int it = 0; it < maxit; ++it) {
+  double resid = 1.0, wnorm = 0.0;
+  bool done = false;
+  for (int it = 0; it < maxit && !done; ++it) {
     double *v = V + (size_t)it * n;
     if ((rc = apply_A_dev(c, P, d_r, nbl, v, u, tmp))) return rc;
-    if (it > 0) rbl_launch_axpby(c->stream, n, 1.0, u, -beta[it - 1], V + (size_t)(it - 1) * n, u);
-    if ((rc = dot2(v, u, nullptr))) return rc;
-    const double al = h2[0];
-    rbl_launch_axpby(c->stream, n, 1.0, u, -al, v, u);
-    if ((rc = dot2(u, u, nullptr))) return rc;
-    const double be = std::sqrt(h2[0]);
-    alpha.push_back(al);
+    rbl_launch_lanczos_step(c->stream, n, u, v, it > 0 ? V + (size_t)(it - 1) * n : nullptr,
+                            it > 0 ? d_beta + (it - 1) : nullptr, d_alpha + it, d_beta + it, V + (size_t)(it + 1) * n,
+                            d_part);
     m = it + 1;
-    // y = wnorm * T^{1/2} e1 in the Krylov basis
-    std::vector<double> d(alpha), e(beta), Z;
-    if (!tridiag_ql(d, e, Z, m)) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: tridiagonal eigensolve failed");
-    y_cur.assign(m, 0.0);
-    double dmax = 0.0;
-    for (int k = 0; k < m; ++k) dmax = std::max(dmax, std::fabs(d[k]));
-    for (int k = 0; k < m; ++k) {
-      if (d[k] < 0.0) {
-        if (d[k] < -1e-10 * dmax) return rbl_fail(c, RBL_ERR_NOT_SPD, "Lanczos: operator is not positive semi-definite");
-        d[k] = 0.0;
-      }
-      const double sk = std::sqrt(d[k]) * Z[k];  // Z[0*m + k] = first component of eigvec k
-      for (int p = 0; p < m; ++p) y_cur[p] += Z[(size_t)p * m + k] * sk;
-    }
-    for (int p = 0; p < m; ++p) y_cur[p] *= wnorm;
-    if (it > 0) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
+    if (m % check_every != 0 && m != maxit) continue;
+    RBL_HIP(c, hipMemcpyAsync(hs.data(), d_alpha, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    alpha.assign(hs.begin(), hs.begin() + m);
+    beta.assign(hs.begin() + maxit, hs.begin() + maxit + m);
+    wnorm = hs[(size_t)2 * maxit];
+    if (!(wnorm > 0.0)) { RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream)); c->lanczos_iters = 0; c->lanczos_resid = 0.0; return RBL_OK; }
+    for (int k = 0; k < m; ++k)
+      if (!std::isfinite(alpha[k]) || !std::isfinite(beta[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: non-finite recurrence");
+    for (int k = 0; k < m - 1; ++k)                       // breakdown before the last step: Krylov space exhausted
+      if (!(beta[k] > 1e-300)) { m = k + 1; done = true; break; }
+    if ((rc = lanczos_coeffs(c, alpha, beta, m, wnorm, y_cur))) return rc;
+    if (m > 1) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
+      if ((rc = lanczos_coeffs(c, alpha, beta, m - 1, wnorm, y_prev))) return rc;
       double dn = 0.0, yn = 0.0;
       for (int p = 0; p < m; ++p) {
-        const double yp = p < (int)y_prev.size() ? y_prev[p] : 0.0;
+        const double yp = p < m - 1 ? y_prev[p] : 0.0;
         dn += (y_cur[p] - yp) * (y_cur[p] - yp);
         yn += y_cur[p] * y_cur[p];
       }
       resid = std::sqrt(dn / yn);
     }
-    y_prev = y_cur;
-    if (resid < c->lanczos_tol || !(be > 1e-300) || it + 1 == maxit) break;
-    beta.push_back(be);
-    rbl_launch_axpby(c->stream, n, 1.0 / be, u, 0.0, nullptr, V + (size_t)(it + 1) * n);
+    if (resid < c->lanczos_tol || !(beta[m - 1] > 1e-300)) done = true;
   }
   c->lanczos_iters = m;
   c->lanczos_resid = resid;
   // d_out = V[:, :m] y
-  RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream));
-  for (int p = 0; p < m; ++p)
-    rbl_launch_axpby(c->stream, n, y_cur[p], V + (size_t)p * n, 1.0, d_out, d_out);
+  RBL_HIP(c, hipMemcpyAsync(d_coef, y_cur.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));            // y_cur is pageable host memory
+  rbl_launch_lanczos_combine(c->stream, n, V, d_coef, m, d_out);
   return RBL_OK;
 }
 

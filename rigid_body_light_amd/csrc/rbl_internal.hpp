@@ -143,6 +143,14 @@ size_t rbl_trmv_part_bytes(int64_t n);
 // small vector kernels (rbl_kernels.hip) used by Lanczos
 void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const double *z,
                      int64_t n, double *d_out2);  // out[0]=x.y out[1]=x.z (z may be null)
+size_t rbl_lanczos_part_doubles(void);
+void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
+                             double *part);
+void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
+                             const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
+                             double *part);
+void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
+                                double *out);
 void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,
                       const double *y, double *out);
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,

@@ -265,29 +265,55 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   if (flags) atomicOr(err, flags);
 }
 
+// Slab reduction.  Block = 64 consecutive entries of U (all in one blob tile J, since a tile is 192 entries)
+// x RG groups; group g adds the slab entries e = g, g+RG, ... (first the row-sum slabs of the chunks that
+// cover J, then the column-sum slabs of the row tiles before J), the RG partial sums are combined in LDS in
+// fixed order.  Many short independent load streams instead of one long one per entry: at 8 100 blobs the
+// one-thread-per-entry form ran 95 workgroups for 33 us on 37 MB.
+constexpr int RG = 16;
+
 template <bool WALL>
-__global__ __launch_bounds__(256) void k_reduce_sym(const double *__restrict__ slabI,
-                                                    const double *__restrict__ slabJ,
-                                                    const double *__restrict__ r,
-                                                    double *__restrict__ out, long N, int T, int C,
-                                                    int nch, int NI, int i_first, int i_step, RblParams P,
-                                                    unsigned *err)
+__global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict__ slabI,
+                                                       const double *__restrict__ slabJ,
+                                                       const double *__restrict__ r,
+                                                       double *__restrict__ out, long N, int T, int C,
+                                                       int nch, int NI, int i_first, int i_step, RblParams P,
+                                                       unsigned *err)
 {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over 3*N
-  if (idx >= 3 * N) return;
-  const long j = idx / 3;
+  __shared__ double sh[RG][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + tx;           // over 3*N
+  const bool live = idx < 3 * N;
+  const long idc = live ? idx : 3 * N - 1;
+  const long j = idc / 3;
   const int J = (int)(j / TS);
   const int Is = J / NI;                                 // super-tile owning row tile J
   const size_t Npad3 = (size_t)T * TS * 3;
+  const bool owned = Is >= i_first && (Is - i_first) % i_step == 0;   // this launch owned the rows of tile J
+  const int c0 = (NI * Is) / C;
+  const int nI = owned ? nch - c0 : 0;
+  const int Ilim = (J + NI - 1) / NI;                    // super-tiles I with NI*I < J
+  const int nJ = (Ilim > i_first) ? (Ilim - i_first + i_step - 1) / i_step : 0;
+  const double *pI = slabI + (size_t)c0 * Npad3 + idc;
+  const double *pJ = slabJ + idc;
   double s = 0.0;
-  if (Is >= i_first && (Is - i_first) % i_step == 0)     // this launch owned the rows of tile J
-    for (int c = (NI * Is) / C; c < nch; ++c) s += slabI[(size_t)c * Npad3 + idx];
-  int k = 0;
-  for (int I = i_first; NI * I < J; I += i_step, ++k) s += slabJ[(size_t)k * Npad3 + idx];
-  double sc = P.nf;
-  if (WALL) sc *= damp_of(P, r[3 * j + 2]);
-  out[idx] = sc * s;
-  if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+  int e = g;
+#pragma unroll 4
+  for (; e < nI; e += RG) s += pI[(size_t)e * Npad3];
+  e -= nI;
+#pragma unroll 4
+  for (; e < nJ; e += RG) s += pJ[(size_t)e * Npad3];
+  sh[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && live) {
+    double t = sh[0][tx];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) t += sh[q][tx];
+    double sc = P.nf;
+    if (WALL) sc *= damp_of(P, r[3 * j + 2]);
+    out[idx] = sc * t;
+    if (!isfinite(t)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -628,6 +654,92 @@ __global__ void k_axpby(long n, double a, const double *__restrict__ x, double b
   if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
 }
 
+// ---- Lanczos recurrence without host round trips -------------------------------------------
+// The three-term recurrence needs two inner products per iteration; here they stay on the device:
+// a kernel leaves per-block partial sums, the NEXT kernel's every block re-adds them in the same
+// fixed order (bitwise identical scalar in all blocks) and uses the result.  alpha / beta are
+// stored for the host, which only looks at them when it tests convergence.
+constexpr int LZ_BLOCKS = 512;
+
+__device__ __forceinline__ double lz_block_sum(double v, double *sh)
+{
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double t = sh[0];
+  __syncthreads();
+  return t;
+}
+
+__device__ __forceinline__ double lz_sum_parts(const double *__restrict__ part, int np, double *sh)
+{
+  double a = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) a += part[i];
+  return lz_block_sum(a, sh);
+}
+
+// u -= beta_prev * vprev (when vprev != null);  partA[block] = sum v_i u_i
+__global__ __launch_bounds__(256) void k_lz_a(long n, double *__restrict__ u, const double *__restrict__ v,
+                                              const double *__restrict__ vprev, const double *__restrict__ bprev,
+                                              double *__restrict__ partA)
+{
+  __shared__ double sh[256];
+  const double b = vprev ? *bprev : 0.0;
+  double a = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double ui = u[i];
+    if (vprev) { ui = __builtin_fma(-b, vprev[i], ui); u[i] = ui; }
+    a = __builtin_fma(v[i], ui, a);
+  }
+  a = lz_block_sum(a, sh);
+  if (threadIdx.x == 0) partA[blockIdx.x] = a;
+}
+
+// alpha = sum(partA);  u -= alpha v;  partB[block] = sum u_i^2
+__global__ __launch_bounds__(256) void k_lz_b(long n, double *__restrict__ u, const double *__restrict__ v,
+                                              const double *__restrict__ partA, int np,
+                                              double *__restrict__ alpha_out, double *__restrict__ partB)
+{
+  __shared__ double sh[256];
+  const double al = lz_sum_parts(partA, np, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = al;
+  double a = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double ui = __builtin_fma(-al, v[i], u[i]);
+    u[i] = ui;
+    a = __builtin_fma(ui, ui, a);
+  }
+  a = lz_block_sum(a, sh);
+  if (threadIdx.x == 0) partB[blockIdx.x] = a;
+}
+
+// beta = sqrt(sum(partB));  vnext = u / beta   (zeros on breakdown)
+__global__ __launch_bounds__(256) void k_lz_c(long n, const double *__restrict__ u,
+                                              const double *__restrict__ partB, int np,
+                                              double *__restrict__ beta_out, double *__restrict__ vnext)
+{
+  __shared__ double sh[256];
+  const double be = sqrt(lz_sum_parts(partB, np, sh));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = be;
+  const double inv = (be > 1e-300) ? 1.0 / be : 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) vnext[i] = inv * u[i];
+}
+
+// out = sum_p coef[p] V[p]   (V: m vectors of length n, contiguous)
+__global__ __launch_bounds__(256) void k_lz_combine(long n, const double *__restrict__ V,
+                                                    const double *__restrict__ coef, int m,
+                                                    double *__restrict__ out)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a = 0.0;
+  for (int p = 0; p < m; ++p) a = __builtin_fma(coef[p], V[(size_t)p * n + i], a);
+  out[i] = a;
+}
+
 __global__ void k_scale_by_damp(RblParams P, const double *__restrict__ r, long n_blobs,
                                 const double *__restrict__ in, double *__restrict__ out)
 {
@@ -748,7 +860,7 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
 {
   dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
   const int64_t n = 3 * n_blobs;
-  dim3 g2((unsigned)((n + 255) / 256)), b2(256);
+  dim3 g2((unsigned)((n + 63) / 64)), b2(64 * RG);
   hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
                      i_first, i_step, P, d_err);
   hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C, nch, NI,
@@ -887,6 +999,44 @@ void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, doub
   if (n <= 0) return;
   hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, a, x,
                      b, y, out);
+}
+
+static int lz_grid(int64_t n)
+{
+  int g = (int)std::min<int64_t>(LZ_BLOCKS, (n + 255) / 256);
+  return g < 1 ? 1 : g;
+}
+
+size_t rbl_lanczos_part_doubles(void) { return 2 * (size_t)LZ_BLOCKS; }
+
+// V0 = W / |W|, *wnorm_out = |W|
+void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
+                             double *part)
+{
+  const int g = lz_grid(n);
+  hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, const_cast<double *>(d_W), d_W,
+                     (const double *)nullptr, (const double *)nullptr, part);
+  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0);
+}
+
+// one Lanczos step after u = A v:  u -= beta_prev vprev; alpha = v.u; u -= alpha v; beta = |u|; vnext = u/beta
+void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
+                             const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
+                             double *part)
+{
+  const int g = lz_grid(n);
+  double *pA = part, *pB = part + LZ_BLOCKS;
+  hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, u, v, vprev, beta_prev, pA);
+  hipLaunchKernelGGL(k_lz_b, dim3(g), dim3(256), 0, st, (long)n, u, v, (const double *)pA, g, alpha_out, pB);
+  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, (const double *)u, (const double *)pB, g,
+                     beta_out, vnext);
+}
+
+void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
+                                double *out)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_lz_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, V, coef, m, out);
 }
 
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,

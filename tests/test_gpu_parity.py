@@ -542,7 +542,7 @@ def test_torch_lanczos_matches_library_lanczos():
     ctx.M_half_W(r.data_ptr(), N, W.data_ptr(), "lanczos", ref.data_ptr())
     ctx.sync_check()
     it, res = ctx.lanczos_report()
-    assert abs(m - it) <= 1
+    assert abs(m - it) <= 4          # the library tests convergence every 4th iteration at this size
     assert float(torch.linalg.norm(y - ref) / torch.linalg.norm(ref)) < 1e-7
     # (M^{1/2})^2 = M :  apply the square root twice
     y2, _, _ = lanczos_mhalf(A, y, max_iter=150, tol=1e-9)
