@@ -8,12 +8,12 @@
 //    oracle.  Used by the dense-build kernel, which is HBM-write bound, so the
 //    extra ALU work is free.
 //
-//  * rbl_pair_accum():  matrix-free  U_i += M_ij F_j  in "vector form"
-//        M F = A F + Bc (r.F) r  +  f1 F + (f2 (e.F) + f3 Fz) e + (f4 (e.F) + f5 Fz) z^
-//    with ONE v_rsq_f64 + a 3rd-order Newton step per distance, no division, and
-//    h_hat eliminated algebraically ( h_hat ez = z_j/R, (1-h_hat) ez = z_i/R ).
-//    Used by the matvec kernels, which are fp64-VALU bound.  Agrees with the
-//    reference to ~1e-15 relative per pair (tests pin <=1e-12 on apply_M).
+//  * rbl_pair_accum() / rbl_pair_sym() / rbl_pair_block_fast():  the fast form used by the matvec
+//    kernels, which are fp64-VALU bound: ONE v_rsq_f64 + a 3rd-order Newton step per distance, no
+//    division, h_hat eliminated algebraically ( h_hat ez = z_j/R, (1-h_hat) ez = z_i/R ), the wall
+//    "facts" as Horner polynomials (rbl_wall_coeffs) and the block applied in vector form
+//        M F = cF F + dl [beta (dl.F) + gxz Fz] + z^ [gzx (dl.F) + (mzz - cF) Fz],   dl = (dx, dy, 0).
+//    Agrees with the reference to ~1e-15 relative per pair (tests pin <=1e-12 on apply_M).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,6 +48,54 @@ __device__ __forceinline__ double rbl_rsqrt(double x)
 }
 
 // ---------------------------------------------------------------------------
+// Wall-corrected block of one pair (i <- j, h = z_j) as five scalars:
+//     M_ij = cF I + beta dl dl^T + gxz dl z^T + gzx z dl^T + (mzz - cF) z z^T,    dl = (dx, dy, 0)
+// (A, Bc: the free-space RPY coefficients; q = dx^2 + dy^2).  With e = (dx, dy, Rz)/R, Rz = z_i + z_j,
+// w = a/R, u = w^2, v = e_z^2, g = z_j/R (= h_hat e_z), k = z_i/R (= (1 - h_hat) e_z) every "fact" of the
+// reference (c_rigid_obj.cpp:108-130) is  w x (polynomial in u), evaluated in Horner form:
+//   fact1 = w b1,  b1 = -1 - 2gk + u[(2v - 2/3) + u(2/3 - 10/3 v)]
+//   fact2 = w b2,  b2 = -1 + 6gk + u[(2 - 10v) + u(70/3 v - 10/3)]
+//   fact5 = w b5,  b5 = -4g^2 + u[-4v + u(20v - 8/3)]
+//   fact2 ez + fact3 = w (T0 - T1),  fact2 ez + fact4 = w (T0 + T1)     with
+//   T0 = 2g - ez,  T1 = ez { 6gk + u[(2 - 10v) + u(70/3 v - 10)] }
+// Swapping the roles of i and j swaps g <-> k, i.e. T1 -> -T1 only: M_ji = M_ij^T exactly.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, double zi, double zj, double q,
+                                                double A, double Bc, double &cF, double &beta, double &gxz,
+                                                double &gzx, double &mzz)
+{
+  const double Rz = zi + zj;
+  const double R2 = __builtin_fma(Rz, Rz, q);
+  const double invR = rbl_rsqrt(R2);
+  const double invR2 = invR * invR;
+  const double w = P.a * invR;
+  const double ez = Rz * invR;
+  const double u = w * w;
+  const double v = ez * ez;
+  const double g = zj * invR;
+  const double gk = g * (zi * invR);
+  const double t1 = __builtin_fma(u, __builtin_fma(v, -10.0 / 3.0, 2.0 / 3.0), __builtin_fma(v, 2.0, -2.0 / 3.0));
+  const double b1 = __builtin_fma(u, t1, __builtin_fma(-2.0, gk, -1.0));
+  const double t2 = __builtin_fma(u, __builtin_fma(v, 70.0 / 3.0, -10.0 / 3.0), __builtin_fma(v, -10.0, 2.0));
+  const double a2 = __builtin_fma(6.0, gk, -1.0);
+  const double f2 = w * __builtin_fma(u, t2, a2);
+  const double T0 = __builtin_fma(2.0, g, -ez);
+  const double T1 = ez * __builtin_fma(u, __builtin_fma(u, -20.0 / 3.0, t2), a2 + 1.0);
+  const double d1 = __builtin_fma(u, __builtin_fma(v, 20.0, -8.0 / 3.0), -4.0 * v);
+  const double b5 = __builtin_fma(u, d1, (-4.0 * g) * g);
+  cF = __builtin_fma(w, b1, A);
+  beta = __builtin_fma(f2, invR2, Bc);                             // lateral dyad: (Bc + f2/R^2) dl dl^T
+  const double Bdz = Bc * dz;
+  const double wi = w * invR;
+  const double gm = __builtin_fma(T0, wi, Bdz), gd = T1 * wi;
+  gxz = gm - gd;                                                   // M_xz = dx gxz, M_yz = dy gxz
+  gzx = gm + gd;                                                   // M_zx = dx gzx, M_zy = dy gzx
+  // f2 ez^2 + (f3 + f4) ez  =  ez [ (f2 ez + f3) + (f2 ez + f4) ] - f2 ez^2  =  2 w ez T0 - f2 ez^2
+  const double zz = __builtin_fma((w + w) * ez, T0, -(f2 * v));
+  mzz = __builtin_fma(Bdz, dz, cF) + __builtin_fma(w, b5, zz);
+}
+
+// ---------------------------------------------------------------------------
 // Fast matrix-free accumulation of one ordered pair (i <- j).
 //   dx,dy,dz = r_i - r_j ;  zi, zj heights ; (Fx,Fy,Fz) = (damped) force on j
 //   SELF: compile-time "this j-tile may contain i" (index-equality self term)
@@ -70,27 +118,24 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
   const double s = P.a * invr;                       // a/r
   const double t = s * s;                            // (a/r)^2
   // far:  A = (a/r)(1 + 2/3 (a/r)^2),  Bc = (a/r)(1 - 2 (a/r)^2)/r^2
-  const double A_far = __builtin_fma(s * t, 2.0 / 3.0, s);
-  const double B_far = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
-  // overlap: A = 4/3 - 3/8 r/a,  Bc = (1/8) / (a r)
-  const double rr = r2 * invr;                       // r
-  const double A_near = __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
-  const double B_near = invr * P.c_near_B;
-  const bool far = r2 >= P.four_a2;
-  double A = far ? A_far : A_near;
-  double Bc = far ? B_far : B_near;
+  double A = __builtin_fma(s * t, 2.0 / 3.0, s);
+  double Bc = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
+  if (__builtin_expect(__any(r2 < P.four_a2), 0)) {  // wave-uniform: the overlap branch (and i == j) is rare
+    // overlap: A = 4/3 - 3/8 r/a,  Bc = (1/8) / (a r)
+    const double rr = r2 * invr;                     // r
+    const bool far = r2 >= P.four_a2;
+    A = far ? A : __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
+    Bc = far ? Bc : invr * P.c_near_B;
+    if (r2 < P.tiny2 && !(SELF && is_self)) flags |= RBL_FLAG_OVERLAP;   // :53-58
+  }
   if (SELF) {                                        // index equality, :40-46
     A = is_self ? 4.0 / 3.0 : A;
     Bc = is_self ? 0.0 : Bc;
-    if (!is_self && r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
-  } else {
-    if (r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
   }
   const double q2 = __builtin_fma(dy, Fy, dx * Fx);
-  const double rF = __builtin_fma(dz, Fz, q2);
-  const double tB = Bc * rF;
 
   if (!WALL) {
+    const double tB = Bc * __builtin_fma(dz, Fz, q2);
     ux = __builtin_fma(A, Fx, __builtin_fma(tB, dx, ux));
     uy = __builtin_fma(A, Fy, __builtin_fma(tB, dy, uy));
     uz = __builtin_fma(A, Fz, __builtin_fma(tB, dz, uz));
@@ -98,44 +143,6 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
   }
 
   // ---- single-wall correction (c_rigid_obj.cpp:98-140), ordered pair, h = z_j
-  const double Rz = zi + zj;                         // (rz + 2 z_j)
-  const double R2 = __builtin_fma(Rz, Rz, q);
-  const double invR = rbl_rsqrt(R2);
-  const double w = P.a * invR;                       // 1/R^ (dimensionless)
-  const double ez = Rz * invR;
-  const double w2 = w * w;
-  const double w3 = w2 * w;
-  const double w5 = w3 * w2;
-  const double ez2 = ez * ez;
-  const double g = zj * invR;                        // h_hat * ez
-  const double k = zi * invR;                        // (1 - h_hat) * ez
-  const double gk = g * k;                           // h_hat (1-h_hat) ez^2
-  const double p3 = __builtin_fma(-3.0, ez2, 1.0);
-  const double p5 = __builtin_fma(-5.0, ez2, 1.0);
-  const double p7 = __builtin_fma(-7.0, ez2, 1.0);
-  const double p5w3 = p5 * w3;
-  // fact1 = -(1+2gk) w - 2/3 (1-3ez2) w^3 + 2/3 (1-5ez2) w^5
-  double f1 = __builtin_fma(-2.0, gk, -1.0) * w;
-  f1 = __builtin_fma(p3 * w3, -2.0 / 3.0, f1);
-  f1 = __builtin_fma(p5 * w5, 2.0 / 3.0, f1);
-  // fact2 = -(1-6gk) w + 2 (1-5ez2) w^3 - 10/3 (1-7ez2) w^5
-  double f2 = __builtin_fma(6.0, gk, -1.0) * w;
-  f2 = __builtin_fma(p5w3, 2.0, f2);
-  f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
-  // fact3 = 2 g w (1 - 6 k ez) + ez ( -4 (1-5ez2) w^3 + 20/3 (2-7ez2) w^5 )
-  const double gw = g * w;
-  const double ezw5 = ez * w5;
-  double f3 = (gw + gw) * __builtin_fma(-6.0 * k, ez, 1.0);
-  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
-  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
-  // fact4 = 2 g w - 20/3 ez w^5
-  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw + gw);
-  // fact5 = -4 g (g w) - 4 ez2 w^3 - 4/3 (2 - 15 ez2) w^5
-  double f5 = -4.0 * (g * gw);
-  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
-  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
-
-  double cF, cE, cZ;   // coefficients of F, of (dx,dy,Rz), of z^
   if (SELF && is_self) {
     // self wall term (:98-104): diag only, args (0,0,2h; h = z_i/a)
     const double iz = P.a / zi;                      // 1/h  (true division kept: rare path)
@@ -148,14 +155,12 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
     uz = __builtin_fma(A + dper, Fz, uz);
     return;
   }
-  const double eF = __builtin_fma(Rz, Fz, q2) * invR; // e . F
-  cF = A + f1;
-  cE = __builtin_fma(f2, eF, f3 * Fz) * invR;        // multiplies (dx,dy,Rz)
-  cZ = __builtin_fma(f4, eF, f5 * Fz);
-  const double cxy = tB + cE;
-  ux = __builtin_fma(cF, Fx, __builtin_fma(cxy, dx, ux));
-  uy = __builtin_fma(cF, Fy, __builtin_fma(cxy, dy, uy));
-  uz = __builtin_fma(cF, Fz, __builtin_fma(tB, dz, __builtin_fma(cE, Rz, uz + cZ)));
+  double cF, beta, gxz, gzx, mzz;
+  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  const double lat = __builtin_fma(beta, q2, gxz * Fz);
+  ux = __builtin_fma(cF, Fx, __builtin_fma(lat, dx, ux));
+  uy = __builtin_fma(cF, Fy, __builtin_fma(lat, dy, uy));
+  uz = __builtin_fma(mzz, Fz, __builtin_fma(gzx, q2, uz));
 }
 
 // ---------------------------------------------------------------------------
@@ -165,8 +170,8 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
 //     U_j += M_ji F_i            (accumulated into ujx,ujy,ujz; caller adds it to j)
 // M_ji = M_ij^T holds exactly for the RPY part and, for the wall part, through the
 // role swap g <-> k (h = z_i instead of z_j): fact1, fact2, the e_z-part of fact3
-// and the h-free part of fact5 are shared.  ~127 fp64 ops per unordered pair vs
-// 2 x 98 for two ordered evaluations.
+// and the h-free part of fact5 are shared.  ~78 fp64 instructions per unordered wall pair
+// (measured in the ISA of k_apply_M_sym<true,2>) vs 2 x ~68 for two ordered evaluations.
 // ---------------------------------------------------------------------------
 template <bool WALL>
 __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, double yi, double zi,
@@ -208,63 +213,22 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
     return;
   }
 
-  // Wall: coefficients for ONE direction (h = z_j), then the nine entries of M_ij explicitly;
-  // M_ji = M_ij^T exactly (fact3(h) + fact4(1-h) = -2 e_z fact2), so U_j += M_ij^T F_i reuses them.
-  const double Rz = zi + zj;
-  const double R2 = __builtin_fma(Rz, Rz, q);
-  const double invR = rbl_rsqrt(R2);
-  const double w = P.a * invR;
-  const double ez = Rz * invR;
-  const double w2 = w * w;
-  const double w3 = w2 * w;
-  const double w5 = w3 * w2;
-  const double ez2 = ez * ez;
-  const double g = zj * invR;                        // h_hat * ez
-  const double k = zi * invR;                        // (1 - h_hat) * ez
-  const double gk = g * k;
-  const double p3 = __builtin_fma(-3.0, ez2, 1.0);
-  const double p5 = __builtin_fma(-5.0, ez2, 1.0);
-  const double p7 = __builtin_fma(-7.0, ez2, 1.0);
-  const double p5w3 = p5 * w3;
-  double f1 = __builtin_fma(-2.0, gk, -1.0) * w;
-  f1 = __builtin_fma(p3 * w3, -2.0 / 3.0, f1);
-  f1 = __builtin_fma(p5 * w5, 2.0 / 3.0, f1);
-  double f2 = __builtin_fma(6.0, gk, -1.0) * w;
-  f2 = __builtin_fma(p5w3, 2.0, f2);
-  f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
-  // f2 ez + f3 = w (T0 - T1),  f2 ez + f4 = w (T0 + T1)  with  T0 = 2 g - ez,
-  // T1 = 6 g k ez + ez w^2 [(2 - 10 ez^2) + w^2 (-10 + 70/3 ez^2)]   (sum / difference of fact3, fact4)
-  const double T0 = __builtin_fma(2.0, g, -ez);
-  const double inner = __builtin_fma(w2, __builtin_fma(ez2, 70.0 / 3.0, -10.0), __builtin_fma(ez2, -10.0, 2.0));
-  const double T1 = __builtin_fma(6.0 * ez, gk, (ez * w2) * inner);
-  const double wi = w * invR;
-  // fact5 = -4 g^2 w - 4 ez^2 w^3 - 4/3 (2 - 15 ez^2) w^5
-  double f5 = (-4.0 * g) * (g * w);
-  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
-  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
-
-  const double cF = A + f1;
-  const double beta = __builtin_fma(f2, invR * invR, Bc);        // lateral dyad: (Bc + f2/R^2) d d^T
-  const double Bdz = Bc * dz;
-  const double gxz = __builtin_fma(T0 - T1, wi, Bdz);            // M_xz = dx gxz, M_yz = dy gxz
-  const double gzx = __builtin_fma(T0 + T1, wi, Bdz);            // M_zx = dx gzx, M_zy = dy gzx
-  // f2 ez^2 + (f3 + f4) ez  =  ez [ (f2 ez + f3) + (f2 ez + f4) ] - f2 ez^2  =  2 w ez T0 - f2 ez^2
-  const double zz = __builtin_fma((w + w) * ez, T0, -(f2 * ez2));
-  const double bx = beta * dx, by = beta * dy;
-  const double mxx = __builtin_fma(bx, dx, cF);
-  const double mxy = bx * dy;
-  const double myy = __builtin_fma(by, dy, cF);
-  const double mxz = dx * gxz, myz = dy * gxz;
-  const double mzx = dx * gzx, mzy = dy * gzx;
-  const double mzz = __builtin_fma(Bdz, dz, cF) + (zz + f5);
+  // Wall: coefficients for ONE direction (h = z_j); M_ji = M_ij^T exactly, so U_j += M_ij^T F_i reuses
+  // them.  Vector form: 20 FMAs for both directions instead of forming nine entries.
+  double cF, beta, gxz, gzx, mzz;
+  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
   // U_i += M F_j
-  uix = __builtin_fma(mxx, Fjx, __builtin_fma(mxy, Fjy, __builtin_fma(mxz, Fjz, uix)));
-  uiy = __builtin_fma(mxy, Fjx, __builtin_fma(myy, Fjy, __builtin_fma(myz, Fjz, uiy)));
-  uiz = __builtin_fma(mzx, Fjx, __builtin_fma(mzy, Fjy, __builtin_fma(mzz, Fjz, uiz)));
+  const double pj = __builtin_fma(dy, Fjy, dx * Fjx);
+  const double lj = __builtin_fma(beta, pj, gxz * Fjz);
+  uix = __builtin_fma(cF, Fjx, __builtin_fma(lj, dx, uix));
+  uiy = __builtin_fma(cF, Fjy, __builtin_fma(lj, dy, uiy));
+  uiz = __builtin_fma(mzz, Fjz, __builtin_fma(gzx, pj, uiz));
   // U_j += M^T F_i
-  ujx = __builtin_fma(mxx, Fix, __builtin_fma(mxy, Fiy, __builtin_fma(mzx, Fiz, ujx)));
-  ujy = __builtin_fma(mxy, Fix, __builtin_fma(myy, Fiy, __builtin_fma(mzy, Fiz, ujy)));
-  ujz = __builtin_fma(mxz, Fix, __builtin_fma(myz, Fiy, __builtin_fma(mzz, Fiz, ujz)));
+  const double pi = __builtin_fma(dy, Fiy, dx * Fix);
+  const double li = __builtin_fma(beta, pi, gzx * Fiz);
+  ujx = __builtin_fma(cF, Fix, __builtin_fma(li, dx, ujx));
+  ujy = __builtin_fma(cF, Fiy, __builtin_fma(li, dy, ujy));
+  ujz = __builtin_fma(mzz, Fiz, __builtin_fma(gxz, pi, ujz));
 }
 
 // ---------------------------------------------------------------------------
@@ -298,44 +262,13 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     A = is_self ? 4.0 / 3.0 : A;
     Bc = is_self ? 0.0 : Bc;
   }
-  const double Bdx = Bc * dx, Bdy = Bc * dy, Bdz = Bc * dz;
   if (!WALL) {
+    const double Bdx = Bc * dx, Bdy = Bc * dy, Bdz = Bc * dz;
     m[0] = __builtin_fma(Bdx, dx, A); m[1] = Bdx * dy; m[2] = Bdx * dz;
     m[3] = m[1]; m[4] = __builtin_fma(Bdy, dy, A); m[5] = Bdy * dz;
     m[6] = m[2]; m[7] = m[5]; m[8] = __builtin_fma(Bdz, dz, A);
     return;
   }
-  const double Rz = zi + zj;
-  const double R2 = __builtin_fma(Rz, Rz, q);
-  const double invR = rbl_rsqrt(R2);
-  const double w = P.a * invR;
-  const double ez = Rz * invR;
-  const double w2 = w * w;
-  const double w3 = w2 * w;
-  const double w5 = w3 * w2;
-  const double ez2 = ez * ez;
-  const double g = zj * invR;
-  const double k = zi * invR;
-  const double gk = g * k;
-  const double p3 = __builtin_fma(-3.0, ez2, 1.0);
-  const double p5 = __builtin_fma(-5.0, ez2, 1.0);
-  const double p7 = __builtin_fma(-7.0, ez2, 1.0);
-  const double p5w3 = p5 * w3;
-  double f1 = __builtin_fma(-2.0, gk, -1.0) * w;
-  f1 = __builtin_fma(p3 * w3, -2.0 / 3.0, f1);
-  f1 = __builtin_fma(p5 * w5, 2.0 / 3.0, f1);
-  double f2 = __builtin_fma(6.0, gk, -1.0) * w;
-  f2 = __builtin_fma(p5w3, 2.0, f2);
-  f2 = __builtin_fma(p7 * w5, -10.0 / 3.0, f2);
-  const double gw2 = 2.0 * (g * w);
-  const double ezw5 = ez * w5;
-  double f3 = gw2 * __builtin_fma(-6.0 * k, ez, 1.0);
-  f3 = __builtin_fma(ez * p5w3, -4.0, f3);
-  f3 = __builtin_fma(ezw5 * (p7 + 1.0), 20.0 / 3.0, f3);
-  const double f4 = __builtin_fma(ezw5, -20.0 / 3.0, gw2);
-  double f5 = -2.0 * (g * gw2);
-  f5 = __builtin_fma(ez2 * w3, -4.0, f5);
-  f5 = __builtin_fma(__builtin_fma(-15.0, ez2, 2.0) * w5, -4.0 / 3.0, f5);
   if (SELF && is_self) {  // self wall term (:98-104): diagonal only
     const double iz = P.a / zi;
     const double iz3 = iz * iz * iz;
@@ -347,20 +280,12 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     m[6] = 0.0; m[7] = 0.0; m[8] = A + dper;
     return;
   }
-  const double cF = A + f1;
-  const double Ex = dx * invR, Ey = dy * invR;
-  const double f2x = f2 * Ex, f2y = f2 * Ey, f2z = f2 * ez;
-  const double cxz = __builtin_fma(Bdx, dz, f2x * ez);
-  const double cyz = __builtin_fma(Bdy, dz, f2y * ez);
-  m[0] = __builtin_fma(Bdx, dx, __builtin_fma(f2x, Ex, cF));
-  m[1] = __builtin_fma(Bdx, dy, f2x * Ey);
-  m[2] = __builtin_fma(f3, Ex, cxz);
-  m[3] = m[1];
-  m[4] = __builtin_fma(Bdy, dy, __builtin_fma(f2y, Ey, cF));
-  m[5] = __builtin_fma(f3, Ey, cyz);
-  m[6] = __builtin_fma(f4, Ex, cxz);
-  m[7] = __builtin_fma(f4, Ey, cyz);
-  m[8] = __builtin_fma(Bdz, dz, __builtin_fma(f2z, ez, cF)) + __builtin_fma(f3 + f4, ez, f5);
+  double cF, beta, gxz, gzx, mzz;
+  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  const double bx = beta * dx, by = beta * dy;
+  m[0] = __builtin_fma(bx, dx, cF); m[1] = bx * dy; m[2] = dx * gxz;
+  m[3] = m[1]; m[4] = __builtin_fma(by, dy, cF); m[5] = dy * gxz;
+  m[6] = dx * gzx; m[7] = dy * gzx; m[8] = mzz;
 }
 
 // ---------------------------------------------------------------------------
