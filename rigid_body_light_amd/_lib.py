@@ -16,7 +16,7 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "librbl.so")
+        path = os.environ.get("RBL_LIBRARY") or os.path.join(_HERE, "librbl.so")   # override: A/B kernel builds
         if not os.path.exists(path):
             raise ImportError("librbl.so not built; run `python rigid_body_light_amd/build.py`")
         L = C.CDLL(path)

@@ -67,7 +67,6 @@ __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, d
   const double Rz = zi + zj;
   const double R2 = __builtin_fma(Rz, Rz, q);
   const double invR = rbl_rsqrt(R2);
-  const double invR2 = invR * invR;
   const double w = P.a * invR;
   const double ez = Rz * invR;
   const double u = w * w;
@@ -78,21 +77,23 @@ __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, d
   const double b1 = __builtin_fma(u, t1, __builtin_fma(-2.0, gk, -1.0));
   const double t2 = __builtin_fma(u, __builtin_fma(v, 70.0 / 3.0, -10.0 / 3.0), __builtin_fma(v, -10.0, 2.0));
   const double a2 = __builtin_fma(6.0, gk, -1.0);
-  const double f2 = w * __builtin_fma(u, t2, a2);
+  const double b2 = __builtin_fma(u, t2, a2);
   const double T0 = __builtin_fma(2.0, g, -ez);
   const double T1 = ez * __builtin_fma(u, __builtin_fma(u, -20.0 / 3.0, t2), a2 + 1.0);
   const double d1 = __builtin_fma(u, __builtin_fma(v, 20.0, -8.0 / 3.0), -4.0 * v);
-  const double b5 = __builtin_fma(u, d1, (-4.0 * g) * g);
-  cF = __builtin_fma(w, b1, A);
-  beta = __builtin_fma(f2, invR2, Bc);                             // lateral dyad: (Bc + f2/R^2) dl dl^T
-  const double Bdz = Bc * dz;
   const double wi = w * invR;
+  cF = __builtin_fma(w, b1, A);
+  beta = __builtin_fma(b2, wi * invR, Bc);                         // lateral dyad: (Bc + fact2/R^2) dl dl^T
+  const double Bdz = Bc * dz;
   const double gm = __builtin_fma(T0, wi, Bdz), gd = T1 * wi;
   gxz = gm - gd;                                                   // M_xz = dx gxz, M_yz = dy gxz
   gzx = gm + gd;                                                   // M_zx = dx gzx, M_zy = dy gzx
-  // f2 ez^2 + (f3 + f4) ez  =  ez [ (f2 ez + f3) + (f2 ez + f4) ] - f2 ez^2  =  2 w ez T0 - f2 ez^2
-  const double zz = __builtin_fma((w + w) * ez, T0, -(f2 * v));
-  mzz = __builtin_fma(Bdz, dz, cF) + __builtin_fma(w, b5, zz);
+  // zz entry beyond cF + Bc dz^2:  f2 ez^2 + (f3 + f4) ez + f5 = w [2 ez T0 - b2 ez^2 + b5]   (using
+  // ez [(f2 ez + f3) + (f2 ez + f4)] = 2 w ez T0)
+  double c = __builtin_fma(ez + ez, T0, -(b2 * v));
+  c = __builtin_fma(u, d1, c);
+  c = __builtin_fma(-4.0 * g, g, c);
+  mzz = __builtin_fma(w, c, __builtin_fma(Bdz, dz, cF));
 }
 
 // ---------------------------------------------------------------------------
