@@ -417,7 +417,7 @@ def main():
                          "frac": achieved / PEAK_FP64_TFLOPS,
                          # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
                          # gfx950 correction + WRITE_SIZE, KB -> B): profiles/r01_bench_cfg3_sym_pmc_summary.txt
-                         "traffic": (2 * 162731e3 + 1.70253e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
+                         "traffic": (2 * 163984e3 + 1.70253e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
                          "kernel_ms": kern_ms,
                          "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch),
                          "note": "fp64 VALU-issue bound; on gfx950 fp64 VALU and fp64 MFMA share one pipe (SQ_VALU_MFMA_COEXEC_CYCLES = 0), "
