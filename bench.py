@@ -311,10 +311,19 @@ def main():
     use_sym = args.variant != 1     # symmetric kernel (each unordered pair once) unless the ordered kernel is forced
     U_part = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
 
+    r_all = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
+
     def step(k=None):
-        # a8: this rank's blob positions from (X,Q); one exchange; then this rank's share of U = B M B F
-        ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
-        r_full = sm.set_positions_local(r_local) if world > 1 else r_local
+        # a8: blob positions from (X,Q); one exchange; then this rank's share of U = B M B F.
+        # Symmetric sharding needs all positions on every rank: the O(N_bod) body state is replicated, so each
+        # rank evaluates them itself (a ~5 us kernel) instead of gathering them; the force vector arrives
+        # sharded (one all-gather) and the partial U is completed by one all-reduce.
+        if use_sym:
+            ctx.blob_positions(0, nb, r_all.data_ptr())
+            r_full = r_all
+        else:
+            ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
+            r_full = sm.set_positions_local(r_local) if world > 1 else r_local
         F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
         if k is not None:
             ev[k][0].record(stream)
@@ -409,7 +418,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 200 bodies x shell_N_642 blobs, wall-corrected mobility"
                                    if args.config == "cfg3" else args.config,
                        "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
-                       "parallelism": ("tile-pair-sharded x%d, all-gather(pos,F) + all-reduce(U)" if use_sym else
+                       "parallelism": ("tile-pair-sharded x%d, positions replicated, all-gather(F) + all-reduce(U)" if use_sym else
                                        "body-row-sharded x%d, all-gather(pos,F)") % world},
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
             "roofline": {"bound": "fp64-valu", "kernel": "%s<%s>" % ("k_apply_M_sym" if use_sym else "k_apply_M", "true" if wall else "false"),
