@@ -21,64 +21,51 @@ constexpr int NB = 512;   // outer panel width (K of the trailing MFMA update)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---- potf2: one wavefront factors the IB x IB diagonal block at (k,k) ------------------
-// The block lives in LDS; a single wavefront needs no barriers (its LDS operations execute
-// in program order).  Column step c: pivot by v_rsq_f64 + Newton (no sqrt/div chain), scale
-// the column, then the 64 lanes update the trailing lower triangle (lane = row, two column
-// parities).  The same wave then inverts L by forward substitution (lane = column of
-// L^-1) and leaves Linv (IB x IB, row-major [c][m]) in Y for the MFMA triangular solve.
+// Everything in registers, no LDS on the dependency chain: lane r < 32 holds row r of the block
+// (x[c] = A[r][c]), lane 32 + m holds the unknowns of L y = e_m (x = e_m), and BOTH half-waves run
+// the same fully unrolled right-looking recurrence
+//     x[c] *= 1/L_cc ;   x[c'] -= x[c] * L[c'][c]   (c' > c)
+// with the uniform L[c'][c] fetched by v_readlane from lane c': for the low half this is the
+// Cholesky update of row r, for the high half it is forward substitution -- so L_kk^-1 (needed by
+// the MFMA triangular solves) comes out of the same instruction stream for free.  Pivots by
+// v_rsq_f64 + Newton (no sqrt/div chain).  Leaves Linv (IB x IB, row-major [c][m]) in Y.
 // t = lane (0..63).  Returns true when a pivot was not positive.
-__device__ __forceinline__ bool potf2_wave(double *__restrict__ A, long n, long k, int nb,
-                                           double (*S)[IB + 1], double (*Y)[IB + 1], double *dinv, int t)
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
 {
-  const int i = t & (IB - 1), par = t >> 5;
-  for (int e = t; e < IB * IB; e += 64) {
-    const int r = e & (IB - 1), c = e >> 5;  // consecutive lanes -> consecutive rows of a column
-    S[r][c] = (r < nb && c < nb && c <= r) ? A[(size_t)(k + c) * n + (k + r)] : ((r == c) ? 1.0 : 0.0);
-  }
-  bool bad = false;
-  for (int c = 0; c < IB; ++c) {
-    const double d = S[c][c];
-    bad = bad || !(d > 0.0);
-    const double inv = rbl_rsqrt(d);
-    const double lic = (i == c) ? d * inv : S[i][c] * inv;   // L[i][c]  (rows i < c hold 0)
-    if (par == 0) S[i][c] = lic;
-    if (t == 0) dinv[c] = inv;
-    // batch: all reads of this column step first, then the FMAs, then the writes (a plain
-    // read-modify-write loop would serialise on possible LDS aliasing: ~150 cycles/entry)
-    double lj[IB / 2], sij[IB / 2];
-#pragma unroll
-    for (int q = 0; q < IB / 2; ++q) {
-      const int j = c + 1 + par + 2 * q;
-      const int jj = j < IB ? j : IB - 1;
-      lj[q] = S[jj][c];
-      sij[q] = S[i][jj];
-    }
-#pragma unroll
-    for (int q = 0; q < IB / 2; ++q) {
-      const int j = c + 1 + par + 2 * q;
-      if (j < IB && i >= j) S[i][j] = __builtin_fma(-lic, lj[q], sij[q]);
-    }
-  }
-  for (int e = t; e < IB * IB; e += 64) {
-    const int r = e & (IB - 1), c = e >> 5;
-    if (r < nb && c < nb && c <= r) A[(size_t)(k + c) * n + (k + r)] = S[r][c];
-  }
-  // ---- Linv: lane c (both half-waves compute the same thing) solves L y = e_c ------------
-  // right-looking substitution with the unknowns in registers (static indices) and the
-  // rows of L broadcast from LDS: no LDS round trip on the dependency chain.
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool potf2_wave(double *__restrict__ A, long n, long k, int nb,
+                                           double (*Y)[IB + 1], int t)
+{
+  const int i = t & (IB - 1);
+  const bool hi = t >= IB;
+  const bool live = !hi && i < nb;
   double x[IB];
 #pragma unroll
-  for (int r = 0; r < IB; ++r) x[r] = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-  for (int m = 0; m < IB; ++m) {
-    const double ym = x[m] * dinv[m];
-    x[m] = ym;
-#pragma unroll
-    for (int r = m + 1; r < IB; ++r) x[r] = __builtin_fma(-S[r][m], ym, x[r]);
+  for (int c = 0; c < IB; ++c) {   // rows/columns beyond nb (ragged last block): identity
+    double v = (c == i) ? 1.0 : 0.0;
+    if (live && c < nb && c <= i) v = A[(size_t)(k + c) * n + (k + i)];
+    x[c] = v;
   }
-  if (par == 0) {
+  bool bad = false;
 #pragma unroll
-    for (int r = 0; r < IB; ++r) Y[r][i] = x[r];
+  for (int c = 0; c < IB; ++c) {
+    const double d = readlane_f64(x[c], c);              // pivot, uniform
+    bad = bad || !(d > 0.0);
+    x[c] *= rbl_rsqrt(d);                                // L[r][c]  /  y_c
+#pragma unroll
+    for (int cp = c + 1; cp < IB; ++cp) x[cp] = __builtin_fma(-x[c], readlane_f64(x[c], cp), x[cp]);
+  }
+  if (!hi) {
+#pragma unroll
+    for (int c = 0; c < IB; ++c)
+      if (live && c < nb && c <= i) A[(size_t)(k + c) * n + (k + i)] = x[c];
+  } else {
+#pragma unroll
+    for (int r = 0; r < IB; ++r) Y[r][i] = x[r];         // Linv[r][m = i]
   }
   return bad;
 }
@@ -89,11 +76,10 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
 {
   A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
   Linv += (size_t)blockIdx.z * (size_t)strideL;
-  __shared__ double S[IB][IB + 1];
   __shared__ double Y[IB][IB + 1];
-  __shared__ double dinv[IB];
   const int t = threadIdx.x;
-  const bool bad = potf2_wave(A, n, k, nb, S, Y, dinv, t);
+  const bool bad = potf2_wave(A, n, k, nb, Y, t);
+  __syncthreads();
   if (bad && t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
   for (int e = t; e < IB * IB; e += 64) {
     const int c = e & (IB - 1), r = e >> 5;
@@ -102,44 +88,131 @@ __global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, lo
 }
 
 // ---- diagonal block of an outer panel: ONE workgroup factors the whole pw x pw block -----------
-// The right-looking IB-steps (potf2 -> trsm -> rank-IB update) of the block run inside one
-// 16-wave workgroup with __syncthreads() between phases instead of ~3 kernel launches per step:
-// on the critical path of the factorisation a launch boundary costs tens of microseconds (queueing
-// behind the big trailing update + write-back of dirtied lines), a workgroup barrier ~1 us.
-// The block (<= 2 MB) stays in L2/L1 of this CU; every phase's global stores are re-read only after
-// a workgroup barrier.  trsm and update are MFMA (transposed tiles, as in the other kernels).
-// Also writes every L_kk^-1 to LinvAll[step] for k_trsm_tall.
-__global__ __launch_bounds__(1024) void k_potrf_block(double *__restrict__ A, long ld, long k, int pw,
-                                                      double *__restrict__ LinvAll, unsigned *err)
+// The right-looking IB-steps (potf2 -> trsm -> rank-IB update) of the block run inside one 8-wave
+// workgroup with __syncthreads() between phases instead of ~3 kernel launches per step: on the
+// critical path of the factorisation a launch boundary costs tens of microseconds (queueing behind
+// the big trailing update + write-back of dirtied lines), a workgroup barrier ~1 us.
+// The block (<= 2 MB) stays in L2 of this CU's XCD; the phases are latency-bound (one CU), so
+//  * every 32x32 tile update issues ALL its loads (operands and the C entries it will overwrite)
+//    before the first MFMA: one memory round trip per tile (8 waves x 256 VGPRs make room for that);
+//  * inner lookahead: the update of step s does the tiles of block column s+1 first; then wave 0
+//    factors diagonal block s+1 (serial, ~20 us) WHILE waves 1..7 finish the rest of the update.
+// trsm and update are MFMA products (transposed tiles, as in the other kernels).  Also writes every
+// L_kk^-1 to LinvAll[step] for k_trsm_tall.
+constexpr int PBW = 8;   // waves of k_potrf_block
+
+typedef unsigned int rbl_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-  __shared__ double S[IB][IB + 1];
-  __shared__ double Y[IB][IB + 1];   // L_kk^-1, row-major [c][m]
-  __shared__ double dinv[IB];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const rbl_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double d)
+{
+  const rbl_u2 v = {(unsigned)__double2loint(d), (unsigned)__double2hiint(d)};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+
+__global__ __launch_bounds__(64 * PBW) void k_potrf_block(double *__restrict__ A, long ld, long k, int pw,
+                                                          double *__restrict__ LinvAll, unsigned *err)
+{
+  __shared__ double Y[IB][IB + 1];   // L_kk^-1 of the current step, row-major [c][m]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform: tile indices live in SGPRs
   const int l15 = lane & 15, l4 = lane >> 4;
   const long pend = k + pw;
   const int nsteps = (pw + IB - 1) / IB;
+
+  auto factor_diag = [&](int s) {      // wave 0 only
+    const long kk = k + (long)s * IB;
+    const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
+    const bool bad = potf2_wave(A, ld, kk, nb, Y, lane);
+    if (bad && lane == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+    for (int e = lane; e < IB * IB; e += 64) {
+      const int c = e & (IB - 1), r = e >> 5;
+      LinvAll[(size_t)s * IB * IB + r * IB + c] = Y[r][c];
+    }
+  };
+
+  // Addressing: the block (columns k..pend-1, < 513 columns, < 2^31 bytes) through ONE buffer descriptor;
+  // an entry (col, row) = scalar byte offset (col - k - (lane>>4)) ld 8  +  per-lane byte offset
+  // ((lane>>4) ld + row) 8, so a tile's 48 loads share 2-4 offset registers instead of 48 address pairs.
+  const unsigned ldb = (unsigned)ld * 8u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)k * (size_t)ld, (short)0, (int)(((size_t)(pw - 1) * (size_t)ld + (size_t)pend) * 8), 0x00020000);
+  auto lane_off = [&](long row0) -> unsigned {     // clamped row (ragged last panel) + this lane's column shift
+    const long r = row0 + l15;
+    return (unsigned)l4 * ldb + 8u * (unsigned)(r < pend ? r : pend - 1);
+  };
+  auto col_off = [&](long col) -> unsigned { return (unsigned)(col - k) * ldb; };   // uniform
+
+  // C[i0.., j0..] -= P[i0..] P[j0..]^T with P = columns kk..kk+31 (already solved), 32x32 tile
+  auto update_tile = [&](long kk, long i0, long j0) {
+    const unsigned oi[2] = {lane_off(i0), lane_off(i0 + 16)}, oj[2] = {lane_off(j0), lane_off(j0 + 16)};
+    double av[IB / 4][2], bv[IB / 4][2], cv[2][2][4];
+#pragma unroll
+    for (int ks = 0; ks < IB / 4; ++ks) {
+      const unsigned so = col_off(kk + 4 * ks);
+      av[ks][0] = buf_ld(rs, oj[0], so); av[ks][1] = buf_ld(rs, oj[1], so);
+      bv[ks][0] = buf_ld(rs, oi[0], so); bv[ks][1] = buf_ld(rs, oi[1], so);
+    }
+    const bool ragged = j0 + 32 > pend;                        // uniform: tile sticks out of the block (last panel)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long cb = j0 + 16 * tj + 4 * v;                  // uniform column of lane group 0
+        if (!ragged) {
+          const unsigned so = col_off(cb);
+          cv[tj][0][v] = buf_ld(rs, oi[0], so); cv[tj][1][v] = buf_ld(rs, oi[1], so);
+        } else {                                               // per-lane clamped column, no scalar part
+          const long cl = (cb + l4 < pend) ? cb + l4 : pend - 1;
+          const unsigned sh = col_off(cl) - (unsigned)l4 * ldb;
+          cv[tj][0][v] = buf_ld(rs, oi[0] + sh, 0u); cv[tj][1][v] = buf_ld(rs, oi[1] + sh, 0u);
+        }
+      }
+    double4_t acc[2][2];   // [tj][ti]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < IB / 4; ++ks) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][0], bv[ks][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][0], bv[ks][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][1], bv[ks][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks][1], bv[ks][1], acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const long cb = j0 + 16 * tj + 4 * v;
+        const unsigned so = col_off(cb);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+          if (i0 + 16 * ti + l15 < pend && cb + l4 < pend) buf_st(rs, oi[ti], so, cv[tj][ti][v] - acc[tj][ti][v]);
+      }
+  };
+
+  if (wave == 0) factor_diag(0);
+  __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const long kk = k + (long)s * IB;
     const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
     const long rem0 = kk + nb;
-    if (wave == 0) {
-      const bool bad = potf2_wave(A, ld, kk, nb, S, Y, dinv, lane);
-      if (bad && lane == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
-      for (int e = lane; e < IB * IB; e += 64) {
-        const int c = e & (IB - 1), r = e >> 5;
-        LinvAll[(size_t)s * IB * IB + r * IB + c] = Y[r][c];
-      }
-    }
-    __syncthreads();
     if (rem0 >= pend) break;            // block-uniform: nothing below / right of this step
     const int nrt = (int)((pend - rem0 + 31) / 32);   // 32-row tiles below the diagonal block
     // ---- trsm: X = A[rows, kk:kk+32] * Linv^T, one 32-row tile per wave-iteration ------------
-    for (int g = wave; g < nrt; g += 16) {
+    for (int g = wave; g < nrt; g += PBW) {
       const long i0 = rem0 + 32L * g;
-      long irow[2];
+      const unsigned oi[2] = {lane_off(i0), lane_off(i0 + 16)};
+      double bv[IB / 4][2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) { long ir = i0 + 16 * q + l15; irow[q] = ir < pend ? ir : pend - 1; }
+      for (int ks = 0; ks < IB / 4; ++ks) {
+        const unsigned so = col_off(kk + 4 * ks);
+        bv[ks][0] = buf_ld(rs, oi[0], so); bv[ks][1] = buf_ld(rs, oi[1], so);
+      }
       double4_t acc[2][2];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -148,67 +221,35 @@ __global__ __launch_bounds__(1024) void k_potrf_block(double *__restrict__ A, lo
 #pragma unroll
       for (int ks = 0; ks < IB / 4; ++ks) {
         const int m = 4 * ks + l4;
-        const double *cp = A + (size_t)(kk + m) * (size_t)ld;
-        const double b0 = cp[irow[0]], b1 = cp[irow[1]];
         const double a0 = Y[l15][m], a1 = Y[16 + l15][m];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[ks][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[ks][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv[ks][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv[ks][1], acc[1][1], 0, 0, 0);
       }
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-          const long row = i0 + 16 * ti + l15;
+        for (int v = 0; v < 4; ++v) {
+          const unsigned so = col_off(kk + 16 * tc + 4 * v);
 #pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (row < pend) A[(size_t)(kk + 16 * tc + l4 + 4 * v) * (size_t)ld + row] = acc[tc][ti][v];
+          for (int ti = 0; ti < 2; ++ti)
+            if (i0 + 16 * ti + l15 < pend) buf_st(rs, oi[ti], so, acc[tc][ti][v]);
         }
     }
     __syncthreads();
-    // ---- rank-IB update of the rest of the block: lower 32x32 tiles dealt round-robin to waves --
-    int idx = 0;
-    for (int bi = 0; bi < nrt; ++bi)
-      for (int bj = 0; bj <= bi; ++bj, ++idx) {
-        if ((idx & 15) != wave) continue;
-        const long i0 = rem0 + 32L * bi, j0 = rem0 + 32L * bj;
-        long irow[2], jrow[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          long ir = i0 + 16 * q + l15; irow[q] = ir < pend ? ir : pend - 1;
-          long jr = j0 + 16 * q + l15; jrow[q] = jr < pend ? jr : pend - 1;
-        }
-        double4_t acc[2][2];   // [tj][ti]
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < IB / 4; ++ks) {
-          const double *cp = A + (size_t)(kk + 4 * ks + l4) * (size_t)ld;
-          const double a0 = cp[jrow[0]], a1 = cp[jrow[1]];
-          const double b0 = cp[irow[0]], b1 = cp[irow[1]];
-          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-          for (int ti = 0; ti < 2; ++ti) {
-            const long row = i0 + 16 * ti + l15;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const long col = j0 + 16 * tj + l4 + 4 * v;
-              if (row < pend && col < pend) {
-                double *pp = A + (size_t)col * (size_t)ld + row;
-                *pp = *pp - acc[tj][ti][v];
-              }
-            }
-          }
-      }
+    // ---- rank-IB update, part 1: block column s+1 (tiles (bi, 0)), all waves ---------------------
+    for (int bi = wave; bi < nrt; bi += PBW) update_tile(kk, rem0 + 32L * bi, rem0);
+    __syncthreads();
+    // ---- part 2: wave 0 factors diagonal block s+1; waves 1.. update the remaining lower tiles ----
+    if (wave == 0) {
+      factor_diag(s + 1);
+    } else {
+      int idx = 0;
+      for (int bi = 1; bi < nrt; ++bi)
+        for (int bj = 1; bj <= bi; ++bj, ++idx)
+          if (idx % (PBW - 1) == wave - 1) update_tile(kk, rem0 + 32L * bi, rem0 + 32L * bj);
+    }
     __syncthreads();
   }
 }
@@ -523,7 +564,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       pending_L = false;
     }
     // the NB x NB diagonal block: one 16-wave workgroup, barriers instead of launches
-    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(1024), 0, sp, d_M, (long)n, (long)k, (int)pw, Linv, d_err);
+    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(64 * PBW), 0, sp, d_M, (long)n, (long)k, (int)pw, Linv, d_err);
     if (pend < n)            // rows below the block: X = A21 L11^-T, all NB/IB column blocks in one launch
       hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128)), dim3(256), 0, sp, d_M, (long)n,
                          (long)n, (long)k, (int)(pw / IB), (long)pend, Linv);
