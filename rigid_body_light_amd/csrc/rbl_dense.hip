@@ -553,7 +553,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
   // panel width: NB while the trailing matrix is large (its rank-NB update then hides the panel
   // chain), NB/2 near the end where the panel chain itself is the critical path
   auto width_at = [n](int64_t k0) -> int64_t {
-    const int64_t w = (n - k0 > 12288) ? NB : NB / 2;
+    const int64_t w = (n - k0 > 6144) ? NB : NB / 2;          // measured: 6144 best at n = 24 300 and 57 780
     return (n - k0 < w) ? (n - k0) : w;
   };
   for (int64_t k = 0; k < n;) {
