@@ -70,23 +70,6 @@ __device__ __forceinline__ bool potf2_wave(double *__restrict__ A, long n, long 
   return bad;
 }
 
-__global__ __launch_bounds__(64) void k_potf2(double *__restrict__ A, long n, long k, int nb,
-                                              double *__restrict__ Linv, unsigned *err, long strideA,
-                                              long strideL)
-{
-  A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
-  Linv += (size_t)blockIdx.z * (size_t)strideL;
-  __shared__ double Y[IB][IB + 1];
-  const int t = threadIdx.x;
-  const bool bad = potf2_wave(A, n, k, nb, Y, t);
-  __syncthreads();
-  if (bad && t == 0) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
-  for (int e = t; e < IB * IB; e += 64) {
-    const int c = e & (IB - 1), r = e >> 5;
-    Linv[r * IB + c] = Y[r][c];
-  }
-}
-
 // ---- diagonal block of an outer panel: ONE workgroup factors the whole pw x pw block -----------
 // The right-looking IB-steps (potf2 -> trsm -> rank-IB update) of the block run inside one 8-wave
 // workgroup with __syncthreads() between phases instead of ~3 kernel launches per step: on the
@@ -114,8 +97,11 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 
 __global__ __launch_bounds__(64 * PBW) void k_potrf_block(double *__restrict__ A, long ld, long k, int pw,
-                                                          double *__restrict__ LinvAll, unsigned *err)
+                                                          double *__restrict__ LinvAll, unsigned *err,
+                                                          long strideA, long strideL)
 {
+  A += (size_t)blockIdx.y * (size_t)strideA;        // batched: one matrix per blockIdx.y
+  LinvAll += (size_t)blockIdx.y * (size_t)strideL;
   __shared__ double Y[IB][IB + 1];   // L_kk^-1 of the current step, row-major [c][m]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform: tile indices live in SGPRs
@@ -254,71 +240,23 @@ __global__ __launch_bounds__(64 * PBW) void k_potrf_block(double *__restrict__ A
   }
 }
 
-// ---- trsm on the matrix cores: rows below the diagonal block, X <- X L_kk^{-T} = X Linv^T --
-// wave = 64 rows x 32 columns; computes the transposed tile D'[c][i] = sum_m Linv[c][m] A[i][m]
-// so that the stores are 128-B runs along the rows of column-major A.  In place: a wave reads
-// all 32 columns of its 64 rows before it writes them.
-__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, long ld, long k, int nb,
-                                                   const double *__restrict__ Linv, long strideA,
-                                                   long strideL, long n /* rows < n are solved */)
-{
-  A += (size_t)blockIdx.z * (size_t)strideA;
-  Linv += (size_t)blockIdx.z * (size_t)strideL;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const long i0 = k + nb + ((long)blockIdx.x * 4 + wave) * 64;
-  if (i0 >= n) return;
-  double4_t acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  long irow[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { long ir = i0 + 16 * q + l15; irow[q] = ir < n ? ir : n - 1; }
-#pragma unroll
-  for (int ks = 0; ks < IB / 4; ++ks) {
-    const int m = 4 * ks + l4;
-    const bool mv = m < nb;
-    const long col = mv ? (k + m) : k;
-    double bv[4], av[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const double v = A[(size_t)col * (size_t)ld + irow[q]]; bv[q] = mv ? v : 0.0; }
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc) av[tc] = Linv[(16 * tc + l15) * IB + m];
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-        acc[tc][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tc], bv[ti], acc[tc][ti], 0, 0, 0);
-  }
-#pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const long row = i0 + 16 * ti + l15;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int cc = 16 * tc + l4 + 4 * v;
-        if (row < n && cc < nb) A[(size_t)(k + cc) * (size_t)ld + row] = acc[tc][ti][v];
-      }
-    }
-}
 
 // ---- tall panel solve: rows below an outer panel, ALL its IB-blocks in one launch -----------
 //   X = A21 L11^{-T}  for rows [r_begin, n) and the panel columns [k0, k0 + nblk*IB)
 // Left-looking per 32-column block j:  X_j = (A_j - sum_{m<j} X_m L_jm^T) L_jj^{-T}.
 // A wave owns 32 rows and walks the column blocks; everything is MFMA, transposed tiles
-// (D'[c][i]) as in k_trsm_mfma.  The fp64 C/D layout (row = (lane>>4) + 4v, col = lane&15) IS the
+// (D'[c][i]) as in the solve of k_potrf_block.  The fp64 C/D layout (row = (lane>>4) + 4v, col = lane&15) IS the
 // B-operand layout (k = lane>>4 (+4 ks), n = lane&15), so T = A_j - S goes from the accumulator
 // registers straight into the product with Linv_jj -- no LDS, no shuffles.  X_m written by this
 // workgroup is re-read (by other lanes) after a workgroup barrier (same CU -> same L1).
-// This replaces nblk x (k_trsm_mfma + rank-32 k_syrk_mfma) launches over the tall rows of the
+// This replaces nblk x (triangular solve + rank-32 update) launches over the tall rows of the
 // right-looking panel: the latency-bound chain on the critical path only sees the NB x NB block.
 __global__ __launch_bounds__(256) void k_trsm_tall(double *__restrict__ A, long ld, long n, long k0,
                                                    int nblk, long r_begin,
-                                                   const double *__restrict__ LinvAll)
+                                                   const double *__restrict__ LinvAll, long strideA, long strideL)
 {
+  A += (size_t)blockIdx.z * (size_t)strideA;        // batched: one matrix per blockIdx.z
+  LinvAll += (size_t)blockIdx.z * (size_t)strideL;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, l4 = lane >> 4;
   const long i0 = r_begin + ((long)blockIdx.x * 4 + wave) * 32;
@@ -564,10 +502,11 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       pending_L = false;
     }
     // the NB x NB diagonal block: one 16-wave workgroup, barriers instead of launches
-    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(64 * PBW), 0, sp, d_M, (long)n, (long)k, (int)pw, Linv, d_err);
+    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(64 * PBW), 0, sp, d_M, (long)n, (long)k, (int)pw, Linv, d_err,
+                       0L, 0L);
     if (pend < n)            // rows below the block: X = A21 L11^-T, all NB/IB column blocks in one launch
       hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128)), dim3(256), 0, sp, d_M, (long)n,
-                         (long)n, (long)k, (int)(pw / IB), (long)pend, Linv);
+                         (long)n, (long)k, (int)(pw / IB), (long)pend, Linv, 0L, 0L);
     if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
       if (look) {
         if (hipEventRecord(aux->ev[0], sp) != hipSuccess) return RBL_ERR_HIP;
@@ -605,8 +544,8 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
 // ---------------------------------------------------------------------------------------------
 // Batched variant for the block-diagonal preconditioner (reference Block_diag_invM, :461-487):
 // `batch` SPD matrices of order n (one per rigid body, n = 3 N_blb), stride strideA doubles.
-// Same kernels with blockIdx.z = matrix, outer panels of 256 columns, no lookahead.  All diagonal-block inverses are KEPT: Linv[b][step][IB*IB] feed the
-// substitution kernel below.  K of the rank update is always IB, a multiple of KC.
+// Same kernels with one matrix per blockIdx.y/z, outer panels of 256 columns, no lookahead.  All diagonal-block
+// inverses are KEPT: Linv[b][step][IB*IB] feed the substitution kernel below.
 // ---------------------------------------------------------------------------------------------
 size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
 {
@@ -623,23 +562,13 @@ int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batc
   for (int64_t k = 0; k < n; k += NBB) {
     const int64_t pw = (n - k < NBB) ? (n - k) : NBB;
     const int64_t pend = k + pw;
-    for (int64_t kk = k; kk < pend; kk += IB) {
-      const int nb = (int)((pend - kk < IB) ? (pend - kk) : IB);
-      double *Lk = d_Linv + (size_t)(kk / IB) * IB * IB;
-      hipLaunchKernelGGL(k_potf2, dim3(1, 1, batch), dim3(64), 0, st, d_M, (long)n, (long)kk, nb, Lk, d_err,
-                         (long)strideA, strideL);
-      const int64_t rows = n - (kk + nb);
-      if (rows > 0) {
-        hipLaunchKernelGGL(k_trsm_mfma, dim3((unsigned)((rows + 255) / 256), 1, batch), dim3(256), 0, st, d_M,
-                           (long)n, (long)kk, nb, Lk, (long)strideA, strideL, (long)n);
-        const int64_t r0 = kk + nb;
-        if (r0 < pend) {   // rest of this panel, K = IB
-          dim3 grid((unsigned)((n - r0 + 127) / 128), (unsigned)((pend - r0 + 127) / 128), batch);
-          hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)r0, (long)pend, (long)kk, nb,
-                             (long)strideA, (long)n);
-        }
-      }
-    }
+    double *Lk = d_Linv + (size_t)(k / IB) * IB * IB;   // this panel's L_kk^-1 blocks (all are kept)
+    // diagonal block of every matrix: one workgroup each; then the rows below it, all column steps fused
+    hipLaunchKernelGGL(k_potrf_block, dim3(1, batch), dim3(64 * PBW), 0, st, d_M, (long)n, (long)k, (int)pw, Lk, d_err,
+                       (long)strideA, strideL);
+    if (pend < n)
+      hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128), 1, batch), dim3(256), 0, st, d_M, (long)n,
+                         (long)n, (long)k, (int)(pw / IB), (long)pend, (const double *)Lk, (long)strideA, strideL);
     if (pend < n) {        // trailing matrix, K = NBB (a short panel is the last one)
       dim3 grid((unsigned)((n - pend + 127) / 128), (unsigned)((n - pend + 127) / 128), batch);
       hipLaunchKernelGGL(k_syrk_mfma, grid, dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n, (long)k, (int)pw,
