@@ -402,8 +402,9 @@ def main():
         flops_alg = FLOPS_PER_PAIR[wall] * pairs_per_launch
         achieved = flops_alg / (kern_ms * 1e-3) / 1e12
         line = {
-            "metric": "apply_M steps/sec (1 step = one matrix-free M.F pass of the hot path: blob positions -> "
-                      "[all-gather] -> U = B M B F), %d x shell_N_%d, %s, fp64" % (nb, nblb, "wall-corrected" if wall else "free-space"),
+            "metric": "timesteps/sec + M.F GFLOP/s (BASELINE.json metric): value = M.F passes/sec, 1 step = one matrix-free "
+                      "apply_M pass of the hot path (blob positions -> [all-gather] -> U = B M B F); M.F GFLOP/s in `mf_gflops`, "
+                      "timesteps/sec in `timestep`; %d x shell_N_%d, %s, fp64" % (nb, nblb, "wall-corrected" if wall else "free-space"),
             "value": 1.0 / sec_per_step,
             "unit": "steps/s",
             "n_gpus": world,
