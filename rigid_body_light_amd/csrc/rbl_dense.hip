@@ -13,6 +13,8 @@
 // are skipped; diagonal tiles are updated whole).
 #include "rbl_internal.hpp"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int IB = 32;    // inner step width
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void k_trsm_tall(double *__restrict__ A, long 
 //   C[i][j] -= sum_{k in [k0,k0+K)} A[i][k] A[j][k]     i in [r0,n), j in [r0,c1), i-tile >= j-tile
 // Workgroup = 4 waves (2x2) on a 128x128 tile; wave = 64x64 = 4x4 MFMA tiles of 16x16x4.
 // The two 128 x KC panel slabs (i rows, j rows) are staged global -> registers -> LDS, double
-// buffered: the loads of stage s+1 are in flight while the 64 MFMAs of stage s run; one
+// buffered in LDS and in registers (prefetch distance two stages, see the loader); one
 // barrier per stage.  LDS column stride 144 doubles (= 32 banks mod 64) keeps the 16-lane x
 // 4-column fragment reads conflict-free.  The MFMA computes the TRANSPOSED tile (A-operand
 // from the j rows, B-operand from the i rows) so a lane group stores 16 consecutive ROWS of one
@@ -379,17 +381,37 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   const bool active = (i0 < n) && (j0 < c1) && !(i0 + 63 < j0);  // wave tile holds lower-triangle entries
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  // loader: thread -> row (t & 127), column group (t >> 7) * 8 .. +7 of the KC-wide slab
+  // loader: thread -> row (t & 127), column group (t >> 7) * 8 .. +7 of the KC-wide slab.
+  // Prefetch distance TWO stages through two register sets: the loads of stage s+3 are issued in stage s and
+  // land in LDS in stage s+2 -- under load the memory latency exceeds one stage (64 MFMAs = 1.7 us), and a
+  // one-stage prefetch left every wave stalled ~40 % of the time in front of its ds_writes.
   const int lrow = t & 127, lcg = (t >> 7) * 8;
   long gi = bi0 + lrow; if (gi >= n) gi = n - 1;
   long gj = bj0 + lrow; if (gj >= n) gj = n - 1;
-  const double *pI = A + (size_t)(k0 + lcg) * (size_t)ld + gi;
-  const double *pJ = A + (size_t)(k0 + lcg) * (size_t)ld + gj;
-  double rI[8], rJ[8];
+  // the K panel columns through one buffer descriptor: scalar offset = column, one per-lane offset per slab
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)k0 * (size_t)ld, (short)0, (int)((size_t)K * (size_t)ld * 8), 0x00020000);
+  const unsigned ldb = (unsigned)ld * 8u;
+  const unsigned vI = (unsigned)lcg * ldb + 8u * (unsigned)gi, vJ = (unsigned)lcg * ldb + 8u * (unsigned)gj;
+  double rI[2][8], rJ[2][8];
+  const int nst = K / KC;
+  auto gload = [&](auto set, int stg) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * ld]; rJ[q] = pJ[(size_t)q * ld]; }
+    for (int q = 0; q < 8; ++q) {
+      const unsigned so = (unsigned)(stg * KC + q) * ldb;
+      rI[set()][q] = buf_ld(rs, vI, so); rJ[set()][q] = buf_ld(rs, vJ, so);
+    }
+  };
+  auto lwrite = [&](auto set, int buf) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { sI[0][(lcg + q) * LDP + lrow] = rI[q]; sJ[0][(lcg + q) * LDP + lrow] = rJ[q]; }
+    for (int q = 0; q < 8; ++q) { sI[buf][(lcg + q) * LDP + lrow] = rI[set()][q]; sJ[buf][(lcg + q) * LDP + lrow] = rJ[set()][q]; }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  gload(S0{}, 0);
+  lwrite(S0{}, 0);
+  if (nst > 1) gload(S1{}, 1);
+  if (nst > 2) gload(S0{}, 2);
   __syncthreads();
 
   double4_t acc[4][4];  // [tj][ti]
@@ -398,34 +420,33 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const int nst = K / KC;
-  for (int s = 0; s < nst; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nst) {
-      pI += (size_t)KC * ld; pJ += (size_t)KC * ld;
+  auto compute = [&](int cur) {
+    if (!active) return;
+    const double *fi = &sI[cur][l4 * LDP + wi * 64 + l15];
+    const double *fj = &sJ[cur][l4 * LDP + wj * 64 + l15];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { rI[q] = pI[(size_t)q * ld]; rJ[q] = pJ[(size_t)q * ld]; }
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { av[q] = fj[ks * 4 * LDP + 16 * q]; bv[q] = fi[ks * 4 * LDP + 16 * q]; }
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
     }
-    if (active) {
-      const double *fi = &sI[cur][l4 * LDP + wi * 64 + l15];
-      const double *fj = &sJ[cur][l4 * LDP + wj * 64 + l15];
-#pragma unroll
-      for (int ks = 0; ks < KC / 4; ++ks) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = fj[ks * 4 * LDP + 16 * q]; bv[q] = fi[ks * 4 * LDP + 16 * q]; }
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-          for (int ti = 0; ti < 4; ++ti)
-            acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
-      }
-    }
-    if (s + 1 < nst) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { sI[cur ^ 1][(lcg + q) * LDP + lrow] = rI[q]; sJ[cur ^ 1][(lcg + q) * LDP + lrow] = rJ[q]; }
-    }
+  };
+  // stage s (data in LDS buffer s & 1): stage s+1 sits in register set (s+1) & 1 -> LDS buffer (s+1) & 1 (free
+  // since the barrier that ended stage s-1), then that set is refilled with stage s+3
+  auto stage = [&](int s_, auto nset) {
+    if (s_ + 1 < nst) lwrite(nset, (s_ + 1) & 1);
+    if (s_ + 3 < nst) gload(nset, s_ + 3);
+    compute(s_ & 1);
     __syncthreads();
+  };
+  for (int s2 = 0; s2 < nst; s2 += 2) {
+    stage(s2, S1{});
+    if (s2 + 1 < nst) stage(s2 + 1, S0{});
   }
   if (!active) return;
   // epilogue C -= acc: per pair of 16-column strips, ALL 32 loads of a lane are issued before the first use (one
