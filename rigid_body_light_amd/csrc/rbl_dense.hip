@@ -654,7 +654,9 @@ namespace {
 //   backward:  x_k = Linv_kk^T y_k ;        y[before] -= L[k-block, before]^T x_k
 constexpr int SOLVE_MAXN = 8192;   // 64 KB of LDS
 
-__global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ L, long n, long strideA,
+constexpr int BS_T = 1024;   // threads per matrix: the sweeps are latency-bound, more rows in flight per step
+
+__global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
                                                      const double *__restrict__ in, double *__restrict__ out,
                                                      long vec_stride)
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
   const double *Lb = L + (size_t)b * (size_t)strideA;
   const double *Lib = Linv + (size_t)b * (size_t)strideL;
   const double *v = in + (size_t)b * (size_t)vec_stride;
-  for (long e = t; e < n; e += 256) y[e] = v[e];
+  for (long e = t; e < n; e += BS_T) y[e] = v[e];
   __syncthreads();
   const int nsteps = (int)((n + IB - 1) / IB);
   for (int s = 0; s < nsteps; ++s) {                 // ---- forward: L y' = v
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
     __syncthreads();
     if (t < nb) y[k + t] = tbuf[t];
     if (nb == IB) {   // full block: 32 independent strided loads per row are issued back to back
-      for (long r = k + IB + t; r < n; r += 256) {
+      for (long r = k + IB + t; r < n; r += BS_T) {
         const double *col = Lb + (size_t)k * (size_t)n + r;
         double lv[IB];
 #pragma unroll
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
         y[r] = a0 + a1;
       }
     } else {
-      for (long r = k + nb + t; r < n; r += 256) {
+      for (long r = k + nb + t; r < n; r += BS_T) {
         double acc = y[r];
         const double *col = Lb + (size_t)k * (size_t)n + r;
         for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[m], acc);
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
     __syncthreads();
     if (t < nb) y[k + t] = tbuf[t];
     if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r  (256 B contiguous per lane)
-      for (long c = t; c < k; c += 256) {
+      for (long c = t; c < k; c += BS_T) {
         const double *row = Lb + (size_t)c * (size_t)n + k;
         double lv[IB];
 #pragma unroll
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
         y[c] = a0 + a1;
       }
     } else {
-      for (long c = t; c < k; c += 256) {
+      for (long c = t; c < k; c += BS_T) {
         double acc = y[c];
         const double *row = Lb + (size_t)c * (size_t)n + k;
         for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[m], acc);
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256) void k_block_solve(const double *__restrict__ 
     __syncthreads();
   }
   double *o = out + (size_t)b * (size_t)vec_stride;
-  for (long e = t; e < n; e += 256) o[e] = y[e];
+  for (long e = t; e < n; e += BS_T) o[e] = y[e];
 }
 }  // namespace
 
@@ -750,7 +752,7 @@ int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int bat
 {
   if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
-  hipLaunchKernelGGL(k_block_solve, dim3(batch), dim3(256), sizeof(double) * (size_t)(n + IB), st, d_L, (long)n,
+  hipLaunchKernelGGL(k_block_solve, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)(n + IB), st, d_L, (long)n,
                      (long)strideA, d_Linv, (long)(nsteps * IB * IB), d_in, d_out, (long)vec_stride);
   return RBL_OK;
 }
