@@ -221,7 +221,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_bd, &c->d_bd2};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -999,14 +999,17 @@ static int pc_block_build(rbl_ctx *c)
   if ((rc = rbl_dev_reserve(c, c->d_blkLinv, rbl_cholesky_batched_work_bytes(m, S.N_bod)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
   const RblParams P = rbl_make_params(S.a, S.eta);
   rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p, S.N_blb, S.N_bod, (double *)c->d_blkL.p,
                              msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, (double *)c->d_blkL.p, m, S.N_bod, msz, c->d_err, (double *)c->d_blkLinv.p);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
-  // Ninv_b = K_b^T invM_b K_b, column by column (bodies do not couple), then its 6x6 Cholesky
-  double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *cols = w2 + n3, *Uunit = cols + 36 * (size_t)S.N_bod;
+  // Ninv_b = K_b^T invM_b K_b, column by column (bodies do not couple), then its 6x6 Cholesky; the six
+  // solved columns invM_b K_b are kept (d_pcMK): every application needs invM K U
+  double *w1 = (double *)c->d_pcw.p, *cols = w1 + 2 * n3, *Uunit = cols + 36 * (size_t)S.N_bod;
   for (int cc = 0; cc < 6; ++cc) {
+    double *w2 = (double *)c->d_pcMK.p + (size_t)cc * n3;
     rbl_launch_unit_U(c->stream, S.N_bod, cc, Uunit);
     rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Uunit, S.N_blb, N, w1, nullptr, 0.0);
     if ((rc = rbl_launch_block_solve(c->stream, (const double *)c->d_blkL.p, m, S.N_bod, msz, (const double *)c->d_blkLinv.p,
@@ -1028,8 +1031,9 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   if ((rc = rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, d_in, w1, m))) return rc;      // invM slip
   rbl_launch_KT_x_Lam(c->stream, lev, w1, S.N_blb, S.N_bod, f6);                                     // K^T (invM slip)
   rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p, d_in + n3, f6, S.N_bod, d_out + n3); // U  (:601-608)
-  rbl_launch_K_x_U(c->stream, lev, d_out + n3, S.N_blb, N, w2, d_in, 1.0);                           // slip + K U
-  return rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, w2, d_out, m);                    // Lambda (:610)
+  // Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over the factors
+  rbl_launch_pc_block_lambda(c->stream, w1, (const double *)c->d_pcMK.p, d_out + n3, S.N_blb, n3, d_out);
+  return RBL_OK;
 }
 
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)

@@ -259,6 +259,21 @@ __global__ void k_pc_block_mid(const double *__restrict__ NL, const double *__re
   for (int p = 0; p < 6; ++p) U[6 * b + p] = u[p];
 }
 
+// Lambda = invM (slip + K U) = invM slip + (invM K) U  (:610): the first term is the vector the
+// preconditioner already solved for, invM K (six columns per body) is kept from the build -- no second
+// pass over the Cholesky factors.  MK: [6][n3], column c of every body stacked.
+__global__ void k_pc_block_lambda(const double *__restrict__ y1, const double *__restrict__ MK,
+                                  const double *__restrict__ U, int N_blb, long n3, double *__restrict__ out)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  const long b = (i / 3) / N_blb;
+  double acc = y1[i];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * n3 + i], U[6 * b + c], acc);
+  out[i] = acc;
+}
+
 __global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +293,14 @@ void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d
 {
   if (N_bod <= 0) return;
   hipLaunchKernelGGL(k_pc_block_mid, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_NL, d_F, d_f, N_bod, d_U);
+}
+
+void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
+                                int64_t n3, double *d_out)
+{
+  if (n3 <= 0) return;
+  hipLaunchKernelGGL(k_pc_block_lambda, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, d_y1, d_MK, d_U, N_blb,
+                     (long)n3, d_out);
 }
 
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)

@@ -68,7 +68,7 @@ struct rbl_ctx {
   hipStream_t stream = nullptr;
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
-  RblDevBuf d_blkL, d_blkLinv, d_pcw;               // block-diagonal PC: per-body Cholesky factors + work
+  RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
   unsigned *d_err = nullptr;
@@ -169,6 +169,8 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
                               int N_blb, int N_bod, const double *d_in, double *d_out);
 void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err);
+void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
+                                int64_t n3, double *d_out);
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
                              double *d_U);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
