@@ -1,0 +1,43 @@
+"""Multi-rank rehearsal of the sharded paths on ONE GPU: two processes (gloo process group, both on cuda:0)
+run the same code the 8-GPU job runs over RCCL -- tile-pair-sharded apply_M with its all-gather / all-reduce,
+and the sharded stochastic midpoint step -- and compare with the oracle / the single-process result."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(nproc, script_args, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_rank_sharded_apply_M_matches_oracle():
+    """bench.py's N = 2 path (cfg 2 size): each rank checks its partial-sum result against the CPU oracle"""
+    p = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3", "--warmup", "1",
+                      "--check", "--cpu-budget", "0", "--timestep-steps", "1"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["check_rel_err_vs_oracle"] < 1e-11
+    assert d["timestep"]["apply_M_per_timestep"] == 21
+
+
+def test_two_rank_sharded_brownian_step_matches_single_process():
+    p = _torchrun(2, ["tools/check_sharded_brownian.py"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "world 2" in p.stdout
