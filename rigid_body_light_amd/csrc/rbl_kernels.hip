@@ -180,6 +180,10 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   const long Npad = (long)T * TS;
   unsigned flags = 0;
 
+  // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
+  // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
+  RblParams Pu = P;
+  Pu.a = 1.0; Pu.inv_a = 1.0; Pu.four_a2 = 4.0; Pu.tiny2 = 1e-24; Pu.c_near_A = -0.375; Pu.c_near_B = 0.125;
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
         if (z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
         d = damp_of(P, z);
       }
+      x *= P.inv_a; y *= P.inv_a; z *= P.inv_a;
       fx = d * F[3 * idx]; fy = d * F[3 * idx + 1]; fz = d * F[3 * idx + 2];
     } else {  // padding blob: zero force, far from everything (and from every other pad)
       x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0; fx = 0.0; fy = 0.0; fz = 0.0;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
         double vx = 0.0, vy = 0.0, vz = 0.0;
 #pragma unroll
         for (int a = 0; a < NI; ++a)
-          rbl_pair_sym<WALL>(P, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
+          rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
                              pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
         __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
 #pragma unroll 4
           for (int jj = 0; jj < TS; ++jj) {
             const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
-            rbl_pair_accum<WALL, true>(P, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane,
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane,
                                        uix[a], uiy[a], uiz[a], flags);
           }
         } else if (J > It0 + a) {
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
             const int jj = (lane + s) & (TS - 1);
             const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
             double vx = 0.0, vy = 0.0, vz = 0.0;
-            rbl_pair_sym<WALL>(P, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
+            rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
                                pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
             __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

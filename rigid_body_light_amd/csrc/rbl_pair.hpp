@@ -60,6 +60,9 @@ __device__ __forceinline__ double rbl_rsqrt(double x)
 //   T0 = 2g - ez,  T1 = ez { 6gk + u[(2 - 10v) + u(70/3 v - 10)] }
 // Swapping the roles of i and j swaps g <-> k, i.e. T1 -> -T1 only: M_ji = M_ij^T exactly.
 // ---------------------------------------------------------------------------
+// UNIT: the caller works in coordinates already divided by the blob radius (a = 1), which removes the
+// a/R and a/r multiplications from every pair.
+template <bool UNIT = false>
 __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, double zi, double zj, double q,
                                                 double A, double Bc, double &cF, double &beta, double &gxz,
                                                 double &gzx, double &mzz)
@@ -67,7 +70,7 @@ __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, d
   const double Rz = zi + zj;
   const double R2 = __builtin_fma(Rz, Rz, q);
   const double invR = rbl_rsqrt(R2);
-  const double w = P.a * invR;
+  const double w = UNIT ? invR : P.a * invR;
   const double ez = Rz * invR;
   const double u = w * w;
   const double v = ez * ez;
@@ -102,7 +105,7 @@ __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, d
 //   SELF: compile-time "this j-tile may contain i" (index-equality self term)
 // Accumulates UNSCALED (units 1/(8 pi eta a)) into ux,uy,uz.
 // ---------------------------------------------------------------------------
-template <bool WALL, bool SELF>
+template <bool WALL, bool SELF, bool UNIT = false>
 __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, double yi,
                                                double zi, double xj, double yj, double zj,
                                                double Fx, double Fy, double Fz, bool is_self,
@@ -116,7 +119,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
   // ---- free-space RPY (c_rigid_obj.cpp:48-79) in physical units ----------
   const double invr = rbl_rsqrt(r2);
   const double invr2 = invr * invr;
-  const double s = P.a * invr;                       // a/r
+  const double s = UNIT ? invr : P.a * invr;         // a/r
   const double t = s * s;                            // (a/r)^2
   // far:  A = (a/r)(1 + 2/3 (a/r)^2),  Bc = (a/r)(1 - 2 (a/r)^2)/r^2
   double A = __builtin_fma(s * t, 2.0 / 3.0, s);
@@ -146,7 +149,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
   // ---- single-wall correction (c_rigid_obj.cpp:98-140), ordered pair, h = z_j
   if (SELF && is_self) {
     // self wall term (:98-104): diag only, args (0,0,2h; h = z_i/a)
-    const double iz = P.a / zi;                      // 1/h  (true division kept: rare path)
+    const double iz = (UNIT ? 1.0 : P.a) / zi;       // 1/h  (true division kept: rare path)
     const double iz3 = iz * iz * iz;
     const double iz5 = iz3 * iz * iz;
     const double dpar = -(9.0 * iz - 2.0 * iz3 + iz5) / 12.0;
@@ -157,7 +160,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
   const double lat = __builtin_fma(beta, q2, gxz * Fz);
   ux = __builtin_fma(cF, Fx, __builtin_fma(lat, dx, ux));
   uy = __builtin_fma(cF, Fy, __builtin_fma(lat, dy, uy));
@@ -174,7 +177,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
 // and the h-free part of fact5 are shared.  ~78 fp64 instructions per unordered wall pair
 // (measured in the ISA of k_apply_M_sym<true,2>) vs 2 x ~68 for two ordered evaluations.
 // ---------------------------------------------------------------------------
-template <bool WALL>
+template <bool WALL, bool UNIT = false>
 __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, double yi, double zi,
                                              double Fix, double Fiy, double Fiz, double xj,
                                              double yj, double zj, double Fjx, double Fjy,
@@ -187,7 +190,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   const double r2 = __builtin_fma(dz, dz, q);
   const double invr = rbl_rsqrt(r2);
   const double invr2 = invr * invr;
-  const double s = P.a * invr;
+  const double s = UNIT ? invr : P.a * invr;
   const double s3 = (s * s) * s;
   double A = __builtin_fma(s3, 2.0 / 3.0, s);              // (a/r)(1 + 2/3 (a/r)^2)
   double Bc = __builtin_fma(s3, -2.0, s) * invr2;          // (a/r)(1 - 2 (a/r)^2) / r^2
@@ -217,7 +220,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   // Wall: coefficients for ONE direction (h = z_j); M_ji = M_ij^T exactly, so U_j += M_ij^T F_i reuses
   // them.  Vector form: 20 FMAs for both directions instead of forming nine entries.
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
   // U_i += M F_j
   const double pj = __builtin_fma(dy, Fjy, dx * Fjx);
   const double lj = __builtin_fma(beta, pj, gxz * Fjz);
