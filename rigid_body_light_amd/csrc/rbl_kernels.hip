@@ -29,6 +29,15 @@ struct __attribute__((aligned(16))) JBlob {
   double x, y, z, fx, fy, fz;  // 48 B: three 16-B LDS broadcasts per j
 };
 
+// parameter set of the radius-scaled coordinates (x/a): the mobility entries depend on r/a only, so the
+// matvec kernels scale positions once when they load them and run the pair arithmetic with a = 1
+__device__ __forceinline__ RblParams unit_params(const RblParams &P)
+{
+  RblParams Pu = P;
+  Pu.a = 1.0; Pu.inv_a = 1.0; Pu.four_a2 = 4.0; Pu.tiny2 = 1e-24; Pu.c_near_A = -0.375; Pu.c_near_B = 0.125;
+  return Pu;
+}
+
 __device__ __forceinline__ double damp_of(const RblParams &P, double z)
 {
   return (z >= P.a) ? 1.0 : z / P.a;  // c_rigid_obj.cpp:629-633
@@ -48,8 +57,8 @@ __device__ __forceinline__ void sweep_tile(const RblParams &P, const JBlob *sj, 
 #pragma unroll 4
   for (int jj = 0; jj < TB; ++jj) {
     const JBlob b = sj[jj];
-    rbl_pair_accum<WALL, SELF>(P, xi, yi, zi, b.x, b.y, b.z, b.fx, b.fy, b.fz,
-                               SELF && (jj == self_jj), ux, uy, uz, flags);
+    rbl_pair_accum<WALL, SELF, true>(P, xi, yi, zi, b.x, b.y, b.z, b.fx, b.fy, b.fz,
+                                     SELF && (jj == self_jj), ux, uy, uz, flags);
   }
 }
 
@@ -67,7 +76,9 @@ __global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
   const long i = i_tile0 + t;
   const bool valid = i < row_end;
   const long ic = valid ? i : row_end - 1;
-  const double xi = r[3 * ic], yi = r[3 * ic + 1], zi = r[3 * ic + 2];
+  const double zi_phys = r[3 * ic + 2];
+  const double xi = r[3 * ic] * P.inv_a, yi = r[3 * ic + 1] * P.inv_a, zi = zi_phys * P.inv_a;   // radius-scaled
+  const RblParams Pu = unit_params(P);
   unsigned flags = 0;
   if (WALL && zi < 0.0) flags |= RBL_FLAG_BELOW_WALL;
 
@@ -86,6 +97,7 @@ __global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
         if (b.z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
         d = damp_of(P, b.z);
       }
+      b.x *= P.inv_a; b.y *= P.inv_a; b.z *= P.inv_a;
       b.fx = d * F[3 * j]; b.fy = d * F[3 * j + 1]; b.fz = d * F[3 * j + 2];
     } else {  // padding: zero force, far away, above the wall
       b.x = 1.0e15; b.y = 1.0e15; b.z = 1.0; b.fx = 0.0; b.fy = 0.0; b.fz = 0.0;
@@ -98,16 +110,16 @@ __global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
     if (diag) {
       const long sjj = i - j0;  // index of i itself inside the tile (may be out of range)
       const int self_jj = (valid && sjj >= 0 && sjj < TB) ? (int)sjj : -1;
-      sweep_tile<WALL, true>(P, sj, xi, yi, zi, self_jj, ux, uy, uz, flags);
+      sweep_tile<WALL, true>(Pu, sj, xi, yi, zi, self_jj, ux, uy, uz, flags);
     } else {
-      sweep_tile<WALL, false>(P, sj, xi, yi, zi, -1, ux, uy, uz, flags);
+      sweep_tile<WALL, false>(Pu, sj, xi, yi, zi, -1, ux, uy, uz, flags);
     }
   }
 
   if (valid) {
     const long o = 3 * (i - row_begin);
     if (jsplit == 1) {
-      const double sc = WALL ? P.nf * damp_of(P, zi) : P.nf;
+      const double sc = WALL ? P.nf * damp_of(P, zi_phys) : P.nf;
       out[o] = sc * ux; out[o + 1] = sc * uy; out[o + 2] = sc * uz;
       if (!(isfinite(ux) && isfinite(uy) && isfinite(uz))) flags |= RBL_FLAG_NONFINITE;
     } else {
@@ -182,8 +194,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
 
   // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
   // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
-  RblParams Pu = P;
-  Pu.a = 1.0; Pu.inv_a = 1.0; Pu.four_a2 = 4.0; Pu.tiny2 = 1e-24; Pu.c_near_A = -0.375; Pu.c_near_B = 0.125;
+  const RblParams Pu = unit_params(P);
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -351,7 +362,7 @@ __device__ __forceinline__ void mrhs_tile(const RblParams &P, const double *sx, 
     const double f0 = fp[0], f1 = fp[MR], f2 = fp[2 * MR];
     fp += (size_t)4 * 3 * MR;
     double m[9];
-    rbl_pair_block_fast<WALL, SELF>(P, xi, yi, zi, sx[jj], sy[jj], sz[jj], SELF && (j0 + jj == i), m, flags);
+    rbl_pair_block_fast<WALL, SELF, true>(P, xi, yi, zi, sx[jj], sy[jj], sz[jj], SELF && (j0 + jj == i), m, flags);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], f0, dx_, 0, 0, 0);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], f1, dx_, 0, 0, 0);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], f2, dx_, 0, 0, 0);
@@ -376,7 +387,8 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
   const long i_blk0 = (long)blockIdx.x * 64;
   const long i = i_blk0 + wave * 16 + l15;
   const long ic = i < N ? i : N - 1;
-  const double xi = r[3 * ic], yi = r[3 * ic + 1], zi = r[3 * ic + 2];
+  const double xi = r[3 * ic] * P.inv_a, yi = r[3 * ic + 1] * P.inv_a, zi = r[3 * ic + 2] * P.inv_a;   // radius-scaled
+  const RblParams Pu = unit_params(P);
   unsigned flags = 0;
   const long j_begin = (long)blockIdx.y * jchunk;
   const long j_end = (j_begin + jchunk < Npad) ? j_begin + jchunk : Npad;
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
     const long j = j0 + t;
     double x, y, z;
     if (j < N) {
-      x = r[3 * j]; y = r[3 * j + 1]; z = r[3 * j + 2];
+      x = r[3 * j] * P.inv_a; y = r[3 * j + 1] * P.inv_a; z = r[3 * j + 2] * P.inv_a;
       if (WALL && z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
     } else {  // padding (its packed forces are zero)
       x = 1.0e15 * (double)(2 + (j - N)); y = 0.0; z = 1.0;
@@ -395,9 +407,9 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
     __syncthreads();
     const bool diag = (j0 < i_blk0 + 64) && (j0 + MTJ > i_blk0);  // block-uniform
     if (diag)
-      mrhs_tile<WALL, true>(P, sx, sy, sz, Fp, j0, i < N ? i : -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+      mrhs_tile<WALL, true>(Pu, sx, sy, sz, Fp, j0, i < N ? i : -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
     else
-      mrhs_tile<WALL, false>(P, sx, sy, sz, Fp, j0, -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+      mrhs_tile<WALL, false>(Pu, sx, sy, sz, Fp, j0, -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
   }
   // D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4 v, col = lane & 15
   double *up = Up + (size_t)blockIdx.y * (size_t)Npad * 3 * MR;

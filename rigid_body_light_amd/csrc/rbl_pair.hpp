@@ -241,7 +241,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
 // block is the A-operand of fp64 MFMAs:  M = cF I + Bc d d^T + f2 e e^T + f3 e z^T
 // + f4 z e^T + f5 z z^T.
 // ---------------------------------------------------------------------------
-template <bool WALL, bool SELF>
+template <bool WALL, bool SELF, bool UNIT = false>
 __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double xi, double yi,
                                                     double zi, double xj, double yj, double zj,
                                                     bool is_self, double *m, unsigned &flags)
@@ -251,7 +251,7 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
   const double r2 = __builtin_fma(dz, dz, q);
   const double invr = rbl_rsqrt(r2);
   const double invr2 = invr * invr;
-  const double s = P.a * invr;
+  const double s = UNIT ? invr : P.a * invr;
   const double t = s * s;
   double A = __builtin_fma(s * t, 2.0 / 3.0, s);
   double Bc = (s * invr2) * __builtin_fma(-2.0, t, 1.0);
@@ -274,7 +274,7 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     return;
   }
   if (SELF && is_self) {  // self wall term (:98-104): diagonal only
-    const double iz = P.a / zi;
+    const double iz = (UNIT ? 1.0 : P.a) / zi;
     const double iz3 = iz * iz * iz;
     const double iz5 = iz3 * iz * iz;
     const double dpar = -(9.0 * iz - 2.0 * iz3 + iz5) / 12.0;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
   const double bx = beta * dx, by = beta * dy;
   m[0] = __builtin_fma(bx, dx, cF); m[1] = bx * dy; m[2] = dx * gxz;
   m[3] = m[1]; m[4] = __builtin_fma(by, dy, cF); m[5] = dy * gxz;
