@@ -195,6 +195,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
   // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
   const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
 #pragma unroll
         for (int a = 0; a < NI; ++a)
           rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
-                             pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
+                             pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags, WK);
         __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
             const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
             double vx = 0.0, vy = 0.0, vz = 0.0;
             rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
-                               pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags);
+                               pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags, WK);
             __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

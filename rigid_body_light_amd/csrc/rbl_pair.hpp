@@ -62,10 +62,25 @@ __device__ __forceinline__ double rbl_rsqrt(double x)
 // ---------------------------------------------------------------------------
 // UNIT: the caller works in coordinates already divided by the blob radius (a = 1), which removes the
 // a/R and a/r multiplications from every pair.
+// Three of the polynomial coefficients come in pairs of non-inline constants (fma(v, -10/3, 2/3), ...).
+// A gfx9 VOP3 instruction reads at most one SGPR/constant, so the compiler re-materialises the second one
+// into a VGPR with a v_mov_b64 on EVERY evaluation.  A caller with registers to spare passes them in as
+// opaque VGPR-resident values (RblWallK from rbl_wall_k_resident()) and saves those two issue slots per pair.
+struct RblWallK {
+  double k1, k2, k3;   // -10/3, 70/3, 20
+};
+__device__ __forceinline__ RblWallK rbl_wall_k_literal() { return RblWallK{-10.0 / 3.0, 70.0 / 3.0, 20.0}; }
+__device__ __forceinline__ RblWallK rbl_wall_k_resident()
+{
+  RblWallK K = rbl_wall_k_literal();
+  asm volatile("" : "+v"(K.k1), "+v"(K.k2), "+v"(K.k3));   // opaque to the optimiser: stays in VGPRs
+  return K;
+}
+
 template <bool UNIT = false>
 __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, double zi, double zj, double q,
                                                 double A, double Bc, double &cF, double &beta, double &gxz,
-                                                double &gzx, double &mzz)
+                                                double &gzx, double &mzz, const RblWallK &K = rbl_wall_k_literal())
 {
   const double Rz = zi + zj;
   const double R2 = __builtin_fma(Rz, Rz, q);
@@ -76,14 +91,14 @@ __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, d
   const double v = ez * ez;
   const double g = zj * invR;
   const double gk = g * (zi * invR);
-  const double t1 = __builtin_fma(u, __builtin_fma(v, -10.0 / 3.0, 2.0 / 3.0), __builtin_fma(v, 2.0, -2.0 / 3.0));
+  const double t1 = __builtin_fma(u, __builtin_fma(v, K.k1, 2.0 / 3.0), __builtin_fma(v, 2.0, -2.0 / 3.0));
   const double b1 = __builtin_fma(u, t1, __builtin_fma(-2.0, gk, -1.0));
-  const double t2 = __builtin_fma(u, __builtin_fma(v, 70.0 / 3.0, -10.0 / 3.0), __builtin_fma(v, -10.0, 2.0));
+  const double t2 = __builtin_fma(u, __builtin_fma(v, K.k2, -10.0 / 3.0), __builtin_fma(v, -10.0, 2.0));
   const double a2 = __builtin_fma(6.0, gk, -1.0);
   const double b2 = __builtin_fma(u, t2, a2);
   const double T0 = __builtin_fma(2.0, g, -ez);
   const double T1 = ez * __builtin_fma(u, __builtin_fma(u, -20.0 / 3.0, t2), a2 + 1.0);
-  const double d1 = __builtin_fma(u, __builtin_fma(v, 20.0, -8.0 / 3.0), -4.0 * v);
+  const double d1 = __builtin_fma(u, __builtin_fma(v, K.k3, -8.0 / 3.0), -4.0 * v);
   const double wi = w * invR;
   cF = __builtin_fma(w, b1, A);
   beta = __builtin_fma(b2, wi * invR, Bc);                         // lateral dyad: (Bc + fact2/R^2) dl dl^T
@@ -183,7 +198,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
                                              double yj, double zj, double Fjx, double Fjy,
                                              double Fjz, double &uix, double &uiy, double &uiz,
                                              double &ujx, double &ujy, double &ujz,
-                                             unsigned &flags)
+                                             unsigned &flags, const RblWallK &K = rbl_wall_k_literal())
 {
   const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
   const double q = __builtin_fma(dy, dy, dx * dx);
@@ -220,7 +235,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   // Wall: coefficients for ONE direction (h = z_j); M_ji = M_ij^T exactly, so U_j += M_ij^T F_i reuses
   // them.  Vector form: 20 FMAs for both directions instead of forming nine entries.
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
   // U_i += M F_j
   const double pj = __builtin_fma(dy, Fjy, dx * Fjx);
   const double lj = __builtin_fma(beta, pj, gxz * Fjz);
