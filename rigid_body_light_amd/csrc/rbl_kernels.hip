@@ -19,6 +19,7 @@
 #include "rbl_internal.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 namespace {
@@ -163,6 +164,55 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__
 // (i_first, i_step) selects the I-tiles of this launch (multi-GPU: I % world == rank).
 // ---------------------------------------------------------------------------
 constexpr int TS = 64;
+
+// Bounding box of every 64-blob tile in radius-scaled coordinates: bbox[tile] = {min x,y,z, max x,y,z}.
+// Lets the symmetric kernel prove "no pair of this tile pair is closer than 2a" and run the sweep without
+// the per-pair overlap test (blobs of different bodies are never that close).
+__global__ __launch_bounds__(TS) void k_tile_bbox(const double *__restrict__ r, long N, double inv_a,
+                                                  double *__restrict__ bbox)
+{
+  const long idx = (long)blockIdx.x * TS + threadIdx.x;
+  double lo[3], hi[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double v = (idx < N) ? r[3 * idx + d] * inv_a : 0.0;
+    lo[d] = (idx < N) ? v : 1.0e300;
+    hi[d] = (idx < N) ? v : -1.0e300;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fmin(lo[d], __shfl_xor(lo[d], m, TS));
+      hi[d] = fmax(hi[d], __shfl_xor(hi[d], m, TS));
+    }
+  if (threadIdx.x == 0) {
+    double *b = bbox + 6 * (size_t)blockIdx.x;
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+  }
+}
+
+// farmap[S][J] = 1 when every blob of tile J is farther than 2a from every blob of row super-tile S
+// (NI consecutive tiles): one byte per (super-tile, tile), read as a wave-uniform value by the matvec kernel.
+__global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbox, int T, int NI,
+                                                  unsigned char *__restrict__ farmap)
+{
+  const int J = blockIdx.x * 256 + threadIdx.x, S = blockIdx.y;
+  if (J >= T) return;
+  double gap2 = 1.0e300;
+  for (int a = 0; a < NI; ++a) {
+    const int I = NI * S + a;
+    if (I >= T) break;
+    const double *bi = bbox + 6 * (size_t)I, *bj = bbox + 6 * (size_t)J;
+    double g2 = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      const double g = fmax(fmax(bj[d] - bi[3 + d], bi[d] - bj[3 + d]), 0.0);
+      g2 = __builtin_fma(g, g, g2);
+    }
+    gap2 = fmin(gap2, g2);
+  }
+  farmap[(size_t)S * T + J] = gap2 > 4.0001 ? 1 : 0;
+}
 #ifndef RBL_SYM_UNROLL
 #define RBL_SYM_UNROLL 2
 #endif
@@ -174,7 +224,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
                                                     double *__restrict__ slabI,
                                                     double *__restrict__ slabJ, long N, int T,
                                                     int C, int i_first, int i_step, RblParams P,
-                                                    unsigned *err)
+                                                    unsigned *err, const unsigned char *__restrict__ farmap)
 {
   // A lane owns NI rows (row "super-tile" I = tiles NI*I .. NI*I+NI-1): the j data read from
   // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.
@@ -222,6 +272,8 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     const long j = (long)J * TS + lane;
     double xj, yj, zj, Fjx, Fjy, Fjz;
     load_blob(j, xj, yj, zj, Fjx, Fjy, Fjz);
+    // wave-uniform: every blob of tile J is farther than 2a from every owned row (k_tile_far)
+    const bool far_tile = farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
     __syncthreads();
     sP0[lane] = (double2_t){xj, yj};
     sP1[lane] = (double2_t){zj, Fjx};
@@ -229,19 +281,24 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     sU[0][lane] = 0.0; sU[1][lane] = 0.0; sU[2][lane] = 0.0;
     __syncthreads();
     if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
+      auto sweep = [&](auto nearchk) {
 #pragma unroll RBL_SYM_UNROLL
-      for (int s = 0; s < TS; ++s) {
-        const int jj = (lane + s) & (TS - 1);
-        const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
-        double vx = 0.0, vy = 0.0, vz = 0.0;
+        for (int s = 0; s < TS; ++s) {
+          const int jj = (lane + s) & (TS - 1);
+          const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
+          double vx = 0.0, vy = 0.0, vz = 0.0;
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
-          rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
-                             pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags, WK);
-        __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+          for (int a = 0; a < NI; ++a)
+            rbl_pair_sym<WALL, true, decltype(nearchk)::value>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x,
+                                                               pa.y, pb.x, pb.y, pd.x, pd.y, uix[a], uiy[a], uiz[a],
+                                                               vx, vy, vz, flags, WK);
+          __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+      if (far_tile) sweep(std::false_type{});   // no pair can overlap: sweep without the per-pair test
+      else sweep(std::true_type{});
     } else {              // J is one of the owned row tiles: per sub-tile diagonal / symmetric / skip
 #pragma unroll
       for (int a = 0; a < NI; ++a) {
@@ -868,7 +925,8 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step)
 {
   int T, NI, C, nch, rowsI;
   sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI);
-  return ((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * sizeof(double);
+  // slabs + tile bounding boxes + far map (one byte per (row super-tile, tile))
+  return (((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 + (size_t)T * 6) * sizeof(double) + (size_t)((T + NI - 1) / NI) * (size_t)T + 64;
 }
 
 template <bool WALL, int NI>
@@ -879,8 +937,17 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
   dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
   const int64_t n = 3 * n_blobs;
   dim3 g2((unsigned)((n + 63) / 64)), b2(64 * RG);
+  unsigned char *farmap = nullptr;
+  if (NI == 2) {   // large systems only: two more tiny launches, then most tile pairs skip the overlap test
+    double *bbox = slabJ + (size_t)rowsI * (size_t)T * TS * 3;
+    farmap = (unsigned char *)(bbox + (size_t)T * 6);
+    const int nsup = (T + NI - 1) / NI;
+    hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)T), dim3(TS), 0, st, d_r, (long)n_blobs, P.inv_a, bbox);
+    hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
+                       (const double *)bbox, T, NI, farmap);
+  }
   hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
-                     i_first, i_step, P, d_err);
+                     i_first, i_step, P, d_err, (const unsigned char *)farmap);
   hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C, nch, NI,
                      i_first, i_step, P, d_err);
 }

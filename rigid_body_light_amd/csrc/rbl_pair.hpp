@@ -192,7 +192,9 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
 // and the h-free part of fact5 are shared.  ~78 fp64 instructions per unordered wall pair
 // (measured in the ISA of k_apply_M_sym<true,2>) vs 2 x ~68 for two ordered evaluations.
 // ---------------------------------------------------------------------------
-template <bool WALL, bool UNIT = false>
+// NEARCHK = false: the caller has proved (tile bounding boxes) that no pair of this sweep is closer than 2a,
+// the overlap branch and its per-pair compare are compiled out.
+template <bool WALL, bool UNIT = false, bool NEARCHK = true>
 __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, double yi, double zi,
                                              double Fix, double Fiy, double Fiz, double xj,
                                              double yj, double zj, double Fjx, double Fjy,
@@ -209,7 +211,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   const double s3 = (s * s) * s;
   double A = __builtin_fma(s3, 2.0 / 3.0, s);              // (a/r)(1 + 2/3 (a/r)^2)
   double Bc = __builtin_fma(s3, -2.0, s) * invr2;          // (a/r)(1 - 2 (a/r)^2) / r^2
-  if (__builtin_expect(__any(r2 < P.four_a2), 0)) {   // wave-uniform: overlap branch is rare
+  if (NEARCHK && __builtin_expect(__any(r2 < P.four_a2), 0)) {   // wave-uniform: overlap branch is rare
     const double rr = r2 * invr;
     const double A_near = __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
     const double B_near = invr * P.c_near_B;

@@ -412,6 +412,53 @@ def test_full_size_properties(orc, nb, nblb, wall):
         assert rel(Mxh[3 * b:3 * b + 48], Uo) < 1e-11
 
 
+@pytest.mark.parametrize("wall", [False, True])
+def test_full_size_interpenetrating_bodies_vs_oracle(orc, wall):
+    """cfg 3 size with two shells pushed into each other: overlapping blob pairs (r < 2a) then sit in DIFFERENT
+    tiles and bodies.  The symmetric kernel classifies tile pairs by bounding boxes and skips the per-pair
+    overlap test for far ones -- rows around the contact region must still match the oracle."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb = 200, 642
+    c = make_config(nb, nblb, wall)
+    c["X"][1] = c["X"][0] + np.array([1.37, 0.21, 0.05])        # shells of radius ~1: they intersect
+    c["X"][57] = c["X"][140] + np.array([0.0, 1.9, 0.02])       # a second, grazing contact far apart in index
+    N = nb * nblb
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    rh = r.cpu().numpy().reshape(-1, 3)
+    # blobs of body 1 that overlap a blob of body 0 (and the 57 / 140 pair)
+    def close_rows(ba, bb):
+        A, B = rh[ba * nblb:(ba + 1) * nblb], rh[bb * nblb:(bb + 1) * nblb]
+        d = np.linalg.norm(A[:, None, :] - B[None, :, :], axis=2)
+        ia, ib = np.nonzero(d < 2.0 * c["a"])
+        return sorted(set(ba * nblb + ia)), sorted(set(bb * nblb + ib)), float(d.min())
+    r1, r0, dmin = close_rows(1, 0)
+    r57, r140, dmin2 = close_rows(57, 140)
+    assert len(r1) >= 5 and dmin > 1e-6 and len(r57) >= 1, (len(r1), dmin, len(r57), dmin2)
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal(3 * N)).to(dev)
+    out = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())
+    ctx.sync_check()
+    oh, xh = out.cpu().numpy(), x.cpu().numpy()
+    rows = (r1[:6] + r0[:6] + r57[:3] + r140[:3])
+    for b in rows:
+        Uo = orc.apply_M_rows(xh, rh.reshape(-1), b, b + 1, c["a"], c["eta"], wall, nthreads=8)
+        assert rel(oh[3 * b:3 * b + 3], Uo) < 1e-11, b
+    # and the symmetric-shard decomposition still adds up with the far map in play
+    acc = torch.zeros_like(x)
+    for first in range(2):
+        p = torch.empty_like(x)
+        ctx.apply_M_sym(x.data_ptr(), r.data_ptr(), N, first, 2, p.data_ptr())
+        acc += p
+    ctx.sync_check()
+    assert float(torch.linalg.norm(acc - out) / torch.linalg.norm(out)) < 1e-13
+
+
 def test_cholesky_cfg2_size_property():
     """BASELINE cfg 2 size (n = 24 300): dense M, in-place Cholesky, L L^T x == M x."""
     import torch
