@@ -282,10 +282,13 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
     __syncthreads();
     if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
       auto sweep = [&](auto nearchk) {
+        unsigned off16 = (unsigned)lane * 16u;       // byte offset of column jj in the 16-B arrays, carried (jj*8 = off16/2)
 #pragma unroll RBL_SYM_UNROLL
         for (int s = 0; s < TS; ++s) {
-          const int jj = (lane + s) & (TS - 1);
-          const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj];
+          const double2_t pa = *(const double2_t *)((const char *)sP0 + off16), pb = *(const double2_t *)((const char *)sP1 + off16),
+                          pd = *(const double2_t *)((const char *)sP2 + off16);
+          const int jj = (int)(off16 >> 4);
+          off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
           double vx = 0.0, vy = 0.0, vz = 0.0;
 #pragma unroll
           for (int a = 0; a < NI; ++a)
