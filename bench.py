@@ -116,7 +116,8 @@ def timestep_mode(args, dev, world=1, rank=0):
         if world > 1:
             stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
         else:
-            stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=args.graph)
+            solver = "graph" if args.graph else ("native" if args.native else args.solver)
+        stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=(solver == "graph"), native=(solver == "native"))
         stp_step = lambda k: stp.step(Fb, iters, rtol)
     res, used = [], []
     for k in range(args.warmup):
@@ -261,6 +262,10 @@ def main():
     ap.add_argument("--mhalf", default="lanczos", choices=["lanczos", "cholesky"], help="square root used by the Brownian step")
     ap.add_argument("--sharded-driver", action="store_true", help="use the multi-GPU Brownian driver also at N = 1")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
+    ap.add_argument("--solver", default="native", choices=["native", "torch", "graph"],
+                    help="--mode timestep, N = 1: librbl's own GMRES (rbl_gmres_saddle_dev, default), the torch Arnoldi "
+                         "loop, or that loop replayed as one hipGraph")
+    ap.add_argument("--native", action="store_true", help="alias of --solver native")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
@@ -378,7 +383,7 @@ def main():
         # preconditioned GMRES iterations on apply_saddle (= 21 apply_M + diagonal PC + K ops) + evolve.  With N > 1
         # the mobility product of every iteration is tile-pair sharded (one all-reduce per iteration).
         from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper
-        stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
+        stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev, native=True))
         Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
         stp.step(Fb, 20)
         barrier(); ts0 = time.perf_counter()

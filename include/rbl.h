@@ -239,6 +239,13 @@ int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /*
 int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */
 int rbl_apply_PC_dev(rbl_ctx *ctx, const double *d_in, double *d_out);        /* apply_PC :589, diagonal PC */
 int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /* src/Rigid.py:73-80 */
+/* Right-preconditioned GMRES(max_iter <= 255, no restart) on the saddle operator of the object's own
+ * configuration (src/Rigid.py:73-80 is what a caller's Krylov solver applies; the reference ships no solver):
+ * solves [M -K; K^T 0] x = rhs with P^-1 = apply_PC, all vectors in HBM.  rtol <= 0: exactly max_iter
+ * iterations, no host round trip inside the loop; rtol > 0: stops at the first iteration whose residual
+ * estimate is below rtol (tested every iteration, or every 4th for small launch-bound systems).  d_rhs, d_x: n3 + 6 N_bod doubles. */
+int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double rtol, double *d_x,
+                         int *iters, double *resid);
 /* RHS_and_Midpoint on device vectors (d_Slip[n3], d_Force[6Nb], d_W[3 n3] or NULL, d_RHS[n3+6Nb]);
  * X_half / Q_half are host arrays (O(N_bod)). */
 int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d_Force, const double *d_W,

@@ -52,6 +52,7 @@ def lib():
         L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
         L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
+        L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
         _LIB = L
@@ -122,6 +123,12 @@ class DeviceContext:
         import numpy as np
         U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_evolve_X_Q(self.h, U.ctypes.data))
+
+    def gmres_saddle(self, d_rhs, max_iter, rtol, d_x):
+        """native right-preconditioned GMRES on the saddle operator -> (iterations, residual estimate)"""
+        it, res = C.c_int(0), C.c_double(0.0)
+        self._chk(self.L.rbl_gmres_saddle_dev(self.h, d_rhs, int(max_iter), float(rtol or 0.0), d_x, C.byref(it), C.byref(res)))
+        return it.value, res.value
 
     def update_X_Q(self, U_host, n_bodies):
         """configuration displaced by U (displacement units), not committed -> (X, Q)"""

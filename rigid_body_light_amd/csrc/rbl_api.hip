@@ -221,7 +221,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -1091,6 +1091,105 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
   rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, d_out, (const double *)c->d_sad.p, -1.0);
   rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, d_x, S.N_blb, S.N_bod, d_out + n3);
   return RBL_OK;
+}
+
+}  // extern "C"
+
+// ---- GMRES on the saddle operator --------------------------------------------
+// Right-preconditioned GMRES(max_iter), no restart:  A = apply_saddle (src/Rigid.py:73-80), P^-1 = apply_PC
+// (c_rigid_obj.cpp:589-616), Arnoldi with classical Gram-Schmidt applied twice.  Everything stays on the
+// device and the stream is not drained inside the loop: the Hessenberg matrix lives in HBM and is read back
+// once at the end (fixed work, rtol <= 0) or, for the convergence test, every iteration (large systems) /
+// every 4th (small, launch-bound ones).
+extern "C" {
+
+int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                         double *resid_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+  if (max_iter + 1 > rbl_gmres_max_vectors()) return rbl_fail(c, RBL_ERR_ARG, "gmres: at most 255 iterations (no restart)");
+  const RblBodyState &S = c->S;
+  const int64_t nsys = (int64_t)3 * S.N_bod * S.N_blb + (int64_t)6 * S.N_bod;
+  const int m = max_iter, ldh = m + 1;
+  const size_t vb = sizeof(double) * (size_t)nsys;
+  // workspace: V[(m+1)][nsys] | w | z | H[(m+1) x m] column-major | beta | y[m] | partial sums
+  const size_t need = vb * (size_t)(m + 3) + sizeof(double) * ((size_t)ldh * m + 1 + m + rbl_gmres_part_doubles() +
+                                                               rbl_lanczos_part_doubles());
+  if ((rc = rbl_dev_reserve(c, c->d_gm, need))) return rc;
+  double *V = (double *)c->d_gm.p, *w = V + (size_t)(m + 1) * nsys, *z = w + nsys, *H = z + nsys,
+         *d_beta = H + (size_t)ldh * m, *d_y = d_beta + 1, *part = d_y + m, *part2 = part + rbl_gmres_part_doubles();
+  RBL_HIP(c, hipMemsetAsync(H, 0, sizeof(double) * (size_t)ldh * m, c->stream));
+  rbl_launch_lanczos_init(c->stream, nsys, d_rhs, d_beta, V, part2);                    // V_0 = b/|b|, beta = |b|
+  std::vector<double> Hh((size_t)ldh * m + 1), y;
+  // convergence test: every iteration when an iteration is expensive, every 4th when it is launch-bound
+  const int check_every = ((int64_t)S.N_bod * S.N_blb > 20000) ? 1 : 4;
+  int used = 0;
+  double resid = 1.0;
+  // least squares min |beta e1 - H_k y| by Givens rotations on a host copy; returns the residual estimate
+  auto solve_ls = [&](int k, std::vector<double> &yout) -> double {
+    std::vector<double> R(Hh.begin(), Hh.begin() + (size_t)ldh * m), g((size_t)k + 1, 0.0);
+    const double beta = Hh[(size_t)ldh * m];
+    g[0] = beta;
+    std::vector<double> cs((size_t)k), sn((size_t)k);
+    for (int j = 0; j < k; ++j) {
+      double *col = R.data() + (size_t)j * ldh;
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+        col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+        col[i] = t;
+      }
+      const double den = std::hypot(col[j], col[j + 1]);
+      cs[j] = den > 0.0 ? col[j] / den : 1.0;
+      sn[j] = den > 0.0 ? col[j + 1] / den : 0.0;
+      col[j] = den; col[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+    }
+    yout.assign((size_t)k, 0.0);
+    for (int i = k - 1; i >= 0; --i) {
+      double v = g[i];
+      for (int j = i + 1; j < k; ++j) v -= R[(size_t)j * ldh + i] * yout[j];
+      const double d = R[(size_t)i * ldh + i];
+      yout[i] = d != 0.0 ? v / d : 0.0;
+    }
+    return beta > 0.0 ? std::fabs(g[k]) / beta : 0.0;
+  };
+  for (int j = 0; j < m; ++j) {
+    const double *vj = V + (size_t)j * nsys;
+    if ((rc = rbl_apply_PC_dev(c, vj, z))) return rc;
+    if ((rc = rbl_apply_saddle_dev(c, z, w))) return rc;
+    double *Hcol = H + (size_t)j * ldh;
+    rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 0, part);
+    rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 1, part);
+    rbl_launch_lanczos_init(c->stream, nsys, w, Hcol + j + 1, V + (size_t)(j + 1) * nsys, part2);   // H[j+1][j] = |w|, V_{j+1}
+    used = j + 1;
+    if (rtol > 0.0 && (used % check_every == 0 || used == m)) {
+      RBL_HIP(c, hipMemcpyAsync(Hh.data(), H, sizeof(double) * Hh.size(), hipMemcpyDeviceToHost, c->stream));
+      RBL_HIP(c, hipStreamSynchronize(c->stream));
+      // the test may only have become true somewhere in the last 4 iterations: take the first k that passes
+      int k0 = used - (check_every - 1) < 1 ? 1 : used - (check_every - 1), hit = 0;
+      for (int k = k0; k <= used; ++k) {
+        resid = solve_ls(k, y);
+        if (resid < rtol) { hit = k; break; }
+      }
+      if (hit) { used = hit; break; }
+    }
+  }
+  if (!(rtol > 0.0) || y.size() != (size_t)used) {
+    RBL_HIP(c, hipMemcpyAsync(Hh.data(), H, sizeof(double) * Hh.size(), hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    resid = solve_ls(used, y);
+  }
+  for (int k = 0; k < used; ++k)
+    if (!std::isfinite(y[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "gmres: non-finite Hessenberg solve");
+  RBL_HIP(c, hipMemcpyAsync(d_y, y.data(), sizeof(double) * (size_t)used, hipMemcpyHostToDevice, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  rbl_launch_lanczos_combine(c->stream, nsys, V, d_y, used, z);                        // z = V y
+  if ((rc = rbl_apply_PC_dev(c, z, d_x))) return rc;                                   // x = P^-1 z
+  if (iters_out) *iters_out = used;
+  if (resid_out) *resid_out = resid;
+  return finish_and_check(c);
 }
 
 }  // extern "C"

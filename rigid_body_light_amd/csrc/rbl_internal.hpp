@@ -70,6 +70,7 @@ struct rbl_ctx {
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
+  RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
@@ -143,6 +144,10 @@ size_t rbl_trmv_part_bytes(int64_t n);
 // small vector kernels (rbl_kernels.hip) used by Lanczos
 void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const double *z,
                      int64_t n, double *d_out2);  // out[0]=x.y out[1]=x.z (z may be null)
+int rbl_gmres_max_vectors(void);
+size_t rbl_gmres_part_doubles(void);
+void rbl_launch_cgs_pass(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, int accumulate,
+                         double *part);
 size_t rbl_lanczos_part_doubles(void);
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
                              double *part);

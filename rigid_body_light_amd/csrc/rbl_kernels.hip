@@ -818,6 +818,41 @@ __global__ __launch_bounds__(256) void k_lz_combine(long n, const double *__rest
   out[i] = a;
 }
 
+// ---- Arnoldi orthogonalisation (GMRES) --------------------------------------------------------
+// h = V[0..k)^T w as per-block partial sums (grid: blocks x vectors); the consumer re-adds them.
+__global__ __launch_bounds__(256) void k_mdot_partial(const double *__restrict__ V, long n, const double *__restrict__ w,
+                                                      double *__restrict__ part)
+{
+  __shared__ double sh[256];
+  const double *v = V + (size_t)blockIdx.y * (size_t)n;
+  double a = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a = __builtin_fma(v[i], w[i], a);
+  a = lz_block_sum(a, sh);
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = a;
+}
+
+// w -= V[0..k) h with h_v = sum of the partials (identical in every block); block 0 adds h to Hcol (+= on
+// the second Gram-Schmidt pass).  k <= RBL_GMRES_MAXK.
+constexpr int GM_MAXK = 256;
+__global__ __launch_bounds__(256) void k_maxpy(const double *__restrict__ V, long n, int k, double *__restrict__ w,
+                                               const double *__restrict__ part, int np, double *__restrict__ Hcol,
+                                               int accumulate)
+{
+  __shared__ double h[GM_MAXK];
+  for (int v = threadIdx.x; v < k; v += 256) {
+    double a = 0.0;
+    for (int b = 0; b < np; ++b) a += part[(size_t)v * np + b];
+    h[v] = a;
+    if (blockIdx.x == 0) Hcol[v] = accumulate ? Hcol[v] + a : a;
+  }
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double a = w[i];
+    for (int v = 0; v < k; ++v) a = __builtin_fma(-h[v], V[(size_t)v * n + i], a);
+    w[i] = a;
+  }
+}
+
 __global__ void k_scale_by_damp(RblParams P, const double *__restrict__ r, long n_blobs,
                                 const double *__restrict__ in, double *__restrict__ out)
 {
@@ -1125,6 +1160,21 @@ void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, cons
 {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_lz_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, V, coef, m, out);
+}
+
+int rbl_gmres_max_vectors(void) { return GM_MAXK; }
+size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * 128; }
+
+// one classical Gram-Schmidt pass of w against V[0..k): Hcol (+)= V^T w ; w -= V (V^T w)
+void rbl_launch_cgs_pass(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, int accumulate,
+                         double *part)
+{
+  if (k <= 0 || n <= 0) return;
+  int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, part);
+  const int g = lz_grid(n);
+  hipLaunchKernelGGL(k_maxpy, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)part, nb, Hcol, accumulate);
 }
 
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,

@@ -57,11 +57,12 @@ class DeterministicStepper:
     configurations are launch-bound (cfg 1: ~14 us of kernels per apply_M), a replay removes the
     per-launch host cost.  The non-launch work (uploads, PC build) happens in ctx.prepare()."""
 
-    def __init__(self, ctx, n_bodies, blobs_per_body, device, use_graph=False):
+    def __init__(self, ctx, n_bodies, blobs_per_body, device, use_graph=False, native=False):
         self.ctx, self.nb, self.nblb, self.dev = ctx, n_bodies, blobs_per_body, device
         self.n3 = 3 * n_bodies * blobs_per_body
         self.size = self.n3 + 6 * n_bodies
         self.use_graph = use_graph
+        self.native = native          # librbl's own GMRES (rbl_gmres_saddle_dev) instead of the torch Arnoldi loop
         self._graph = None
 
     def _A(self, x):
@@ -103,6 +104,12 @@ class DeterministicStepper:
     def solve(self, F_body, iters=20, rtol=None):
         """Solve the saddle system for rhs = [0 ; -F_body]; returns (lambda, U, iterations, residual)."""
         Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
+        if self.native:
+            b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
+            b[self.n3:] = -Fb
+            x = torch.empty_like(b)
+            m, resid = self.ctx.gmres_saddle(b.data_ptr(), iters, rtol, x.data_ptr())
+            return x[: self.n3], x[self.n3:], m, resid
         if rtol is not None or not self.use_graph:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
             b[self.n3:] = -Fb

@@ -802,3 +802,36 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall):
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9)
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-9)
     assert np.linalg.norm(out[0][0] - X) > 1e-4
+
+
+@pytest.mark.parametrize("block", [False, True])
+def test_native_gmres_equals_torch_gmres(shell12, block):
+    """rbl_gmres_saddle_dev (librbl's own right-preconditioned GMRES) == the torch Arnoldi driver, fixed work and
+    converged, and solves the saddle system."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    from rigid_body_light_amd.krylov import DeterministicStepper
+    nb = 6
+    X, Q = random_positions(nb, wall=True, seed=150)
+    X[:, 2] += 1.5
+    dev = torch.device("cuda:0")
+    Fb = np.tile([0.1, 0, -1.0, 0.2, 0, 0.05], nb)
+    sols = {}
+    for native in (False, True):
+        ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        if block:
+            lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(X, Q)
+        st = DeterministicStepper(ctx, nb, 12, dev, native=native)
+        lam, U, m, resid = st.solve(Fb, iters=12)                       # fixed work
+        lam2, U2, m2, resid2 = st.solve(Fb, iters=120, rtol=1e-11)      # converged
+        sols[native] = (U.cpu().numpy(), resid, U2.cpu().numpy(), m2, resid2)
+        if native:                                                      # residual of the converged solution, explicitly
+            x = torch.cat([lam2, U2]); out = torch.empty_like(x)
+            ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
+            b = torch.zeros_like(x); b[36 * nb:] = torch.from_numpy(-Fb).to(dev)
+            assert float(torch.linalg.norm(out - b) / torch.linalg.norm(b)) < 1e-9
+    (Ua, ra, Ua2, ma, ra2), (Ub, rb, Ub2, mb, rb2) = sols[False], sols[True]
+    assert rel(Ub, Ua) < 1e-9 and abs(ra - rb) < 1e-9 * max(ra, 1e-30) + 1e-12
+    assert rb2 < 1e-11 and abs(mb - ma) <= 3            # the native loop tests convergence every 4th iteration
+    assert rel(Ub2, Ua2) < 1e-8
