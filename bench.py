@@ -109,7 +109,7 @@ def timestep_mode(args, dev, world=1, rank=0):
             lanczos_its = lambda: list(bst.lanczos_iterations)
         else:
             ctx.set_lanczos(100, 1e-3)
-            bst = BrownianStepper(ctx, nb, nblb, dev)
+            bst = BrownianStepper(ctx, nb, nblb, dev, native=(not args.graph and (args.native or args.solver == "native")))
             stp_step = lambda k: bst.step(Fb, seed=k, method=method, iters=iters, rtol=rtol)
             lanczos_its = (lambda: [ctx.lanczos_report()[0]]) if method == 1 else None
     else:

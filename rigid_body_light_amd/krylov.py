@@ -243,7 +243,11 @@ class BrownianStepper(DeterministicStepper):
         Xh, Qh = self.ctx.RHS_and_Midpoint(sl.data_ptr(), Fb.data_ptr(), None if Wd is None else Wd.data_ptr(),
                                            seed, method, split_rand, delta, rhs.data_ptr(), self.nb)
         self.ctx.set_config(Xh, Qh)                      # operators and preconditioner at the predictor configuration
-        x, m, resid = gmres_right_pc(self._A, self._Pinv, rhs, iters, rtol)
+        if self.native:
+            x = torch.empty_like(rhs)
+            m, resid = self.ctx.gmres_saddle(rhs.data_ptr(), iters, rtol, x.data_ptr())
+        else:
+            x, m, resid = gmres_right_pc(self._A, self._Pinv, rhs, iters, rtol)
         U = x[self.n3:].cpu().numpy()
         self.ctx.set_config(Xn, Qn)                      # the update starts from q^n
         self.ctx.evolve(U)

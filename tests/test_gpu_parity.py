@@ -751,7 +751,7 @@ def test_brownian_step_vs_dense_numpy(orc, shell12, wall):
     dev = torch.device("cuda:0")
     ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(X, Q)
-    st = BrownianStepper(ctx, nb, 12, dev)
+    st = BrownianStepper(ctx, nb, 12, dev, native=wall)          # both Krylov drivers: native with the wall, torch without
     m, resid = st.step(force, slip=slip, W=W, method=0, iters=80, rtol=1e-11)
     assert resid < 1e-11
     Xg, Qg = ctx.get_config(nb)
