@@ -207,6 +207,10 @@ int rbl_apply_M_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, in
  * i_first = 0, i_step = 1 is the whole product. */
 int rbl_apply_M_sym_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,
                         int i_first, int i_step, double *d_out);
+/* the same for nrhs = 1 or 2 force vectors at once (d_F, d_out: [nrhs][3 n_blobs]); with two vectors the pair
+ * coefficients are evaluated once for both (the two Brownian increments of the stochastic step) */
+int rbl_apply_M_sym_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs, int nrhs,
+                              int i_first, int i_step, double *d_out);
 
 /* blob positions of bodies [body_begin, body_end) into d_out
  * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */

@@ -42,6 +42,7 @@ def lib():
         L.rbl_set_blk_pc.argtypes = [vp, C.c_int]
         L.rbl_apply_M_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, vp]
         L.rbl_apply_M_sym_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
+        L.rbl_apply_M_sym_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp]
         L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
         L.rbl_rotne_prager_tensor_dev.argtypes = [vp, vp, i64, C.c_int, vp]
         L.rbl_cholesky_lower_dev.argtypes = [vp, vp, i64, C.c_int]
@@ -167,6 +168,10 @@ class DeviceContext:
     def apply_M_sym(self, dF, dr, n_blobs, i_first, i_step, dout):
         """partial product over the tile rows I % i_step == i_first (sum over ranks = full U)."""
         self._chk(self.L.rbl_apply_M_sym_dev(self.h, dF, dr, n_blobs, i_first, i_step, dout))
+
+    def apply_M_sym_multi(self, dF, dr, n_blobs, nrhs, i_first, i_step, dout):
+        """the same for nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); two vectors share the pair coefficients"""
+        self._chk(self.L.rbl_apply_M_sym_multi_dev(self.h, dF, dr, n_blobs, nrhs, i_first, i_step, dout))
 
     def blob_positions(self, body_begin, body_end, dout):
         self._chk(self.L.rbl_blob_positions_dev(self.h, body_begin, body_end, dout))

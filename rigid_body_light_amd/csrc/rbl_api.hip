@@ -192,8 +192,15 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
   if (c->tune_variant == 3) mfma = true;
   if (c->tune_variant == 1 || c->tune_variant == 2) mfma = false;
   int rc;
-  if (!mfma) {
-    for (int k = 0; k < nrhs; ++k)
+  if (!mfma) {   // 1-3 vectors: pairs of vectors through the two-vector symmetric kernel, a single one alone
+    int k = 0;
+    const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2) <= c->sym_workspace_budget;
+    for (; sym2 && k + 2 <= nrhs; k += 2) {
+      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2)))) return rc;
+      rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
+                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2);
+    }
+    for (; k < nrhs; ++k)
       if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
     return RBL_OK;
   }
@@ -661,13 +668,17 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 //   LANCZOS : Krylov approximation of the symmetric square root with the
 //             matrix-free matvec (no O(n^2) memory).
 // ---------------------------------------------------------------------------
+// y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
 static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
-                       const double *d_x, double *d_y, double *d_tmp)
+                       const double *d_x, double *d_y, double *d_tmp, int nvec = 1)
 {
-  if (c->S.wall) return apply_M_enqueue(c, true, d_x, d_r, nbl, 0, nbl, d_y);  // kernel applies B M B itself
-  rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x, d_tmp);                 // free-space M, damping around it
-  int rc = apply_M_enqueue(c, false, d_tmp, d_r, nbl, 0, nbl, d_y);
-  rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_y, d_y);
+  const int64_t n = 3 * nbl;
+  if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
+  for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
+    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x + (size_t)v * n, d_tmp + (size_t)v * n);
+  int rc = apply_M_multi_enqueue(c, false, d_tmp, d_r, nbl, nvec, d_y);
+  for (int v = 0; v < nvec; ++v)
+    rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_y + (size_t)v * n, d_y + (size_t)v * n);
   return rc;
 }
 
@@ -695,64 +706,84 @@ static int lanczos_coeffs(rbl_ctx *c, const std::vector<double> &alpha, const st
 // The recurrence runs entirely on the device (rbl_launch_lanczos_step keeps alpha, beta there); the host
 // reads them back only to test convergence: every iteration when a product is expensive, every 4th when the
 // iteration is launch-bound (small systems), so the stream is not drained twice per iteration.
-static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out)
+static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out,
+                             int nvec = 1)
 {
+  // nvec = 1 or 2 independent recurrences advanced in lock step: with two (the Brownian step's W1, W2) every
+  // iteration is ONE two-vector product whose pair coefficients are shared.
   const int64_t n = 3 * nbl;
   const int maxit = c->lanczos_max_iter;
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   int rc;
-  // workspace: V (n x (maxit+1)) | u, tmp | alpha[maxit], beta[maxit], |W|, coef[maxit], partial sums
+  // workspace: V[(maxit+1)][nvec][n] | u[nvec][n], tmp[nvec][n] | per vector: alpha[maxit], beta[maxit], |W|, coef[maxit] | partial sums
   const size_t vbytes = sizeof(double) * (size_t)n;
   const size_t nsc = (size_t)3 * maxit + 1;
-  if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1)))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 2 + sizeof(double) * (nsc + rbl_lanczos_part_doubles())))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1) * nvec))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 2 * nvec + sizeof(double) * (nsc * nvec + rbl_lanczos_part_doubles())))) return rc;
   double *V = (double *)c->d_tmp.p;
-  double *u = (double *)c->d_tmp2.p, *tmp = u + n;
-  double *d_alpha = tmp + n, *d_beta = d_alpha + maxit, *d_wn = d_beta + maxit, *d_coef = d_wn + 1,
-         *d_part = d_coef + maxit;
-  rbl_launch_lanczos_init(c->stream, n, d_W, d_wn, V, d_part);
+  double *u = (double *)c->d_tmp2.p, *tmp = u + (size_t)nvec * n, *sc = tmp + (size_t)nvec * n;
+  double *d_part = sc + nsc * nvec;
+  auto d_alpha = [&](int v) { return sc + nsc * v; };
+  auto d_beta = [&](int v) { return sc + nsc * v + maxit; };
+  auto d_wn = [&](int v) { return sc + nsc * v + 2 * maxit; };
+  auto d_coef = [&](int v) { return sc + nsc * v + 2 * maxit + 1; };
+  auto Vp = [&](int it, int v) { return V + ((size_t)it * nvec + v) * n; };
+  for (int v = 0; v < nvec; ++v) rbl_launch_lanczos_init(c->stream, n, d_W + (size_t)v * n, d_wn(v), Vp(0, v), d_part);
   const int check_every = (nbl > 20000) ? 1 : 4;
-  std::vector<double> hs((size_t)2 * maxit + 1), alpha, beta, y_cur, y_prev;
+  std::vector<double> hs(nsc * nvec), alpha, beta, y_prev;
+  std::vector<std::vector<double>> y_cur(nvec);
+  std::vector<double> wnorm(nvec, 0.0), resid(nvec, 1.0);
   int m = 0;
-  double resid = 1.0, wnorm = 0.0;
   bool done = false;
   for (int it = 0; it < maxit && !done; ++it) {
-    double *v = V + (size_t)it * n;
-    if ((rc = apply_A_dev(c, P, d_r, nbl, v, u, tmp))) return rc;
-    rbl_launch_lanczos_step(c->stream, n, u, v, it > 0 ? V + (size_t)(it - 1) * n : nullptr,
-                            it > 0 ? d_beta + (it - 1) : nullptr, d_alpha + it, d_beta + it, V + (size_t)(it + 1) * n,
-                            d_part);
+    if ((rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec))) return rc;
+    for (int v = 0; v < nvec; ++v)
+      rbl_launch_lanczos_step(c->stream, n, u + (size_t)v * n, Vp(it, v), it > 0 ? Vp(it - 1, v) : nullptr,
+                              it > 0 ? d_beta(v) + (it - 1) : nullptr, d_alpha(v) + it, d_beta(v) + it, Vp(it + 1, v),
+                              d_part);
     m = it + 1;
     if (m % check_every != 0 && m != maxit) continue;
-    RBL_HIP(c, hipMemcpyAsync(hs.data(), d_alpha, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipMemcpyAsync(hs.data(), sc, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
     RBL_HIP(c, hipStreamSynchronize(c->stream));
-    alpha.assign(hs.begin(), hs.begin() + m);
-    beta.assign(hs.begin() + maxit, hs.begin() + maxit + m);
-    wnorm = hs[(size_t)2 * maxit];
-    if (!(wnorm > 0.0)) { RBL_HIP(c, hipMemsetAsync(d_out, 0, vbytes, c->stream)); c->lanczos_iters = 0; c->lanczos_resid = 0.0; return RBL_OK; }
-    for (int k = 0; k < m; ++k)
-      if (!std::isfinite(alpha[k]) || !std::isfinite(beta[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: non-finite recurrence");
-    for (int k = 0; k < m - 1; ++k)                       // breakdown before the last step: Krylov space exhausted
-      if (!(beta[k] > 1e-300)) { m = k + 1; done = true; break; }
-    if ((rc = lanczos_coeffs(c, alpha, beta, m, wnorm, y_cur))) return rc;
-    if (m > 1) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
-      if ((rc = lanczos_coeffs(c, alpha, beta, m - 1, wnorm, y_prev))) return rc;
-      double dn = 0.0, yn = 0.0;
-      for (int p = 0; p < m; ++p) {
-        const double yp = p < m - 1 ? y_prev[p] : 0.0;
-        dn += (y_cur[p] - yp) * (y_cur[p] - yp);
-        yn += y_cur[p] * y_cur[p];
+    bool all_conv = true;
+    for (int v = 0; v < nvec; ++v) {
+      const double *h = hs.data() + nsc * v;
+      alpha.assign(h, h + m);
+      beta.assign(h + maxit, h + maxit + m);
+      wnorm[v] = h[2 * maxit];
+      if (!(wnorm[v] > 0.0)) { y_cur[v].assign(m, 0.0); resid[v] = 0.0; continue; }   // zero noise vector -> zero increment
+      for (int k = 0; k < m; ++k)
+        if (!std::isfinite(alpha[k]) || !std::isfinite(beta[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "Lanczos: non-finite recurrence");
+      int mv = m;
+      for (int k = 0; k < m - 1; ++k)                     // breakdown before the last step: Krylov space exhausted
+        if (!(beta[k] > 1e-300)) { mv = k + 1; break; }
+      if ((rc = lanczos_coeffs(c, alpha, beta, mv, wnorm[v], y_cur[v]))) return rc;
+      if (mv > 1) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
+        if ((rc = lanczos_coeffs(c, alpha, beta, mv - 1, wnorm[v], y_prev))) return rc;
+        double dn = 0.0, yn = 0.0;
+        for (int p = 0; p < mv; ++p) {
+          const double yp = p < mv - 1 ? y_prev[p] : 0.0;
+          dn += (y_cur[v][p] - yp) * (y_cur[v][p] - yp);
+          yn += y_cur[v][p] * y_cur[v][p];
+        }
+        resid[v] = std::sqrt(dn / yn);
       }
-      resid = std::sqrt(dn / yn);
+      y_cur[v].resize(m, 0.0);                            // a recurrence that broke down early contributes no further vectors
+      const bool conv = resid[v] < c->lanczos_tol || mv < m || !(beta[mv - 1] > 1e-300);
+      all_conv = all_conv && conv;
     }
-    if (resid < c->lanczos_tol || !(beta[m - 1] > 1e-300)) done = true;
+    if (all_conv) done = true;
   }
   c->lanczos_iters = m;
-  c->lanczos_resid = resid;
-  // d_out = V[:, :m] y
-  RBL_HIP(c, hipMemcpyAsync(d_coef, y_cur.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+  c->lanczos_resid = *std::max_element(resid.begin(), resid.end());
+  // d_out_v = V_v[:, :m] y_v
+  for (int v = 0; v < nvec; ++v) {
+    if ((int)y_cur[v].size() < m) y_cur[v].resize(m, 0.0);
+    RBL_HIP(c, hipMemcpyAsync(d_coef(v), y_cur[v].data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+  }
   RBL_HIP(c, hipStreamSynchronize(c->stream));            // y_cur is pageable host memory
-  rbl_launch_lanczos_combine(c->stream, n, V, d_coef, m, d_out);
+  for (int v = 0; v < nvec; ++v)
+    rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, d_out + (size_t)v * n, (int64_t)nvec * n);
   return RBL_OK;
 }
 
@@ -763,9 +794,12 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
 {
   const int64_t n = 3 * nbl;
   int rc;
-  if (method == RBL_MHALF_LANCZOS) {
-    for (int v = 0; v < nvec; ++v)
-      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n))) return rc;
+  if (method == RBL_MHALF_LANCZOS) {   // pairs of vectors in lock step (shared pair coefficients), a single one alone
+    int v = 0;
+    for (; v + 2 <= nvec; v += 2)
+      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 2))) return rc;
+    for (; v < nvec; ++v)
+      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 1))) return rc;
     return RBL_OK;
   }
   if (method != RBL_MHALF_CHOLESKY) return rbl_fail(c, RBL_ERR_ARG, "M_half_W: unknown method");
@@ -884,6 +918,19 @@ int rbl_apply_M_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int6
   return apply_M_multi_enqueue(c, c->S.wall, d_F, d_r, n_blobs, nrhs, d_out);
 }
 
+int rbl_apply_M_sym_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int nrhs,
+                              int i_first, int i_step, double *d_out)
+{
+  int rc = need_params(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step || nrhs < 1 || nrhs > 2)
+    return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_multi_dev: need n_blobs > 0, 0 <= i_first < i_step, nrhs 1 or 2");
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs)))) return rc;
+  rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs, i_first,
+                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs);
+  return RBL_OK;
+}
+
 int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int i_first,
                         int i_step, double *d_out)
 {
@@ -934,6 +981,7 @@ int rbl_sync_check(rbl_ctx *c)
 
 int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
+  if (variant == 21 || variant == 22) { rbl_set_sym2_ni(variant - 20); return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
   if (!c) return RBL_ERR_ARG;
   rbl_set_sym_chunk_override(variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;

@@ -109,11 +109,13 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
                         const double *d_r, int64_t n_blobs, int64_t row_begin,
                         int64_t row_end, double *d_out, double *d_part, int jsplit,
                         int variant, unsigned *d_err);
-size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step);
+size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs = 1);
+void rbl_set_sym2_ni(int ni);
 void rbl_set_sym_chunk_override(int c);   // tuning hook: chunk length C of the symmetric kernel (0 = heuristic)
+// nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); workspace rbl_apply_M_sym_bytes(..., nrhs)
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err);
+                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs = 1);
 size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu);
 void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                              const double *d_r, int64_t n_blobs, int nrhs, double *d_out,
@@ -155,7 +157,7 @@ void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double 
                              const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
                              double *part);
 void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
-                                double *out);
+                                double *out, int64_t stride = 0);
 void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,
                       const double *y, double *out);
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,

@@ -342,6 +342,133 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   if (flags) atomicOr(err, flags);
 }
 
+// ---------------------------------------------------------------------------
+// The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
+// coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back:
+// slabI[chunk][2][Npad][3], slabJ[row][2][Npad][3].
+// ---------------------------------------------------------------------------
+template <bool WALL, int NI>
+__global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
+                                                     double *__restrict__ slabI, double *__restrict__ slabJ, long N,
+                                                     int T, int C, int i_first, int i_step, RblParams P, unsigned *err,
+                                                     const unsigned char *__restrict__ farmap)
+{
+  __shared__ double2_t sP0[TS], sP1[TS], sP2[TS], sP3[TS], sP4[TS];  // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
+  __shared__ double sU[2][3][TS];
+  const int lane = threadIdx.x;
+  const int I = i_first + (int)blockIdx.x * i_step;
+  const int c = blockIdx.y;
+  const int It0 = NI * I;
+  if (It0 >= T) return;
+  int J0 = c * C;
+  const int J1 = (J0 + C < T) ? J0 + C : T;
+  if (J0 < It0) J0 = It0;
+  if (J0 >= J1) return;
+  const long Npad = (long)T * TS, n3 = 3 * N;
+  unsigned flags = 0;
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  auto load_blob = [&](long idx, double &x, double &y, double &z, RblV3 &f0, RblV3 &f1) {
+    if (idx < N) {
+      x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
+      double d = 1.0;
+      if (WALL) {
+        if (z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+        d = damp_of(P, z);
+      }
+      x *= P.inv_a; y *= P.inv_a; z *= P.inv_a;
+      f0 = RblV3{d * F[3 * idx], d * F[3 * idx + 1], d * F[3 * idx + 2]};
+      f1 = RblV3{d * F[n3 + 3 * idx], d * F[n3 + 3 * idx + 1], d * F[n3 + 3 * idx + 2]};
+    } else {
+      x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0;
+      f0 = RblV3{0.0, 0.0, 0.0}; f1 = f0;
+    }
+  };
+  double xi[NI], yi[NI], zi[NI];
+  RblV3 Fi0[NI], Fi1[NI], ui0[NI], ui1[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
+    ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = ui0[a];
+  }
+  for (int J = J0; J < J1; ++J) {
+    const long j = (long)J * TS + lane;
+    double xj, yj, zj;
+    RblV3 Fj0, Fj1;
+    load_blob(j, xj, yj, zj, Fj0, Fj1);
+    const bool far_tile = farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    __syncthreads();
+    sP0[lane] = (double2_t){xj, yj};
+    sP1[lane] = (double2_t){zj, Fj0.x};
+    sP2[lane] = (double2_t){Fj0.y, Fj0.z};
+    sP3[lane] = (double2_t){Fj1.x, Fj1.y};
+    sP4[lane] = (double2_t){Fj1.z, 0.0};
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) sU[v][d][lane] = 0.0;
+    __syncthreads();
+    auto pair_step = [&](int jj, int a, auto nearchk) {
+      const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj], pe = sP3[jj], pf = sP4[jj];
+      RblV3 v0{0.0, 0.0, 0.0}, v1{0.0, 0.0, 0.0};
+      rbl_pair_sym2<WALL, true, decltype(nearchk)::value>(Pu, xi[a], yi[a], zi[a], Fi0[a], Fi1[a], pa.x, pa.y, pb.x,
+                                                          RblV3{pb.y, pd.x, pd.y}, RblV3{pe.x, pe.y, pf.x}, ui0[a],
+                                                          ui1[a], v0, v1, flags, WK);
+      __hip_atomic_fetch_add(&sU[0][0][jj], v0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[0][1][jj], v0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[0][2][jj], v0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[1][0][jj], v1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[1][1][jj], v1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (J >= It0 + NI) {
+      auto sweep = [&](auto nearchk) {
+#pragma unroll 2
+        for (int s = 0; s < TS; ++s) {
+          const int jj = (lane + s) & (TS - 1);
+#pragma unroll
+          for (int a = 0; a < NI; ++a) pair_step(jj, a, nearchk);
+        }
+      };
+      if (far_tile) sweep(std::false_type{});
+      else sweep(std::true_type{});
+    } else {
+#pragma unroll
+      for (int a = 0; a < NI; ++a) {
+        if (J == It0 + a) {       // diagonal tile: ordered pairs with the self term, one vector after the other
+          for (int jj = 0; jj < TS; ++jj) {
+            const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj], pe = sP3[jj], pf = sP4[jj];
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane,
+                                             ui0[a].x, ui0[a].y, ui0[a].z, flags);
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pe.x, pe.y, pf.x, jj == lane,
+                                             ui1[a].x, ui1[a].y, ui1[a].z, flags);
+          }
+        } else if (J > It0 + a) {
+          for (int s = 0; s < TS; ++s) pair_step((lane + s) & (TS - 1), a, std::true_type{});
+        }
+      }
+    }
+    if (J > It0) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        double *p = slabJ + (((size_t)blockIdx.x * 2 + v) * (size_t)Npad + (size_t)j) * 3;
+        p[0] = sU[v][0][lane]; p[1] = sU[v][1][lane]; p[2] = sU[v][2][lane];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    if (It0 + a < T) {
+      double *p = slabI + (((size_t)c * 2) * (size_t)Npad + (size_t)(It0 + a) * TS + lane) * 3;
+      p[0] = ui0[a].x; p[1] = ui0[a].y; p[2] = ui0[a].z;
+      double *p1 = p + (size_t)Npad * 3;
+      p1[0] = ui1[a].x; p1[1] = ui1[a].y; p1[2] = ui1[a].z;
+    }
+  }
+  if (flags) atomicOr(err, flags);
+}
+
 // Slab reduction.  Block = 64 consecutive entries of U (all in one blob tile J, since a tile is 192 entries)
 // x RG groups; group g adds the slab entries e = g, g+RG, ... (first the row-sum slabs of the chunks that
 // cover J, then the column-sum slabs of the row tiles before J), the RG partial sums are combined in LDS in
@@ -357,6 +484,11 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
                                                        int nch, int NI, int i_first, int i_step, RblParams P,
                                                        unsigned *err)
 {
+  // blockIdx.y = right-hand side (slabs of gridDim.y vectors lie back to back, out is [gridDim.y][3N])
+  const size_t Npad3v = (size_t)T * TS * 3;
+  slabI += (size_t)blockIdx.y * Npad3v;
+  slabJ += (size_t)blockIdx.y * Npad3v;
+  out += (size_t)blockIdx.y * (size_t)(3 * N);
   __shared__ double sh[RG][64];
   const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long idx = (long)blockIdx.x * 64 + tx;           // over 3*N
@@ -365,7 +497,7 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
   const long j = idc / 3;
   const int J = (int)(j / TS);
   const int Is = J / NI;                                 // super-tile owning row tile J
-  const size_t Npad3 = (size_t)T * TS * 3;
+  const size_t Npad3 = (size_t)T * TS * 3 * gridDim.y;   // distance between consecutive slabs
   const bool owned = Is >= i_first && (Is - i_first) % i_step == 0;   // this launch owned the rows of tile J
   const int c0 = (NI * Is) / C;
   const int nI = owned ? nch - c0 : 0;
@@ -809,12 +941,12 @@ __global__ __launch_bounds__(256) void k_lz_c(long n, const double *__restrict__
 // out = sum_p coef[p] V[p]   (V: m vectors of length n, contiguous)
 __global__ __launch_bounds__(256) void k_lz_combine(long n, const double *__restrict__ V,
                                                     const double *__restrict__ coef, int m,
-                                                    double *__restrict__ out)
+                                                    double *__restrict__ out, long stride)
 {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double a = 0.0;
-  for (int p = 0; p < m; ++p) a = __builtin_fma(coef[p], V[(size_t)p * n + i], a);
+  for (int p = 0; p < m; ++p) a = __builtin_fma(coef[p], V[(size_t)p * stride + i], a);
   out[i] = a;
 }
 
@@ -938,12 +1070,16 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 static int g_sym_chunk_override = 0;   // tuning hook (rbl_set_tuning jsplit with variant 2): forces C
 void rbl_set_sym_chunk_override(int c) { g_sym_chunk_override = c; }
 
-static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI)
+static int g_sym2_ni = 0;   // experiment hook: rows per lane of the two-vector kernel (0 = same rule as one vector)
+void rbl_set_sym2_ni(int ni) { g_sym2_ni = ni; }
+
+static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI, int nrhs = 1)
 {
   const int t = (int)((n_blobs + TS - 1) / TS);
   // 2 rows per lane once there is parallelism to spare: same speed on one GPU (the kernel is
   // VALU-issue bound either way) but half the column-sum slab to write and re-read
-  const int ni = (t >= 128 * i_step) ? 2 : 1;
+  int ni = (t >= 128 * i_step) ? 2 : 1;
+  if (nrhs == 2 && g_sym2_ni > 0) ni = g_sym2_ni;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   const int rowsI = (tsup + i_step - 1) / i_step;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
@@ -959,52 +1095,57 @@ static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI,
   *T = t; *NI = ni; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
 }
 
-size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step)
+size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs)
 {
   int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI);
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs);
   // slabs + tile bounding boxes + far map (one byte per (row super-tile, tile))
-  return (((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 + (size_t)T * 6) * sizeof(double) + (size_t)((T + NI - 1) / NI) * (size_t)T + 64;
+  return (((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * nrhs + (size_t)T * 6) * sizeof(double) + (size_t)((T + NI - 1) / NI) * (size_t)T + 64;
 }
 
 template <bool WALL, int NI>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
                        int i_first, int i_step, double *d_out, double *slabI, double *slabJ, int T, int C, int nch,
-                       int rowsI, unsigned *d_err)
+                       int rowsI, unsigned *d_err, int nrhs)
 {
   dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
   const int64_t n = 3 * n_blobs;
-  dim3 g2((unsigned)((n + 63) / 64)), b2(64 * RG);
+  dim3 g2((unsigned)((n + 63) / 64), (unsigned)nrhs), b2(64 * RG);
   unsigned char *farmap = nullptr;
   if (NI == 2) {   // large systems only: two more tiny launches, then most tile pairs skip the overlap test
-    double *bbox = slabJ + (size_t)rowsI * (size_t)T * TS * 3;
+    double *bbox = slabJ + (size_t)rowsI * (size_t)T * TS * 3 * nrhs;
     farmap = (unsigned char *)(bbox + (size_t)T * 6);
     const int nsup = (T + NI - 1) / NI;
     hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)T), dim3(TS), 0, st, d_r, (long)n_blobs, P.inv_a, bbox);
     hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
                        (const double *)bbox, T, NI, farmap);
   }
-  hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
-                     i_first, i_step, P, d_err, (const unsigned char *)farmap);
+  if (nrhs == 2)
+    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
+                       i_first, i_step, P, d_err, (const unsigned char *)farmap);
+  else
+    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
+                       i_first, i_step, P, d_err, (const unsigned char *)farmap);
   hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C, nch, NI,
                      i_first, i_step, P, d_err);
 }
 
+// nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...) * nrhs
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err)
+                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs)
 {
   if (n_blobs <= 0) return;
   int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI);
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs);
   double *slabI = d_work;
-  double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3;
+  double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3 * nrhs;
   if (NI == 2) {
-    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
-    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
+    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
+    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
   } else {
-    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
-    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err);
+    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
+    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
   }
 }
 
@@ -1155,11 +1296,13 @@ void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double 
                      beta_out, vnext);
 }
 
+// out = sum_p coef[p] V_p, consecutive basis vectors `stride` doubles apart (0: contiguous, = n)
 void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
-                                double *out)
+                                double *out, int64_t stride)
 {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_lz_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, V, coef, m, out);
+  hipLaunchKernelGGL(k_lz_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, V, coef, m, out,
+                     (long)(stride > 0 ? stride : n));
 }
 
 int rbl_gmres_max_vectors(void) { return GM_MAXK; }

@@ -253,6 +253,60 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
 }
 
 // ---------------------------------------------------------------------------
+// The same for TWO right-hand sides at once: the scalar coefficients (~60 of the ~84 fp64 instructions of
+// a wall pair) are shared, only the 20-FMA application is repeated.  Used for the two Brownian increments
+// of the stochastic step (lock-step Lanczos) and for 2-3 simultaneous vectors in general.
+// ---------------------------------------------------------------------------
+struct RblV3 {
+  double x, y, z;
+};
+
+template <bool WALL, bool UNIT = false, bool NEARCHK = true>
+__device__ __forceinline__ void rbl_pair_sym2(const RblParams &P, double xi, double yi, double zi, const RblV3 &Fi0,
+                                              const RblV3 &Fi1, double xj, double yj, double zj, const RblV3 &Fj0,
+                                              const RblV3 &Fj1, RblV3 &ui0, RblV3 &ui1, RblV3 &uj0, RblV3 &uj1,
+                                              unsigned &flags, const RblWallK &K = rbl_wall_k_literal())
+{
+  const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
+  const double q = __builtin_fma(dy, dy, dx * dx);
+  const double r2 = __builtin_fma(dz, dz, q);
+  const double invr = rbl_rsqrt(r2);
+  const double invr2 = invr * invr;
+  const double s = UNIT ? invr : P.a * invr;
+  const double s3 = (s * s) * s;
+  double A = __builtin_fma(s3, 2.0 / 3.0, s);
+  double Bc = __builtin_fma(s3, -2.0, s) * invr2;
+  if (NEARCHK && __builtin_expect(__any(r2 < P.four_a2), 0)) {
+    const double rr = r2 * invr;
+    const bool far = r2 >= P.four_a2;
+    A = far ? A : __builtin_fma(rr, P.c_near_A, 4.0 / 3.0);
+    Bc = far ? Bc : invr * P.c_near_B;
+    if (r2 < P.tiny2) flags |= RBL_FLAG_OVERLAP;
+  }
+  if (!WALL) {
+    auto app = [&](const RblV3 &F, RblV3 &u) {
+      const double tB = Bc * __builtin_fma(dz, F.z, __builtin_fma(dy, F.y, dx * F.x));
+      u.x = __builtin_fma(A, F.x, __builtin_fma(tB, dx, u.x));
+      u.y = __builtin_fma(A, F.y, __builtin_fma(tB, dy, u.y));
+      u.z = __builtin_fma(A, F.z, __builtin_fma(tB, dz, u.z));
+    };
+    app(Fj0, ui0); app(Fj1, ui1); app(Fi0, uj0); app(Fi1, uj1);
+    return;
+  }
+  double cF, beta, gxz, gzx, mzz;
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
+  auto app = [&](const RblV3 &F, RblV3 &u, double g_lat, double g_z) {   // M F (g_lat = gxz, g_z = gzx) or M^T F (swapped)
+    const double p = __builtin_fma(dy, F.y, dx * F.x);
+    const double l = __builtin_fma(beta, p, g_lat * F.z);
+    u.x = __builtin_fma(cF, F.x, __builtin_fma(l, dx, u.x));
+    u.y = __builtin_fma(cF, F.y, __builtin_fma(l, dy, u.y));
+    u.z = __builtin_fma(mzz, F.z, __builtin_fma(g_z, p, u.z));
+  };
+  app(Fj0, ui0, gxz, gzx); app(Fj1, ui1, gxz, gzx);      // U_i += M F_j
+  app(Fi0, uj0, gzx, gxz); app(Fi1, uj1, gzx, gxz);      // U_j += M^T F_i
+}
+
+// ---------------------------------------------------------------------------
 // Full 3x3 block of one ORDERED pair (i <- j, h = z_j) from the fast coefficient
 // arithmetic, row-major m[9], unscaled.  Used by the multi-RHS kernel, where the
 // block is the A-operand of fp64 MFMAs:  M = cF I + Bc d d^T + f2 e e^T + f3 e z^T

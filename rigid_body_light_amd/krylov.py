@@ -296,11 +296,20 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
             A = lambda v: B * self._product(r_n, B * v)
         W1, W2, Wr = W[:n3], W[n3:2 * n3], W[2 * n3:]
         self.lanczos_iterations = []
-        mw1, it1, _ = lanczos_mhalf(A, W1, self.lmax, self.ltol)                      # :927
-        self.lanczos_iterations.append(it1)
-        if split_rand:                                                                # :934-936
-            mw2, it2, _ = lanczos_mhalf(A, W2, self.lmax, self.ltol)
-            self.lanczos_iterations.append(it2)
+        if split_rand:   # :927-936 -- the two increments in lock step: one two-vector product per iteration
+            def A2(V2):                                   # (2, n3) -> (2, n3), sharded pairs, shared pair coefficients
+                X = (V2 if self.wall else V2 * B).contiguous()
+                part = torch.empty_like(X)
+                self.ctx.apply_M_sym_multi(X.data_ptr(), r_n.data_ptr(), n3 // 3, 2, self.sm.rank, self.sm.world,
+                                           part.data_ptr())
+                out = self.sm.all_reduce_sum(part)
+                return out if self.wall else out * B
+            Y, its, _ = lanczos_mhalf_multi(A2, torch.stack([W1, W2]), self.lmax, self.ltol)
+            mw1, mw2 = Y[0], Y[1]
+            self.lanczos_iterations = [its, its]
+        else:
+            mw1, it1, _ = lanczos_mhalf(A, W1, self.lmax, self.ltol)                  # :927
+            self.lanczos_iterations.append(it1)
         uom = self.ctx.Kinv_x_V(Wr.cpu().numpy(), self.nb)                            # M_RFD :776-794
         Mpm = [self._product(self._positions_at(*self.ctx.update_X_Q(sg * 0.5 * delta * uom, self.nb)), Wr)
                for sg in (1.0, -1.0)]

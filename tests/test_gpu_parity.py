@@ -142,7 +142,7 @@ def test_apply_M_cfg2_size_vs_oracle_rows(orc):
 
 
 @pytest.mark.parametrize("wall", [False, True])
-@pytest.mark.parametrize("nrhs", [1, 5, 16, 19])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 16, 19])      # 2, 3: two-vector symmetric kernel; >= 4: MFMA kernel
 def test_apply_M_multi_mfma_vs_oracle(orc, wall, nrhs):
     """Multi-RHS product (fp64-MFMA kernel for >= 4 vectors, 16 per pass) against the oracle."""
     from rigid_body_light_amd import RigidBody, make_config
