@@ -432,17 +432,17 @@ def main():
                          "frac": achieved / PEAK_FP64_TFLOPS,
                          # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
                          # gfx950 correction + WRITE_SIZE, KB -> B): profiles/r01_bench_cfg3_sym_pmc_summary.txt
-                         "traffic": (2 * 162209e3 + 1.70253e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
+                         "traffic": (2 * 164947e3 + 1.70253e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
                          "kernel_ms": kern_ms,
                          "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch),
                          # executed-instruction view of the same launch (PMC, same profile file): what the VALU actually issued
-                         "executed": ({"valu_insts_per_launch": 1.1555e10, "valu_insts_per_ordered_pair": 44.9,
-                                       "valu_issue_cycles_frac": 0.895, "sustained_clock_ghz": 2.04,
+                         "executed": ({"valu_insts_per_launch": 1.1108e10, "valu_insts_per_ordered_pair": 43.1,
+                                       "valu_issue_cycles_frac": 0.90, "sustained_clock_ghz": 2.13,
                                        "source": "profiles/r01_bench_cfg3_sym_pmc_summary.txt (SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}
                                       if (args.config == "cfg3" and world == 1 and use_sym) else None),
                          "note": "fp64 VALU-issue bound; on gfx950 fp64 VALU and fp64 MFMA share one pipe (SQ_VALU_MFMA_COEXEC_CYCLES = 0), "
                                  "so `peak` is the fp64 vector = fp64 MFMA peak.  frac > 1 because `achieved` prices the launch at the "
-                                 "reference's 204 flop per ordered pair while the kernel issues 45 VALU instructions per ordered pair "
+                                 "reference's 204 flop per ordered pair while the kernel issues 43 VALU instructions per ordered pair "
                                  "(each unordered pair once, division-free Horner-form algebra): see `executed` -- the VALU issues "
                                  "90 % of the kernel's cycles, the two quarter-rate v_rsq_f64 per pair account for most of the rest"},
         }
