@@ -99,7 +99,7 @@ def timestep_mode(args, dev, world=1, rank=0):
     lanczos_its = None
     if brownian:   # stochastic midpoint step: 2 M^{1/2}W + M_RFD + Kinv, then the saddle solve at q^{n+1/2}
         from rigid_body_light_amd.krylov import BrownianStepper, ShardedBrownianStepper
-        method = 0 if args.mhalf == "cholesky" else 1
+        method = {"cholesky": 0, "lanczos": 1, "lanczos_pc": 2}[args.mhalf]
         if world > 1 or args.sharded_driver:
             if method == 0:
                 raise SystemExit("the sharded Brownian step uses the Lanczos square root")
@@ -111,7 +111,7 @@ def timestep_mode(args, dev, world=1, rank=0):
             ctx.set_lanczos(100, 1e-3)
             bst = BrownianStepper(ctx, nb, nblb, dev, native=(not args.graph and (args.native or args.solver == "native")))
             stp_step = lambda k: bst.step(Fb, seed=k, method=method, iters=iters, rtol=rtol)
-            lanczos_its = (lambda: [ctx.lanczos_report()[0]]) if method == 1 else None
+            lanczos_its = (lambda: [ctx.lanczos_report()[0]]) if method != 0 else None
     else:
         if world > 1:
             stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
@@ -259,7 +259,8 @@ def main():
     ap.add_argument("--nvec", type=int, default=1, help="--mode brownian: independent noise vectors advanced in lockstep "
                     "(>= 4 uses the fp64-MFMA multi-RHS product; 1 GPU)")
     ap.add_argument("--kBT", type=float, default=0.0, help="--mode timestep: > 0 runs the stochastic midpoint (Brownian) step")
-    ap.add_argument("--mhalf", default="lanczos", choices=["lanczos", "cholesky"], help="square root used by the Brownian step")
+    ap.add_argument("--mhalf", default="lanczos_pc", choices=["lanczos_pc", "lanczos", "cholesky"],
+                    help="square root used by the Brownian step (lanczos_pc: block-Jacobi preconditioned Lanczos)")
     ap.add_argument("--sharded-driver", action="store_true", help="use the multi-GPU Brownian driver also at N = 1")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
     ap.add_argument("--solver", default="native", choices=["native", "torch", "graph"],

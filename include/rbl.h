@@ -128,6 +128,9 @@ int rbl_rotne_prager_tensor(rbl_ctx *ctx, const double *r_vecs, int64_t n3,
  * RBL_MHALF_LANCZOS is matrix-free (a different square root of the same M). */
 #define RBL_MHALF_CHOLESKY 0
 #define RBL_MHALF_LANCZOS 1
+/* Lanczos on the block-Jacobi preconditioned matrix S = L^-1 M L^-T (L L^T = per-body mobility), then
+ * x = B L S^{1/2} W: covariance B M B exactly, a handful of iterations instead of ~30 (own configuration only) */
+#define RBL_MHALF_LANCZOS_PC 2
 int rbl_M_half_W(rbl_ctx *ctx, const double *W, uint64_t seed, int method, double *out);
 
 /* same on caller-supplied positions (n3 free, like apply_M) */
@@ -243,6 +246,14 @@ int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /*
 int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */
 int rbl_apply_PC_dev(rbl_ctx *ctx, const double *d_in, double *d_out);        /* apply_PC :589, diagonal PC */
 int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /* src/Rigid.py:73-80 */
+/* Per-body Cholesky factors L L^T = M_body of the object's own configuration (wall term per wall_PC, undamped;
+ * the block-diagonal preconditioner's factors), applied to a blob vector d_in[n3] -> d_out[n3]:
+ * mode 0: (L L^T)^-1 x, 1: L^-1 x, 2: L^-T x, 3: L x.  rbl_set_no_damp(ctx, 1) makes the matvec entry points
+ * apply the plain wall-corrected M (no damping B) until switched off again: together they let a caller compose
+ * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product. */
+int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode);
+int rbl_set_no_damp(rbl_ctx *ctx, int on);
+
 /* Right-preconditioned GMRES(max_iter <= 255, no restart) on the saddle operator of the object's own
  * configuration (src/Rigid.py:73-80 is what a caller's Krylov solver applies; the reference ships no solver):
  * solves [M -K; K^T 0] x = rhs with P^-1 = apply_PC, all vectors in HBM.  rtol <= 0: exactly max_iter

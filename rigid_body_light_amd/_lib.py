@@ -53,6 +53,8 @@ def lib():
         L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
         L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
+        L.rbl_block_solve_dev.argtypes = [vp, vp, vp, C.c_int]
+        L.rbl_set_no_damp.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
@@ -125,6 +127,13 @@ class DeviceContext:
         U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_evolve_X_Q(self.h, U.ctypes.data))
 
+    def block_solve(self, din, dout, mode):
+        """per-body Cholesky factors L L^T = M_body: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x"""
+        self._chk(self.L.rbl_block_solve_dev(self.h, din, dout, mode))
+
+    def set_no_damp(self, on):
+        self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))
+
     def gmres_saddle(self, d_rhs, max_iter, rtol, d_x):
         """native right-preconditioned GMRES on the saddle operator -> (iterations, residual estimate)"""
         it, res = C.c_int(0), C.c_double(0.0)
@@ -186,7 +195,7 @@ class DeviceContext:
         self._chk(self.L.rbl_trmv_lower_dev(self.h, dL, n, dW, dout))
 
     def M_half_W(self, dr, n_blobs, dW, method, dout):
-        self._chk(self.L.rbl_M_half_W_dev(self.h, dr, n_blobs, dW, {"cholesky": 0, "lanczos": 1}[method], dout))
+        self._chk(self.L.rbl_M_half_W_dev(self.h, dr, n_blobs, dW, {"cholesky": 0, "lanczos": 1, "lanczos_pc": 2}[method], dout))
 
     def set_lanczos(self, max_iter, tol):
         self._chk(self.L.rbl_set_lanczos(self.h, max_iter, tol))

@@ -23,6 +23,14 @@ using darr = py::array_t<double, py::array::c_style | py::array::forcecast>;
 
 namespace {
 
+static int mhalf_method(const std::string &method)
+{
+  if (method == "cholesky") return RBL_MHALF_CHOLESKY;
+  if (method == "lanczos") return RBL_MHALF_LANCZOS;
+  if (method == "lanczos_pc") return RBL_MHALF_LANCZOS_PC;
+  throw std::runtime_error("M_half_W: method must be 'cholesky', 'lanczos' or 'lanczos_pc'");
+}
+
 struct CManyBodies {
   rbl_ctx *ctx;
   CManyBodies() : ctx(rbl_create())
@@ -153,8 +161,7 @@ struct CManyBodies {
 
   darr M_half_W(py::object W, uint64_t seed, const std::string &method)   // :661 (unbound in the reference)
   {
-    const int m = method == "lanczos" ? RBL_MHALF_LANCZOS : RBL_MHALF_CHOLESKY;
-    if (method != "lanczos" && method != "cholesky") throw std::runtime_error("M_half_W: method must be 'cholesky' or 'lanczos'");
+    const int m = mhalf_method(method);
     darr out(n3());
     int rc;
     if (W.is_none()) {
@@ -172,8 +179,7 @@ struct CManyBodies {
 
   darr M_half_W_r(darr r_vecs, darr W, const std::string &method)
   {
-    if (method != "lanczos" && method != "cholesky") throw std::runtime_error("M_half_W_r: method must be 'cholesky' or 'lanczos'");
-    const int m = method == "lanczos" ? RBL_MHALF_LANCZOS : RBL_MHALF_CHOLESKY;
+    const int m = mhalf_method(method);
     if (W.size() != r_vecs.size()) throw std::runtime_error("M_half_W_r: W and r_vecs must have the same length");
     darr out(W.size());
     int rc;
@@ -225,7 +231,7 @@ struct CManyBodies {
     const py::ssize_t nb = n_bod();
     if (Slip.size() != n3()) throw std::runtime_error("RHS_and_Midpoint: Slip must have length 3*N_blobs");
     if (Force.size() != 6 * nb) throw std::runtime_error("RHS_and_Midpoint: Force must have length 6*N_bod");
-    const int m = method == "lanczos" ? RBL_MHALF_LANCZOS : RBL_MHALF_CHOLESKY;
+    const int m = mhalf_method(method);
     darr RHS(n3() + 6 * nb), X(3 * nb), Q(4 * nb);
     darr Wa;
     const double *Wp = nullptr;

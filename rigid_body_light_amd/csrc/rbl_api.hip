@@ -155,10 +155,17 @@ static int finish_and_check(rbl_ctx *c)
 // Enqueue rows [row_begin,row_end) of U = [B] M [B] F on the context stream, choosing the
 // kernel variant: 1 = symmetric (unordered pairs, needs the full row range), 0 = ordered rows.
 // tune_variant: 0 = heuristic, 1 = force ordered, 2 = force symmetric.
+static RblParams ctx_params(const rbl_ctx *c)
+{
+  RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  P.no_damp = c->no_damp ? 1 : 0;
+  return P;
+}
+
 static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
                            int64_t row_begin, int64_t row_end, double *d_out)
 {
-  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  const RblParams P = ctx_params(c);
   const bool full = (row_begin == 0 && row_end == nbl);
   bool sym = full;   // measured faster at every size, N = 120 ... 128 400 (profiles/r01_apply_M_all_configs.md)
   // its row/column-sum slabs grow like N^2/128 * 24 B (1.7 GB at 128 400 blobs, ~100 GB at 10^6):
@@ -197,7 +204,7 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
     const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2) <= c->sym_workspace_budget;
     for (; sym2 && k + 2 <= nrhs; k += 2) {
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2)))) return rc;
-      rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
+      rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
                              d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2);
     }
     for (; k < nrhs; ++k)
@@ -205,7 +212,7 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
     return RBL_OK;
   }
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_mrhs_bytes(nbl, c->n_cu)))) return rc;
-  const RblParams P = rbl_make_params(c->S.a, c->S.eta);
+  const RblParams P = ctx_params(c);
   for (int k = 0; k < nrhs; k += 16) {
     const int nb = (nrhs - k < 16) ? nrhs - k : 16;
     rbl_launch_apply_M_mrhs(c->stream, P, wall, d_F + (size_t)k * n3, d_r, nbl, nb, d_out + (size_t)k * n3,
@@ -264,12 +271,12 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   S.N_blb = N_blb;
   S.params_set = true;
   S.M_scale = 1.0;
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
   return RBL_OK;
 }
 
 int rbl_set_blk_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.block_pc = v != 0; c->S.pc_set = false; c->dev_pc_valid = false; return RBL_OK; }
-int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; c->dev_pc_valid = false; return RBL_OK; }
+int rbl_set_wall_pc(rbl_ctx *c, int v) { if (!c) return RBL_ERR_ARG; c->S.wall = v != 0; c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }
 
 int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
 {
@@ -285,7 +292,7 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
   }
   S.cfg_set = true;
   S.K_set = false;
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
   // NOTE the reference does NOT reset PC_mat_Set here (SURVEY.md 8b "state quirks");
   // a stale preconditioner after set_config is a trap, so we do invalidate it.
   S.pc_set = false;
@@ -558,7 +565,7 @@ int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
   rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
   S.X.swap(Xo);
   S.Q.swap(Qo);
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
   rc = rbl_body_set_K(S, c->last_error);                          // :876
   S.pc_set = false;                                               // :877
   return rc;
@@ -668,11 +675,31 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 //   LANCZOS : Krylov approximation of the symmetric square root with the
 //             matrix-free matvec (no O(n^2) memory).
 // ---------------------------------------------------------------------------
+static int sync_bodies(rbl_ctx *c);
+static int pc_block_factors(rbl_ctx *c);
+
 // y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
+// precond: y_v = L^-1 M L^-T x_v with the per-body Cholesky factors L L^T = M_body (block Jacobi), M undamped
 static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
-                       const double *d_x, double *d_y, double *d_tmp, int nvec = 1)
+                       const double *d_x, double *d_y, double *d_tmp, int nvec = 1, bool precond = false)
 {
   const int64_t n = 3 * nbl;
+  if (precond) {
+    const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
+    const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
+    int rc;
+    for (int v = 0; v < nvec; ++v)
+      if ((rc = rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, msz, Li, d_x + (size_t)v * n, d_tmp + (size_t)v * n, m, 2)))
+        return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+    c->no_damp = true;
+    rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
+    c->no_damp = false;
+    if (rc) return rc;
+    for (int v = 0; v < nvec; ++v)
+      if ((rc = rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, msz, Li, d_y + (size_t)v * n, d_y + (size_t)v * n, m, 1)))
+        return rc;
+    return RBL_OK;
+  }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
     rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, d_x + (size_t)v * n, d_tmp + (size_t)v * n);
@@ -707,8 +734,11 @@ static int lanczos_coeffs(rbl_ctx *c, const std::vector<double> &alpha, const st
 // reads them back only to test convergence: every iteration when a product is expensive, every 4th when the
 // iteration is launch-bound (small systems), so the stream is not drained twice per iteration.
 static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out,
-                             int nvec = 1)
+                             int nvec = 1, bool precond = false)
 {
+  // precond (RBL_MHALF_LANCZOS_PC): Lanczos on S = L^-1 M L^-T (eigenvalues clustered around 1: a handful of
+  // iterations), then  x = B L S^{1/2} W, whose covariance is B L S L^T B = B M B exactly -- another valid
+  // square root of the same matrix (Chow & Saad's preconditioned sampling).
   // nvec = 1 or 2 independent recurrences advanced in lock step: with two (the Brownian step's W1, W2) every
   // iteration is ONE two-vector product whose pair coefficients are shared.
   const int64_t n = 3 * nbl;
@@ -736,7 +766,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   int m = 0;
   bool done = false;
   for (int it = 0; it < maxit && !done; ++it) {
-    if ((rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec))) return rc;
+    if ((rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec, precond))) return rc;
     for (int v = 0; v < nvec; ++v)
       rbl_launch_lanczos_step(c->stream, n, u + (size_t)v * n, Vp(it, v), it > 0 ? Vp(it - 1, v) : nullptr,
                               it > 0 ? d_beta(v) + (it - 1) : nullptr, d_alpha(v) + it, d_beta(v) + it, Vp(it + 1, v),
@@ -784,6 +814,14 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   RBL_HIP(c, hipStreamSynchronize(c->stream));            // y_cur is pageable host memory
   for (int v = 0; v < nvec; ++v)
     rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, d_out + (size_t)v * n, (int64_t)nvec * n);
+  if (precond) {   // x = B (L y)
+    const int64_t mb = 3 * (int64_t)c->S.N_blb;
+    for (int v = 0; v < nvec; ++v) {
+      double *o = d_out + (size_t)v * n;
+      if ((rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_blkL.p, mb, c->S.N_bod, mb * mb, o, tmp, mb))) return rc;
+      rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, tmp, o);
+    }
+  }
   return RBL_OK;
 }
 
@@ -794,12 +832,19 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
 {
   const int64_t n = 3 * nbl;
   int rc;
-  if (method == RBL_MHALF_LANCZOS) {   // pairs of vectors in lock step (shared pair coefficients), a single one alone
-    int v = 0;
+  if (method == RBL_MHALF_LANCZOS || method == RBL_MHALF_LANCZOS_PC) {
+    const bool pc = method == RBL_MHALF_LANCZOS_PC;
+    if (pc) {   // block-Jacobi factors of the object's own configuration: d_r must be its own blob positions
+      if (!c->S.cfg_set || nbl != (int64_t)c->S.N_bod * c->S.N_blb)
+        return rbl_fail(c, RBL_ERR_SIZE, "M_half_W (preconditioned Lanczos) works on the object's own configuration only");
+      if ((rc = sync_bodies(c))) return rc;
+      if ((rc = pc_block_factors(c))) return rc;
+    }
+    int v = 0;   // pairs of vectors in lock step (shared pair coefficients), a single one alone
     for (; v + 2 <= nvec; v += 2)
-      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 2))) return rc;
+      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 2, pc))) return rc;
     for (; v < nvec; ++v)
-      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 1))) return rc;
+      if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 1, pc))) return rc;
     return RBL_OK;
   }
   if (method != RBL_MHALF_CHOLESKY) return rbl_fail(c, RBL_ERR_ARG, "M_half_W: unknown method");
@@ -918,6 +963,29 @@ int rbl_apply_M_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int6
   return apply_M_multi_enqueue(c, c->S.wall, d_F, d_r, n_blobs, nrhs, d_out);
 }
 
+// ---- per-body (block-Jacobi) Cholesky factors of the object's own configuration, for callers that compose the
+// preconditioned square root themselves (the multi-GPU driver): L L^T = M_body (wall term per wall_PC, undamped)
+int rbl_block_solve_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (mode < 0 || mode > 3 || !d_in || !d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x");
+  if ((rc = pc_block_factors(c))) return rc;
+  const int64_t m = 3 * (int64_t)c->S.N_blb;
+  const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
+  rc = mode == 3 ? rbl_launch_block_trmv(c->stream, L, m, c->S.N_bod, m * m, d_in, d_out, m)
+                 : rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, m * m, Li, d_in, d_out, m, mode);
+  if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
+  return RBL_OK;
+}
+
+// transient switch: the matvec entry points skip the damping B (plain, wall-corrected M) while it is on
+int rbl_set_no_damp(rbl_ctx *c, int on)
+{
+  if (!c) return RBL_ERR_ARG;
+  c->no_damp = on != 0;
+  return RBL_OK;
+}
+
 int rbl_apply_M_sym_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_t n_blobs, int nrhs,
                               int i_first, int i_step, double *d_out)
 {
@@ -926,7 +994,7 @@ int rbl_apply_M_sym_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, 
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step || nrhs < 1 || nrhs > 2)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_multi_dev: need n_blobs > 0, 0 <= i_first < i_step, nrhs 1 or 2");
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs)))) return rc;
-  rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs, i_first,
+  rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
                          i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs);
   return RBL_OK;
 }
@@ -939,7 +1007,7 @@ int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_dev: need n_blobs > 0 and 0 <= i_first < i_step");
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step)))) return rc;
-  rbl_launch_apply_M_sym(c->stream, rbl_make_params(c->S.a, c->S.eta), c->S.wall, d_F, d_r, n_blobs, i_first,
+  rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
                          i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err);
   return RBL_OK;
 }
@@ -1006,6 +1074,7 @@ static int sync_bodies(rbl_ctx *c)
                        (double *)c->d_pos.p);
   c->dev_bodies_valid = true;
   c->dev_pc_valid = false;
+  c->dev_blk_valid = false;
   return RBL_OK;
 }
 
@@ -1038,21 +1107,33 @@ int rbl_KT_x_Lam_dev(rbl_ctx *c, const double *d_lam, double *d_out)
 
 // Block_diag_invM on the device (:461-487): per-body dense mobility (batched k_build_M), batched
 // in-place Cholesky on the matrix cores, then invM_b v = (L L^T)^-1 v by k_block_solve.
-static int pc_block_build(rbl_ctx *c)
+// per-body mobility (wall-corrected per wall_PC, undamped) and its Cholesky factor, for every body at once
+static int pc_block_factors(rbl_ctx *c)
 {
+  if (c->dev_blk_valid) return RBL_OK;
   const RblBodyState &S = c->S;
-  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m;
   int rc;
   if ((rc = rbl_dev_reserve(c, c->d_blkL, sizeof(double) * (size_t)msz * S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_blkLinv, rbl_cholesky_batched_work_bytes(m, S.N_bod)))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
   const RblParams P = rbl_make_params(S.a, S.eta);
   rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p, S.N_blb, S.N_bod, (double *)c->d_blkL.p,
                              msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, (double *)c->d_blkL.p, m, S.N_bod, msz, c->d_err, (double *)c->d_blkLinv.p);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
+  c->dev_blk_valid = true;
+  return RBL_OK;
+}
+
+static int pc_block_build(rbl_ctx *c)
+{
+  const RblBodyState &S = c->S;
+  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  int rc;
+  if ((rc = pc_block_factors(c))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
   // Ninv_b = K_b^T invM_b K_b, column by column (bodies do not couple), then its 6x6 Cholesky; the six
   // solved columns invM_b K_b are kept (d_pcMK): every application needs invM K U
   double *w1 = (double *)c->d_pcw.p, *cols = w1 + 2 * n3, *Uunit = cols + 36 * (size_t)S.N_bod;

@@ -659,7 +659,7 @@ constexpr int BS_T = 1024;   // threads per matrix: the sweeps are latency-bound
 __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
                                                      const double *__restrict__ in, double *__restrict__ out,
-                                                     long vec_stride)
+                                                     long vec_stride, int mode /* 0: L L^T, 1: L only, 2: L^T only */)
 {
   extern __shared__ double y[];                      // n doubles + IB scratch
   double *tbuf = y + n;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
   for (long e = t; e < n; e += BS_T) y[e] = v[e];
   __syncthreads();
   const int nsteps = (int)((n + IB - 1) / IB);
-  for (int s = 0; s < nsteps; ++s) {                 // ---- forward: L y' = v
+  for (int s = 0; s < nsteps && mode != 2; ++s) {    // ---- forward: L y' = v
     const long k = (long)s * IB;
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     }
     __syncthreads();
   }
-  for (int s = nsteps - 1; s >= 0; --s) {            // ---- backward: L^T x = y'
+  for (int s = nsteps - 1; s >= 0 && mode != 1; --s) {   // ---- backward: L^T x = y'
     const long k = (long)s * IB;
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
@@ -747,13 +747,49 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
 }
 }  // namespace
 
+// y_b = L_b x_b for every matrix of the batch (lower-triangular product): one workgroup per matrix, x in LDS,
+// column sweep with rows spread over the threads.
+__global__ __launch_bounds__(BS_T) void k_block_trmv(const double *__restrict__ L, long n, long strideA,
+                                                     const double *__restrict__ in, double *__restrict__ out,
+                                                     long vec_stride)
+{
+  extern __shared__ double x[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double *Lb = L + (size_t)b * (size_t)strideA;
+  const double *v = in + (size_t)b * (size_t)vec_stride;
+  for (long e = t; e < n; e += BS_T) x[e] = v[e];
+  __syncthreads();
+  double *o = out + (size_t)b * (size_t)vec_stride;
+  for (long r = t; r < n; r += BS_T) {
+    double a0 = 0.0, a1 = 0.0;
+    const double *row = Lb + r;
+    long c = 0;
+    for (; c + 1 <= r; c += 2) {
+      a0 = __builtin_fma(row[(size_t)c * n], x[c], a0);
+      a1 = __builtin_fma(row[(size_t)(c + 1) * n], x[c + 1], a1);
+    }
+    if (c <= r) a0 = __builtin_fma(row[(size_t)c * n], x[c], a0);
+    o[r] = a0 + a1;
+  }
+}
+
+int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
+                          double *d_out, int64_t vec_stride)
+{
+  if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
+  hipLaunchKernelGGL(k_block_trmv, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)n, st, d_L, (long)n, (long)strideA,
+                     d_in, d_out, (long)vec_stride);
+  return RBL_OK;
+}
+
+// mode 0: x = (L L^T)^-1 v ;  1: x = L^-1 v ;  2: x = L^-T v
 int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
-                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride)
+                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode)
 {
   if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
   hipLaunchKernelGGL(k_block_solve, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)(n + IB), st, d_L, (long)n,
-                     (long)strideA, d_Linv, (long)(nsteps * IB * IB), d_in, d_out, (long)vec_stride);
+                     (long)strideA, d_Linv, (long)(nsteps * IB * IB), d_in, d_out, (long)vec_stride, mode);
   return RBL_OK;
 }
 

@@ -72,10 +72,12 @@ struct rbl_ctx {
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
+  bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
   RblCholAux chol_aux;
+  bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
   int tune_jsplit = 0;
@@ -138,7 +140,9 @@ size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch);
 int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
                                 unsigned *d_err, double *d_Linv);
 int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
-                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride);
+                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode = 0);
+int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
+                          double *d_out, int64_t vec_stride);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
                            double *d_out, double *d_part);
 size_t rbl_trmv_part_bytes(int64_t n);

@@ -41,6 +41,7 @@ __device__ __forceinline__ RblParams unit_params(const RblParams &P)
 
 __device__ __forceinline__ double damp_of(const RblParams &P, double z)
 {
+  if (P.no_damp) return 1.0;
   return (z >= P.a) ? 1.0 : z / P.a;  // c_rigid_obj.cpp:629-633
 }
 
@@ -1007,6 +1008,7 @@ RblParams rbl_make_params(double a, double eta)
   P.tiny2 = (1e-12 * a) * (1e-12 * a);
   P.c_near_A = -0.375 / a;
   P.c_near_B = 0.125 / a;
+  P.no_damp = 0;
   return P;
 }
 

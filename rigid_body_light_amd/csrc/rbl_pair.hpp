@@ -30,6 +30,7 @@ struct RblParams {
   double tiny2;    // (1e-12 a)^2, overlap abort c_rigid_obj.cpp:53
   double c_near_A; // -(3/8)/a   : 4/3 (1 - 9/32 r/a) = 4/3 + c_near_A r
   double c_near_B; // (1/8)/a    : 4/3 * 3/32 (a/r) / a^2 = c_near_B / r
+  int no_damp;     // 1: the matvec kernels skip the damping B (plain wall-corrected M), used by the preconditioned square root
 };
 
 // ---------------------------------------------------------------------------

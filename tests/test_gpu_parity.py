@@ -772,8 +772,9 @@ def test_brownian_step_vs_dense_numpy(orc, shell12, wall):
     assert np.linalg.norm(Xg - X) > 1e-4                     # the bodies did move
 
 
+@pytest.mark.parametrize("precondition", [False, True])
 @pytest.mark.parametrize("wall", [False, True])
-def test_sharded_brownian_step_equals_library_step(shell12, wall):
+def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
     """krylov.ShardedBrownianStepper (the multi-GPU composition; here world = 1) == BrownianStepper, both with
     a tightly converged Lanczos square root (the symmetric root is unique, so they must agree)."""
     import torch
@@ -790,13 +791,13 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall):
         ctx.set_config(X, Q)
         if sharded:
             st = ShardedBrownianStepper(ctx, ShardedMobility(nb, 12, device=dev, ctx=ctx), nb, 12, dev, a, wall, kBT, dt,
-                                        lanczos_tol=1e-12, lanczos_max_iter=144)
+                                        lanczos_tol=1e-12, lanczos_max_iter=144, precondition=precondition)
             m, resid = st.step(force, slip=slip, W=W, iters=80, rtol=1e-11)
             assert len(st.lanczos_iterations) == 2
         else:
             ctx.set_lanczos(144, 1e-12)
             st = BrownianStepper(ctx, nb, 12, dev)
-            m, resid = st.step(force, slip=slip, W=W, method=1, iters=80, rtol=1e-11)
+            m, resid = st.step(force, slip=slip, W=W, method=2 if precondition else 1, iters=80, rtol=1e-11)
         assert resid < 1e-11
         out.append(ctx.get_config(nb))
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9)
@@ -835,3 +836,41 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub, Ua) < 1e-9 and abs(ra - rb) < 1e-9 * max(ra, 1e-30) + 1e-12
     assert rb2 < 1e-11 and abs(mb - ma) <= 3            # the native loop tests convergence every 4th iteration
     assert rel(Ub2, Ua2) < 1e-8
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
+    """method 'lanczos_pc': x = B L S^{1/2} W with S = L^-1 M L^-T (L L^T = per-body mobility) -- against the same
+    expression assembled from the oracle's dense matrix; and its covariance factor is exact: (B L S^1/2)(...)^T = B M B."""
+    from oracle import oracle as onp
+    nb = 5
+    X, Q = random_positions(nb, wall=wall, seed=160)
+    if wall:
+        X[:, 2] += 1.3
+    else:
+        X[:, 2] = np.abs(X[:, 2]) + 0.6          # some blobs inside the damping zone 0 < z < a, none below z = 0
+    cb = create_solver(X, Q, wall_PC=wall)
+    cb.cb.set_lanczos(36 * nb, 1e-13)
+    n3 = 36 * nb
+    W = np.random.default_rng(161).standard_normal(n3)
+    x = cb.M_half_W(W, method="lanczos_pc")
+    r = cb.get_blob_positions().reshape(-1)
+    M = orc.rotne_prager_tensor(r, 1.0, 1.0, wall)
+    B = orc.damp(r, 1.0)
+    L = np.zeros_like(M)
+    for b in range(nb):
+        sl = slice(36 * b, 36 * (b + 1))
+        L[sl, sl] = np.linalg.cholesky(M[sl, sl])
+    Li = np.linalg.inv(L)
+    S = Li @ M @ Li.T
+    lam, Z = np.linalg.eigh(0.5 * (S + S.T))
+    Sh = (Z * np.sqrt(lam)) @ Z.T
+    ref = B * (L @ (Sh @ W))
+    assert rel(x, ref) < 1e-9
+    G = (B[:, None] * L) @ Sh                                         # the square root this method realises
+    assert np.linalg.norm(G @ G.T - (B[:, None] * M) * B[None, :]) < 1e-10 * np.linalg.norm(M)
+    it, res = cb.cb.lanczos_report()
+    cb.cb.set_lanczos(100, 1e-3)
+    cb.M_half_W(W, method="lanczos_pc"); it_pc = cb.cb.lanczos_report()[0]
+    cb.M_half_W(W, method="lanczos"); it_plain = cb.cb.lanczos_report()[0]
+    assert it_pc <= it_plain

@@ -35,7 +35,7 @@ def main():
             m, resid = st.step(Fb, W=W, iters=150, rtol=1e-10)
         else:
             ctx.set_lanczos(300, 1e-11)
-            m, resid = BrownianStepper(ctx, nb, nblb, dev).step(Fb, W=W, method=1, iters=150, rtol=1e-10)
+            m, resid = BrownianStepper(ctx, nb, nblb, dev).step(Fb, W=W, method=2, iters=150, rtol=1e-10)   # preconditioned square root, as the sharded driver
         out.append(ctx.get_config(nb))
     dX = float(np.abs(out[0][0] - out[1][0]).max()); dQ = float(np.abs(out[0][1] - out[1][1]).max())
     moved = float(np.abs(out[0][0] - c["X"]).max())
