@@ -211,14 +211,19 @@ def brownian_mode(args, dev, world, rank):
             "lanczos_iterations": its, "mf_gflops": args.nvec * its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
         return
     its = 0
+    from rigid_body_light_amd.krylov import sharded_mhalf_W
+    pc = args.mhalf == "lanczos_pc"       # block-Jacobi preconditioned square root (default) or plain Lanczos
+    if args.mhalf == "cholesky":
+        raise SystemExit("--mode brownian measures the matrix-free square roots (--mhalf lanczos_pc | lanczos)")
+    one = lambda: sharded_mhalf_W(ctx, sm, sm.r_full, W[None, :], c["a"], wall, 1e-3, 100, pc)
     for _ in range(args.warmup):
-        lanczos_mhalf(A, W, 100, 1e-3)
+        one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        y, its, ch = lanczos_mhalf(A, W, 100, 1e-3)
+        y, its = one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -229,8 +234,8 @@ def brownian_mode(args, dev, world, rank):
     if rank == 0:
         sec = float(sec.item())
         print(json.dumps({
-            "metric": "Brownian increments/sec (M^{1/2} W by Lanczos to 1e-3, %d iterations), %d x shell_N_%d, %s, fp64"
-                      % (its, nb, nblb, "wall-corrected" if wall else "free-space"),
+            "metric": "Brownian increments/sec (M^{1/2} W by %s to 1e-3, %d iterations), %d x shell_N_%d, %s, fp64"
+                      % ("block-Jacobi preconditioned Lanczos" if pc else "Lanczos", its, nb, nblb, "wall-corrected" if wall else "free-space"),
             "value": 1.0 / sec, "unit": "increments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": "BASELINE.json configs[3]" if args.config == "cfg3" else args.config,

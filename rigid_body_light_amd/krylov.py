@@ -255,6 +255,49 @@ class BrownianStepper(DeterministicStepper):
         return m, resid
 
 
+def sharded_mhalf_W(ctx, sm, r_full, Wk, a, wall, tol=1e-3, max_iter=100, precondition=True):
+    """Brownian increments (B M B)^{1/2} W_k for the nv = 1 or 2 rows of Wk on the tile-pair-sharded product
+    (sm: ShardedMobility; all vectors replicated, one all-reduce per iteration).  Two vectors advance in lock step
+    through ONE two-vector product per iteration (shared pair coefficients).
+      precondition=True : x = B L S^{1/2} W with S = L^-1 M L^-T and the per-body Cholesky factors L (replicated
+                          O(N N_blb) substitutions): covariance B M B exactly, ~7 iterations instead of ~35;
+      precondition=False: Lanczos on B M B itself (the symmetric square root).
+    Returns (Y (nv, n), iterations)."""
+    nv, n3 = Wk.shape
+    z = r_full.view(-1, 3)[:, 2]
+    B = torch.where(z >= a, torch.ones_like(z), z / a).repeat_interleave(3)            # make_damp_mat :618-639
+
+    def product(X, no_damp):
+        X = X.contiguous()
+        part = torch.empty_like(X)
+        if no_damp:
+            ctx.set_no_damp(True)
+        try:
+            ctx.apply_M_sym_multi(X.data_ptr(), r_full.data_ptr(), n3 // 3, nv, sm.rank, sm.world, part.data_ptr())
+        finally:
+            if no_damp:
+                ctx.set_no_damp(False)
+        return sm.all_reduce_sum(part)
+
+    def bsolve(v, mode):
+        out = torch.empty_like(v)
+        ctx.block_solve(v.contiguous().data_ptr(), out.data_ptr(), mode)
+        return out
+
+    if precondition:
+        def S_op(Vk):
+            out = product(torch.stack([bsolve(Vk[k], 2) for k in range(nv)]), True)
+            return torch.stack([bsolve(out[k], 1) for k in range(nv)])
+        Y, its, _ = lanczos_mhalf_multi(S_op, Wk, max_iter, tol)
+        return torch.stack([B * bsolve(Y[k], 3) for k in range(nv)]), its
+    if wall:                 # the wall kernel applies B M B itself (M_half_W always damps, :668-669)
+        A_op = lambda Vk: product(Vk, False)
+    else:
+        A_op = lambda Vk: B * product(B * Vk, False)
+    Y, its, _ = lanczos_mhalf_multi(A_op, Wk, max_iter, tol)
+    return Y, its
+
+
 class ShardedBrownianStepper(ShardedDeterministicStepper):
     """The stochastic midpoint step of BrownianStepper on P GPUs (BASELINE.json configs[3]).  The right-hand
     side of c_rigid_obj.cpp:917-976 is composed here from device vector operations so that every mobility
@@ -270,10 +313,6 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
         self.precondition = precondition      # block-Jacobi preconditioned square root (librbl's RBL_MHALF_LANCZOS_PC)
         self.lanczos_iterations = []
 
-    def _bsolve(self, v, mode):
-        out = torch.empty_like(v)
-        self.ctx.block_solve(v.contiguous().data_ptr(), out.data_ptr(), mode)
-        return out
 
     def _product(self, r_full, v):
         """apply_M (reference :641-659) on the sharded pairs: B M B with the wall term, plain M without"""
@@ -294,50 +333,12 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
         n3 = self.n3
         Xn, Qn = self.ctx.get_config(self.nb)
         r_n = self._positions_at(Xn, Qn)
-        z = r_n.view(-1, 3)[:, 2]
-        B = torch.where(z >= self.a, torch.ones_like(z), z / self.a).repeat_interleave(3)       # make_damp_mat :618-639
-        if self.wall:                                     # M_half_W always damps (:668-669); the wall kernel does it itself
-            A = lambda v: self._product(r_n, v)
-        else:
-            A = lambda v: B * self._product(r_n, B * v)
         W1, W2, Wr = W[:n3], W[n3:2 * n3], W[2 * n3:]
-        self.lanczos_iterations = []
-        if self.precondition:
-            # x = B L S^{1/2} W,  S = L^-1 M L^-T with the per-body Cholesky factors (replicated, O(N N_blb) work):
-            # covariance B M B exactly, ~7 iterations instead of ~35; the product inside stays sharded
-            Wk = torch.stack([W1, W2]) if split_rand else W1[None, :]
-            nv = Wk.shape[0]
-
-            def S_op(Vk):
-                X = torch.stack([self._bsolve(Vk[k], 2) for k in range(nv)])
-                part = torch.empty_like(X)
-                self.ctx.set_no_damp(True)
-                try:
-                    self.ctx.apply_M_sym_multi(X.data_ptr(), r_n.data_ptr(), n3 // 3, nv, self.sm.rank, self.sm.world,
-                                               part.data_ptr())
-                finally:
-                    self.ctx.set_no_damp(False)
-                out = self.sm.all_reduce_sum(part)
-                return torch.stack([self._bsolve(out[k], 1) for k in range(nv)])
-            Y, its, _ = lanczos_mhalf_multi(S_op, Wk, self.lmax, self.ltol)
-            mw = [B * self._bsolve(Y[k], 3) for k in range(nv)]
-            mw1 = mw[0]
-            mw2 = mw[1] if split_rand else None
-            self.lanczos_iterations = [its] * nv
-        elif split_rand:   # :927-936 -- the two increments in lock step: one two-vector product per iteration
-            def A2(V2):                                   # (2, n3) -> (2, n3), sharded pairs, shared pair coefficients
-                X = (V2 if self.wall else V2 * B).contiguous()
-                part = torch.empty_like(X)
-                self.ctx.apply_M_sym_multi(X.data_ptr(), r_n.data_ptr(), n3 // 3, 2, self.sm.rank, self.sm.world,
-                                           part.data_ptr())
-                out = self.sm.all_reduce_sum(part)
-                return out if self.wall else out * B
-            Y, its, _ = lanczos_mhalf_multi(A2, torch.stack([W1, W2]), self.lmax, self.ltol)
-            mw1, mw2 = Y[0], Y[1]
-            self.lanczos_iterations = [its, its]
-        else:
-            mw1, it1, _ = lanczos_mhalf(A, W1, self.lmax, self.ltol)                  # :927
-            self.lanczos_iterations.append(it1)
+        Wk = torch.stack([W1, W2]) if split_rand else W1[None, :]                      # :927-936
+        Y, its = sharded_mhalf_W(self.ctx, self.sm, r_n, Wk, self.a, self.wall, self.ltol, self.lmax, self.precondition)
+        mw1 = Y[0]
+        mw2 = Y[1] if split_rand else None
+        self.lanczos_iterations = [its] * Wk.shape[0]
         uom = self.ctx.Kinv_x_V(Wr.cpu().numpy(), self.nb)                            # M_RFD :776-794
         Mpm = [self._product(self._positions_at(*self.ctx.update_X_Q(sg * 0.5 * delta * uom, self.nb)), Wr)
                for sg in (1.0, -1.0)]
