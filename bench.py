@@ -118,6 +118,7 @@ def timestep_mode(args, dev, world=1, rank=0):
         else:
             solver = "graph" if args.graph else ("native" if args.native else args.solver)
         stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=(solver == "graph"), native=(solver == "native"))
+        stp.warm_start = args.warm_start
         stp_step = lambda k: stp.step(Fb, iters, rtol)
     res, used = [], []
     for k in range(args.warmup):
@@ -272,6 +273,7 @@ def main():
                     help="--mode timestep, N = 1: librbl's own GMRES (rbl_gmres_saddle_dev, default), the torch Arnoldi "
                          "loop, or that loop replayed as one hipGraph")
     ap.add_argument("--native", action="store_true", help="alias of --solver native")
+    ap.add_argument("--warm-start", action="store_true", help="--mode timestep --rtol ...: native GMRES starts from the previous step's solution")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")

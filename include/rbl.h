@@ -260,6 +260,7 @@ int rbl_set_no_damp(rbl_ctx *ctx, int on);
  * iterations, no host round trip inside the loop; rtol > 0: stops at the first iteration whose residual
  * estimate is below rtol (tested every iteration, or every 4th for small launch-bound systems).  d_rhs, d_x: n3 + 6 N_bod doubles. */
 int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double rtol, double *d_x,
+                         int use_x0 /* d_x holds an initial guess, e.g. the previous step's solution */,
                          int *iters, double *resid);
 /* RHS_and_Midpoint on device vectors (d_Slip[n3], d_Force[6Nb], d_W[3 n3] or NULL, d_RHS[n3+6Nb]);
  * X_half / Q_half are host arrays (O(N_bod)). */

@@ -55,7 +55,7 @@ def lib():
         L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
         L.rbl_block_solve_dev.argtypes = [vp, vp, vp, C.c_int]
         L.rbl_set_no_damp.argtypes = [vp, C.c_int]
-        L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.POINTER(C.c_int), C.POINTER(dbl)]
+        L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
         _LIB = L
@@ -134,10 +134,12 @@ class DeviceContext:
     def set_no_damp(self, on):
         self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))
 
-    def gmres_saddle(self, d_rhs, max_iter, rtol, d_x):
-        """native right-preconditioned GMRES on the saddle operator -> (iterations, residual estimate)"""
+    def gmres_saddle(self, d_rhs, max_iter, rtol, d_x, use_x0=False):
+        """native right-preconditioned GMRES on the saddle operator -> (iterations, residual estimate);
+        use_x0: d_x holds an initial guess (warm start from the previous time step)"""
         it, res = C.c_int(0), C.c_double(0.0)
-        self._chk(self.L.rbl_gmres_saddle_dev(self.h, d_rhs, int(max_iter), float(rtol or 0.0), d_x, C.byref(it), C.byref(res)))
+        self._chk(self.L.rbl_gmres_saddle_dev(self.h, d_rhs, int(max_iter), float(rtol or 0.0), d_x, int(bool(use_x0)),
+                                              C.byref(it), C.byref(res)))
         return it.value, res.value
 
     def update_X_Q(self, U_host, n_bodies):

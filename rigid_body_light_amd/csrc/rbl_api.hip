@@ -1232,8 +1232,43 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
 // every 4th (small, launch-bound ones).
 extern "C" {
 
-int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
-                         double *resid_out)
+static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                             double *resid_out);
+
+// use_x0 != 0: d_x holds an initial guess (e.g. the previous time step's solution): the solver iterates on the
+// residual b - A x0 (one extra product) and the tolerance stays relative to |b|.
+int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int use_x0,
+                         int *iters_out, double *resid_out)
+{
+  if (!use_x0) return gmres_saddle_core(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (!d_rhs || !d_x) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+  const int64_t nsys = (int64_t)3 * c->S.N_bod * c->S.N_blb + (int64_t)6 * c->S.N_bod;
+  const size_t vb = sizeof(double) * (size_t)nsys;
+  if ((rc = rbl_dev_reserve(c, c->d_bd2, 3 * vb + sizeof(double) * (2 + 2 * 512)))) return rc;   // + dot2 scratch
+  double *r0 = (double *)c->d_bd2.p, *dx = r0 + nsys, *x0 = dx + nsys, *dn = x0 + nsys;
+  RBL_HIP(c, hipMemcpyAsync(x0, d_x, vb, hipMemcpyDeviceToDevice, c->stream));
+  if ((rc = rbl_apply_saddle_dev(c, x0, r0))) return rc;
+  rbl_launch_axpby(c->stream, nsys, 1.0, d_rhs, -1.0, r0, r0);                          // r0 = b - A x0
+  double nn[2] = {0.0, 0.0};
+  rbl_launch_dot2(c->stream, d_rhs, d_rhs, nullptr, nsys, dn);                          // |b|^2
+  RBL_HIP(c, hipMemcpyAsync(&nn[0], dn, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  rbl_launch_dot2(c->stream, r0, r0, nullptr, nsys, dn);                                // |r0|^2
+  RBL_HIP(c, hipMemcpyAsync(&nn[1], dn, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  const double nb2 = nn[0], nr2 = nn[1];
+  const double scale = (nb2 > 0.0 && nr2 > 0.0) ? std::sqrt(nb2 / nr2) : 1.0;          // |b| / |r0|
+  if (nr2 == 0.0) { if (iters_out) *iters_out = 0; if (resid_out) *resid_out = 0.0; return RBL_OK; }   // x0 already solves it
+  double resid = 0.0;
+  if ((rc = gmres_saddle_core(c, r0, max_iter, rtol > 0.0 ? rtol * scale : rtol, dx, iters_out, &resid))) return rc;
+  rbl_launch_axpby(c->stream, nsys, 1.0, x0, 1.0, dx, d_x);                             // x = x0 + dx
+  if (resid_out) *resid_out = resid / scale;
+  return finish_and_check(c);
+}
+
+static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                             double *resid_out)
 {
   int rc = sync_bodies(c); if (rc) return rc;
   if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");

@@ -63,6 +63,8 @@ class DeterministicStepper:
         self.size = self.n3 + 6 * n_bodies
         self.use_graph = use_graph
         self.native = native          # librbl's own GMRES (rbl_gmres_saddle_dev) instead of the torch Arnoldi loop
+        self.warm_start = False       # native solver, converged mode: start from the previous step's solution
+        self._x_prev = None
         self._graph = None
 
     def _A(self, x):
@@ -107,8 +109,11 @@ class DeterministicStepper:
         if self.native:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
             b[self.n3:] = -Fb
-            x = torch.empty_like(b)
-            m, resid = self.ctx.gmres_saddle(b.data_ptr(), iters, rtol, x.data_ptr())
+            warm = self.warm_start and rtol is not None and self._x_prev is not None
+            x = self._x_prev.clone() if warm else torch.empty_like(b)
+            m, resid = self.ctx.gmres_saddle(b.data_ptr(), iters, rtol, x.data_ptr(), use_x0=warm)
+            if self.warm_start:
+                self._x_prev = x
             return x[: self.n3], x[self.n3:], m, resid
         if rtol is not None or not self.use_graph:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)

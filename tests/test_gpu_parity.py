@@ -874,3 +874,28 @@ def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
     cb.M_half_W(W, method="lanczos_pc"); it_pc = cb.cb.lanczos_report()[0]
     cb.M_half_W(W, method="lanczos"); it_plain = cb.cb.lanczos_report()[0]
     assert it_pc <= it_plain
+
+
+def test_native_gmres_warm_start(shell12):
+    """use_x0: starting from a nearby solution needs fewer iterations and lands on the same answer; starting from the
+    exact solution needs none."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    nb = 6
+    X, Q = random_positions(nb, wall=True, seed=170)
+    X[:, 2] += 1.5
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    n3 = 36 * nb
+    b = torch.zeros(n3 + 6 * nb, dtype=torch.float64, device=dev)
+    b[n3:] = torch.from_numpy(-np.tile([0.1, 0, -1.0, 0.2, 0, 0.05], nb)).to(dev)
+    x_cold = torch.empty_like(b)
+    it_cold, res_cold = ctx.gmres_saddle(b.data_ptr(), 120, 1e-10, x_cold.data_ptr())
+    x_warm = x_cold * (1.0 + 1e-4)                                   # a nearby guess
+    it_warm, res_warm = ctx.gmres_saddle(b.data_ptr(), 120, 1e-10, x_warm.data_ptr(), use_x0=True)
+    assert it_warm < it_cold and res_warm < 1e-10
+    assert float(torch.linalg.norm(x_warm - x_cold) / torch.linalg.norm(x_cold)) < 1e-6     # residual 1e-10 x condition number
+    x_exact = x_warm.clone()
+    it0, res0 = ctx.gmres_saddle(b.data_ptr(), 120, 1e-6, x_exact.data_ptr(), use_x0=True)
+    assert it0 <= 4 and float(torch.linalg.norm(x_exact - x_cold) / torch.linalg.norm(x_cold)) < 1e-6
