@@ -49,6 +49,9 @@ int rbl_dev_init(rbl_ctx *c)
   hipDeviceProp_t prop;
   RBL_HIP(c, hipGetDeviceProperties(&prop, c->device));
   c->n_cu = prop.multiProcessorCount;
+  // the symmetric kernel may use a quarter of the card for its row/column-sum slabs (72 GB of 288: N up to ~580 000
+  // blobs); beyond that the ordered kernel (O(N) workspace, ~1.7x the time) takes over
+  if (prop.totalGlobalMem / 4 > c->sym_workspace_budget) c->sym_workspace_budget = prop.totalGlobalMem / 4;
   RBL_HIP(c, hipMalloc((void **)&c->d_err, sizeof(unsigned)));
   RBL_HIP(c, hipHostMalloc((void **)&c->h_err, sizeof(unsigned), hipHostMallocDefault));
   RBL_HIP(c, hipMemset(c->d_err, 0, sizeof(unsigned)));
