@@ -140,6 +140,23 @@ def test_evolve_numeric(shell12):                              # :199-211 + nume
         cb.evolve_rigid_bodies(np.zeros(6 * n - 1))
 
 
+def test_update_X_Q_numeric_and_non_committing(shell12):       # c_rigid_obj.cpp:798-863 (C++ only in the reference)
+    n = 4
+    X, Q = random_positions(n, seed=14)
+    cb = create_solver(X, Q, dt=0.2)
+    U = np.random.default_rng(15).standard_normal(6 * n) * 0.3
+    U0 = U.copy()
+    Xu, Qu = cb.update_X_Q(U)
+    Xr, Qr = onp.update_X_Q(X, onp.normalize_quats(Q), U)          # displacement units: no dt
+    np.testing.assert_allclose(Xu.reshape(-1, 3), Xr, atol=1e-14)
+    np.testing.assert_allclose(Qu.reshape(-1, 4), Qr, atol=1e-14)
+    assert np.array_equal(U, U0)
+    Xc, Qc = cb.get_config()
+    np.testing.assert_allclose(Xc, X, atol=0)                     # nothing committed
+    with pytest.raises(RuntimeError):
+        cb.update_X_Q(np.zeros(6 * n + 1))
+
+
 def test_size_errors_without_gpu():
     X, Q = random_positions(2, seed=12)
     cb = create_solver(X, Q)
