@@ -19,10 +19,15 @@ def _free_port():
 
 
 def _torchrun(nproc, script_args, timeout=300):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    p = None
+    for attempt in range(2):       # a second try on another port if the rendezvous itself could not be set up
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if p.returncode == 0 or not any(k in p.stderr for k in ("EADDRINUSE", "address already in use", "RendezvousConnectionError")):
+            break
+    return p
 
 
 def test_two_rank_sharded_apply_M_matches_oracle():
