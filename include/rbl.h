@@ -262,6 +262,19 @@ int rbl_set_no_damp(rbl_ctx *ctx, int on);
 int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double rtol, double *d_x,
                          int use_x0 /* d_x holds an initial guess, e.g. the previous step's solution */,
                          int *iters, double *resid);
+/* Whole time steps in one call, on the object's own configuration (the reference has no driver; these are what
+ * rigid_body_light_amd/krylov.py's steppers do, for hosts without a Python loop).
+ *   rbl_step_deterministic: solve [M -K; K^T 0][lambda; U] = [slip; -F_body] (rbl_gmres_saddle_dev; slip NULL = 0;
+ *       warm_start: begin from the previous call's solution), then evolve_X_Q(U).
+ *   rbl_step_brownian: stochastic midpoint step -- RHS_and_Midpoint at q^n (W = [W1|W2|W_rfd] host, or NULL for
+ *       seeded device noise; method RBL_MHALF_*), saddle solve at q^{n+1/2}, update from q^n.
+ * F_body: host, 6 N_bod; slip: host, 3 N_blobs.  iters / resid report the GMRES run. */
+int rbl_step_deterministic(rbl_ctx *ctx, const double *F_body, const double *slip, int max_iter, double rtol,
+                           int warm_start, int *iters, double *resid);
+int rbl_step_brownian(rbl_ctx *ctx, const double *F_body, const double *slip, const double *W, uint64_t seed,
+                      int method, int split_rand, double delta, int max_iter, double rtol, int *iters,
+                      double *resid);
+
 /* RHS_and_Midpoint on device vectors (d_Slip[n3], d_Force[6Nb], d_W[3 n3] or NULL, d_RHS[n3+6Nb]);
  * X_half / Q_half are host arrays (O(N_bod)). */
 int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d_Force, const double *d_W,

@@ -53,6 +53,8 @@ def lib():
         L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
         L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
+        L.rbl_step_deterministic.argtypes = [vp, vp, vp, C.c_int, dbl, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
+        L.rbl_step_brownian.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, C.c_int, dbl, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_block_solve_dev.argtypes = [vp, vp, vp, C.c_int]
         L.rbl_set_no_damp.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
@@ -133,6 +135,29 @@ class DeviceContext:
 
     def set_no_damp(self, on):
         self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))
+
+    def step_deterministic(self, F_body, max_iter=20, rtol=None, slip=None, warm_start=False):
+        """one deterministic time step inside librbl (solve + evolve) -> (iterations, residual estimate)"""
+        import numpy as np
+        F = np.ascontiguousarray(F_body, dtype=np.float64).reshape(-1)
+        sl = None if slip is None else np.ascontiguousarray(slip, dtype=np.float64).reshape(-1)
+        it, res = C.c_int(0), C.c_double(0.0)
+        self._chk(self.L.rbl_step_deterministic(self.h, F.ctypes.data, None if sl is None else sl.ctypes.data, int(max_iter),
+                                                float(rtol or 0.0), int(bool(warm_start)), C.byref(it), C.byref(res)))
+        return it.value, res.value
+
+    def step_brownian(self, F_body, max_iter=20, rtol=None, slip=None, W=None, seed=0, method=2, split_rand=True,
+                      delta=1.0e-4):
+        """one stochastic midpoint step inside librbl -> (iterations, residual estimate)"""
+        import numpy as np
+        F = np.ascontiguousarray(F_body, dtype=np.float64).reshape(-1)
+        sl = None if slip is None else np.ascontiguousarray(slip, dtype=np.float64).reshape(-1)
+        Wh = None if W is None else np.ascontiguousarray(W, dtype=np.float64).reshape(-1)
+        it, res = C.c_int(0), C.c_double(0.0)
+        self._chk(self.L.rbl_step_brownian(self.h, F.ctypes.data, None if sl is None else sl.ctypes.data,
+                                           None if Wh is None else Wh.ctypes.data, int(seed), int(method), int(bool(split_rand)),
+                                           float(delta), int(max_iter), float(rtol or 0.0), C.byref(it), C.byref(res)))
+        return it.value, res.value
 
     def gmres_saddle(self, d_rhs, max_iter, rtol, d_x, use_x0=False):
         """native right-preconditioned GMRES on the saddle operator -> (iterations, residual estimate);

@@ -238,7 +238,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -1357,6 +1357,87 @@ static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, doub
   if (iters_out) *iters_out = used;
   if (resid_out) *resid_out = resid;
   return finish_and_check(c);
+}
+
+}  // extern "C"
+
+// ---- whole time steps in one call (what krylov.py's steppers do, for hosts without a Python driver) ----------
+extern "C" {
+
+static int step_buffers(rbl_ctx *c, int64_t n3, int64_t nb6, double **rhs, double **x, double **slip, double **force)
+{
+  const int64_t nsys = n3 + nb6;
+  int rc = rbl_dev_reserve(c, c->d_step, sizeof(double) * (size_t)(2 * nsys + n3 + nb6));
+  if (rc) return rc;
+  if (c->step_x_size != nsys) { c->step_x_valid = false; c->step_x_size = nsys; }
+  *x = (double *)c->d_step.p;            // first: survives from step to step (warm start)
+  *rhs = *x + nsys;
+  *slip = *rhs + nsys;
+  *force = *slip + n3;
+  return RBL_OK;
+}
+
+// One deterministic time step on the object's own configuration: solve [M -K; K^T 0][lambda; U] = [slip; -F] by
+// right-preconditioned GMRES (rbl_gmres_saddle_dev), then evolve_X_Q(U) (:865-878).  F_body: host, 6 N_bod;
+// slip: host, 3 N_blobs, or NULL for zero.  warm_start != 0 starts the solve from the previous call's solution.
+int rbl_step_deterministic(rbl_ctx *c, const double *F_body, const double *slip, int max_iter, double rtol,
+                           int warm_start, int *iters, double *resid)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!F_body) return rbl_fail(c, RBL_ERR_ARG, "step_deterministic: F_body is NULL");
+  const int64_t n3 = (int64_t)3 * c->S.N_bod * c->S.N_blb, nb6 = (int64_t)6 * c->S.N_bod;
+  double *rhs, *x, *dslip, *dforce;
+  if ((rc = step_buffers(c, n3, nb6, &rhs, &x, &dslip, &dforce))) return rc;
+  if (slip) { if ((rc = copy_h2d(c, rhs, slip, sizeof(double) * (size_t)n3))) return rc; }
+  else RBL_HIP(c, hipMemsetAsync(rhs, 0, sizeof(double) * (size_t)n3, c->stream));
+  if ((rc = copy_h2d(c, dforce, F_body, sizeof(double) * (size_t)nb6))) return rc;
+  rbl_launch_axpby(c->stream, nb6, -1.0, dforce, 0.0, nullptr, rhs + n3);
+  const int use_x0 = (warm_start && c->step_x_valid) ? 1 : 0;
+  if ((rc = rbl_gmres_saddle_dev(c, rhs, max_iter, rtol, x, use_x0, iters, resid))) { c->step_x_valid = false; return rc; }
+  c->step_x_valid = true;
+  std::vector<double> U((size_t)nb6);
+  if ((rc = copy_d2h(c, U.data(), x + n3, sizeof(double) * (size_t)nb6))) return rc;
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return rbl_evolve_X_Q(c, U.data());
+}
+
+// One stochastic midpoint step: right-hand side and predictor configuration at q^n (rbl_RHS_and_Midpoint_dev,
+// reference :917-976), saddle solve at q^{n+1/2}, update from q^n with dt U.  W: host, [W1 | W2 | W_rfd] = 9 N_blobs
+// standard normals, or NULL to draw them from `seed`.
+int rbl_step_brownian(rbl_ctx *c, const double *F_body, const double *slip, const double *W, uint64_t seed, int method,
+                      int split_rand, double delta, int max_iter, double rtol, int *iters, double *resid)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!F_body) return rbl_fail(c, RBL_ERR_ARG, "step_brownian: F_body is NULL");
+  const int Nb = c->S.N_bod;
+  const int64_t n3 = (int64_t)3 * Nb * c->S.N_blb, nb6 = (int64_t)6 * Nb;
+  double *rhs, *x, *dslip, *dforce;
+  if ((rc = step_buffers(c, n3, nb6, &rhs, &x, &dslip, &dforce))) return rc;
+  c->step_x_valid = false;                                  // the random part of the solution does not carry over
+  if (slip) { if ((rc = copy_h2d(c, dslip, slip, sizeof(double) * (size_t)n3))) return rc; }
+  else RBL_HIP(c, hipMemsetAsync(dslip, 0, sizeof(double) * (size_t)n3, c->stream));
+  if ((rc = copy_h2d(c, dforce, F_body, sizeof(double) * (size_t)nb6))) return rc;
+  double *dW = nullptr;
+  if (W) {
+    if ((rc = rbl_dev_reserve(c, c->d_W, sizeof(double) * 3 * (size_t)n3))) return rc;
+    dW = (double *)c->d_W.p;
+    if ((rc = copy_h2d(c, dW, W, sizeof(double) * 3 * (size_t)n3))) return rc;
+  }
+  const std::vector<double> Xn = c->S.X, Qn = c->S.Q;
+  std::vector<double> Xh((size_t)3 * Nb), Qh((size_t)4 * Nb);
+  if ((rc = rbl_RHS_and_Midpoint_dev(c, dslip, dforce, dW, seed, method, split_rand, delta, rhs, Xh.data(), Qh.data())))
+    return rc;
+  if ((rc = rbl_set_config(c, Xh.data(), Qh.data(), Nb))) return rc;       // operators at the predictor configuration
+  rc = rbl_gmres_saddle_dev(c, rhs, max_iter, rtol, x, 0, iters, resid);
+  std::vector<double> U((size_t)nb6);
+  if (!rc) rc = copy_d2h(c, U.data(), x + n3, sizeof(double) * (size_t)nb6);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = RBL_ERR_HIP;
+  const int rc2 = rbl_set_config(c, Xn.data(), Qn.data(), Nb);              // the update starts from q^n (also on failure)
+  if (rc) return rc;
+  if (rc2) return rc2;
+  return rbl_evolve_X_Q(c, U.data());
 }
 
 }  // extern "C"

@@ -899,3 +899,39 @@ def test_native_gmres_warm_start(shell12):
     x_exact = x_warm.clone()
     it0, res0 = ctx.gmres_saddle(b.data_ptr(), 120, 1e-6, x_exact.data_ptr(), use_x0=True)
     assert it0 <= 4 and float(torch.linalg.norm(x_exact - x_cold) / torch.linalg.norm(x_cold)) < 1e-6
+
+
+def test_one_call_time_steps_equal_python_steppers(shell12):
+    """rbl_step_deterministic / rbl_step_brownian (whole steps inside librbl) == krylov.py's steppers."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import DeterministicStepper, BrownianStepper
+    nb = 5
+    X, Q, W, slip, force = _brownian_case(shell12, True, nb=nb, seed=180)
+    dev = torch.device("cuda:0")
+    def fresh(kBT):
+        ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.004, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        return ctx
+    # deterministic, three steps, warm start on
+    a, b = fresh(0.0), fresh(0.0)
+    st = DeterministicStepper(a, nb, 12, dev, native=True); st.warm_start = True
+    for k in range(3):
+        m_py, r_py = st.step(force, iters=100, rtol=1e-10)
+        m_c, r_c = b.step_deterministic(force, 100, 1e-10, warm_start=True)
+        assert m_py == m_c
+    np.testing.assert_allclose(b.get_config(nb)[0], a.get_config(nb)[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.get_config(nb)[1], a.get_config(nb)[1], rtol=0, atol=1e-12)
+    # stochastic, injected noise, preconditioned square root
+    a, b = fresh(0.02), fresh(0.02)
+    a.set_lanczos(144, 1e-12); b.set_lanczos(144, 1e-12)
+    m_py, r_py = BrownianStepper(a, nb, 12, dev, native=True).step(force, slip=slip, W=W, method=2, iters=100, rtol=1e-10)
+    m_c, r_c = b.step_brownian(force, 100, 1e-10, slip=slip, W=W, method=2)
+    assert m_py == m_c and r_c < 1e-10
+    np.testing.assert_allclose(b.get_config(nb)[0], a.get_config(nb)[0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.get_config(nb)[1], a.get_config(nb)[1], rtol=0, atol=1e-12)
+    assert np.linalg.norm(b.get_config(nb)[0] - X) > 1e-4
+    # seeded device noise: reproducible
+    c1, c2 = fresh(0.02), fresh(0.02)
+    c1.step_brownian(force, 30, None, seed=5); c2.step_brownian(force, 30, None, seed=5)
+    assert np.array_equal(c1.get_config(nb)[0], c2.get_config(nb)[0])
