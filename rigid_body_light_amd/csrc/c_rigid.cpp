@@ -224,6 +224,52 @@ struct CManyBodies {
     return py::make_tuple(X, Q);
   }
 
+  // whole time steps inside librbl (no counterpart in the reference, which ships no driver) -> (iterations, residual)
+  py::tuple step_deterministic(darr F, py::object slip, int max_iter, double rtol, bool warm_start)
+  {
+    if (F.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("step_deterministic: F must have length 6*N_bod");
+    darr sl;
+    const double *sp = nullptr;
+    if (!slip.is_none()) {
+      sl = slip.cast<darr>();
+      if (sl.size() != n3()) throw std::runtime_error("step_deterministic: slip must have length 3*N_blobs");
+      sp = sl.data();
+    }
+    int it = 0, rc; double res = 0.0;
+    {
+      py::gil_scoped_release rel;
+      rc = rbl_step_deterministic(ctx, F.data(), sp, max_iter, rtol, warm_start ? 1 : 0, &it, &res);
+    }
+    check(rc);
+    return py::make_tuple(it, res);
+  }
+
+  py::tuple step_brownian(darr F, py::object slip, py::object W, uint64_t seed, const std::string &method, bool split_rand,
+                          double delta, int max_iter, double rtol)
+  {
+    if (F.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("step_brownian: F must have length 6*N_bod");
+    darr sl, Wa;
+    const double *sp = nullptr, *wp = nullptr;
+    if (!slip.is_none()) {
+      sl = slip.cast<darr>();
+      if (sl.size() != n3()) throw std::runtime_error("step_brownian: slip must have length 3*N_blobs");
+      sp = sl.data();
+    }
+    if (!W.is_none()) {
+      Wa = W.cast<darr>();
+      if (Wa.size() != 3 * n3()) throw std::runtime_error("step_brownian: W must have length 9*N_blobs (W1|W2|W_rfd)");
+      wp = Wa.data();
+    }
+    const int m = mhalf_method(method);
+    int it = 0, rc; double res = 0.0;
+    {
+      py::gil_scoped_release rel;
+      rc = rbl_step_brownian(ctx, F.data(), sp, wp, seed, m, split_rand ? 1 : 0, delta, max_iter, rtol, &it, &res);
+    }
+    check(rc);
+    return py::make_tuple(it, res);
+  }
+
   // RHS_and_Midpoint(Slip, Force) :917 (unbound in the reference) -> (RHS, X_half, Q_half)
   py::tuple RHS_and_Midpoint(darr Slip, darr Force, py::object W, uint64_t seed, const std::string &method,
                              bool split_rand, double delta)
@@ -329,6 +375,11 @@ PYBIND11_MODULE(c_rigid, m)
       .def("M_RFD", &CManyBodies::M_RFD, py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("delta") = 1.0e-4)
       .def("KTinv_RFD", &CManyBodies::KTinv_RFD, py::arg("W"), py::arg("delta") = 1.0e-4)
       .def("update_X_Q", &CManyBodies::update_X_Q, py::arg("U"))
+      .def("step_deterministic", &CManyBodies::step_deterministic, py::arg("F"), py::arg("slip") = py::none(),
+           py::arg("max_iter") = 50, py::arg("rtol") = 1.0e-8, py::arg("warm_start") = false)
+      .def("step_brownian", &CManyBodies::step_brownian, py::arg("F"), py::arg("slip") = py::none(),
+           py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("method") = "lanczos_pc", py::arg("split_rand") = true,
+           py::arg("delta") = 1.0e-4, py::arg("max_iter") = 50, py::arg("rtol") = 1.0e-8)
       .def("RHS_and_Midpoint", &CManyBodies::RHS_and_Midpoint, py::arg("Slip"), py::arg("Force"),
            py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("method") = "cholesky",
            py::arg("split_rand") = true, py::arg("delta") = 1.0e-4)

@@ -143,6 +143,20 @@ class RigidBody:
         return self.cb.RHS_and_Midpoint(self._require(slip, "blob"), self._require(force, "body"), W, seed,
                                         method, split_rand, delta)
 
+    def step_deterministic(self, F_body, slip=None, max_iter=50, rtol=1.0e-8, warm_start=False):
+        """One deterministic time step inside the library: GMRES on the saddle system with rhs [slip ; -F_body]
+        (apply_PC as preconditioner), then evolve_rigid_bodies(U).  Returns (iterations, residual estimate)."""
+        return self.cb.step_deterministic(self._require(F_body, "body"), None if slip is None else self._require(slip, "blob"),
+                                          max_iter, rtol, warm_start)
+
+    def step_brownian(self, F_body, slip=None, W=None, seed=0, method="lanczos_pc", split_rand=True, delta=1.0e-4,
+                      max_iter=50, rtol=1.0e-8):
+        """One stochastic midpoint step inside the library (RHS_and_Midpoint at q^n, solve at q^{n+1/2}, update from q^n).
+        Note the reference wrapper fixes kBT = 1 (src/Rigid.py:23); scale dt / forces accordingly."""
+        W = None if W is None else np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(-1))
+        return self.cb.step_brownian(self._require(F_body, "body"), None if slip is None else self._require(slip, "blob"),
+                                     W, seed, method, split_rand, delta, max_iter, rtol)
+
     def apply_M_multi(self, forces, positions):
         """k right-hand sides at once, forces (k, 3N); k >= 4 runs on the fp64 matrix cores."""
         return self.cb.apply_M_multi(np.atleast_2d(np.asarray(forces)), np.asarray(positions).reshape(-1))

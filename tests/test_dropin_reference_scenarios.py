@@ -163,3 +163,23 @@ def test_under_wall(shell12):
                  lambda: cb.apply_M(vec[:3 * BLOBS], cb.get_blob_positions())):
         with pytest.raises(RuntimeError, match="below the wall"):
             call()
+
+
+def test_one_call_steps_through_the_dropin_class(shell12):
+    """beyond the reference's surface: RigidBody.step_deterministic / step_brownian move the bodies consistently
+    with solving the saddle system by hand and calling evolve_rigid_bodies."""
+    cb, X, Q = _solver(shell12, 4, wall=True, seed=20, dt=0.01)
+    F = np.tile([0.0, 0.0, 1.0, 0.0, 0.0, 0.0], 4)
+    # by hand: dense solve of the saddle operator columns, then evolve
+    n3, nb6 = 3 * 4 * BLOBS, 24
+    A = np.column_stack([cb.apply_saddle(e) for e in np.eye(n3 + nb6)])
+    U = np.linalg.solve(A, np.concatenate([np.zeros(n3), -F]))[n3:]
+    ref, _, _ = _solver(shell12, 4, wall=True, seed=20, dt=0.01)
+    ref.evolve_rigid_bodies(U)
+    it, res = cb.step_deterministic(F, max_iter=150, rtol=1e-11)
+    assert res < 1e-11 and it > 0
+    np.testing.assert_allclose(cb.get_config()[0], ref.get_config()[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(cb.get_config()[1], ref.get_config()[1], rtol=0, atol=1e-9)
+    X1 = cb.get_config()[0].copy()
+    it, res = cb.step_brownian(F, seed=3, max_iter=80, rtol=1e-8)
+    assert res < 1e-8 and np.linalg.norm(cb.get_config()[0] - X1) > 0
