@@ -25,3 +25,8 @@ print("M^(1/2) W :", np.linalg.norm(cb.M_half_W(seed=7)))    # Brownian incremen
 print("M_RFD     :", np.linalg.norm(cb.M_RFD(seed=8)))       # thermal drift by random finite differences
 cb.evolve_rigid_bodies(np.tile([0, 0, -1.0, 0, 0, 0], 3))
 print("new X     :", cb.get_config()[0])
+# beyond the reference's surface: whole time steps inside the library (GMRES on the saddle system + evolve)
+its, res = cb.step_deterministic(np.tile([0, 0, 1.0, 0, 0, 0], 3), rtol=1e-8)
+print("det. step :", its, "GMRES iterations, residual %.1e" % res, "-> z =", cb.get_config()[0][:, 2])
+its, res = cb.step_brownian(np.tile([0, 0, 1.0, 0, 0, 0], 3), seed=1, rtol=1e-8)   # stochastic midpoint step (kBT = 1)
+print("Brownian  :", its, "GMRES iterations, residual %.1e" % res, "-> z =", cb.get_config()[0][:, 2])
