@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
-    ap.add_argument("--check", action="store_true", help="verify the result against the CPU oracle on a row sample")
+    ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -373,17 +373,10 @@ def main():
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item()); kern_ms = float(kern_ms.item())
 
-    check = None
-    if args.check:   # parity of what was just timed: oracle on a row sample (rank 0 rows / full vector)
-        from oracle import Oracle
-        orc = Oracle()
-        cfg0 = c["cfg"] - c["cfg"].mean(axis=0)
-        r_ref = orc.multi_body_pos(c["X"], c["Q"], cfg0)
+    if args.dump_check:   # for tests/: a row sample of what was just timed (the oracle comparison happens in the test)
         b0 = sm.row0 + (nrows // 2)
-        Uo = orc.apply_M_rows(F_full_host, r_ref, b0, b0 + 8, c["a"], c["eta"], wall, nthreads=8)
         got = (U_part[3 * b0:3 * b0 + 24] if use_sym else U_local[3 * (b0 - sm.row0):3 * (b0 - sm.row0) + 24]).cpu().numpy()
-        check = float(np.linalg.norm(got - Uo) / np.linalg.norm(Uo))
-        assert check < 1e-11, "rank %d: parity vs oracle failed: %g" % (rank, check)
+        np.savez("%s.rank%d.npz" % (args.dump_check, rank), row0=b0, values=got, world=world, rank=rank)
 
     tstep = None
     if args.timestep_steps > 0:
@@ -454,8 +447,6 @@ def main():
                                  "(each unordered pair once, division-free Horner-form algebra): see `executed` -- the VALU issues "
                                  "90 % of the kernel's cycles, the two quarter-rate v_rsq_f64 per pair account for most of the rest"},
         }
-        if check is not None:
-            line["check_rel_err_vs_oracle"] = check
         if tstep is not None:
             line["timestep"] = tstep
         if world == 1 and args.cpu_budget > 0:

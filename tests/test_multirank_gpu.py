@@ -30,16 +30,26 @@ def _torchrun(nproc, script_args, timeout=300):
     return p
 
 
-def test_two_rank_sharded_apply_M_matches_oracle():
-    """bench.py's N = 2 path (cfg 2 size): each rank checks its partial-sum result against the CPU oracle"""
-    p = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3", "--warmup", "1",
-                      "--check", "--cpu-budget", "0", "--timestep-steps", "1"])
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
+    """bench.py's N = 2 path (cfg 2 size): every rank's partial-sum result, all-reduced, against the CPU oracle"""
     import json
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["check_rel_err_vs_oracle"] < 1e-11
-    assert d["timestep"]["apply_M_per_timestep"] == 21
+    import numpy as np
+    from rigid_body_light_amd import make_config
+    dump = str(tmp_path / "chk")
+    p = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3", "--warmup", "1",
+                      "--dump-check", dump, "--cpu-budget", "0", "--timestep-steps", "1"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["timestep"]["apply_M_per_timestep"] == 21
+    nb, nblb, wall = 50, 162, False                       # cfg2, as bench.py builds it
+    c = make_config(nb, nblb, wall)
+    F = np.random.default_rng(2).standard_normal(3 * nb * nblb)
+    r = orc.multi_body_pos(c["X"], c["Q"], c["cfg"] - c["cfg"].mean(axis=0))
+    for rank in range(2):
+        z = np.load("%s.rank%d.npz" % (dump, rank))
+        b0 = int(z["row0"])
+        Uo = orc.apply_M_rows(F, r, b0, b0 + 8, c["a"], c["eta"], wall, nthreads=8)
+        assert np.linalg.norm(z["values"] - Uo) / np.linalg.norm(Uo) < 1e-11
 
 
 def test_two_rank_sharded_brownian_step_matches_single_process():
