@@ -935,3 +935,32 @@ def test_one_call_time_steps_equal_python_steppers(shell12):
     c1, c2 = fresh(0.02), fresh(0.02)
     c1.step_brownian(force, 30, None, seed=5); c2.step_brownian(force, 30, None, seed=5)
     assert np.array_equal(c1.get_config(nb)[0], c2.get_config(nb)[0])
+
+
+@pytest.mark.parametrize("nb,nblb,wall", [(7, 162, True), (200, 642, False)])
+def test_two_vector_symmetric_shards_add_up(nb, nblb, wall):
+    """rbl_apply_M_sym_multi_dev: two vectors at once, sharded over the row tiles (I % step == first) -- the partial
+    results add up to the two single-vector products (both tile geometries: one and two rows per lane)."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    F = torch.from_numpy(np.random.default_rng(6).standard_normal((2, 3 * N))).to(dev)
+    ref = torch.empty_like(F)
+    for k in range(2):
+        ctx.apply_M(F[k].data_ptr(), r.data_ptr(), N, 0, N, ref[k].data_ptr())
+    acc = torch.zeros_like(F)
+    for first in range(3):
+        part = torch.empty_like(F)
+        ctx.apply_M_sym_multi(F.data_ptr(), r.data_ptr(), N, 2, first, 3, part.data_ptr())
+        acc += part
+    ctx.sync_check()
+    assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 1e-13
+    with pytest.raises(Exception):
+        ctx.apply_M_sym_multi(F.data_ptr(), r.data_ptr(), N, 3, 0, 1, acc.data_ptr())      # only 1 or 2 vectors
