@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   const int bi = SI * G.SBI + (int)(in / (unsigned)G.SBJ), bj = SJ * G.SBJ + (int)(in % (unsigned)G.SBJ);
   if (bi >= G.TI || bj >= G.TJ || bi < bj) return;  // outside / strictly-upper block tile (block-uniform)
   const int t = threadIdx.x;
-  const int wave = t >> 6, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // provably uniform: scalar offsets below
   const int wi = wave & 1, wj = wave >> 1;
   const long bi0 = r0 + (long)bi * 128, bj0 = r0 + (long)bj * 128;
   if (bj0 >= c1) return;  // block-uniform
@@ -436,39 +436,55 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
           acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
     }
   };
-  // stage s (data in LDS buffer s & 1): stage s+1 sits in register set (s+1) & 1 -> LDS buffer (s+1) & 1 (free
-  // since the barrier that ended stage s-1), then that set is refilled with stage s+3
-  auto stage = [&](int s_, auto nset) {
-    if (s_ + 1 < nst) lwrite(nset, (s_ + 1) & 1);
-    if (s_ + 3 < nst) gload(nset, s_ + 3);
-    compute(s_ & 1);
-    __syncthreads();
-  };
-  for (int s2 = 0; s2 < nst; s2 += 2) {
-    stage(s2, S1{});
-    if (s2 + 1 < nst) stage(s2 + 1, S0{});
-  }
-  if (!active) return;
-  // epilogue C -= acc: per pair of 16-column strips, ALL 32 loads of a lane are issued before the first use (one
-  // memory round trip per pair; a guarded read-modify-write per element costs one round trip EACH and
-  // was 2/3 of a tile's time), then 32 stores.  Interior tiles (block-uniform test) skip the guards.
+  // epilogue pieces, C -= acc: per pair of 16-column strips, ALL 32 loads of a lane are issued before the first use
+  // (a guarded read-modify-write per element costs one memory round trip EACH and was 2/3 of a tile's time).
+  // Interior tiles (block-uniform test) skip the guards.
   const bool interior = (i0 + 64 <= n) && (j0 + 64 <= c1);
+  // interior tiles address C through a buffer descriptor over the 64 columns of this wave: scalar offset =
+  // column, four per-lane offsets (one per 16-row group) instead of 32 address pairs
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)j0 * (size_t)ld, (short)0, (int)((size_t)64 * (size_t)ld * 8), 0x00020000);
+  unsigned vC[4];
 #pragma unroll
-  for (int tp = 0; tp < 4; tp += 2) {          // two 16-column strips per round trip
-    double cv[2][4][4];
+  for (int ti = 0; ti < 4; ++ti) vC[ti] = (unsigned)l4 * ldb + 8u * (unsigned)(i0 + 16 * ti + l15);
+  auto load_C_fast = [&](int tp, double (&cv)[2][4][4]) {      // interior tiles only
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const unsigned so = (unsigned)(16 * (tp + h) + 4 * v) * ldb;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) cv[h][ti][v] = buf_ld(rc, vC[ti], so);
+      }
+  };
+  auto load_C = [&](int tp, double (&cv)[2][4][4]) {
+    if (interior) { load_C_fast(tp, cv); return; }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         long row = i0 + 16 * ti + l15;
-        if (!interior && row >= n) row = n - 1;
+        if (row >= n) row = n - 1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           long col = j0 + 16 * (tp + h) + l4 + 4 * v;
-          if (!interior && col >= c1) col = c1 - 1;
+          if (col >= c1) col = c1 - 1;
           cv[h][ti][v] = A[(size_t)col * (size_t)ld + row];
         }
       }
+  };
+  auto store_C = [&](int tp, const double (&cv)[2][4][4]) {
+    if (interior) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const unsigned so = (unsigned)(16 * (tp + h) + 4 * v) * ldb;
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) buf_st(rc, vC[ti], so, cv[h][ti][v] - acc[tp + h][ti][v]);
+        }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -477,11 +493,45 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const long col = j0 + 16 * (tp + h) + l4 + 4 * v;
-          if (interior || (row < n && col < c1))
-            A[(size_t)col * (size_t)ld + row] = cv[h][ti][v] - acc[tp + h][ti][v];
+          if (row < n && col < c1) A[(size_t)col * (size_t)ld + row] = cv[h][ti][v] - acc[tp + h][ti][v];
         }
       }
+  };
+  // stage s (data in LDS buffer s & 1): stage s+1 sits in register set (s+1) & 1 -> LDS buffer (s+1) & 1 (free
+  // since the barrier that ended stage s-1), then that set is refilled with stage s+3.  No panel loads are
+  // issued in the last three stages, so the first half of the C tile is requested two stages before the
+  // end (its registers are the then idle prefetch sets) and has landed when the epilogue starts.
+  auto stage = [&](int s_, auto nset) {
+    if (s_ + 1 < nst) lwrite(nset, (s_ + 1) & 1);
+    if (s_ + 3 < nst) gload(nset, s_ + 3);
+    compute(s_ & 1);
+    __syncthreads();
+  };
+  double cv0[2][4][4];
+  if ((nst & 1) == 0 && nst >= 4) {       // the usual case (K = 256, 512): last two stages peeled
+    for (int s2 = 0; s2 < nst - 2; s2 += 2) {
+      stage(s2, S1{});
+      stage(s2 + 1, S0{});
+    }
+    lwrite(S1{}, (nst - 1) & 1);          // stage nst-2: the last slab goes to LDS, both register sets are idle now
+    if (active && interior) load_C_fast(0, cv0);   // (edge tiles load late: their clamped addresses need the registers)
+    compute((nst - 2) & 1);
+    __syncthreads();
+    compute((nst - 1) & 1);               // stage nst-1
+    if (!active) return;
+    if (!interior) load_C(0, cv0);
+  } else {
+    for (int s2 = 0; s2 < nst; s2 += 2) {
+      stage(s2, S1{});
+      if (s2 + 1 < nst) stage(s2 + 1, S0{});
+    }
+    if (!active) return;
+    load_C(0, cv0);
   }
+  store_C(0, cv0);
+  double cv1[2][4][4];
+  load_C(2, cv1);
+  store_C(2, cv1);
 }
 
 __global__ void k_zero_upper(double *__restrict__ A, long n)
