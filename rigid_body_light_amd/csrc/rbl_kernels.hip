@@ -54,13 +54,13 @@ __device__ __forceinline__ double damp_of(const RblParams &P, double z)
 template <bool WALL, bool SELF>
 __device__ __forceinline__ void sweep_tile(const RblParams &P, const JBlob *sj, double xi,
                                            double yi, double zi, int self_jj, double &ux,
-                                           double &uy, double &uz, unsigned &flags)
+                                           double &uy, double &uz, unsigned &flags, const RblWallK &K)
 {
 #pragma unroll 4
   for (int jj = 0; jj < TB; ++jj) {
     const JBlob b = sj[jj];
     rbl_pair_accum<WALL, SELF, true>(P, xi, yi, zi, b.x, b.y, b.z, b.fx, b.fy, b.fz,
-                                     SELF && (jj == self_jj), ux, uy, uz, flags);
+                                     SELF && (jj == self_jj), ux, uy, uz, flags, K);
   }
 }
 
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
   const double zi_phys = r[3 * ic + 2];
   const double xi = r[3 * ic] * P.inv_a, yi = r[3 * ic + 1] * P.inv_a, zi = zi_phys * P.inv_a;   // radius-scaled
   const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
   unsigned flags = 0;
   if (WALL && zi < 0.0) flags |= RBL_FLAG_BELOW_WALL;
 
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(TB) void k_apply_M(const double *__restrict__ r,
     if (diag) {
       const long sjj = i - j0;  // index of i itself inside the tile (may be out of range)
       const int self_jj = (valid && sjj >= 0 && sjj < TB) ? (int)sjj : -1;
-      sweep_tile<WALL, true>(Pu, sj, xi, yi, zi, self_jj, ux, uy, uz, flags);
+      sweep_tile<WALL, true>(Pu, sj, xi, yi, zi, self_jj, ux, uy, uz, flags, WK);
     } else {
-      sweep_tile<WALL, false>(Pu, sj, xi, yi, zi, -1, ux, uy, uz, flags);
+      sweep_tile<WALL, false>(Pu, sj, xi, yi, zi, -1, ux, uy, uz, flags, WK);
     }
   }
 
@@ -547,7 +548,7 @@ __device__ __forceinline__ void mrhs_tile(const RblParams &P, const double *sx, 
                                           const double *sz, const double *__restrict__ Fp, long j0,
                                           long i, double xi, double yi, double zi, int l15, int l4,
                                           double4m_t &dx_, double4m_t &dy_, double4m_t &dz_,
-                                          unsigned &flags)
+                                          unsigned &flags, const RblWallK &K)
 {
   const double *fp = Fp + ((size_t)(j0 + l4) * 3) * MR + l15;
 #pragma unroll 2
@@ -556,7 +557,7 @@ __device__ __forceinline__ void mrhs_tile(const RblParams &P, const double *sx, 
     const double f0 = fp[0], f1 = fp[MR], f2 = fp[2 * MR];
     fp += (size_t)4 * 3 * MR;
     double m[9];
-    rbl_pair_block_fast<WALL, SELF, true>(P, xi, yi, zi, sx[jj], sy[jj], sz[jj], SELF && (j0 + jj == i), m, flags);
+    rbl_pair_block_fast<WALL, SELF, true>(P, xi, yi, zi, sx[jj], sy[jj], sz[jj], SELF && (j0 + jj == i), m, flags, K);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], f0, dx_, 0, 0, 0);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], f1, dx_, 0, 0, 0);
     dx_ = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], f2, dx_, 0, 0, 0);
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
   const long ic = i < N ? i : N - 1;
   const double xi = r[3 * ic] * P.inv_a, yi = r[3 * ic + 1] * P.inv_a, zi = r[3 * ic + 2] * P.inv_a;   // radius-scaled
   const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_literal();   // (resident constants cost this kernel 1 %: register pressure)
   unsigned flags = 0;
   const long j_begin = (long)blockIdx.y * jchunk;
   const long j_end = (j_begin + jchunk < Npad) ? j_begin + jchunk : Npad;
@@ -601,9 +603,9 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
     __syncthreads();
     const bool diag = (j0 < i_blk0 + 64) && (j0 + MTJ > i_blk0);  // block-uniform
     if (diag)
-      mrhs_tile<WALL, true>(Pu, sx, sy, sz, Fp, j0, i < N ? i : -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+      mrhs_tile<WALL, true>(Pu, sx, sy, sz, Fp, j0, i < N ? i : -1, xi, yi, zi, l15, l4, ax, ay, az, flags, WK);
     else
-      mrhs_tile<WALL, false>(Pu, sx, sy, sz, Fp, j0, -1, xi, yi, zi, l15, l4, ax, ay, az, flags);
+      mrhs_tile<WALL, false>(Pu, sx, sy, sz, Fp, j0, -1, xi, yi, zi, l15, l4, ax, ay, az, flags, WK);
   }
   // D layout of v_mfma_f64_16x16x4: row = (lane>>4) + 4 v, col = lane & 15
   double *up = Up + (size_t)blockIdx.y * (size_t)Npad * 3 * MR;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
                                                double zi, double xj, double yj, double zj,
                                                double Fx, double Fy, double Fz, bool is_self,
                                                double &ux, double &uy, double &uz,
-                                               unsigned &flags)
+                                               unsigned &flags, const RblWallK &K = rbl_wall_k_literal())
 {
   const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
   const double q = __builtin_fma(dy, dy, dx * dx);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
   const double lat = __builtin_fma(beta, q2, gxz * Fz);
   ux = __builtin_fma(cF, Fx, __builtin_fma(lat, dx, ux));
   uy = __builtin_fma(cF, Fy, __builtin_fma(lat, dy, uy));
@@ -316,7 +316,8 @@ __device__ __forceinline__ void rbl_pair_sym2(const RblParams &P, double xi, dou
 template <bool WALL, bool SELF, bool UNIT = false>
 __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double xi, double yi,
                                                     double zi, double xj, double yj, double zj,
-                                                    bool is_self, double *m, unsigned &flags)
+                                                    bool is_self, double *m, unsigned &flags,
+                                                    const RblWallK &K = rbl_wall_k_literal())
 {
   const double dx = xi - xj, dy = yi - yj, dz = zi - zj;
   const double q = __builtin_fma(dy, dy, dx * dx);
@@ -357,7 +358,7 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
   const double bx = beta * dx, by = beta * dy;
   m[0] = __builtin_fma(bx, dx, cF); m[1] = bx * dy; m[2] = dx * gxz;
   m[3] = m[1]; m[4] = __builtin_fma(by, dy, cF); m[5] = dy * gxz;
