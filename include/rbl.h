@@ -286,7 +286,8 @@ int rbl_sync_check(rbl_ctx *ctx);
 
 /* tuning / test hook.  jsplit: j-split of the ordered kernel (0 = heuristic).  variant: 0 = heuristic
  * (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 = force the ordered kernel,
- * 2 = force the symmetric kernel, 3 = force the MFMA multi-RHS kernel. */
+ * 2 = force the symmetric kernel (with jsplit > 0: its column-chunk length), 3 = force the MFMA multi-RHS kernel;
+ * 21 / 22 (process-wide experiment switch): one / two rows per lane in the two-vector symmetric kernel. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus
