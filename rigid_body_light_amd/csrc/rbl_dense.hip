@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void k_trsm_tall(double *__restrict__ A, long 
 // barrier per stage.  LDS column stride 144 doubles (= 32 banks mod 64) keeps the 16-lane x
 // 4-column fragment reads conflict-free.  The MFMA computes the TRANSPOSED tile (A-operand
 // from the j rows, B-operand from the i rows) so a lane group stores 16 consecutive ROWS of one
-// column of C: 128-B runs in column-major C.  K must be a multiple of KC.
+// column of C: 128-B runs in column-major C.  K must be a multiple of 2 KC and >= 4 KC (syrk_K_ok): the
+// launchers only ever pass whole panels (256 or 512).  A second, generic stage loop next to the peeled one made
+// the register allocator spill the prefetch sets (73 VGPRs, each reload behind its own vmcnt(0)).
 constexpr int KC = 16;
 constexpr int LDP = 144;
 
@@ -345,6 +347,8 @@ struct SyrkGrid {
   int NSI, NSJ;      // super-blocks per direction
   unsigned nwg;      // = NSI * NSJ * 64
 };
+
+static bool syrk_K_ok(int64_t K) { return K >= 4 * KC && K % (2 * KC) == 0; }
 
 static SyrkGrid syrk_grid(int64_t rows, int64_t cols)
 {
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
     __syncthreads();
   };
   double cv0[2][4][4];
-  if ((nst & 1) == 0 && nst >= 4) {       // the usual case (K = 256, 512): last two stages peeled
+  {                                        // nst is even and >= 4 (K = 256, 512; checked by the launchers): last two stages peeled
     for (int s2 = 0; s2 < nst - 2; s2 += 2) {
       stage(s2, S1{});
       stage(s2 + 1, S0{});
@@ -520,13 +524,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
     compute((nst - 1) & 1);               // stage nst-1
     if (!active) return;
     if (!interior) load_C(0, cv0);
-  } else {
-    for (int s2 = 0; s2 < nst; s2 += 2) {
-      stage(s2, S1{});
-      if (s2 + 1 < nst) stage(s2 + 1, S0{});
-    }
-    if (!active) return;
-    load_C(0, cv0);
   }
   store_C(0, cv0);
   double cv1[2][4][4];
@@ -626,6 +623,7 @@ int rbl_launch_cholesky(hipStream_t st, double *d_M, int64_t n, bool zero_upper,
       hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128)), dim3(256), 0, sp, d_M, (long)n,
                          (long)n, (long)k, (int)(pw / IB), (long)pend, Linv, 0L, 0L);
     if (pend < n) {  // trailing update with the whole panel, K = pw = NB (a short panel is the last one)
+      if (!syrk_K_ok(pw)) return RBL_ERR_ARG;
       if (look) {
         if (hipEventRecord(aux->ev[0], sp) != hipSuccess) return RBL_ERR_HIP;
         if (hipStreamWaitEvent(su, aux->ev[0], 0) != hipSuccess) return RBL_ERR_HIP;
@@ -688,6 +686,7 @@ int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batc
       hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((n - pend + 127) / 128), 1, batch), dim3(256), 0, st, d_M, (long)n,
                          (long)n, (long)k, (int)(pw / IB), (long)pend, (const double *)Lk, (long)strideA, strideL);
     if (pend < n) {        // trailing matrix, K = NBB (a short panel is the last one)
+      if (!syrk_K_ok(pw)) return RBL_ERR_ARG;
       const SyrkGrid G = syrk_grid(n - pend, n - pend);
       hipLaunchKernelGGL(k_syrk_mfma, dim3(G.nwg, 1, batch), dim3(256), 0, st, d_M, (long)n, (long)pend, (long)n, (long)k,
                          (int)pw, (long)strideA, (long)n, G);
