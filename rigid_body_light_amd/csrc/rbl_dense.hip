@@ -92,6 +92,13 @@ __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff
   const rbl_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
   return __hiloint2double((int)v.y, (int)v.x);
 }
+typedef unsigned int rbl_u4 __attribute__((ext_vector_type(4)));
+typedef double rbl_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rbl_d2 buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)   // 16 B: two rows
+{
+  const rbl_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return (rbl_d2){__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
+}
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double d)
 {
   const rbl_u2 v = {(unsigned)__double2loint(d), (unsigned)__double2hiint(d)};
@@ -345,7 +352,9 @@ struct SyrkGrid {
   int TI, TJ;        // tiles (128) of the updated region: rows, columns (same origin r0)
   int SBI, SBJ;      // super-block shape, SBI * SBJ = 64
   int NSI, NSJ;      // super-blocks per direction
-  unsigned nwg;      // = NSI * NSJ * 64
+  int tri;           // square update with square super-blocks: only the NSI (NSI + 1) / 2 super-blocks on or below
+                     // the diagonal are enumerated (a workgroup of an empty tile still waits for a half-CU slot)
+  unsigned nwg;      // = (tri ? NSI (NSI + 1) / 2 : NSI * NSJ) * 64
 };
 
 static bool syrk_K_ok(int64_t K) { return K >= 4 * KC && K % (2 * KC) == 0; }
@@ -360,24 +369,49 @@ static SyrkGrid syrk_grid(int64_t rows, int64_t cols)
   g.SBI = 64 / g.SBJ;
   g.NSI = (g.TI + g.SBI - 1) / g.SBI;
   g.NSJ = (g.TJ + g.SBJ - 1) / g.SBJ;
-  g.nwg = (unsigned)g.NSI * (unsigned)g.NSJ * 64u;
+  g.tri = (rows == cols && g.SBI == g.SBJ) ? 1 : 0;
+  g.nwg = (g.tri ? (unsigned)g.NSI * (unsigned)(g.NSI + 1) / 2u : (unsigned)g.NSI * (unsigned)g.NSJ) * 64u;
   return g;
 }
 
+// Diagnostic build only (RBL_EXTRA_FLAGS=-DRBL_SYRK_PROF, tools/syrk_phase_profile.py): s_memtime stamps around the
+// phases of a stage, summed over the interior tiles by wave 0 of each workgroup.  No stamp exists in the normal build.
+#ifdef RBL_SYRK_PROF
+__device__ unsigned long long g_syrk_prof[16];
+#define PT(i) { const unsigned long long now_ = clock64(); prof[i] += now_ - tprev; tprev = now_; }
+#else
+#define PT(i)
+#endif
 __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, long ld, long r0,
                                                       long c1, long k0, int K, long strideA,
                                                       long n /* rows < n are updated */, SyrkGrid G)
 {
   A += (size_t)blockIdx.z * (size_t)strideA;
-  __shared__ double sI[2][KC * LDP];
-  __shared__ double sJ[2][KC * LDP];
+  __shared__ __attribute__((aligned(16))) double sI[2][KC * LDP];
+  __shared__ __attribute__((aligned(16))) double sJ[2][KC * LDP];
   const unsigned w = blockIdx.x;
   const unsigned sb = w >> 6, in = w & 63u;
-  const int SJ = (int)(sb / (unsigned)G.NSI), SI = (int)(sb % (unsigned)G.NSI);
+  int SJ, SI;
+  if (G.tri) {   // sb = off(SJ) + SI - SJ, off(c) = c (2 NS - c + 1) / 2: super-column SJ holds the NS - SJ blocks SI >= SJ
+    const int NS = G.NSI;
+    auto off = [NS](int c) { return (unsigned)(c * (2 * NS - c + 1)) >> 1; };
+    const float bq = 2.f * (float)NS + 1.f;
+    int c = (int)((bq - __builtin_sqrtf(bq * bq - 8.f * (float)sb)) * 0.5f);
+    c = c < 0 ? 0 : (c > NS - 1 ? NS - 1 : c);
+    while (c + 1 < NS && off(c + 1) <= sb) ++c;
+    while (c > 0 && off(c) > sb) --c;
+    SJ = c; SI = c + (int)(sb - off(c));
+  } else {
+    SJ = (int)(sb / (unsigned)G.NSI); SI = (int)(sb % (unsigned)G.NSI);
+  }
   const int bi = SI * G.SBI + (int)(in / (unsigned)G.SBJ), bj = SJ * G.SBJ + (int)(in % (unsigned)G.SBJ);
   if (bi >= G.TI || bj >= G.TJ || bi < bj) return;  // outside / strictly-upper block tile (block-uniform)
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // provably uniform: scalar offsets below
+#ifdef RBL_SYRK_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+  const unsigned long long tstart = tprev, rstart = __builtin_amdgcn_s_memrealtime();   // shader cycles, 100 MHz ticks
+#endif
   const int wi = wave & 1, wj = wave >> 1;
   const long bi0 = r0 + (long)bi * 128, bj0 = r0 + (long)bj * 128;
   if (bj0 >= c1) return;  // block-uniform
@@ -385,30 +419,35 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   const bool active = (i0 < n) && (j0 < c1) && !(i0 + 63 < j0);  // wave tile holds lower-triangle entries
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  // loader: thread -> row (t & 127), column group (t >> 7) * 8 .. +7 of the KC-wide slab.
+  // loader: thread -> row PAIR 2 (t & 63), column group (t >> 6) * 4 .. +3 of the KC-wide slab: 16-byte loads
+  // (one wave instruction = 128 consecutive rows of a column) and ds_write_b128 -- half the memory and LDS
+  // instructions of 8-byte pieces; a wave spent 19 % of its time issuing those.
   // Prefetch distance TWO stages through two register sets: the loads of stage s+3 are issued in stage s and
   // land in LDS in stage s+2 -- under load the memory latency exceeds one stage (64 MFMAs = 1.7 us), and a
   // one-stage prefetch left every wave stalled ~40 % of the time in front of its ds_writes.
-  const int lrow = t & 127, lcg = (t >> 7) * 8;
-  long gi = bi0 + lrow; if (gi >= n) gi = n - 1;
-  long gj = bj0 + lrow; if (gj >= n) gj = n - 1;
+  const int lrow = (t & 63) * 2, lcg = (t >> 6) * 4;
+  long gi = bi0 + lrow; if (gi >= n) gi = n - 2;      // rows >= n feed accumulators that are never stored; a pair
+  long gj = bj0 + lrow; if (gj >= n) gj = n - 2;      // (n-1, n) reads one element of the next column: in range
   // the K panel columns through one buffer descriptor: scalar offset = column, one per-lane offset per slab
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       A + (size_t)k0 * (size_t)ld, (short)0, (int)((size_t)K * (size_t)ld * 8), 0x00020000);
   const unsigned ldb = (unsigned)ld * 8u;
   const unsigned vI = (unsigned)lcg * ldb + 8u * (unsigned)gi, vJ = (unsigned)lcg * ldb + 8u * (unsigned)gj;
-  double rI[2][8], rJ[2][8];
+  rbl_d2 rI[2][4], rJ[2][4];
   const int nst = K / KC;
   auto gload = [&](auto set, int stg) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const unsigned so = (unsigned)(stg * KC + q) * ldb;
-      rI[set()][q] = buf_ld(rs, vI, so); rJ[set()][q] = buf_ld(rs, vJ, so);
+      rI[set()][q] = buf_ld2(rs, vI, so); rJ[set()][q] = buf_ld2(rs, vJ, so);
     }
   };
   auto lwrite = [&](auto set, int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { sI[buf][(lcg + q) * LDP + lrow] = rI[set()][q]; sJ[buf][(lcg + q) * LDP + lrow] = rJ[set()][q]; }
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<rbl_d2 *>(&sI[buf][(lcg + q) * LDP + lrow]) = rI[set()][q];
+      *reinterpret_cast<rbl_d2 *>(&sJ[buf][(lcg + q) * LDP + lrow]) = rJ[set()][q];
+    }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -507,11 +546,16 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   // end (its registers are the then idle prefetch sets) and has landed when the epilogue starts.
   auto stage = [&](int s_, auto nset) {
     if (s_ + 1 < nst) lwrite(nset, (s_ + 1) & 1);
+    PT(0)
     if (s_ + 3 < nst) gload(nset, s_ + 3);
+    PT(1)
     compute(s_ & 1);
+    PT(2)
     __syncthreads();
+    PT(3)
   };
   double cv0[2][4][4];
+  PT(4)
   {                                        // nst is even and >= 4 (K = 256, 512; checked by the launchers): last two stages peeled
     for (int s2 = 0; s2 < nst - 2; s2 += 2) {
       stage(s2, S1{});
@@ -522,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
     compute((nst - 2) & 1);
     __syncthreads();
     compute((nst - 1) & 1);               // stage nst-1
+    PT(5)
     if (!active) return;
     if (!interior) load_C(0, cv0);
   }
@@ -529,6 +574,16 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   double cv1[2][4][4];
   load_C(2, cv1);
   store_C(2, cv1);
+#ifdef RBL_SYRK_PROF
+  __builtin_amdgcn_s_waitcnt(0);
+  PT(6)
+  if (lane == 0 && wave == 0 && interior) {
+    for (int q = 0; q < 7; ++q) atomicAdd(&g_syrk_prof[q], prof[q]);
+    atomicAdd(&g_syrk_prof[7], tprev - tstart);
+    atomicAdd(&g_syrk_prof[8], 1ull);
+    atomicAdd(&g_syrk_prof[9], __builtin_amdgcn_s_memrealtime() - rstart);
+  }
+#endif
 }
 
 __global__ void k_zero_upper(double *__restrict__ A, long n)
@@ -580,6 +635,16 @@ __global__ void k_trmv_reduce(const double *__restrict__ part, long n, int nchun
 }
 
 }  // namespace
+
+#ifdef RBL_SYRK_PROF
+extern "C" __attribute__((visibility("default"))) int rbl_debug_syrk_prof(unsigned long long *out, int reset)
+{
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_syrk_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 size_t rbl_cholesky_work_bytes(int64_t) { return sizeof(double) * (NB / IB) * IB * IB; }   // one L_kk^-1 per IB-step of a panel
 
