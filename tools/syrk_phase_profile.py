@@ -1,12 +1,32 @@
 #!/usr/bin/env python3
 """Phase breakdown of the trailing-update kernel k_syrk_mfma from in-kernel s_memtime stamps.
 
-Needs a DIAGNOSTIC library (the normal build has no stamps):
-    hipcc ... -DRBL_SYRK_PROF -c rigid_body_light_amd/csrc/rbl_dense.hip   (or RBL_EXTRA_FLAGS=-DRBL_SYRK_PROF build.py
-    into a scratch copy), linked as a second librbl, and selected with RBL_LIBRARY=/path/to/librbl_prof.so.
-usage: RBL_LIBRARY=... syrk_phase_profile.py n_bodies blobs_per_body"""
+Runs against a DIAGNOSTIC library (the normal build has no stamps): rbl_dense.hip compiled with -DRBL_SYRK_PROF and
+linked with the other objects of the normal build into rigid_body_light_amd/build/librbl_prof.so.  `--build-only`
+makes that library (hipcc cross-compiles, no GPU needed); a run builds it when missing and loads it via RBL_LIBRARY.
+usage: syrk_phase_profile.py n_bodies blobs_per_body | --build-only"""
 import os, sys, ctypes, subprocess
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF_LIB = os.path.join(ROOT, "rigid_body_light_amd", "build", "librbl_prof.so")
+
+
+def build_prof_lib():
+    from rigid_body_light_amd import build as b
+    b.build()
+    obj = os.path.join(b.OBJ, "rbl_dense_prof.o")
+    subprocess.check_call([b.HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + b.ARCH, "-x", "hip", "-DRBL_SYRK_PROF",
+                           "-c", os.path.join(b.CSRC, "rbl_dense.hip"), "-o", obj])
+    others = [os.path.join(b.OBJ, s.rsplit(".", 1)[0] + ".o") for s in b.HIP_SOURCES if s != "rbl_dense.hip"]
+    subprocess.check_call([b.HIPCC, "-shared", "-fPIC", "--offload-arch=" + b.ARCH, "-o", PROF_LIB, obj] + others)
+
+
+if "--build-only" in sys.argv:
+    build_prof_lib(); print(PROF_LIB); sys.exit(0)
+if "RBL_LIBRARY" not in os.environ:
+    if not os.path.exists(PROF_LIB):
+        build_prof_lib()
+    os.environ["RBL_LIBRARY"] = PROF_LIB
 import numpy as np, torch, time
 from rigid_body_light_amd import make_config
 from rigid_body_light_amd._lib import DeviceContext, lib
