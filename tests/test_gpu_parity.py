@@ -275,7 +275,7 @@ def test_dense_build_bit_exact(orc, wall):
     assert np.array_equal(Md, (B[:, None] * Mo) * B[None, :])
 
 
-@pytest.mark.parametrize("n", [8, 33, 360, 1000, 2307])
+@pytest.mark.parametrize("n", [8, 33, 257, 360, 513, 771, 1000, 2307])   # odd sizes: the (n-1, n) row pair of the 16-byte panel loads
 def test_cholesky_vs_oracle(orc, n):
     rng = np.random.default_rng(50 + n)
     A = rng.standard_normal((n, n + 5))
