@@ -340,7 +340,7 @@ def main():
         F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
         if k is not None:
             ev[k][0].record(stream)
-        if use_sym:   # unordered tile pairs with I % world == rank -> partial full-length U -> all-reduce
+        if use_sym:   # this rank's share of the unordered tile pairs -> partial full-length U -> all-reduce
             ctx.apply_M_sym(F_full.data_ptr(), r_full.data_ptr(), N, rank, world, U_part.data_ptr())
         else:         # ordered pairs, this rank's rows, no reduction
             ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())

@@ -202,7 +202,7 @@ class DeviceContext:
         self._chk(self.L.rbl_apply_M_multi_dev(self.h, dF, dr, n_blobs, nrhs, dout))
 
     def apply_M_sym(self, dF, dr, n_blobs, i_first, i_step, dout):
-        """partial product over the tile rows I % i_step == i_first (sum over ranks = full U)."""
+        """partial product over share i_first of i_step of the tile rows (sum over the shares = full U)."""
         self._chk(self.L.rbl_apply_M_sym_dev(self.h, dF, dr, n_blobs, i_first, i_step, dout))
 
     def apply_M_sym_multi(self, dF, dr, n_blobs, nrhs, i_first, i_step, dout):

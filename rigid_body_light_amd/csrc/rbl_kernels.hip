@@ -163,9 +163,25 @@ __global__ __launch_bounds__(256) void k_reduce_parts(const double *__restrict__
 //            with ds_add_f64 (one lane per address per step -> deterministic order).
 // Row sums go to slabI[chunk][i], column sums to slabJ[I-row][j]; k_reduce_sym adds
 // them in a fixed order (no global atomics -> bitwise reproducible).
-// (i_first, i_step) selects the I-tiles of this launch (multi-GPU: I % world == rank).
+// (i_first, i_step) selects the I-tiles of this launch (multi-GPU: rank, world size; see sym_row_of).
 // ---------------------------------------------------------------------------
 constexpr int TS = 64;
+
+// Row super-tiles of launch (i_first, i_step) -- rank, world size with several GPUs.  Row I carries T - I tile pairs, so
+// plain striding (I = i_first + e i_step) leaves rank 0 with (i_step - 1) / i_step of a row more than the last rank in
+// EVERY block of i_step rows (8.8 % at 8 ranks, cfg 3).  The e-th owned row is taken from the e-th block of i_step
+// consecutive rows, offset i_first in even blocks and i_step - 1 - i_first in odd ones: two consecutive blocks give
+// every rank the same 2 (T - e i_step) - (i_step - 1) pairs.  Still increasing in e (the column-sum slabs rely on it).
+__device__ __forceinline__ int sym_row_of(int e, int i_first, int i_step)
+{
+  return e * i_step + ((e & 1) ? i_step - 1 - i_first : i_first);
+}
+__device__ __forceinline__ bool sym_row_owned(int I, int i_first, int i_step) { return sym_row_of(I / i_step, i_first, i_step) == I; }
+__device__ __forceinline__ int sym_rows_below(int Ilim, int i_first, int i_step)   // owned rows I < Ilim
+{
+  const int e = Ilim / i_step;                                        // blocks 0 .. e-1 lie wholly below Ilim
+  return e + (sym_row_of(e, i_first, i_step) < Ilim ? 1 : 0);
+}
 
 // Bounding box of every 64-blob tile in radius-scaled coordinates: bbox[tile] = {min x,y,z, max x,y,z}.
 // Lets the symmetric kernel prove "no pair of this tile pair is closer than 2a" and run the sweep without
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS];  // (x,y) (z,fx) (fy,fz) of the j tile
   __shared__ double sU[3][TS];                      // M_ji F_i sums for the j tile
   const int lane = threadIdx.x;
-  const int I = i_first + (int)blockIdx.x * i_step;  // super-tile index
+  const int I = sym_row_of((int)blockIdx.x, i_first, i_step);  // super-tile index
   const int c = blockIdx.y;
   const int It0 = NI * I;                            // first 64-row tile of this super-tile
   if (It0 >= T) return;
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ 
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS], sP3[TS], sP4[TS];  // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
   __shared__ double sU[2][3][TS];
   const int lane = threadIdx.x;
-  const int I = i_first + (int)blockIdx.x * i_step;
+  const int I = sym_row_of((int)blockIdx.x, i_first, i_step);
   const int c = blockIdx.y;
   const int It0 = NI * I;
   if (It0 >= T) return;
@@ -500,11 +516,11 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
   const int J = (int)(j / TS);
   const int Is = J / NI;                                 // super-tile owning row tile J
   const size_t Npad3 = (size_t)T * TS * 3 * gridDim.y;   // distance between consecutive slabs
-  const bool owned = Is >= i_first && (Is - i_first) % i_step == 0;   // this launch owned the rows of tile J
+  const bool owned = sym_row_owned(Is, i_first, i_step);   // this launch owned the rows of tile J
   const int c0 = (NI * Is) / C;
   const int nI = owned ? nch - c0 : 0;
   const int Ilim = (J + NI - 1) / NI;                    // super-tiles I with NI*I < J
-  const int nJ = (Ilim > i_first) ? (Ilim - i_first + i_step - 1) / i_step : 0;
+  const int nJ = sym_rows_below(Ilim, i_first, i_step);
   const double *pI = slabI + (size_t)c0 * Npad3 + idc;
   const double *pJ = slabJ + idc;
   double s = 0.0;

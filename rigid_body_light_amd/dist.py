@@ -6,8 +6,8 @@ matvec) over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
 
 Two per-rank work splits:
   rows      (apply_M_local)     rank owns its bodies' rows, ordered-pair kernel, no reduction;
-  symmetric (apply_M_allreduce) rank owns the unordered blob-tile pairs {I,J>=I} with
-            I % world == rank (interleaved -> balanced triangle), symmetric kernel (each
+  symmetric (apply_M_allreduce) rank owns the unordered blob-tile pairs {I,J>=I} of one row tile I in every
+            `world` consecutive ones (offset rank, mirrored in odd groups -> balanced triangle), symmetric kernel (each
             unordered pair once, ~1.5x less arithmetic), then ONE all-reduce of the 24 N-byte
             partial U.
 
@@ -89,8 +89,8 @@ class ShardedMobility:
         return self.all_gather_rows(U_local) if gather_output else U_local
 
     def apply_M_allreduce(self, F_local):
-        """Symmetric-kernel sharding: every rank evaluates the unordered tile pairs whose row
-        tile I satisfies I % world == rank and produces a PARTIAL full-length U; one
+        """Symmetric-kernel sharding: every rank evaluates the unordered tile pairs of its share of
+        the row tiles (rbl_apply_M_sym_dev: i_first = rank, i_step = world) and produces a PARTIAL full-length U; one
         all-reduce (sum) completes it.  Returns the full U on every rank."""
         F_full = self.all_gather_rows(F_local.contiguous())
         if self.sym_apply is not None:
