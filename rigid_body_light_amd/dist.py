@@ -60,8 +60,11 @@ class ShardedMobility:
         largest shard so a single all_gather_into_tensor moves everything."""
         if self.world == 1:
             return local.clone()
-        pad = torch.zeros(self.max_rows * 3, dtype=local.dtype, device=local.device)
-        pad[: local.numel()] = local
+        if local.numel() == self.max_rows * 3:      # equal shards (the usual case): no staging copy
+            pad = local
+        else:
+            pad = torch.zeros(self.max_rows * 3, dtype=local.dtype, device=local.device)
+            pad[: local.numel()] = local
         if self.stage_cpu:
             hbuf = torch.empty(self.world * self.max_rows * 3, dtype=local.dtype)
             dist.all_gather_into_tensor(hbuf, pad.cpu(), group=self.group)
