@@ -20,7 +20,8 @@ F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev)
 U = torch.empty_like(F)
 full = None
 REPS = 10
-for world in (1, 2, 4, 8):
+WORLDS = [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]
+for world in WORLDS:
     ts = []; acc = torch.zeros_like(F)
     for rank in range(world):
         ctx.apply_M_sym(F.data_ptr(), r.data_ptr(), N, rank, world, U.data_ptr()); ctx.sync_check()
