@@ -253,6 +253,10 @@ int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /*
  * apply the plain wall-corrected M (no damping B) until switched off again: together they let a caller compose
  * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product. */
 int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode);
+/* the same for the bodies [body_begin, body_end) only (body_end < 0: to the last body): d_in / d_out are still
+ * full-length blob vectors, only the entries of those bodies are read and written, and only those bodies are
+ * factored -- a multi-GPU driver gives every rank its own bodies and all-gathers the result. */
+int rbl_block_solve_range_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode, int body_begin, int body_end);
 int rbl_set_no_damp(rbl_ctx *ctx, int on);
 
 /* Right-preconditioned GMRES(max_iter <= 255, no restart) on the saddle operator of the object's own

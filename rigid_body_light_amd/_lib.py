@@ -56,6 +56,7 @@ def lib():
         L.rbl_step_deterministic.argtypes = [vp, vp, vp, C.c_int, dbl, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_step_brownian.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, C.c_int, dbl, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_block_solve_dev.argtypes = [vp, vp, vp, C.c_int]
+        L.rbl_block_solve_range_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
         L.rbl_set_no_damp.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
@@ -129,9 +130,10 @@ class DeviceContext:
         U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_evolve_X_Q(self.h, U.ctypes.data))
 
-    def block_solve(self, din, dout, mode):
-        """per-body Cholesky factors L L^T = M_body: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x"""
-        self._chk(self.L.rbl_block_solve_dev(self.h, din, dout, mode))
+    def block_solve(self, din, dout, mode, body_begin=0, body_end=-1):
+        """per-body Cholesky factors L L^T = M_body: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x; full-length blob
+        vectors, only the bodies [body_begin, body_end) are factored, read and written (default: all)"""
+        self._chk(self.L.rbl_block_solve_range_dev(self.h, din, dout, mode, int(body_begin), int(body_end)))
 
     def set_no_damp(self, on):
         self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))

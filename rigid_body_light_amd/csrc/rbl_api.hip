@@ -679,7 +679,7 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 //             matrix-free matvec (no O(n^2) memory).
 // ---------------------------------------------------------------------------
 static int sync_bodies(rbl_ctx *c);
-static int pc_block_factors(rbl_ctx *c);
+static int pc_block_factors(rbl_ctx *c, int b0 = 0, int b1 = -1);
 
 // y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
 // precond: y_v = L^-1 M L^-T x_v with the per-body Cholesky factors L L^T = M_body (block Jacobi), M undamped
@@ -968,17 +968,29 @@ int rbl_apply_M_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, int6
 
 // ---- per-body (block-Jacobi) Cholesky factors of the object's own configuration, for callers that compose the
 // preconditioned square root themselves (the multi-GPU driver): L L^T = M_body (wall term per wall_PC, undamped)
-int rbl_block_solve_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode)
+int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode, int body_begin, int body_end)
 {
+  if (!c) return RBL_ERR_ARG;
   int rc = sync_bodies(c); if (rc) return rc;
   if (mode < 0 || mode > 3 || !d_in || !d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x");
-  if ((rc = pc_block_factors(c))) return rc;
+  if (body_end < 0) body_end = c->S.N_bod;
+  if ((rc = pc_block_factors(c, body_begin, body_end))) return rc;
   const int64_t m = 3 * (int64_t)c->S.N_blb;
-  const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
-  rc = mode == 3 ? rbl_launch_block_trmv(c->stream, L, m, c->S.N_bod, m * m, d_in, d_out, m)
-                 : rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, m * m, Li, d_in, d_out, m, mode);
+  const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
+  const double *L = (const double *)c->d_blkL.p + (size_t)body_begin * (size_t)(m * m);
+  const double *Li = (const double *)c->d_blkLinv.p + (size_t)body_begin * lstride;
+  const double *in = d_in + (size_t)body_begin * (size_t)m;
+  double *out = d_out + (size_t)body_begin * (size_t)m;
+  const int nb = body_end - body_begin;
+  rc = mode == 3 ? rbl_launch_block_trmv(c->stream, L, m, nb, m * m, in, out, m)
+                 : rbl_launch_block_solve(c->stream, L, m, nb, m * m, Li, in, out, m, mode);
   if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
   return RBL_OK;
+}
+
+int rbl_block_solve_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode)
+{
+  return rbl_block_solve_range_dev(c, d_in, d_out, mode, 0, -1);
 }
 
 // transient switch: the matvec entry points skip the damping B (plain, wall-corrected M) while it is on
@@ -1111,20 +1123,26 @@ int rbl_KT_x_Lam_dev(rbl_ctx *c, const double *d_lam, double *d_out)
 // Block_diag_invM on the device (:461-487): per-body dense mobility (batched k_build_M), batched
 // in-place Cholesky on the matrix cores, then invM_b v = (L L^T)^-1 v by k_block_solve.
 // per-body mobility (wall-corrected per wall_PC, undamped) and its Cholesky factor, for every body at once
-static int pc_block_factors(rbl_ctx *c)
+// Bodies [b0, b1) (default: all).  Storage is always laid out for all bodies (body b at offset b); factors that are
+// valid for a range containing the requested one are re-used, otherwise exactly the requested range is rebuilt.
+static int pc_block_factors(rbl_ctx *c, int b0, int b1)
 {
-  if (c->dev_blk_valid) return RBL_OK;
   const RblBodyState &S = c->S;
+  if (b1 < 0) b1 = S.N_bod;
+  if (b0 < 0 || b0 >= b1 || b1 > S.N_bod) return rbl_fail(c, RBL_ERR_ARG, "block factors: need 0 <= body_begin < body_end <= N_bodies");
+  if (c->dev_blk_valid && c->blk_b0 <= b0 && b1 <= c->blk_b1) return RBL_OK;
   const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m;
+  const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);      // L_kk^-1 blocks of one body
   int rc;
   if ((rc = rbl_dev_reserve(c, c->d_blkL, sizeof(double) * (size_t)msz * S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_blkLinv, rbl_cholesky_batched_work_bytes(m, S.N_bod)))) return rc;
   const RblParams P = rbl_make_params(S.a, S.eta);
-  rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p, S.N_blb, S.N_bod, (double *)c->d_blkL.p,
+  double *Lb = (double *)c->d_blkL.p + (size_t)b0 * (size_t)msz;
+  rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p + (size_t)b0 * (size_t)m, S.N_blb, b1 - b0, Lb,
                              msz, c->d_err);
-  rc = rbl_launch_cholesky_batched(c->stream, (double *)c->d_blkL.p, m, S.N_bod, msz, c->d_err, (double *)c->d_blkLinv.p);
+  rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
-  c->dev_blk_valid = true;
+  c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1;
   return RBL_OK;
 }
 

@@ -75,7 +75,8 @@ struct rbl_ctx {
   bool step_x_valid = false;                        // d_step holds the previous step's solution
   int64_t step_x_size = 0;
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
-  bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration
+  bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration ...
+  int blk_b0 = 0, blk_b1 = 0;   // ... for the bodies [blk_b0, blk_b1) (a multi-GPU driver factors only its own bodies)
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies

@@ -264,8 +264,9 @@ def sharded_mhalf_W(ctx, sm, r_full, Wk, a, wall, tol=1e-3, max_iter=100, precon
     """Brownian increments (B M B)^{1/2} W_k for the nv = 1 or 2 rows of Wk on the tile-pair-sharded product
     (sm: ShardedMobility; all vectors replicated, one all-reduce per iteration).  Two vectors advance in lock step
     through ONE two-vector product per iteration (shared pair coefficients).
-      precondition=True : x = B L S^{1/2} W with S = L^-1 M L^-T and the per-body Cholesky factors L (replicated
-                          O(N N_blb) substitutions): covariance B M B exactly, ~7 iterations instead of ~35;
+      precondition=True : x = B L S^{1/2} W with S = L^-1 M L^-T and the per-body Cholesky factors L: every rank
+                          factors and substitutes only ITS bodies (sm.b0 .. sm.b1) and one all-gather per
+                          substitution shares the result; covariance B M B exactly, ~7 iterations instead of ~35;
       precondition=False: Lanczos on B M B itself (the symmetric square root).
     Returns (Y (nv, n), iterations)."""
     nv, n3 = Wk.shape
@@ -285,9 +286,12 @@ def sharded_mhalf_W(ctx, sm, r_full, Wk, a, wall, tol=1e-3, max_iter=100, precon
         return sm.all_reduce_sum(part)
 
     def bsolve(v, mode):
+        v = v.contiguous()
         out = torch.empty_like(v)
-        ctx.block_solve(v.contiguous().data_ptr(), out.data_ptr(), mode)
-        return out
+        ctx.block_solve(v.data_ptr(), out.data_ptr(), mode, sm.b0, sm.b1)
+        if sm.world == 1:
+            return out
+        return sm.all_gather_rows(out[3 * sm.row0:3 * sm.row1])
 
     if precondition:
         def S_op(Vk):

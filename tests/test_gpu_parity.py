@@ -805,6 +805,51 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
     assert np.linalg.norm(out[0][0] - X) > 1e-4
 
 
+@pytest.mark.parametrize("wall", [False, True])
+def test_block_solve_body_ranges(orc, shell12, wall):
+    """rbl_block_solve_range_dev: the solves of disjoint body ranges fill one vector with exactly what the full solve
+    gives (every mode), entries of other bodies stay untouched, a range request after a full build re-uses it, and
+    the values are those of the dense per-body Cholesky factors (multi-GPU drivers give each rank its own bodies)."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    nb = 7
+    X, Q = random_positions(nb, wall=wall, seed=170)
+    if wall:
+        X[:, 2] += 1.4
+    dev = torch.device("cuda:0")
+    v = torch.from_numpy(np.random.default_rng(171).standard_normal(36 * nb)).to(dev)
+    full = {}
+    for order in ("ranges_first", "full_first"):
+        ctx = DeviceContext(1.0, 1.0, wall, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        for mode in (0, 1, 2, 3):
+            if order == "full_first":
+                f = torch.empty_like(v); ctx.block_solve(v.data_ptr(), f.data_ptr(), mode); ctx.sync_check()
+                full[mode] = f
+            out = torch.full_like(v, 7.5)
+            for b0, b1 in ((3, 5), (0, 3), (5, 7)):
+                ctx.block_solve(v.data_ptr(), out.data_ptr(), mode, b0, b1); ctx.sync_check()
+                if (b0, b1) == (3, 5):
+                    assert torch.all(out[:36 * 3] == 7.5) and torch.all(out[36 * 5:] == 7.5)
+            if order == "full_first":
+                assert torch.equal(out, full[mode])
+            else:
+                full[("r", mode)] = out
+        if order == "full_first":
+            for mode in (0, 1, 2, 3):
+                assert torch.equal(full[("r", mode)], full[mode])
+            with pytest.raises(RuntimeError):
+                ctx.block_solve(v.data_ptr(), out.data_ptr(), 0, 5, 9)
+    r = np.empty(36 * nb); rt = torch.empty(36 * nb, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, rt.data_ptr()); ctx.sync_check(); r = rt.cpu().numpy()
+    M = orc.rotne_prager_tensor(r, 1.0, 1.0, wall)
+    ref = np.empty(36 * nb)
+    for b in range(nb):
+        sl = slice(36 * b, 36 * (b + 1))
+        ref[sl] = np.linalg.solve(M[sl, sl], v.cpu().numpy()[sl])
+    assert rel(full[0].cpu().numpy(), ref) < 1e-11
+
+
 @pytest.mark.parametrize("block", [False, True])
 def test_native_gmres_equals_torch_gmres(shell12, block):
     """rbl_gmres_saddle_dev (librbl's own right-preconditioned GMRES) == the torch Arnoldi driver, fixed work and
