@@ -270,7 +270,8 @@ int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double
 /* Whole time steps in one call, on the object's own configuration (the reference has no driver; these are what
  * rigid_body_light_amd/krylov.py's steppers do, for hosts without a Python loop).
  *   rbl_step_deterministic: solve [M -K; K^T 0][lambda; U] = [slip; -F_body] (rbl_gmres_saddle_dev; slip NULL = 0;
- *       warm_start: begin from the previous call's solution), then evolve_X_Q(U).
+ *       warm_start: 0 cold, 1 begin from the previous call's solution, 2 / 3 from the linear / quadratic extrapolation
+ *       of the last two / three solutions), then evolve_X_Q(U).
  *   rbl_step_brownian: stochastic midpoint step -- RHS_and_Midpoint at q^n (W = [W1|W2|W_rfd] host, or NULL for
  *       seeded device noise; method RBL_MHALF_*), saddle solve at q^{n+1/2}, update from q^n.
  * F_body: host, 6 N_bod; slip: host, 3 N_blobs.  iters / resid report the GMRES run. */

@@ -139,13 +139,14 @@ class DeviceContext:
         self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))
 
     def step_deterministic(self, F_body, max_iter=20, rtol=None, slip=None, warm_start=False):
-        """one deterministic time step inside librbl (solve + evolve) -> (iterations, residual estimate)"""
+        """one deterministic time step inside librbl (solve + evolve) -> (iterations, residual estimate);
+        warm_start 0..3: cold / previous solution / linear / quadratic extrapolation of the last solutions"""
         import numpy as np
         F = np.ascontiguousarray(F_body, dtype=np.float64).reshape(-1)
         sl = None if slip is None else np.ascontiguousarray(slip, dtype=np.float64).reshape(-1)
         it, res = C.c_int(0), C.c_double(0.0)
         self._chk(self.L.rbl_step_deterministic(self.h, F.ctypes.data, None if sl is None else sl.ctypes.data, int(max_iter),
-                                                float(rtol or 0.0), int(bool(warm_start)), C.byref(it), C.byref(res)))
+                                                float(rtol or 0.0), int(warm_start), C.byref(it), C.byref(res)))
         return it.value, res.value
 
     def step_brownian(self, F_body, max_iter=20, rtol=None, slip=None, W=None, seed=0, method=2, split_rand=True,

@@ -225,7 +225,7 @@ struct CManyBodies {
   }
 
   // whole time steps inside librbl (no counterpart in the reference, which ships no driver) -> (iterations, residual)
-  py::tuple step_deterministic(darr F, py::object slip, int max_iter, double rtol, bool warm_start)
+  py::tuple step_deterministic(darr F, py::object slip, int max_iter, double rtol, int warm_start)
   {
     if (F.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("step_deterministic: F must have length 6*N_bod");
     darr sl;
@@ -238,7 +238,7 @@ struct CManyBodies {
     int it = 0, rc; double res = 0.0;
     {
       py::gil_scoped_release rel;
-      rc = rbl_step_deterministic(ctx, F.data(), sp, max_iter, rtol, warm_start ? 1 : 0, &it, &res);
+      rc = rbl_step_deterministic(ctx, F.data(), sp, max_iter, rtol, warm_start, &it, &res);
     }
     check(rc);
     return py::make_tuple(it, res);
@@ -376,7 +376,7 @@ PYBIND11_MODULE(c_rigid, m)
       .def("KTinv_RFD", &CManyBodies::KTinv_RFD, py::arg("W"), py::arg("delta") = 1.0e-4)
       .def("update_X_Q", &CManyBodies::update_X_Q, py::arg("U"))
       .def("step_deterministic", &CManyBodies::step_deterministic, py::arg("F"), py::arg("slip") = py::none(),
-           py::arg("max_iter") = 50, py::arg("rtol") = 1.0e-8, py::arg("warm_start") = false)
+           py::arg("max_iter") = 50, py::arg("rtol") = 1.0e-8, py::arg("warm_start") = 0)
       .def("step_brownian", &CManyBodies::step_brownian, py::arg("F"), py::arg("slip") = py::none(),
            py::arg("W") = py::none(), py::arg("seed") = 0, py::arg("method") = "lanczos_pc", py::arg("split_rand") = true,
            py::arg("delta") = 1.0e-4, py::arg("max_iter") = 50, py::arg("rtol") = 1.0e-8)

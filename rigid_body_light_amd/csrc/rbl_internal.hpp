@@ -71,8 +71,9 @@ struct rbl_ctx {
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
-  RblDevBuf d_step;                                 // time-step entry points: rhs, solution (kept for the warm start), slip, force
-  bool step_x_valid = false;                        // d_step holds the previous step's solution
+  RblDevBuf d_step;                                 // time-step entry points: solution, rhs, slip, force
+  RblDevBuf d_hist;                                 // the last (up to 3) deterministic-step solutions, a ring: warm start
+  int step_hist_n = 0, step_hist_head = 0;          // entries held, slot of the newest one
   int64_t step_x_size = 0;
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
   bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration ...

@@ -876,8 +876,7 @@ __global__ __launch_bounds__(256) void k_dot2_final(const double *__restrict__ p
   if (threadIdx.x == 0) { out2[0] = s0[0]; out2[1] = s1[0]; }
 }
 
-__global__ void k_axpby(long n, double a, const double *__restrict__ x, double b,
-                        const double *__restrict__ y, double *__restrict__ out)
+__global__ void k_axpby(long n, double a, const double *x, double b, const double *y, double *out)   // out may alias x or y
 {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);

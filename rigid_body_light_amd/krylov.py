@@ -63,8 +63,9 @@ class DeterministicStepper:
         self.size = self.n3 + 6 * n_bodies
         self.use_graph = use_graph
         self.native = native          # librbl's own GMRES (rbl_gmres_saddle_dev) instead of the torch Arnoldi loop
-        self.warm_start = False       # native solver, converged mode: start from the previous step's solution
-        self._x_prev = None
+        self.warm_start = False       # native solver, converged mode: start from the previous step's solution ...
+        self.extrapolate = 0          # ... 1: from 2 x_n - x_{n-1}, 2: from 3 x_n - 3 x_{n-1} + x_{n-2} (the solution moves
+        self._x_hist = []             #     smoothly with the configuration); history of the last solutions, newest first
         self._graph = None
 
     def _A(self, x):
@@ -109,11 +110,20 @@ class DeterministicStepper:
         if self.native:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
             b[self.n3:] = -Fb
-            warm = self.warm_start and rtol is not None and self._x_prev is not None
-            x = self._x_prev.clone() if warm else torch.empty_like(b)
+            h = self._x_hist
+            warm = self.warm_start and rtol is not None and len(h) > 0
+            order = min(int(self.extrapolate), len(h) - 1) if warm else 0
+            if not warm:
+                x = torch.empty_like(b)
+            elif order >= 2:
+                x = 3.0 * h[0] - 3.0 * h[1] + h[2]
+            elif order == 1:
+                x = 2.0 * h[0] - h[1]
+            else:
+                x = h[0].clone()
             m, resid = self.ctx.gmres_saddle(b.data_ptr(), iters, rtol, x.data_ptr(), use_x0=warm)
             if self.warm_start:
-                self._x_prev = x
+                self._x_hist = [x] + h[:2]
             return x[: self.n3], x[self.n3:], m, resid
         if rtol is not None or not self.use_graph:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)

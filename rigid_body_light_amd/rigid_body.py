@@ -145,9 +145,11 @@ class RigidBody:
 
     def step_deterministic(self, F_body, slip=None, max_iter=50, rtol=1.0e-8, warm_start=False):
         """One deterministic time step inside the library: GMRES on the saddle system with rhs [slip ; -F_body]
-        (apply_PC as preconditioner), then evolve_rigid_bodies(U).  Returns (iterations, residual estimate)."""
+        (apply_PC as preconditioner), then evolve_rigid_bodies(U).  warm_start: False/0 cold, True/1 start from the previous
+        step's solution, 2 / 3 from the linear / quadratic extrapolation of the last solutions (smooth forcing: far fewer
+        iterations).  Returns (iterations, residual estimate)."""
         return self.cb.step_deterministic(self._require(F_body, "body"), None if slip is None else self._require(slip, "blob"),
-                                          max_iter, rtol, warm_start)
+                                          max_iter, rtol, int(warm_start))
 
     def step_brownian(self, F_body, slip=None, W=None, seed=0, method="lanczos_pc", split_rand=True, delta=1.0e-4,
                       max_iter=50, rtol=1.0e-8):

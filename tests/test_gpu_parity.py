@@ -982,6 +982,43 @@ def test_one_call_time_steps_equal_python_steppers(shell12):
     assert np.array_equal(c1.get_config(nb)[0], c2.get_config(nb)[0])
 
 
+def test_extrapolated_warm_start(shell12):
+    """Initial guess 2 x_n - x_{n-1} / 3 x_n - 3 x_{n-1} + x_{n-2} from the last solutions (stepper.extrapolate = 1 / 2,
+    rbl_step_deterministic warm_start = 2 / 3): the trajectory is the cold-started one to the solver tolerance, the later
+    steps need fewer iterations than a cold start, and the one-call library step does exactly what the Python stepper does."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    from rigid_body_light_amd.krylov import DeterministicStepper
+    nb = 5
+    X, Q, W, slip, force = _brownian_case(shell12, True, nb=nb, seed=190)
+    dev = torch.device("cuda:0")
+    def fresh():
+        ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.002, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        return ctx
+    nsteps, runs = 7, {}
+    for name, level in (("cold", None), ("prev", 0), ("lin", 1), ("quad", 2)):
+        ctx = fresh()
+        st = DeterministicStepper(ctx, nb, 12, dev, native=True)
+        st.warm_start = level is not None; st.extrapolate = level or 0
+        its = [st.step(force, iters=100, rtol=1e-10)[0] for _ in range(nsteps)]
+        runs[name] = (its, ctx.get_config(nb))
+    for name in ("prev", "lin", "quad"):
+        np.testing.assert_allclose(runs[name][1][0], runs["cold"][1][0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(runs[name][1][1], runs["cold"][1][1], rtol=0, atol=1e-9)
+        assert sum(runs[name][0][3:]) < sum(runs["cold"][0][3:])
+    assert sum(runs["lin"][0][3:]) <= sum(runs["prev"][0][3:])      # (quadratic vs linear depends on dt and the tolerance:
+                                                                    #  the error of the older solutions is amplified 7x vs 3x)
+    assert np.linalg.norm(runs["cold"][1][0] - X) > 1e-4
+    for level in (2, 3):                                       # the library's own ring of the last three solutions
+        ctx = fresh()
+        its = [ctx.step_deterministic(force, 100, 1e-10, warm_start=level)[0] for _ in range(nsteps)]
+        ref = runs["lin" if level == 2 else "quad"]
+        assert its == ref[0]
+        np.testing.assert_allclose(ctx.get_config(nb)[0], ref[1][0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ctx.get_config(nb)[1], ref[1][1], rtol=0, atol=1e-12)
+
+
 @pytest.mark.parametrize("nb,nblb,wall", [(7, 162, True), (200, 642, False)])
 def test_two_vector_symmetric_shards_add_up(nb, nblb, wall):
     """rbl_apply_M_sym_multi_dev: two vectors at once, sharded over the row tiles (I % step == first) -- the partial
