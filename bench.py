@@ -119,6 +119,8 @@ def timestep_mode(args, dev, world=1, rank=0):
             solver = "graph" if args.graph else ("native" if args.native else args.solver)
         stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=(solver == "graph"), native=(solver == "native"))
         stp.warm_start = args.warm_start or args.extrapolate > 0
+        if args.block_refresh > 1:
+            ctx.set_block_refresh(args.block_refresh)
         stp.extrapolate = args.extrapolate
         stp_step = lambda k: stp.step(Fb, iters, rtol)
     res, used = [], []
@@ -160,7 +162,7 @@ def timestep_mode(args, dev, world=1, rank=0):
         "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
         "mf_gflops": extra.get("apply_M_per_step", iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used,
-        "initial_guess": (["previous solution", "2 x_n - x_{n-1}", "3 x_n - 3 x_{n-1} + x_{n-2}"][args.extrapolate]
+        "block_refresh": args.block_refresh, "initial_guess": (["previous solution", "2 x_n - x_{n-1}", "3 x_n - 3 x_{n-1} + x_{n-2}"][args.extrapolate]
                           if (args.warm_start or args.extrapolate) and not brownian else "zero"), **extra}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -279,6 +281,8 @@ def main():
     ap.add_argument("--warm-start", action="store_true", help="--mode timestep --rtol ...: native GMRES starts from the previous step's solution")
     ap.add_argument("--extrapolate", type=int, default=0, choices=[0, 1, 2], help="--mode timestep --rtol ...: start from the linear (1) "
                     "or quadratic (2) extrapolation of the last solutions (implies --warm-start)")
+    ap.add_argument("--block-refresh", type=int, default=1, help="--mode timestep --pc block: rebuild the per-body Cholesky factors only "
+                    "every k-th configuration (rbl_set_block_refresh)")
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
@@ -408,6 +412,7 @@ def main():
             from rigid_body_light_amd._lib import lib
             lib().rbl_set_blk_pc(ctx.h, 1)
             stp.warm_start = True; stp.extrapolate = 2     # initial guess 3 x_n - 3 x_{n-1} + x_{n-2}
+            ctx.set_block_refresh(4)                       # per-body factors rebuilt every 4th configuration
             for _ in range(3):                             # fill the history (18, 12, 6 iterations), then 2-3 per step
                 stp.step(Fb, 200, 1e-8)
             barrier(); ts0 = time.perf_counter()
@@ -417,8 +422,8 @@ def main():
                 its.append(m_it)
             barrier()
             tc = (time.perf_counter() - ts0) / args.timestep_steps
-            lib().rbl_set_blk_pc(ctx.h, 0)
-            tstep["converged"] = {"rtol": 1e-8, "preconditioner": "block-diagonal",
+            lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
+            tstep["converged"] = {"rtol": 1e-8, "preconditioner": "block-diagonal, per-body factors rebuilt every 4th step",
                                   "warm_start": "quadratic extrapolation of the last three solutions (12 iterations from the "
                                                 "previous solution alone, 18 cold)", "gmres_iterations": its,
                                   "gmres_residual": res_it, "timesteps_per_sec": 1.0 / tc, "ms_per_timestep": tc * 1e3}

@@ -258,6 +258,11 @@ int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mod
  * factored -- a multi-GPU driver gives every rank its own bodies and all-gathers the result. */
 int rbl_block_solve_range_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode, int body_begin, int body_end);
 int rbl_set_no_damp(rbl_ctx *ctx, int on);
+/* Keep the per-body Cholesky factors for `every` configuration changes (default 1: rebuilt after each change) before
+ * they are rebuilt: both of their uses -- the block-diagonal preconditioner and the L of the preconditioned square
+ * root -- stay exact with factors of a nearby configuration, only the iteration counts move.  M^-1 K and
+ * (K^T M^-1 K)^-1 are still rebuilt for every configuration (with the kept factors). */
+int rbl_set_block_refresh(rbl_ctx *ctx, int every);
 
 /* Right-preconditioned GMRES(max_iter <= 255, no restart) on the saddle operator of the object's own
  * configuration (src/Rigid.py:73-80 is what a caller's Krylov solver applies; the reference ships no solver):

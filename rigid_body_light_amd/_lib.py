@@ -58,6 +58,7 @@ def lib():
         L.rbl_block_solve_dev.argtypes = [vp, vp, vp, C.c_int]
         L.rbl_block_solve_range_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
         L.rbl_set_no_damp.argtypes = [vp, C.c_int]
+        L.rbl_set_block_refresh.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
@@ -134,6 +135,10 @@ class DeviceContext:
         """per-body Cholesky factors L L^T = M_body: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x; full-length blob
         vectors, only the bodies [body_begin, body_end) are factored, read and written (default: all)"""
         self._chk(self.L.rbl_block_solve_range_dev(self.h, din, dout, mode, int(body_begin), int(body_end)))
+
+    def set_block_refresh(self, every):
+        """keep the per-body Cholesky factors for `every` configuration changes (1 = rebuild after each)"""
+        self._chk(self.L.rbl_set_block_refresh(self.h, int(every)))
 
     def set_no_damp(self, on):
         self._chk(self.L.rbl_set_no_damp(self.h, int(bool(on))))

@@ -285,6 +285,7 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
 {
   if (!c || !X || !Q || N_bod <= 0) return rbl_fail(c, RBL_ERR_ARG, "setConfig: bad arguments");
   RblBodyState &S = c->S;
+  if (S.N_bod != N_bod) c->dev_blk_valid = false;
   S.N_bod = N_bod;
   S.X.assign(X, X + (size_t)3 * N_bod);
   S.Q.resize((size_t)4 * N_bod);
@@ -295,7 +296,7 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
   }
   S.cfg_set = true;
   S.K_set = false;
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;   // (block factors: aged in sync_bodies)
   // NOTE the reference does NOT reset PC_mat_Set here (SURVEY.md 8b "state quirks");
   // a stale preconditioner after set_config is a trap, so we do invalidate it.
   S.pc_set = false;
@@ -568,7 +569,7 @@ int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
   rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
   S.X.swap(Xo);
   S.Q.swap(Qo);
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
   rc = rbl_body_set_K(S, c->last_error);                          // :876
   S.pc_set = false;                                               // :877
   return rc;
@@ -988,6 +989,13 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
   return RBL_OK;
 }
 
+int rbl_set_block_refresh(rbl_ctx *c, int every)
+{
+  if (!c || every < 1) return rbl_fail(c, RBL_ERR_ARG, "set_block_refresh: every >= 1");
+  c->blk_refresh = every; c->blk_age = 0; c->dev_blk_valid = false;
+  return RBL_OK;
+}
+
 int rbl_block_solve_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode)
 {
   return rbl_block_solve_range_dev(c, d_in, d_out, mode, 0, -1);
@@ -1089,7 +1097,9 @@ static int sync_bodies(rbl_ctx *c)
                        (double *)c->d_pos.p);
   c->dev_bodies_valid = true;
   c->dev_pc_valid = false;
-  c->dev_blk_valid = false;
+  // the per-body Cholesky factors follow every configuration change unless the caller asked to keep them for a few
+  // (rbl_set_block_refresh): as a preconditioner, or as the L of B L (L^-1 M L^-T)^{1/2} W, any nearby factor serves
+  if (c->dev_blk_valid && ++c->blk_age >= c->blk_refresh) c->dev_blk_valid = false;   // blk_age: changes since the build
   return RBL_OK;
 }
 
@@ -1142,7 +1152,7 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
                              msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
-  c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1;
+  c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1; c->blk_age = 0;
   return RBL_OK;
 }
 

@@ -78,6 +78,7 @@ struct rbl_ctx {
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
   bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration ...
   int blk_b0 = 0, blk_b1 = 0;   // ... for the bodies [blk_b0, blk_b1) (a multi-GPU driver factors only its own bodies)
+  int blk_refresh = 1, blk_age = 0;   // rbl_set_block_refresh: keep the factors for blk_refresh configuration changes
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies

@@ -982,6 +982,64 @@ def test_one_call_time_steps_equal_python_steppers(shell12):
     assert np.array_equal(c1.get_config(nb)[0], c2.get_config(nb)[0])
 
 
+def test_block_refresh_keeps_factors(orc, shell12):
+    """rbl_set_block_refresh(k): the per-body factors survive k - 1 configuration changes.  Their two uses stay exact:
+    the preconditioned square root with the KEPT factors L_A at configuration B is B_B L_A (L_A^-1 M_B L_A^-T)^{1/2} W
+    (a square root of B M_B B for any invertible L), and a converged step with the kept preconditioner lands where
+    the step with fresh factors does."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, n3 = 4, 36 * 4
+    XA, QA = random_positions(nb, wall=True, seed=200); XA[:, 2] += 1.4
+    XB = XA + 0.02 * np.random.default_rng(201).standard_normal(XA.shape)
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_block_refresh(2)
+    ctx.set_lanczos(n3, 1e-13)
+    v = torch.from_numpy(np.random.default_rng(202).standard_normal(n3)).to(dev)
+    def solve():
+        o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check(); return o.cpu().numpy()
+    def blocks(r):
+        M = orc.rotne_prager_tensor(r, 1.0, 1.0, True)
+        L = np.zeros_like(M)
+        for b in range(nb):
+            sl = slice(36 * b, 36 * (b + 1)); L[sl, sl] = np.linalg.cholesky(M[sl, sl])
+        return M, L
+    def positions():
+        rt = torch.empty(n3, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, rt.data_ptr()); ctx.sync_check()
+        return rt.cpu().numpy()
+    ctx.set_config(XA, QA); sA = solve(); MA, LA = blocks(positions())
+    assert rel(sA, np.linalg.solve(LA @ LA.T, v.cpu().numpy())) < 1e-11
+    ctx.set_config(XB, QA); sB = solve()                       # first change: factors of A are kept
+    assert np.array_equal(sB, sA)
+    rB = positions(); MB, LB = blocks(rB)
+    W = np.random.default_rng(203).standard_normal(n3)
+    out = np.empty(n3)
+    Wd = torch.from_numpy(W).to(dev); od = torch.empty_like(Wd)
+    rBd = torch.from_numpy(rB).to(dev)
+    x = ctx.M_half_W(rBd.data_ptr(), n3 // 3, Wd.data_ptr(), "lanczos_pc", od.data_ptr()); ctx.sync_check()
+    Li = np.linalg.inv(LA); S = Li @ MB @ Li.T
+    lam, Z = np.linalg.eigh(0.5 * (S + S.T))
+    ref = orc.damp(rB, 1.0) * (LA @ ((Z * np.sqrt(lam)) @ Z.T @ W))
+    assert rel(od.cpu().numpy(), ref) < 1e-9
+    ctx.set_config(XA, QA); ctx.set_config(XB, QA)             # two more changes: rebuilt at the second
+    sB2 = solve()
+    assert not np.array_equal(sB2, sA) and rel(sB2, np.linalg.solve(LB @ LB.T, v.cpu().numpy())) < 1e-11
+    # converged steps with kept factors == with fresh ones
+    force = np.tile([0.1, 0, -1.0, 0.2, 0, 0.05], nb)
+    ends = []
+    for every in (1, 3):
+        c2 = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.002, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(c2.h, 1)
+        c2.set_block_refresh(every); c2.set_config(XA, QA)
+        for _ in range(5):
+            it, res = c2.step_deterministic(force, 100, 1e-10, warm_start=2)
+            assert res < 1e-10
+        ends.append(c2.get_config(nb))
+    np.testing.assert_allclose(ends[1][0], ends[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ends[1][1], ends[0][1], rtol=0, atol=1e-9)
+
+
 def test_extrapolated_warm_start(shell12):
     """Initial guess 2 x_n - x_{n-1} / 3 x_n - 3 x_{n-1} + x_{n-2} from the last solutions (stepper.extrapolate = 1 / 2,
     rbl_step_deterministic warm_start = 2 / 3): the trajectory is the cold-started one to the solver tolerance, the later
