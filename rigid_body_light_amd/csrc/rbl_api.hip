@@ -692,17 +692,13 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
     const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
     int rc;
-    for (int v = 0; v < nvec; ++v)
-      if ((rc = rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, msz, Li, d_x + (size_t)v * n, d_tmp + (size_t)v * n, m, 2)))
-        return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+    if ((rc = rbl_launch_block_solve_multi(c->stream, L, m, c->S.N_bod, msz, Li, d_x, d_tmp, m, nvec, n, 2)))   // both vectors in one pass over L
+      return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
     c->no_damp = true;
     rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
     c->no_damp = false;
     if (rc) return rc;
-    for (int v = 0; v < nvec; ++v)
-      if ((rc = rbl_launch_block_solve(c->stream, L, m, c->S.N_bod, msz, Li, d_y + (size_t)v * n, d_y + (size_t)v * n, m, 1)))
-        return rc;
-    return RBL_OK;
+    return rbl_launch_block_solve_multi(c->stream, L, m, c->S.N_bod, msz, Li, d_y, d_y, m, nvec, n, 1);
   }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
@@ -1168,15 +1164,18 @@ static int pc_block_build(rbl_ctx *c)
   // Ninv_b = K_b^T invM_b K_b, column by column (bodies do not couple), then its 6x6 Cholesky; the six
   // solved columns invM_b K_b are kept (d_pcMK): every application needs invM K U
   double *w1 = (double *)c->d_pcw.p, *cols = w1 + 2 * n3, *Uunit = cols + 36 * (size_t)S.N_bod;
-  for (int cc = 0; cc < 6; ++cc) {
-    double *w2 = (double *)c->d_pcMK.p + (size_t)cc * n3;
+  (void)w1;
+  double *MK = (double *)c->d_pcMK.p;
+  for (int cc = 0; cc < 6; ++cc) {                       // the six columns of K ...
     rbl_launch_unit_U(c->stream, S.N_bod, cc, Uunit);
-    rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Uunit, S.N_blb, N, w1, nullptr, 0.0);
-    if ((rc = rbl_launch_block_solve(c->stream, (const double *)c->d_blkL.p, m, S.N_bod, msz, (const double *)c->d_blkLinv.p,
-                                     w1, w2, m)))
-      return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
-    rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, w2, S.N_blb, S.N_bod, cols + (size_t)cc * 6 * S.N_bod);
+    rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Uunit, S.N_blb, N, MK + (size_t)cc * n3, nullptr, 0.0);
   }
+  // ... solved in place, three per pass over the factors (the sweeps are latency chains: 6 single solves cost 10 ms at cfg 3)
+  if ((rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p, m, S.N_bod, msz, (const double *)c->d_blkLinv.p,
+                                         MK, MK, m, 6, n3, 0)))
+    return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
+  for (int cc = 0; cc < 6; ++cc)
+    rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, MK + (size_t)cc * n3, S.N_blb, S.N_bod, cols + (size_t)cc * 6 * S.N_bod);
   rbl_launch_pc_block_ninv(c->stream, cols, S.N_bod, (double *)c->d_NL.p, c->d_err);
   return RBL_OK;
 }

@@ -770,52 +770,66 @@ constexpr int SOLVE_MAXN = 8192;   // 64 KB of LDS
 
 constexpr int BS_T = 1024;   // threads per matrix: the sweeps are latency-bound, more rows in flight per step
 
+// NV right-hand sides per matrix (vector v of body b at in + v * rhs_pitch + b * vec_stride): L is streamed ONCE for
+// all of them -- the sweeps are latency chains, so NV vectors cost about what one does.
+template <int NV>
 __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
-                                                     const double *__restrict__ in, double *__restrict__ out,
-                                                     long vec_stride, int mode /* 0: L L^T, 1: L only, 2: L^T only */)
+                                                     const double *in, double *out, long vec_stride, long rhs_pitch,
+                                                     int mode /* 0: L L^T, 1: L only, 2: L^T only */)
 {
-  extern __shared__ double y[];                      // n doubles + IB scratch
-  double *tbuf = y + n;
+  extern __shared__ double y[];                      // NV x n doubles + NV x IB scratch
+  double *tbuf = y + (size_t)NV * n;                 // tbuf[v * IB + m]
   const int b = blockIdx.x, t = threadIdx.x;
   const double *Lb = L + (size_t)b * (size_t)strideA;
   const double *Lib = Linv + (size_t)b * (size_t)strideL;
-  const double *v = in + (size_t)b * (size_t)vec_stride;
-  for (long e = t; e < n; e += BS_T) y[e] = v[e];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    for (long e = t; e < n; e += BS_T) y[(size_t)v * n + e] = vin[e];
+  }
   __syncthreads();
   const int nsteps = (int)((n + IB - 1) / IB);
+  const int tv = t / IB, tt = t % IB;                // threads 0 .. NV*IB-1: (vector, row of the diagonal block)
   for (int s = 0; s < nsteps && mode != 2; ++s) {    // ---- forward: L y' = v
     const long k = (long)s * IB;
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
-    if (t < IB) {
+    if (t < IB * NV) {
       double acc = 0.0;
-      if (t < nb)
-        for (int m = 0; m <= t; ++m) acc = __builtin_fma(Li[t * IB + m], y[k + m], acc);
+      const double *yv = y + (size_t)tv * n + k;
+      if (tt < nb)
+        for (int m = 0; m <= tt; ++m) acc = __builtin_fma(Li[tt * IB + m], yv[m], acc);
       tbuf[t] = acc;
     }
     __syncthreads();
-    if (t < nb) y[k + t] = tbuf[t];
+    if (t < IB * NV && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
     if (nb == IB) {   // full block: 32 independent strided loads per row are issued back to back
       for (long r = k + IB + t; r < n; r += BS_T) {
         const double *col = Lb + (size_t)k * (size_t)n + r;
         double lv[IB];
 #pragma unroll
         for (int m = 0; m < IB; ++m) lv[m] = col[(size_t)m * n];
-        double a0 = y[r], a1 = 0.0;
 #pragma unroll
-        for (int m = 0; m < IB; m += 2) {
-          a0 = __builtin_fma(-lv[m], tbuf[m], a0);
-          a1 = __builtin_fma(-lv[m + 1], tbuf[m + 1], a1);
+        for (int v = 0; v < NV; ++v) {
+          double a0 = y[(size_t)v * n + r], a1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < IB; m += 2) {
+            a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
+            a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
+          }
+          y[(size_t)v * n + r] = a0 + a1;
         }
-        y[r] = a0 + a1;
       }
     } else {
       for (long r = k + nb + t; r < n; r += BS_T) {
-        double acc = y[r];
         const double *col = Lb + (size_t)k * (size_t)n + r;
-        for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[m], acc);
-        y[r] = acc;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double acc = y[(size_t)v * n + r];
+          for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[v * IB + m], acc);
+          y[(size_t)v * n + r] = acc;
+        }
       }
     }
     __syncthreads();
@@ -824,40 +838,50 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     const long k = (long)s * IB;
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
-    if (t < IB) {
+    if (t < IB * NV) {
       double acc = 0.0;
-      if (t < nb)
-        for (int m = t; m < nb; ++m) acc = __builtin_fma(Li[m * IB + t], y[k + m], acc);   // Linv^T
+      const double *yv = y + (size_t)tv * n + k;
+      if (tt < nb)
+        for (int m = tt; m < nb; ++m) acc = __builtin_fma(Li[m * IB + tt], yv[m], acc);   // Linv^T
       tbuf[t] = acc;
     }
     __syncthreads();
-    if (t < nb) y[k + t] = tbuf[t];
+    if (t < IB * NV && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
     if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r  (256 B contiguous per lane)
       for (long c = t; c < k; c += BS_T) {
         const double *row = Lb + (size_t)c * (size_t)n + k;
         double lv[IB];
 #pragma unroll
         for (int m = 0; m < IB; ++m) lv[m] = row[m];
-        double a0 = y[c], a1 = 0.0;
 #pragma unroll
-        for (int m = 0; m < IB; m += 2) {
-          a0 = __builtin_fma(-lv[m], tbuf[m], a0);
-          a1 = __builtin_fma(-lv[m + 1], tbuf[m + 1], a1);
+        for (int v = 0; v < NV; ++v) {
+          double a0 = y[(size_t)v * n + c], a1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < IB; m += 2) {
+            a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
+            a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
+          }
+          y[(size_t)v * n + c] = a0 + a1;
         }
-        y[c] = a0 + a1;
       }
     } else {
       for (long c = t; c < k; c += BS_T) {
-        double acc = y[c];
         const double *row = Lb + (size_t)c * (size_t)n + k;
-        for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[m], acc);
-        y[c] = acc;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double acc = y[(size_t)v * n + c];
+          for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[v * IB + m], acc);
+          y[(size_t)v * n + c] = acc;
+        }
       }
     }
     __syncthreads();
   }
-  double *o = out + (size_t)b * (size_t)vec_stride;
-  for (long e = t; e < n; e += BS_T) o[e] = y[e];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * n + e];
+  }
 }
 }  // namespace
 
@@ -896,15 +920,39 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
   return RBL_OK;
 }
 
-// mode 0: x = (L L^T)^-1 v ;  1: x = L^-1 v ;  2: x = L^-T v
-int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
-                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode)
+// mode 0: x = (L L^T)^-1 v ;  1: x = L^-1 v ;  2: x = L^-T v.  nv vectors per matrix, rhs_pitch doubles apart: up to three
+// share one pass over L (LDS: nv (n + 32) doubles <= 64 KB), more are done in groups.  In place (d_out == d_in) is fine.
+int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
+                                 const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
+                                 int64_t rhs_pitch, int mode)
 {
   if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
-  hipLaunchKernelGGL(k_block_solve, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)(n + IB), st, d_L, (long)n,
-                     (long)strideA, d_Linv, (long)(nsteps * IB * IB), d_in, d_out, (long)vec_stride, mode);
+  const long strideL = (long)(nsteps * IB * IB);
+  for (int v0 = 0; v0 < nv;) {
+    int g = nv - v0 >= 3 ? 3 : nv - v0;
+    while (g > 1 && (size_t)g * (size_t)(n + IB) * sizeof(double) > 65536) --g;
+    const size_t lds = sizeof(double) * (size_t)g * (size_t)(n + IB);
+    const double *in = d_in + (size_t)v0 * (size_t)rhs_pitch;
+    double *out = d_out + (size_t)v0 * (size_t)rhs_pitch;
+    if (g == 3)
+      hipLaunchKernelGGL(k_block_solve<3>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
+                         (long)vec_stride, (long)rhs_pitch, mode);
+    else if (g == 2)
+      hipLaunchKernelGGL(k_block_solve<2>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
+                         (long)vec_stride, (long)rhs_pitch, mode);
+    else
+      hipLaunchKernelGGL(k_block_solve<1>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
+                         (long)vec_stride, (long)rhs_pitch, mode);
+    v0 += g;
+  }
   return RBL_OK;
+}
+
+int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
+                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode)
+{
+  return rbl_launch_block_solve_multi(st, d_L, n, batch, strideA, d_Linv, d_in, d_out, vec_stride, 1, 0, mode);
 }
 
 size_t rbl_trmv_part_bytes(int64_t n)

@@ -147,6 +147,9 @@ int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batc
                                 unsigned *d_err, double *d_Linv);
 int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
                            const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode = 0);
+int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
+                                 const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
+                                 int64_t rhs_pitch, int mode);
 int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                           double *d_out, int64_t vec_stride);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
