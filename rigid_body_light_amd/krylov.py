@@ -13,12 +13,18 @@ import numpy as np
 import torch
 
 
-def gmres_right_pc(apply_A, apply_Pinv, b, iters, rtol=None):
+def gmres_right_pc(apply_A, apply_Pinv, b, iters, rtol=None, x0=None):
     """Right-preconditioned GMRES(iters), no restart.  apply_A / apply_Pinv: tensor -> tensor.
     Arnoldi with classical Gram-Schmidt applied twice (two GEMVs each, no host sync inside the
-    loop unless rtol is given).  Returns (x, number of iterations, relative residual estimate)."""
+    loop unless rtol is given).  x0: initial guess -- the correction is solved for from r0 = b - A x0, the
+    residual stays relative to |b|.  Returns (x, number of iterations, relative residual estimate)."""
     n = b.numel()
     dev, dt = b.device, b.dtype
+    bnorm = float(torch.linalg.norm(b))
+    if x0 is not None:
+        b = b - apply_A(x0)
+        if rtol is not None and float(torch.linalg.norm(b)) <= rtol * bnorm:
+            return x0.clone(), 0, float(torch.linalg.norm(b)) / bnorm
     V = torch.zeros(iters + 1, n, dtype=dt, device=dev)
     H = torch.zeros(iters + 1, iters, dtype=dt, device=dev)
     beta = torch.linalg.norm(b)
@@ -37,16 +43,17 @@ def gmres_right_pc(apply_A, apply_Pinv, b, iters, rtol=None):
             Hh = H[: j + 2, : j + 1].cpu().numpy()
             e1 = np.zeros(j + 2); e1[0] = float(beta)
             y, res, *_ = np.linalg.lstsq(Hh, e1, rcond=None)
-            r = np.linalg.norm(Hh @ y - e1) / float(beta)
+            r = np.linalg.norm(Hh @ y - e1) / bnorm
             if r < rtol:
                 m = j + 1
                 break
     Hh = H[: m + 1, :m].cpu().numpy()
     e1 = np.zeros(m + 1); e1[0] = float(beta)
     y, *_ = np.linalg.lstsq(Hh, e1, rcond=None)
-    resid = float(np.linalg.norm(Hh @ y - e1) / float(beta))
+    resid = float(np.linalg.norm(Hh @ y - e1) / bnorm)
     z = torch.from_numpy(y).to(dev) @ V[:m]
-    return apply_Pinv(z), m, resid
+    x = apply_Pinv(z)
+    return (x if x0 is None else x0 + x), m, resid
 
 
 class DeterministicStepper:
@@ -107,20 +114,14 @@ class DeterministicStepper:
     def solve(self, F_body, iters=20, rtol=None):
         """Solve the saddle system for rhs = [0 ; -F_body]; returns (lambda, U, iterations, residual)."""
         Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
+        h = self._x_hist
+        warm = self.warm_start and rtol is not None and len(h) > 0 and h[0].numel() == self.size
+        order = min(int(self.extrapolate), len(h) - 1) if warm else 0
+        x0 = None if not warm else (3.0 * h[0] - 3.0 * h[1] + h[2] if order >= 2 else 2.0 * h[0] - h[1] if order == 1 else h[0].clone())
         if self.native:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
             b[self.n3:] = -Fb
-            h = self._x_hist
-            warm = self.warm_start and rtol is not None and len(h) > 0
-            order = min(int(self.extrapolate), len(h) - 1) if warm else 0
-            if not warm:
-                x = torch.empty_like(b)
-            elif order >= 2:
-                x = 3.0 * h[0] - 3.0 * h[1] + h[2]
-            elif order == 1:
-                x = 2.0 * h[0] - h[1]
-            else:
-                x = h[0].clone()
+            x = x0 if warm else torch.empty_like(b)
             m, resid = self.ctx.gmres_saddle(b.data_ptr(), iters, rtol, x.data_ptr(), use_x0=warm)
             if self.warm_start:
                 self._x_hist = [x] + h[:2]
@@ -128,7 +129,9 @@ class DeterministicStepper:
         if rtol is not None or not self.use_graph:
             b = torch.zeros(self.size, dtype=torch.float64, device=self.dev)
             b[self.n3:] = -Fb
-            x, m, resid = gmres_right_pc(self._A, self._Pinv, b, iters, rtol)
+            x, m, resid = gmres_right_pc(self._A, self._Pinv, b, iters, rtol, x0=x0)
+            if self.warm_start:
+                self._x_hist = [x] + h[:2]
             return x[: self.n3], x[self.n3:], m, resid
         self.ctx.prepare()
         if self._graph is None or self._graph_iters != iters:

@@ -1068,6 +1068,11 @@ def test_extrapolated_warm_start(shell12):
     assert sum(runs["lin"][0][3:]) <= sum(runs["prev"][0][3:])      # (quadratic vs linear depends on dt and the tolerance:
                                                                     #  the error of the older solutions is amplified 7x vs 3x)
     assert np.linalg.norm(runs["cold"][1][0] - X) > 1e-4
+    ctx = fresh()                                              # the torch Arnoldi loop takes the same initial guess
+    st = DeterministicStepper(ctx, nb, 12, dev, native=False); st.warm_start = True; st.extrapolate = 1
+    its_t = [st.step(force, iters=100, rtol=1e-10)[0] for _ in range(nsteps)]
+    assert sum(its_t[3:]) < sum(runs["cold"][0][3:])
+    np.testing.assert_allclose(ctx.get_config(nb)[0], runs["cold"][1][0], rtol=0, atol=1e-9)
     for level in (2, 3):                                       # the library's own ring of the last three solutions
         ctx = fresh()
         its = [ctx.step_deterministic(force, 100, 1e-10, warm_start=level)[0] for _ in range(nsteps)]

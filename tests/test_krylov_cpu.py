@@ -21,6 +21,15 @@ def test_gmres_right_preconditioned_solves_spd_and_saddle_like_systems():
     # fixed-work form: no host check inside the loop, residual reported at the end
     x2, m2, r2 = gmres_right_pc(lambda v: St @ v, lambda v: Pinv @ v, torch.from_numpy(b), iters=10)
     assert m2 == 10 and r2 < 1.0
+    # initial guess: the correction is solved for, the tolerance stays relative to |b|
+    xs = np.linalg.solve(S, b)
+    x3, m3, r3 = gmres_right_pc(lambda v: St @ v, lambda v: Pinv @ v, torch.from_numpy(b), iters=66, rtol=1e-12,
+                                x0=torch.from_numpy(xs * (1.0 + 1e-6)))
+    assert r3 < 1e-12 and m3 < m
+    np.testing.assert_allclose(x3.numpy(), xs, rtol=1e-8, atol=1e-10)
+    x4, m4, r4 = gmres_right_pc(lambda v: St @ v, lambda v: Pinv @ v, torch.from_numpy(b), iters=66, rtol=1e-9,
+                                x0=torch.from_numpy(xs))
+    assert m4 == 0 and r4 < 1e-9 and np.array_equal(x4.numpy(), xs)
 
 
 def test_lanczos_square_root():
