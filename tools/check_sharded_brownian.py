@@ -19,7 +19,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda:0")
-    nb, nblb, wall, kBT = 6, 162, True, 0.05
+    nb, nblb, wall, kBT = int(os.environ.get("RBL_CHECK_BODIES", "6")), 162, True, 0.05
     c = make_config(nb, nblb, wall)
     n3 = 3 * nb * nblb
     W = np.random.default_rng(11).standard_normal(3 * n3)
