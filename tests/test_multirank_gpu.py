@@ -52,7 +52,20 @@ def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
         assert np.linalg.norm(z["values"] - Uo) / np.linalg.norm(Uo) < 1e-11
 
 
+def _max_diff(stdout, world):
+    line = [l for l in stdout.splitlines() if l.startswith("world %d:" % world)][-1]
+    return float(line.split("=")[1].split(",")[0])
+
+
 def test_two_rank_sharded_brownian_step_matches_single_process():
     p = _torchrun(2, ["tools/check_sharded_brownian.py"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "world 2" in p.stdout
+    assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10
+
+
+def test_three_rank_uneven_split_brownian_step(monkeypatch):
+    """7 bodies over 3 ranks (3 + 2 + 2): padded all-gathers, per-rank body ranges of the block factors"""
+    monkeypatch.setenv("RBL_CHECK_BODIES", "7")
+    p = _torchrun(3, ["tools/check_sharded_brownian.py"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "world 3" in p.stdout and _max_diff(p.stdout, 3) < 1e-10
