@@ -427,6 +427,23 @@ def main():
                                   "warm_start": "quadratic extrapolation of the last three solutions (12 iterations from the "
                                                 "previous solution alone, 18 cold)", "gmres_iterations": its,
                                   "gmres_residual": res_it, "timesteps_per_sec": 1.0 / tc, "ms_per_timestep": tc * 1e3}
+            # SURVEY 8d's Brownian step (BASELINE configs[3] on one GPU): 2 M^{1/2} W + M_RFD + Kinv before the fixed-work
+            # solve at the predictor configuration.  With N > 1: `--mode timestep --kBT 1 --gpus N` (sharded driver).
+            from rigid_body_light_amd.krylov import BrownianStepper
+            bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
+            bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(100, 1e-3)
+            bst = BrownianStepper(bctx, nb, nblb, dev, native=True)
+            bst.step(Fb, seed=0, method=2, iters=20, rtol=None)
+            barrier(); ts0 = time.perf_counter()
+            for k in range(args.timestep_steps):
+                bst.step(Fb, seed=1 + k, method=2, iters=20, rtol=None)
+            barrier()
+            tb = (time.perf_counter() - ts0) / args.timestep_steps
+            tstep["brownian"] = {"kBT": 1.0, "definition": "stochastic midpoint step: 2 M^{1/2}W (block-Jacobi preconditioned Lanczos to 1e-3, "
+                                 "two vectors in lock step) + M_RFD (2 apply_M) + Kinv, then 20 GMRES iterations (diag PC) at the "
+                                 "predictor configuration + evolve", "lanczos_iterations": bctx.lanczos_report()[0],
+                                 "timesteps_per_sec": 1.0 / tb, "ms_per_timestep": tb * 1e3}
+            del bst, bctx
 
     if rank == 0:
         sec_per_step = elapsed / args.steps

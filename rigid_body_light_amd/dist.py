@@ -104,6 +104,15 @@ class ShardedMobility:
                                  part.data_ptr())
         return self.all_reduce_sum(part)
 
+    def agree(self, flag):
+        """rank 0's value of a control-flow decision on every rank: data-dependent loop exits (Lanczos convergence)
+        must not depend on every rank having bitwise the same numbers, or one rank would leave a collective behind"""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=torch.device("cpu") if self.stage_cpu else self.device)
+        dist.broadcast(t, src=0, group=self.group)
+        return bool(int(t.item()))
+
     def all_reduce_sum(self, part):
         if self.world > 1:
             if self.stage_cpu:

@@ -310,13 +310,13 @@ def sharded_mhalf_W(ctx, sm, r_full, Wk, a, wall, tol=1e-3, max_iter=100, precon
         def S_op(Vk):
             out = product(torch.stack([bsolve(Vk[k], 2) for k in range(nv)]), True)
             return torch.stack([bsolve(out[k], 1) for k in range(nv)])
-        Y, its, _ = lanczos_mhalf_multi(S_op, Wk, max_iter, tol)
+        Y, its, _ = lanczos_mhalf_multi(S_op, Wk, max_iter, tol, agree=sm.agree)
         return torch.stack([B * bsolve(Y[k], 3) for k in range(nv)]), its
     if wall:                 # the wall kernel applies B M B itself (M_half_W always damps, :668-669)
         A_op = lambda Vk: product(Vk, False)
     else:
         A_op = lambda Vk: B * product(B * Vk, False)
-    Y, its, _ = lanczos_mhalf_multi(A_op, Wk, max_iter, tol)
+    Y, its, _ = lanczos_mhalf_multi(A_op, Wk, max_iter, tol, agree=sm.agree)
     return Y, its
 
 
@@ -398,11 +398,12 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
         return m, resid
 
 
-def lanczos_mhalf_multi(apply_A_multi, W, max_iter=100, tol=1e-3):
+def lanczos_mhalf_multi(apply_A_multi, W, max_iter=100, tol=1e-3, agree=None):
     """k independent Brownian increments M^{1/2} W_c at once: k Lanczos recurrences advanced in lockstep,
     so that every iteration is ONE multi-vector product -- which librbl runs on the fp64 matrix
     cores for k >= 4 (rbl_apply_M_multi_dev, 16 vectors per pass).  W: (k, n) tensor.
-    apply_A_multi: (k, n) -> (k, n) computing (B M B) v_c for every row.  Returns (Y (k,n), iterations, change)."""
+    apply_A_multi: (k, n) -> (k, n) computing (B M B) v_c for every row.  agree: bool -> bool, makes the stopping
+    decision the same on every rank of a sharded product (ShardedMobility.agree).  Returns (Y (k,n), iterations, change)."""
     k, n = W.shape
     dev = W.device
     V = torch.empty(max_iter + 1, k, n, dtype=W.dtype, device=dev)
@@ -432,7 +433,8 @@ def lanczos_mhalf_multi(apply_A_multi, W, max_iter=100, tol=1e-3):
                 yp = np.zeros(m); yp[: y_prev[c].size] = y_prev[c]
                 change[c] = np.linalg.norm(coef[c] - yp) / np.linalg.norm(coef[c])
             y_prev[c] = coef[c]
-        if change.max() < tol or it + 1 == max_iter or beta[it].min() < 1e-300:
+        done = bool(change.max() < tol or it + 1 == max_iter or beta[it].min() < 1e-300)
+        if agree(done) if agree is not None else done:
             break
         V[it + 1] = U / be[:, None]
     Y = torch.einsum("ck,kcn->cn", torch.from_numpy(coef).to(dev), V[:m])
