@@ -41,6 +41,59 @@ CONFIGS = {
 }
 FLOPS_PER_PAIR = {False: 59.0, True: 204.0}   # reference arithmetic per ordered pair
 PEAK_FP64_TFLOPS = 78.6                       # MI355X fp64 vector == fp64 matrix peak
+PEAK_CLOCK_GHZ = 2.4                          # the clock that peak is quoted at
+N_SIMD = 1024                                 # 256 CUs x 4 SIMDs; one wave64 fp64 VALU instruction occupies a SIMD for 4 cycles
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without torchrun: start the N-rank job as a CHILD process (one rank per GPU,
+    RCCL) before this process has touched the GPU, relay its output and exit with its status."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    if args.backend == "nccl" and ndev < args.gpus:
+        raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d (use --backend gloo to rehearse several "
+                         "ranks on one GPU)" % (args.gpus, args.gpus, ndev))
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def isa_counts(kernel):
+    """executed instructions per unordered pair of `kernel` in the far-tile sweep, from the assembly of the
+    sources librbl.so was built from (tools/isa_stats.py, written by rigid_body_light_amd/build.py)"""
+    path = os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")
+    lib = os.path.join(ROOT, "rigid_body_light_amd", "librbl.so")
+    try:
+        if os.path.getmtime(path) + 120 < os.path.getmtime(lib):
+            return None                        # stale: the library was rebuilt without its instruction counts
+        return json.load(open(path))["kernels"][kernel]["per_unordered_pair"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_traffic(kernel, config, world):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only when that
+    profile was taken from the kernel sources this library was built from (hash recorded in the file)."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r02_bench_%s_pmc.json" % config)
+    try:
+        d = json.load(open(path))
+        h = hashlib.sha256()
+        for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
+            h.update(open(os.path.join(ROOT, "rigid_body_light_amd", "csrc", f), "rb").read())
+        if d.get("kernel_source_sha256") != h.hexdigest() or world != 1 or d.get("kernel") != kernel:
+            return None, None
+        return d["hbm_bytes_per_launch"], d
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(c, nb, nblb, wall, budget_s):
@@ -252,6 +305,83 @@ def brownian_mode(args, dev, world, rank):
         dist.destroy_process_group()
 
 
+def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier):
+    """Time steps built on the hot path (the reference has no driver; SURVEY.md 8d defines them).  Every variant is timed
+    over args.timestep_steps consecutive steps and carries its GMRES residuals and iteration counts.
+      deterministic_fixed : 20 right-preconditioned GMRES iterations (diagonal PC) = 21 apply_M + K ops + evolve
+      converged           : deterministic, block-diagonal PC, GMRES to 1e-8, extrapolated initial guess (N = 1)
+      brownian_converged  : stochastic midpoint step (2 M^{1/2}W + M_RFD + Kinv at q^n, solve at q^{n+1/2}): block PC,
+                            GMRES to 1e-8 from a zero guess, square root by block-Jacobi preconditioned Lanczos to 1e-3 / 1e-6."""
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper, BrownianStepper, ShardedBrownianStepper
+    K = args.timestep_steps
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+
+    def timed(step_fn, k0=0):
+        barrier(); t0 = time.perf_counter()
+        its, res = [], []
+        for k in range(K):
+            m, r = step_fn(k0 + k)
+            its.append(int(m)); res.append(float(r))
+        barrier()
+        tv = torch.tensor([(time.perf_counter() - t0) / K], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        t = float(tv.item())
+        return {"timesteps_per_sec": 1.0 / t, "ms_per_timestep": t * 1e3, "steps_timed": K, "gmres_iterations": its,
+                "gmres_residual_max": max(res), "gmres_residual_last": res[-1]}
+
+    out = {}
+    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev, native=True))
+    stp.step(Fb, 20)
+    d = timed(lambda k: stp.step(Fb, 20))
+    d.update({"apply_M_per_timestep": 21, "definition": "deterministic fixed-work step (SURVEY.md 8d): 20 GMRES iterations on the saddle "
+              "operator, diagonal PC, + evolve; NOT converged (see gmres_residual_max)"})
+    out["deterministic_fixed"] = d
+    out.update({k: d[k] for k in ("timesteps_per_sec", "ms_per_timestep", "apply_M_per_timestep", "steps_timed")})
+    out["definition"] = d["definition"]
+    out["gmres_residual"] = d["gmres_residual_last"]
+    if world == 1:
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        stp.warm_start = True; stp.extrapolate = 2     # initial guess 3 x_n - 3 x_{n-1} + x_{n-2}
+        ctx.set_block_refresh(4)                       # per-body factors rebuilt every 4th configuration
+        for _ in range(3):                             # fill the history (18, 12, 6 iterations), then 2-3 per step
+            stp.step(Fb, 200, 1e-8)
+        d = timed(lambda k: stp.step(Fb, 200, 1e-8))
+        lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
+        d.update({"rtol": 1e-8, "preconditioner": "block-diagonal, per-body factors rebuilt every 4th step",
+                  "initial_guess": "quadratic extrapolation of the last three solutions (constant body force)"})
+        out["converged"] = d
+    # stochastic midpoint step, converged: BASELINE configs[3] (on N GPUs: `--mode timestep --kBT 1 --gpus N`)
+    bro = {}
+    for ltol in (1e-3, 1e-6):
+        bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
+        lib().rbl_set_blk_pc(bctx.h, 1)
+        bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(200, ltol)
+        bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
+        if world > 1:
+            from rigid_body_light_amd.dist import ShardedMobility
+            bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
+                                         lanczos_tol=ltol, lanczos_max_iter=200)
+            one = lambda k: bst.step(Fb, seed=k, iters=200, rtol=1e-8)
+            lz = lambda: list(bst.lanczos_iterations)
+        else:
+            bst = BrownianStepper(bctx, nb, nblb, dev, native=True)
+            one = lambda k: bst.step(Fb, seed=k, method=2, iters=200, rtol=1e-8)
+            lz = lambda: [bctx.lanczos_report()[0]]
+        one(0)
+        d = timed(one, 1)
+        d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz()})
+        bro["lanczos_%g" % ltol] = d
+        del bst, bctx
+    bro.update({"kBT": 1.0, "rtol": 1e-8, "initial_guess": "zero (fresh noise every step)",
+                "definition": "stochastic midpoint step: 2 M^{1/2}W (block-Jacobi preconditioned Lanczos, two vectors in lock step) + "
+                              "M_RFD (2 apply_M) + Kinv at q^n, GMRES with the block-diagonal PC to 1e-8 at the predictor "
+                              "configuration, update from q^n"})
+    out["brownian_converged"] = bro
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +396,7 @@ def main():
     ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep", "brownian"],
                     help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
                          "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
-    ap.add_argument("--timestep-steps", type=int, default=2, help="also time this many deterministic time steps (0 = skip)")
+    ap.add_argument("--timestep-steps", type=int, default=10, help="also time this many time steps of every variant (0 = skip)")
     ap.add_argument("--nvec", type=int, default=1, help="--mode brownian: independent noise vectors advanced in lockstep "
                     "(>= 4 uses the fp64-MFMA multi-RHS product; 1 GPU)")
     ap.add_argument("--kBT", type=float, default=0.0, help="--mode timestep: > 0 runs the stochastic midpoint (Brownian) step")
@@ -289,12 +419,18 @@ def main():
     ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])       # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     ndev = torch.cuda.device_count()
+    if ndev < 1 or (args.backend == "nccl" and ndev < world):
+        raise SystemExit("bench.py: %d ranks need %d visible GPUs, found %d" % (world, world, ndev))
     dev_index = local_rank % max(ndev, 1)     # several ranks may share a GPU only in a gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -389,69 +525,51 @@ def main():
 
     tstep = None
     if args.timestep_steps > 0:
-        # the reference has no time-step driver; ours (SURVEY.md 8d "fixed-work" step, krylov.py): 20 right-
-        # preconditioned GMRES iterations on apply_saddle (= 21 apply_M + diagonal PC + K ops) + evolve.  With N > 1
-        # the mobility product of every iteration is tile-pair sharded (one all-reduce per iteration).
-        from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper
-        stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev, native=True))
-        Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
-        stp.step(Fb, 20)
-        barrier(); ts0 = time.perf_counter()
-        for _ in range(args.timestep_steps):
-            m_it, res_it = stp.step(Fb, 20)
-        barrier()
-        tsv = torch.tensor([(time.perf_counter() - ts0) / args.timestep_steps], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tsv, op=dist.ReduceOp.MAX)
-        ts = float(tsv.item())
-        tstep = {"timesteps_per_sec": 1.0 / ts, "ms_per_timestep": ts * 1e3, "apply_M_per_timestep": 21,
-                 "definition": "deterministic fixed-work step: 20 GMRES iterations on the saddle operator (diagonal PC) "
-                               "+ evolve, all operators on the GPU(s)",
-                 "gmres_residual": res_it, "steps_timed": args.timestep_steps}
-        if world == 1:   # SURVEY 8d's second variant: converged to 1e-8 (block-diagonal PC, extrapolated warm start)
-            from rigid_body_light_amd._lib import lib
-            lib().rbl_set_blk_pc(ctx.h, 1)
-            stp.warm_start = True; stp.extrapolate = 2     # initial guess 3 x_n - 3 x_{n-1} + x_{n-2}
-            ctx.set_block_refresh(4)                       # per-body factors rebuilt every 4th configuration
-            for _ in range(3):                             # fill the history (18, 12, 6 iterations), then 2-3 per step
-                stp.step(Fb, 200, 1e-8)
-            barrier(); ts0 = time.perf_counter()
-            its = []
-            for _ in range(args.timestep_steps):
-                m_it, res_it = stp.step(Fb, 200, 1e-8)
-                its.append(m_it)
-            barrier()
-            tc = (time.perf_counter() - ts0) / args.timestep_steps
-            lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
-            tstep["converged"] = {"rtol": 1e-8, "preconditioner": "block-diagonal, per-body factors rebuilt every 4th step",
-                                  "warm_start": "quadratic extrapolation of the last three solutions (12 iterations from the "
-                                                "previous solution alone, 18 cold)", "gmres_iterations": its,
-                                  "gmres_residual": res_it, "timesteps_per_sec": 1.0 / tc, "ms_per_timestep": tc * 1e3}
-            # SURVEY 8d's Brownian step (BASELINE configs[3] on one GPU): 2 M^{1/2} W + M_RFD + Kinv before the fixed-work
-            # solve at the predictor configuration.  With N > 1: `--mode timestep --kBT 1 --gpus N` (sharded driver).
-            from rigid_body_light_amd.krylov import BrownianStepper
-            bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
-            bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(100, 1e-3)
-            bst = BrownianStepper(bctx, nb, nblb, dev, native=True)
-            bst.step(Fb, seed=0, method=2, iters=20, rtol=None)
-            barrier(); ts0 = time.perf_counter()
-            for k in range(args.timestep_steps):
-                bst.step(Fb, seed=1 + k, method=2, iters=20, rtol=None)
-            barrier()
-            tb = (time.perf_counter() - ts0) / args.timestep_steps
-            tstep["brownian"] = {"kBT": 1.0, "definition": "stochastic midpoint step: 2 M^{1/2}W (block-Jacobi preconditioned Lanczos to 1e-3, "
-                                 "two vectors in lock step) + M_RFD (2 apply_M) + Kinv, then 20 GMRES iterations (diag PC) at the "
-                                 "predictor configuration + evolve", "lanczos_iterations": bctx.lanczos_report()[0],
-                                 "timesteps_per_sec": 1.0 / tb, "ms_per_timestep": tb * 1e3}
-            del bst, bctx
+        tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
         # ordered-pair equivalents one launch (this rank) covers: its rows x all columns, or its
         # 1/world share of the unordered tile pairs (each standing for two ordered pairs)
         pairs_per_launch = float(N) * float(N) / world if use_sym else float(nrows) * float(N)
-        flops_alg = FLOPS_PER_PAIR[wall] * pairs_per_launch
-        achieved = flops_alg / (kern_ms * 1e-3) / 1e12
+        ref_tflops = FLOPS_PER_PAIR[wall] * pairs_per_launch / (kern_ms * 1e-3) / 1e12
+        kname = "k_apply_M<%s>" % ("true" if wall else "false")
+        isa = None
+        sym_info = None
+        if use_sym:
+            ni, chunk, wbytes = ctx.apply_M_sym_info(N, world, 1)
+            kname = "k_apply_M_sym<%s,%d>" % ("true" if wall else "false", ni)
+            isa = isa_counts(kname)
+            sym_info = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
+        # EXECUTED work: what the kernel's far-tile sweep issues per unordered pair (assembly of this build) x the
+        # unordered pairs of one launch.  achieved <= peak by construction; the reference-arithmetic price
+        # (204 / 59 flop per ORDERED pair) is kept beside it as reference_equivalent_tflops.
+        roof = {"bound": "fp64-valu", "kernel": kname, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "kernel_ms": kern_ms,
+                "reference_equivalent_tflops": ref_tflops,
+                "reference_equivalent": "%.0f flop/ordered pair (SURVEY.md 8d, reference arithmetic) x %.4g ordered pairs/launch"
+                                        % (FLOPS_PER_PAIR[wall], pairs_per_launch)}
+        if isa is not None:
+            upairs = 0.5 * pairs_per_launch
+            achieved = isa["flop"] * upairs / (kern_ms * 1e-3) / 1e12
+            issue = isa["valu"] * upairs / 64.0 * 4.0 / (N_SIMD * PEAK_CLOCK_GHZ * 1e9) / (kern_ms * 1e-3)
+            traffic, tsrc = pmc_traffic(kname, args.config, world)
+            roof.update({"achieved": achieved, "frac": achieved / PEAK_FP64_TFLOPS,
+                         "valu_issue_frac": issue,
+                         "traffic": traffic,
+                         "algorithmic": "%.0f executed flop (%.0f fma x2 + %.0f mul + %.0f add + %.0f rsq) and %.1f VALU instructions per "
+                                        "UNORDERED pair in the far-tile sweep of this build (librbl.isa.json) x %.4g unordered pairs/launch"
+                                        % (isa["flop"], isa["fma"], isa["mul"], isa["add"], isa["trans"], isa["valu"], upairs),
+                         "note": "fp64 VALU-issue bound (fp64 VALU and fp64 MFMA share one pipe on gfx950, so peak = the fp64 vector = "
+                                 "matrix peak at 2.4 GHz).  frac = executed flops / peak; valu_issue_frac = VALU instructions x 4 cycles / "
+                                 "(1024 SIMDs x 2.4 GHz x kernel time): the share of the chip's issue slots at the spec clock the kernel "
+                                 "fills (the rest: the clock the chip sustains under fp64 load, ~2.1 GHz, and the quarter-rate v_rsq_f64)."})
+            if tsrc is not None:
+                roof["traffic_source"] = tsrc.get("source")
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None,
+                         "note": "librbl.isa.json missing or older than librbl.so: run rigid_body_light_amd/build.py"})
+        if sym_info:
+            roof["launch"] = sym_info
         line = {
             "metric": "timesteps/sec + M.F GFLOP/s (BASELINE.json metric): value = M.F passes/sec, 1 step = one matrix-free "
                       "apply_M pass of the hot path (blob positions -> [all-gather] -> U = B M B F); M.F GFLOP/s in `mf_gflops`, "
@@ -473,24 +591,7 @@ def main():
                        "parallelism": ("tile-pair-sharded x%d, positions replicated, all-gather(F) + all-reduce(U)" if use_sym else
                                        "body-row-sharded x%d, all-gather(pos,F)") % world},
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
-            "roofline": {"bound": "fp64-valu", "kernel": "%s<%s>" % ("k_apply_M_sym" if use_sym else "k_apply_M", "true" if wall else "false"),
-                         "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS,
-                         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
-                         # gfx950 correction + WRITE_SIZE, KB -> B): profiles/r01_bench_cfg3_sym_pmc_summary.txt
-                         "traffic": (2 * 164947e3 + 1.70253e9) if (args.config == "cfg3" and world == 1 and use_sym) else None,
-                         "kernel_ms": kern_ms,
-                         "algorithmic": "%.0f flop/ordered pair (SURVEY.md 8d) x %.4g pairs/launch" % (FLOPS_PER_PAIR[wall], pairs_per_launch),
-                         # executed-instruction view of the same launch (PMC, same profile file): what the VALU actually issued
-                         "executed": ({"valu_insts_per_launch": 1.1108e10, "valu_insts_per_ordered_pair": 43.1,
-                                       "valu_issue_cycles_frac": 0.90, "sustained_clock_ghz": 2.13,
-                                       "source": "profiles/r01_bench_cfg3_sym_pmc_summary.txt (SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}
-                                      if (args.config == "cfg3" and world == 1 and use_sym) else None),
-                         "note": "fp64 VALU-issue bound; on gfx950 fp64 VALU and fp64 MFMA share one pipe (SQ_VALU_MFMA_COEXEC_CYCLES = 0), "
-                                 "so `peak` is the fp64 vector = fp64 MFMA peak.  frac > 1 because `achieved` prices the launch at the "
-                                 "reference's 204 flop per ordered pair while the kernel issues 43 VALU instructions per ordered pair "
-                                 "(each unordered pair once, division-free Horner-form algebra): see `executed` -- the VALU issues "
-                                 "90 % of the kernel's cycles, the two quarter-rate v_rsq_f64 per pair account for most of the rest"},
+            "roofline": roof,
         }
         if tstep is not None:
             line["timestep"] = tstep

@@ -216,6 +216,11 @@ int rbl_apply_M_sym_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int6
 int rbl_apply_M_sym_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs, int nrhs,
                               int i_first, int i_step, double *d_out);
 
+/* launch geometry rbl_apply_M_sym[_multi]_dev would use (reporting: bench.py names the kernel instantiation it
+ * times -- k_apply_M_sym<wall, rows_per_lane> -- and the slab workspace it needs) */
+int rbl_apply_M_sym_info(rbl_ctx *ctx, int64_t n_blobs, int i_step, int nrhs, int *rows_per_lane, int *chunk_tiles,
+                         int64_t *workspace_bytes);
+
 /* blob positions of bodies [body_begin, body_end) into d_out
  * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */
 int rbl_blob_positions_dev(rbl_ctx *ctx, int body_begin, int body_end, double *d_out);
@@ -298,7 +303,7 @@ int rbl_sync_check(rbl_ctx *ctx);
 /* tuning / test hook.  jsplit: j-split of the ordered kernel (0 = heuristic).  variant: 0 = heuristic
  * (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 = force the ordered kernel,
  * 2 = force the symmetric kernel (with jsplit > 0: its column-chunk length), 3 = force the MFMA multi-RHS kernel;
- * 21 / 22 (process-wide experiment switch): one / two rows per lane in the two-vector symmetric kernel. */
+ * 21 / 22 (experiment switch): one / two rows per lane in the two-vector symmetric kernel.  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

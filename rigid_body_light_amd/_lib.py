@@ -43,6 +43,7 @@ def lib():
         L.rbl_apply_M_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, vp]
         L.rbl_apply_M_sym_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
         L.rbl_apply_M_sym_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp]
+        L.rbl_apply_M_sym_info.argtypes = [vp, i64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64)]
         L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
         L.rbl_rotne_prager_tensor_dev.argtypes = [vp, vp, i64, C.c_int, vp]
         L.rbl_cholesky_lower_dev.argtypes = [vp, vp, i64, C.c_int]
@@ -216,6 +217,12 @@ class DeviceContext:
     def apply_M_sym_multi(self, dF, dr, n_blobs, nrhs, i_first, i_step, dout):
         """the same for nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); two vectors share the pair coefficients"""
         self._chk(self.L.rbl_apply_M_sym_multi_dev(self.h, dF, dr, n_blobs, nrhs, i_first, i_step, dout))
+
+    def apply_M_sym_info(self, n_blobs, i_step=1, nrhs=1):
+        """(rows per lane NI, column tiles per work unit, slab workspace bytes) of the symmetric kernel launch"""
+        ni, ch, wb = C.c_int(0), C.c_int(0), C.c_int64(0)
+        self._chk(self.L.rbl_apply_M_sym_info(self.h, n_blobs, i_step, nrhs, C.byref(ni), C.byref(ch), C.byref(wb)))
+        return ni.value, ch.value, wb.value
 
     def blob_positions(self, body_begin, body_end, dout):
         self._chk(self.L.rbl_blob_positions_dev(self.h, body_begin, body_end, dout))

@@ -26,6 +26,10 @@ def lib_path():
     return os.path.join(HERE, "librbl.so")
 
 
+def isa_path():
+    return os.path.join(HERE, "librbl.isa.json")
+
+
 def ext_path():
     return os.path.join(HERE, "c_rigid" + sysconfig.get_config_var("EXT_SUFFIX"))
 
@@ -61,6 +65,15 @@ def build(force=False, verbose_resources=False):
             list(ex.map(_run, jobs))
     if force or jobs or _newer(lib_path(), objs):
         _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib_path()] + objs)
+    # executed-instruction counts of the matvec kernels (bench.py prices its roofline with them): the gfx950
+    # assembly of the same source with the same flags, analysed by tools/isa_stats.py
+    ksrc = os.path.join(CSRC, "rbl_kernels.hip")
+    tool = os.path.join(HERE, "..", "tools", "isa_stats.py")
+    if force or _newer(isa_path(), [ksrc, tool] + hdrs):
+        asm = os.path.join(OBJ, "rbl_kernels.s")
+        _run([HIPCC, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-x", "hip", "--offload-device-only", "-S",
+              "-Wno-unused-command-line-argument"] + os.environ.get("RBL_EXTRA_FLAGS", "").split() + [ksrc, "-o", asm])
+        _run([sys.executable, tool, asm, isa_path()])
     ext_src = os.path.join(CSRC, "c_rigid.cpp")
     if force or _newer(ext_path(), [ext_src, lib_path(), hdrs[-1]]):
         import pybind11

@@ -173,14 +173,14 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   bool sym = full;   // measured faster at every size, N = 120 ... 128 400 (profiles/r01_apply_M_all_configs.md)
   // its row/column-sum slabs grow like N^2/128 * 24 B (1.7 GB at 128 400 blobs, ~100 GB at 10^6):
   // beyond a budget the ordered kernel (O(N) workspace, ~1.6x the time) takes over
-  if (sym && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1) > c->sym_workspace_budget) sym = false;
+  if (sym && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune) > c->sym_workspace_budget) sym = false;
   if (c->tune_variant == 1) sym = false;
   if (c->tune_variant == 2) sym = full;
   int rc;
   if (sym) {
-    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1)))) return rc;
+    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune)))) return rc;
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
-                           c->d_err);
+                           c->d_err, 1, c->sym_tune);
   } else {
     int js = 1;
     const size_t pb = rbl_apply_M_part_bytes(nbl, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);
@@ -204,11 +204,11 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
   int rc;
   if (!mfma) {   // 1-3 vectors: pairs of vectors through the two-vector symmetric kernel, a single one alone
     int k = 0;
-    const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2) <= c->sym_workspace_budget;
+    const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune) <= c->sym_workspace_budget;
     for (; sym2 && k + 2 <= nrhs; k += 2) {
-      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2)))) return rc;
+      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune)))) return rc;
       rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
-                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2);
+                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, c->sym_tune);
     }
     for (; k < nrhs; ++k)
       if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
@@ -1012,9 +1012,9 @@ int rbl_apply_M_sym_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, 
   if ((rc = rbl_dev_init(c))) return rc;
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step || nrhs < 1 || nrhs > 2)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_multi_dev: need n_blobs > 0, 0 <= i_first < i_step, nrhs 1 or 2");
-  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs, c->sym_tune)))) return rc;
   rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
-                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs);
+                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs, c->sym_tune);
   return RBL_OK;
 }
 
@@ -1025,9 +1025,22 @@ int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_
   if ((rc = rbl_dev_init(c))) return rc;
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_dev: need n_blobs > 0 and 0 <= i_first < i_step");
-  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, 1, c->sym_tune)))) return rc;
   rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
-                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err);
+                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, c->sym_tune);
+  return RBL_OK;
+}
+
+int rbl_apply_M_sym_info(rbl_ctx *c, int64_t n_blobs, int i_step, int nrhs, int *rows_per_lane, int *chunk_tiles,
+                         int64_t *workspace_bytes)
+{
+  if (!c || n_blobs <= 0 || i_step < 1 || nrhs < 1 || nrhs > 2) return rbl_fail(c, RBL_ERR_ARG, "apply_M_sym_info: bad arguments");
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  int ni = 0, ch = 0;
+  const size_t b = rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs, c->sym_tune, &ni, &ch);
+  if (rows_per_lane) *rows_per_lane = ni;
+  if (chunk_tiles) *chunk_tiles = ch;
+  if (workspace_bytes) *workspace_bytes = (int64_t)b;
   return RBL_OK;
 }
 
@@ -1068,9 +1081,9 @@ int rbl_sync_check(rbl_ctx *c)
 
 int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
-  if (variant == 21 || variant == 22) { rbl_set_sym2_ni(variant - 20); return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
   if (!c) return RBL_ERR_ARG;
-  rbl_set_sym_chunk_override(variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
+  if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
+  c->sym_tune.chunk = (variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;
   return RBL_OK;
 }
@@ -1229,7 +1242,7 @@ int rbl_prepare_dev(rbl_ctx *c)
   const RblBodyState &S = c->S;
   const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(N, c->n_cu, 1)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(N, c->n_cu, 1, 1, c->sym_tune)))) return rc;
   if (!c->dev_pc_valid) {   // build the preconditioner eagerly (apply on a scratch vector)
     const size_t nv = (size_t)n3 + 6 * (size_t)S.N_bod;
     if ((rc = rbl_dev_reserve(c, c->d_tmp, sizeof(double) * 2 * nv))) return rc;

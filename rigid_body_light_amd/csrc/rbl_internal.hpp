@@ -53,6 +53,11 @@ struct RblDevBuf {
   size_t bytes = 0;
 };
 
+struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
+  int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
+  int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
+};
+
 struct RblCholAux {        // second stream + events for the one-panel lookahead
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -88,6 +93,7 @@ struct rbl_ctx {
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
   int tune_jsplit = 0;
   int tune_variant = 0;
+  RblSymTune sym_tune;
   // lanczos
   int lanczos_max_iter = 100;
   double lanczos_tol = 1e-10;
@@ -117,13 +123,12 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
                         const double *d_r, int64_t n_blobs, int64_t row_begin,
                         int64_t row_end, double *d_out, double *d_part, int jsplit,
                         int variant, unsigned *d_err);
-size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs = 1);
-void rbl_set_sym2_ni(int ni);
-void rbl_set_sym_chunk_override(int c);   // tuning hook: chunk length C of the symmetric kernel (0 = heuristic)
+size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune,
+                             int *NI_out = nullptr, int *C_out = nullptr);
 // nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); workspace rbl_apply_M_sym_bytes(..., nrhs)
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs = 1);
+                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune);
 size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu);
 void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                              const double *d_r, int64_t n_blobs, int nrhs, double *d_out,

@@ -1086,19 +1086,15 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 }
 
 // ---- symmetric variant ------------------------------------------------------
-static int g_sym_chunk_override = 0;   // tuning hook (rbl_set_tuning jsplit with variant 2): forces C
-void rbl_set_sym_chunk_override(int c) { g_sym_chunk_override = c; }
-
-static int g_sym2_ni = 0;   // experiment hook: rows per lane of the two-vector kernel (0 = same rule as one vector)
-void rbl_set_sym2_ni(int ni) { g_sym2_ni = ni; }
-
-static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI, int nrhs = 1)
+// tune (per context, rbl_set_tuning): chunk > 0 forces the chunk length C; ni2 > 0 the rows per lane of the two-vector kernel
+static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI, int nrhs,
+                         const RblSymTune &tune)
 {
   const int t = (int)((n_blobs + TS - 1) / TS);
   // 2 rows per lane once there is parallelism to spare: same speed on one GPU (the kernel is
   // VALU-issue bound either way) but half the column-sum slab to write and re-read
   int ni = (t >= 128 * i_step) ? 2 : 1;
-  if (nrhs == 2 && g_sym2_ni > 0) ni = g_sym2_ni;
+  if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   const int rowsI = (tsup + i_step - 1) / i_step;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
@@ -1110,14 +1106,16 @@ static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI,
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
-  if (g_sym_chunk_override > 0) c = g_sym_chunk_override;
+  if (tune.chunk > 0) c = tune.chunk;
   *T = t; *NI = ni; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
 }
 
-size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs)
+size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, int *NI_out, int *C_out)
 {
   int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs);
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs, tune);
+  if (NI_out) *NI_out = NI;
+  if (C_out) *C_out = C;
   // slabs + tile bounding boxes + far map (one byte per (row super-tile, tile))
   return (((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * nrhs + (size_t)T * 6) * sizeof(double) + (size_t)((T + NI - 1) / NI) * (size_t)T + 64;
 }
@@ -1152,11 +1150,11 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
 // nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...) * nrhs
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs)
+                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune)
 {
   if (n_blobs <= 0) return;
   int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs);
+  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs, tune);
   double *slabI = d_work;
   double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3 * nrhs;
   if (NI == 2) {

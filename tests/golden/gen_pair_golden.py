@@ -72,5 +72,69 @@ def main():
     print("wrote", len(cases_rpy), "rpy cases,", len(cases_wall), "wall cases; below-wall throws:", throws)
 
 
+def assembly_cases():
+    """Second fixture, pair_blocks_assembly.json: whole 3x3 blocks as the reference's ASSEMBLY loop forms them
+    (c_rigid_obj.cpp:432-447: r = r_i - r_j; mobilityUFRPY(r, i, j, 1/a); wall correction with the a-normalised
+    image vector (rx/a, ry/a, (rz + 2 z_j)/a) and h = z_j/a), unscaled (before `Mob *= 1/(8 pi eta a)`, :456),
+    in the regimes the BASELINE geometries feed the kernels: blob radii of the shell files, heights from 1e-6 a to
+    1e3 a, |r| within 1e-9 of the 2a branch switch WITH the wall term, blob touching its neighbour's image, equal
+    heights (h_hat = 1/2), self blocks.  The argument preparation below is the same sequence of IEEE double
+    operations the reference performs; the two kernels are the reference's own compiled functions."""
+    ref = RefPair()
+    rng = np.random.default_rng(20261004)
+    radii = [0.13100878, 0.03420498, 0.06752768, 0.41642068, 1.0]
+    cases = []
+
+    def add(ri, rj, i, j, a, wall):
+        ri = np.asarray(ri, dtype=np.float64); rj = np.asarray(rj, dtype=np.float64)
+        a = float(a)
+        rx, ry, rz = ri[0] - rj[0], ri[1] - rj[1], ri[2] - rj[2]                  # :432-434
+        s = ref.rpy(float(rx), float(ry), float(rz), i, j, 1.0 / a)               # :435-436
+        M = np.array([s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]])      # :437-439
+        if wall:                                                                  # :440-445
+            M = ref.wall(float(rx / a), float(ry / a), float((rz + 2 * rj[2]) / a), M, i, j, float(rj[2] / a))
+        cases.append({"ri": hx(ri), "rj": hx(rj), "i": i, "j": j, "a": a.hex(), "wall": bool(wall), "out9": hx(M)})
+
+    for a in radii:
+        for wall in (True, False):
+            for _ in range(24):                                   # generic pairs, heights 0.05 a .. 8 a
+                ri = np.append(rng.uniform(-5, 5, 2), rng.uniform(0.05, 8)) * a
+                rj = np.append(rng.uniform(-5, 5, 2), rng.uniform(0.05, 8)) * a
+                add(ri, rj, 0, 1, a, wall)
+        for _ in range(16):                                       # far above the wall: h/a up to 1e3
+            h = 10.0 ** rng.uniform(1, 3)
+            ri = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), h + rng.uniform(-2, 2)]) * a
+            rj = np.array([0.0, 0.0, h]) * a
+            add(ri, rj, 2, 7, a, True)
+        for _ in range(16):                                       # h -> 0+: both blobs within 1e-6 a .. 1e-2 a of the wall
+            zi, zj = 10.0 ** rng.uniform(-6, -2, 2)
+            d = rng.uniform(2.0, 6.0); th = rng.uniform(0, 2 * np.pi)
+            add(np.array([d * np.cos(th), d * np.sin(th), zi]) * a, np.array([0.0, 0.0, zj]) * a, 0, 1, a, True)
+        for _ in range(24):                                       # |r|/a within 1e-9 of 2 (branch switch :62), with the wall term
+            d = rng.standard_normal(3); d /= np.linalg.norm(d)
+            d *= 2.0 + rng.uniform(-1e-9, 1e-9)
+            zj = rng.uniform(1.5, 4.0)
+            add((np.array([0.3, -0.2, zj]) + d) * a, np.array([0.3, -0.2, zj]) * a, 0, 1, a, True)
+        for _ in range(12):                                       # equal heights: h_hat = h_j / R_z = 1/2
+            z = 10.0 ** rng.uniform(-1, 1.5)
+            d = rng.uniform(0.5, 5.0); th = rng.uniform(0, 2 * np.pi)
+            add(np.array([d * np.cos(th), d * np.sin(th), z]) * a, np.array([0.0, 0.0, z]) * a, 3, 4, a, True)
+        for _ in range(12):                                       # blob i touching the IMAGE of j: |r_i - image(r_j)| ~ 2a
+            zj = rng.uniform(0.2, 1.8); zi = 2.0 - zj + rng.uniform(-1e-9, 1e-9)
+            lat = rng.uniform(0.0, 1e-3, 2)
+            add(np.array([lat[0], lat[1], zi]) * a, np.array([0.0, 0.0, zj]) * a, 0, 1, a, True)
+        for h in (1e-6, 1e-3, 0.3, 1.0, 2.0, 31.0, 1e3):          # self blocks (:40-46, :98-104)
+            add(np.array([0.1, 0.2, h]) * a, np.array([0.1, 0.2, h]) * a, 5, 5, a, True)
+        add(np.array([0.1, 0.2, 0.7]) * a, np.array([0.1, 0.2, 0.7]) * a, 5, 5, a, False)
+    doc = {"source": "reference src/c_rigid_obj.cpp:31-142 compiled by oracle/build_ref.sh (g++ -O2 -ffp-contract=off, double), "
+                     "called with the arguments the assembly loop :432-447 forms",
+           "format": "C99 hex floats; out9 = row-major 3x3 block (i <= j roles), NOT scaled by 1/(8 pi eta a)",
+           "blocks": cases}
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pair_blocks_assembly.json"), "w") as f:
+        json.dump(doc, f, indent=0)
+    print("wrote", len(cases), "assembly-level blocks")
+
+
 if __name__ == "__main__":
     main()
+    assembly_cases()

@@ -65,6 +65,32 @@ def test_pair_blocks_vs_reference_golden():
         assert np.max(np.abs(fast - ref9 * nf) / scale) < 2e-14
 
 
+def test_assembly_blocks_vs_reference_golden():
+    """HIP blocks against the REFERENCE's outputs directly (no oracle in between): the assembly-level fixture holds
+    blocks computed by the reference's own compiled kernels with the arguments its loop :432-447 forms, in the regimes
+    the BASELINE geometries produce (shell radii, h/a 1e-6 .. 1e3, |r| ~ 2a with the wall term, image contact)."""
+    with open(os.path.join(HERE, "golden", "pair_blocks_assembly.json")) as f:
+        g = json.load(f)
+    groups = {}
+    for c in g["blocks"]:
+        groups.setdefault((c["a"], c["wall"]), []).append(c)
+    eta = 0.9
+    for (a_hex, wall), cases in groups.items():
+        a = float.fromhex(a_hex)
+        nf = 1.0 / (8.0 * np.pi * eta * a)
+        rb = solver(a, eta, wall)
+        ri = np.array([unhex(c["ri"]) for c in cases]); rj = np.array([unhex(c["rj"]) for c in cases])
+        ii = np.array([c["i"] for c in cases], dtype=np.int32); jj = np.array([c["j"] for c in cases], dtype=np.int32)
+        ref = np.array([unhex(c["out9"]) for c in cases]).reshape(-1, 3, 3) * nf
+        exact = rb.cb.pair_blocks(ri, rj, ii, jj, wall, 0)            # reference-order arithmetic (dense build kernel)
+        assert np.array_equal(exact, ref)                             # bit-exact
+        fast = rb.cb.pair_blocks(ri, rj, ii, jj, wall, 1)             # fast matvec arithmetic
+        rhat = np.linalg.norm(ri - rj, axis=1) / a
+        free = np.minimum(4.0 / 3.0, 1.0 / np.maximum(rhat, 1e-30)) * nf   # size of the free-space block the wall term is added to
+        scale = np.maximum(np.linalg.norm(ref, axis=(1, 2)), free)[:, None, None]
+        assert np.max(np.abs(fast - ref) / scale) < 5e-13
+
+
 def test_wall_blocks_vs_oracle_roles(orc):
     """Full wall-corrected blocks, both index orders (i<j and i>j -> transposed roles)."""
     rng = np.random.default_rng(21)
@@ -410,6 +436,13 @@ def test_full_size_properties(orc, nb, nblb, wall):
     for b in (0, 300, N // 3, N - 16):          # rows of damped bodies, interior rows, the last (ragged) tile
         Uo = orc.apply_M_rows(xh, rh, b, b + 16, c["a"], c["eta"], wall, nthreads=8)
         assert rel(Mxh[3 * b:3 * b + 48], Uo) < 1e-11
+    if nb == 200:       # cfg 3: EVERY row of two whole bodies -- body 3 (pushed into the damping zone) and body 117
+        for body in (3, 117):
+            b0, b1 = body * nblb, (body + 1) * nblb
+            Uo = orc.apply_M_rows(xh, rh, b0, b1, c["a"], c["eta"], wall, nthreads=16)
+            assert rel(Mxh[3 * b0:3 * b1], Uo) < 1e-12
+            worst = np.max(np.abs(Mxh[3 * b0:3 * b1] - Uo).reshape(-1, 3).max(axis=1) / np.linalg.norm(Uo.reshape(-1, 3), axis=1))
+            assert worst < 1e-10        # and no single row off
 
 
 @pytest.mark.parametrize("wall", [False, True])
@@ -457,6 +490,89 @@ def test_full_size_interpenetrating_bodies_vs_oracle(orc, wall):
         acc += p
     ctx.sync_check()
     assert float(torch.linalg.norm(acc - out) / torch.linalg.norm(out)) < 1e-13
+
+
+def test_cfg2_full_size_lanczos_square_roots():
+    """BASELINE configs[1] at full size (50 x shell_N_162 = 8 100 blobs, free-space M + Brownian noise): the two
+    matrix-free square roots against the dense matrix of the SAME configuration (k_build_M, bit-identical to the oracle's
+    assembly).  Any exact root G of A = B M B gives |G^T-free identities| we can test with one vector:
+      plain Lanczos (symmetric root S):   y = S W:  y.y = W.A W  and  S y = A W;
+      preconditioned (G = B L Sp^{1/2}, Sp = L^-1 M L^-T):  s = L^-1 B^-1 (G W) = Sp^{1/2} W:  s.s = v.M v with
+      v = L^-T W, and G s = B M v."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb, wall = 50, 162, False
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb; n = 3 * N
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    A = torch.empty(n * n, dtype=torch.float64, device=dev)
+    ctx.build_M(r.data_ptr(), N, True, A.data_ptr())              # A = B M B (what M_half_W factors, :667-669)
+    Mu = torch.empty(n * n, dtype=torch.float64, device=dev)
+    ctx.build_M(r.data_ptr(), N, False, Mu.data_ptr())            # M itself
+    ctx.sync_check()
+    A = A.view(n, n); Mu = Mu.view(n, n)                          # symmetric: storage order is irrelevant
+    z = r.view(-1, 3)[:, 2]
+    B = torch.where(z >= c["a"], torch.ones_like(z), z / c["a"]).repeat_interleave(3)
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(n)).to(dev)
+    AW = A @ W
+    WAW = float(W @ AW)
+
+    def root(vec, method):
+        out = torch.empty_like(vec)
+        ctx.M_half_W(r.data_ptr(), N, vec.contiguous().data_ptr(), method, out.data_ptr())
+        ctx.sync_check()
+        return out
+
+    def bsolve(vec, mode):
+        out = torch.empty_like(vec)
+        ctx.block_solve(vec.contiguous().data_ptr(), out.data_ptr(), mode)
+        ctx.sync_check()
+        return out
+
+    report = {}
+    for tol, acc in ((1e-3, 2e-2), (1e-9, 1e-6)):
+        ctx.set_lanczos(300, tol)
+        y = root(W, "lanczos")
+        its = ctx.lanczos_report()[0]
+        e_norm = abs(float(y @ y) - WAW) / WAW
+        e_sq = float(torch.linalg.norm(root(y, "lanczos") - AW) / torch.linalg.norm(AW))
+        assert e_norm < acc and e_sq < acc, (tol, its, e_norm, e_sq)
+        x = root(W, "lanczos_pc")
+        its_pc = ctx.lanczos_report()[0]
+        s_ = bsolve(x / B, 1)                                     # Sp^{1/2} W
+        v = bsolve(W, 2)                                          # L^-T W
+        Mv = Mu @ v
+        e_norm_pc = abs(float(s_ @ s_) - float(v @ Mv)) / float(v @ Mv)
+        e_sq_pc = float(torch.linalg.norm(root(s_, "lanczos_pc") - B * Mv) / torch.linalg.norm(B * Mv))
+        assert e_norm_pc < acc and e_sq_pc < acc, (tol, its_pc, e_norm_pc, e_sq_pc)
+        assert its_pc < its                                       # the point of the preconditioner
+        report[tol] = (its, e_norm, e_sq, its_pc, e_norm_pc, e_sq_pc)
+    # the block factors the preconditioned root relies on: L L^T = M_body for a sampled body, from the dense matrix
+    b = 17
+    blk = Mu[3 * nblb * b:3 * nblb * (b + 1), 3 * nblb * b:3 * nblb * (b + 1)]
+    e = torch.zeros(n, dtype=torch.float64, device=dev); e[3 * nblb * b:3 * nblb * (b + 1)] = W[3 * nblb * b:3 * nblb * (b + 1)]
+    sol = bsolve(e, 0)[3 * nblb * b:3 * nblb * (b + 1)]
+    assert float(torch.linalg.norm(blk @ sol - e[3 * nblb * b:3 * nblb * (b + 1)]) / torch.linalg.norm(W[3 * nblb * b:3 * nblb * (b + 1)])) < 1e-10
+    print("cfg2 full size, (iterations, |y.y - W.AW|/W.AW, |S y - A W|/|A W|) plain | preconditioned:", report)
+    ctx.close()
+
+
+def test_block_pc_rejects_bodies_over_the_lds_limit():
+    """the block-diagonal preconditioner keeps a body's substitution vector in 64 KB of LDS: bodies of more than
+    2730 blobs are refused with a message, not silently mis-solved"""
+    from rigid_body_light_amd import RigidBody
+    nblb = 2731
+    k = np.arange(nblb) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / nblb); th = np.pi * (1.0 + 5.0 ** 0.5) * k
+    cfg = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)   # Fibonacci sphere, radius 1
+    rb = RigidBody(cfg, np.array([[0.0, 0.0, 40.0]]), np.array([[1.0, 0, 0, 0]]), 0.02, 1.0, 0.01, block_PC=True)
+    with pytest.raises(RuntimeError, match="2730"):
+        rb.apply_PC(np.ones(3 * nblb + 6))
 
 
 def test_cholesky_cfg2_size_property():

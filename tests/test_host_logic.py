@@ -2,6 +2,8 @@
 the behaviour checks of reference tests/test_interface.py + tests/test_precision.py
 that do not touch the mobility, plus numeric checks of K, K^T, K^-1, apply_PC (diagonal
 PC) and evolve against the numpy restatement in oracle/oracle.py."""
+import os
+
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation
@@ -192,3 +194,22 @@ def test_KTinv_RFD_numeric():
         np.testing.assert_allclose(out, ref, rtol=0, atol=1e-14 / delta * 50)   # difference quotient: rounding / delta
     with pytest.raises(RuntimeError):
         cb.KTinv_RFD(W[:-1])
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` must never run on fewer devices and print n_gpus N (or 1): with RCCL and fewer than N
+    visible GPUs it exits non-zero with a message -- here, on the CPU-only container, for N = 2."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert "needs 2 visible GPUs" in (p.stdout + p.stderr)
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())

@@ -30,3 +30,82 @@ def test_apply_M_large_N_rows_vs_oracle(orc, nb, nblb, wall):
     ctx.close()
     del r, x, out
     torch.cuda.empty_cache()
+
+
+def test_cfg5_full_size_dense_cholesky(orc):
+    """BASELINE configs[4] at FULL size: 20 x shell_N_2562 = 51 240 blobs, n = 153 720, 2.36e10 matrix entries
+    (> 2^31: 64-bit indexing everywhere), 189 GB.  The reference's M_half_W (c_rigid_obj.cpp:661-675): B Mob B
+    assembled (k_build_M), factored in place (blocked MFMA Cholesky), L W.  Checks: sampled 3x3 blocks beyond flat
+    index 2^31 bit-equal to the oracle's blocks; diag(L L^T) = diag(M); L L^T x = (B M B) x with the right-hand side
+    from the matrix-free kernel; L W rows against row sums of the stored factor."""
+    import time
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    nb, nblb, wall = 20, 2562, False
+    N = nb * nblb; n = 3 * N
+    if free < 8 * n * n + (12 << 30):
+        pytest.skip("needs %.0f GB of free HBM, %.0f GB free" % ((8 * n * n + (12 << 30)) / 1e9, free / 1e9))
+    dev = torch.device("cuda:0")
+    c = make_config(nb, nblb, wall)
+    a, eta = c["a"], c["eta"]
+    ctx = DeviceContext(a, eta, wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    rh = r.cpu().numpy().reshape(-1, 3)
+    M = torch.empty(n * n, dtype=torch.float64, device=dev)
+    assert M.numel() > 2 ** 31
+    ctx.build_M(r.data_ptr(), N, True, M.data_ptr())            # B Mob B, :667-669
+    ctx.sync_check()
+    V = M.view(n, n)                                             # column-major storage: V[col][row]
+    # -- (1) sampled blocks, all at flat offsets beyond 2^31 (column index > 2^31 / n ~ 13 970)
+    damp = np.where(rh[:, 2] >= a, 1.0, rh[:, 2] / a)            # make_damp_mat :618-639
+    nf = 1.0 / (8.0 * np.pi * eta * a)
+    rng = np.random.default_rng(5)
+    pairs = [(N - 1, N - 1), (0, N - 1), (N - 1, 4700), (N - 2, N - 1), (123, 40000)]
+    pairs += [(int(rng.integers(0, N)), int(rng.integers(4700, N))) for _ in range(59)]
+    for (i, j) in pairs:
+        assert (3 * j) * n + 3 * i > 2 ** 31
+        got = V[3 * j:3 * j + 3, 3 * i:3 * i + 3].cpu().numpy().T           # rows 3i.., columns 3j..
+        blk = orc.pair_block(rh[i], rh[j], i, j, a, eta, wall) if i <= j else orc.pair_block(rh[j], rh[i], j, i, a, eta, wall).T
+        assert np.array_equal(got, (damp[i] * blk) * damp[j]), (i, j)       # (di * v) * dj, the kernel's order
+    d0 = M[:: n + 1].clone()
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal(n)).to(dev)
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(n)).to(dev)
+    Bd = torch.from_numpy(np.repeat(damp, 3)).to(dev)
+    Mx = torch.empty_like(x)
+    Bx = (Bd * x).contiguous()
+    ctx.apply_M(Bx.data_ptr(), r.data_ptr(), N, 0, N, Mx.data_ptr())      # free-space M (no wall): damping applied here
+    Mx = Bd * Mx
+    # -- (2) in-place lower Cholesky, :670-671
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.cholesky(M.data_ptr(), n, zero_upper=True)
+    ctx.sync_check()
+    t_chol = time.perf_counter() - t0
+    acc = torch.zeros(n, dtype=torch.float64, device=dev)
+    CH = 2048
+    for a0 in range(0, n, CH):
+        acc += (V[a0:a0 + CH] ** 2).sum(0)                      # sum_j L_ij^2
+    assert float(((acc - d0).abs() / d0.abs()).max()) < 1e-12
+    # -- (3) L (L^T x) = (B M B) x ; V = L^T as a row-major matrix
+    t = torch.empty_like(x)
+    for a0 in range(0, n, CH):
+        t[a0:a0 + CH] = V[a0:a0 + CH] @ x                       # (L^T x)_a = sum_b L[b][a] x[b]
+    LLtx = torch.empty_like(x)
+    ctx.trmv_lower(M.data_ptr(), n, t.data_ptr(), LLtx.data_ptr())       # our kernel: L t
+    ctx.sync_check()
+    assert float(torch.linalg.norm(LLtx - Mx) / torch.linalg.norm(Mx)) < 1e-10
+    # -- (4) L W (:672) against row sums of the stored factor on sampled rows
+    LW = torch.empty_like(W)
+    ctx.trmv_lower(M.data_ptr(), n, W.data_ptr(), LW.data_ptr())
+    ctx.sync_check()
+    rows = torch.tensor([0, 1, n // 3, n // 2, n - 2, n - 1], device=dev)
+    ref = (V[:, rows] * W[:, None]).sum(0)
+    assert float(((LW[rows] - ref).abs() / ref.abs()).max()) < 1e-11
+    print("cfg5 full size: Cholesky n=%d in %.2f s = %.1f TFLOP/s" % (n, t_chol, n ** 3 / 3.0 / t_chol / 1e12))
+    ctx.close()
+    del M, V, acc, t, LLtx, LW
+    torch.cuda.empty_cache()

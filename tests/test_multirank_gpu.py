@@ -52,6 +52,22 @@ def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
         assert np.linalg.norm(z["values"] - Uo) / np.linalg.norm(Uo) < 1e-11
 
 
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (the way the driver calls it): bench.py starts the two ranks itself
+    (a child torchrun, before touching the GPU) and the line it prints says n_gpus = 2."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3",
+                        "--warmup", "1", "--cpu-budget", "0", "--timestep-steps", "0"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"]
+    assert 0.0 < d["roofline"]["frac"] <= 1.0
+
+
 def _max_diff(stdout, world):
     line = [l for l in stdout.splitlines() if l.startswith("world %d:" % world)][-1]
     return float(line.split("=")[1].split(",")[0])
@@ -69,3 +85,19 @@ def test_three_rank_uneven_split_brownian_step(monkeypatch):
     p = _torchrun(3, ["tools/check_sharded_brownian.py"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "world 3" in p.stdout and _max_diff(p.stdout, 3) < 1e-10
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_cfg4_size_sharded_brownian_step(monkeypatch, world):
+    """BASELINE configs[3] at full size (200 x shell_N_642, wall-corrected + Brownian), ONE stochastic midpoint step:
+    the multi-GPU driver (ShardedBrownianStepper: tile-pair-sharded products, block-Jacobi preconditioned Lanczos with
+    per-rank body factors, block-PC GMRES) at world size 1 and as a 2-rank gloo rehearsal on one GPU, against the
+    single-process BrownianStepper with the same injected noise."""
+    monkeypatch.setenv("RBL_CHECK_BODIES", "200")
+    monkeypatch.setenv("RBL_CHECK_BLOBS", "642")
+    monkeypatch.setenv("RBL_CHECK_BLOCK_PC", "1")
+    monkeypatch.setenv("RBL_CHECK_LANCZOS_TOL", "1e-10")
+    monkeypatch.setenv("RBL_CHECK_GMRES_TOL", "1e-10")
+    p = _torchrun(world, ["tools/check_sharded_brownian.py"], timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "world %d" % world in p.stdout and _max_diff(p.stdout, world) < 1e-8

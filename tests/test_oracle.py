@@ -34,6 +34,21 @@ def test_wall_bit_exact_vs_reference_golden(orc, golden):
     assert golden["below_wall_throws"]
 
 
+def test_assembly_blocks_bit_exact_vs_reference_golden(orc):
+    """whole blocks as the reference's assembly loop forms them (:432-447) in the regimes of the BASELINE geometries
+    (shell radii, h/a from 1e-6 to 1e3, |r| within 1e-9 of 2a with the wall term, image contact, equal heights):
+    the oracle's block equals the reference's compiled kernels fed the same way, bit for bit"""
+    with open(os.path.join(HERE, "golden", "pair_blocks_assembly.json")) as f:
+        g = json.load(f)
+    assert len(g["blocks"]) >= 600
+    eta = 0.9
+    for c in g["blocks"]:
+        a = float.fromhex(c["a"])
+        nf = 1.0 / (8.0 * np.pi * eta * a)
+        out = orc.pair_block(unhex(c["ri"]), unhex(c["rj"]), c["i"], c["j"], a, eta, c["wall"])
+        assert np.array_equal(out.reshape(-1), unhex(c["out9"]) * nf)
+
+
 def test_survey_known_answers(orc):
     # SURVEY.md section 8c vectors, produced from the verbatim-compiled reference kernels
     np.testing.assert_allclose(

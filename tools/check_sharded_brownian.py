@@ -19,7 +19,9 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device("cuda:0")
-    nb, nblb, wall, kBT = int(os.environ.get("RBL_CHECK_BODIES", "6")), 162, True, 0.05
+    nb, nblb, wall, kBT = int(os.environ.get("RBL_CHECK_BODIES", "6")), int(os.environ.get("RBL_CHECK_BLOBS", "162")), True, 0.05
+    block_pc = os.environ.get("RBL_CHECK_BLOCK_PC", "0") == "1"      # block-diagonal preconditioner in the saddle solve
+    ltol, gtol = float(os.environ.get("RBL_CHECK_LANCZOS_TOL", "1e-11")), float(os.environ.get("RBL_CHECK_GMRES_TOL", "1e-10"))
     c = make_config(nb, nblb, wall)
     n3 = 3 * nb * nblb
     W = np.random.default_rng(11).standard_normal(3 * n3)
@@ -29,20 +31,23 @@ def main():
         ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=kBT,
                             stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(c["X"], c["Q"])
+        if block_pc:
+            from rigid_body_light_amd._lib import lib
+            lib().rbl_set_blk_pc(ctx.h, 1)
         if sharded:
             st = ShardedBrownianStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
-                                        c["dt"], lanczos_tol=1e-11, lanczos_max_iter=300)
-            m, resid = st.step(Fb, W=W, iters=150, rtol=1e-10)
+                                        c["dt"], lanczos_tol=ltol, lanczos_max_iter=300)
+            m, resid = st.step(Fb, W=W, iters=150, rtol=gtol)
         else:
-            ctx.set_lanczos(300, 1e-11)
-            m, resid = BrownianStepper(ctx, nb, nblb, dev).step(Fb, W=W, method=2, iters=150, rtol=1e-10)   # preconditioned square root, as the sharded driver
+            ctx.set_lanczos(300, ltol)
+            m, resid = BrownianStepper(ctx, nb, nblb, dev, native=block_pc).step(Fb, W=W, method=2, iters=150, rtol=gtol)   # preconditioned square root, as the sharded driver
         out.append(ctx.get_config(nb))
     dX = float(np.abs(out[0][0] - out[1][0]).max()); dQ = float(np.abs(out[0][1] - out[1][1]).max())
     moved = float(np.abs(out[0][0] - c["X"]).max())
     t = torch.tensor([dX, dQ]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         print("world %d: max |X_sharded - X_single| = %.3e, max |Q diff| = %.3e (bodies moved by %.3e)" % (world, t[0], t[1], moved))
-    ok = t[0] < 1e-8 and t[1] < 1e-8 and moved > 1e-4
+    ok = t[0] < 1e-8 and t[1] < 1e-8 and moved > 1e-4 and resid < gtol
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 

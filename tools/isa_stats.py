@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-pair instruction counts of the matvec kernels, taken from the gfx950 assembly of the SAME sources
+librbl.so is built from (rigid_body_light_amd/build.py runs this after every kernel build and leaves the
+result next to the library: librbl.isa.json).  bench.py prices its roofline with these EXECUTED counts
+(frac <= 1 by construction) instead of the reference-arithmetic 204 flop per ordered pair.
+
+For every k_apply_M_sym / k_apply_M_sym2 / k_apply_M_sym4 instantiation the hot block is the far-tile
+systolic sweep: the basic block with the most v_rsq_f64 that has ds_add_f64 column sums and no division.
+Pairs per trip of that block = v_rsq_f64 / (2 with the wall term, 1 without).
+
+usage: isa_stats.py kernels.s out.json
+"""
+import json
+import re
+import sys
+
+
+def blocks_of(lines, start, end):
+    out = []
+    cur = ["entry", {}]
+    out.append(cur)
+    for l in lines[start + 1:end]:
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            cur = [l.split(":")[0], {}]
+            out.append(cur)
+            continue
+        t = l.strip().split(" ")[0].split("\t")[0] if l.strip() else ""
+        if t and not t.startswith(";") and not t.startswith("."):
+            cur[1][t] = cur[1].get(t, 0) + 1
+    return out
+
+
+def classify(ops):
+    g = lambda pred: sum(v for k, v in ops.items() if pred(k))
+    fma = g(lambda k: k.startswith(("v_fma_f64", "v_fmac_f64")))
+    mul = g(lambda k: k.startswith("v_mul_f64"))
+    add = g(lambda k: k.startswith("v_add_f64"))
+    trans = g(lambda k: k.startswith(("v_rsq_f64", "v_rcp_f64", "v_sqrt_f64")))
+    div = g(lambda k: k.startswith("v_div_"))
+    mfma = g(lambda k: k.startswith("v_mfma"))
+    f64 = g(lambda k: k.startswith("v_") and "f64" in k and not k.startswith("v_mfma"))
+    valu = g(lambda k: k.startswith("v_") and not k.startswith("v_mfma"))
+    lds = g(lambda k: k.startswith("ds_"))
+    salu = g(lambda k: k.startswith("s_") and not k.startswith(("s_waitcnt", "s_nop", "s_barrier")))
+    return {"fma": fma, "mul": mul, "add": add, "trans": trans, "div": div, "mfma": mfma, "f64": f64,
+            "valu": valu, "valu_other": valu - f64, "lds": lds, "salu": salu,
+            "rsq": g(lambda k: k.startswith("v_rsq_f64")), "ds_add": g(lambda k: k.startswith("ds_add_f64"))}
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lines = open(src).read().split("\n")
+    res = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)EE\S*):", l)
+        if not m:
+            continue
+        kern, wall, ni = m.group(2), m.group(3) == "1", int(m.group(4))
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        best = None
+        for name, ops in blocks_of(lines, i, end):
+            c = classify(ops)
+            if c["rsq"] == 0 or c["ds_add"] == 0 or c["div"] or c["trans"] != c["rsq"]:
+                continue
+            if best is None or c["rsq"] > best[1]["rsq"]:
+                best = (name, c)
+        if best is None:
+            continue
+        c = best[1]
+        pairs = c["rsq"] / (2.0 if wall else 1.0)
+        per = {k: c[k] / pairs for k in ("fma", "mul", "add", "trans", "f64", "valu", "valu_other", "lds", "salu")}
+        per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]   # a transcendental counted as ONE flop
+        res["%s<%s,%d>" % (kern, "true" if wall else "false", ni)] = {
+            "block": best[0], "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
+    json.dump({"source": "hipcc -S --offload-device-only of csrc/rbl_kernels.hip (same flags as librbl.so)",
+               "kernels": res}, open(dst, "w"), indent=1, sort_keys=True)
+    for k, v in sorted(res.items()):
+        p = v["per_unordered_pair"]
+        print("%-28s %s: %.1f VALU (%.1f f64: %.1f fma %.1f mul %.1f add %.1f trans) %.1f LDS -> %.0f flop / unordered pair"
+              % (k, v["block"], p["valu"], p["f64"], p["fma"], p["mul"], p["add"], p["trans"], p["lds"], p["flop"]))
+
+
+if __name__ == "__main__":
+    main()
