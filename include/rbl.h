@@ -303,7 +303,10 @@ int rbl_sync_check(rbl_ctx *ctx);
 /* tuning / test hook.  jsplit: j-split of the ordered kernel (0 = heuristic).  variant: 0 = heuristic
  * (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 = force the ordered kernel,
  * 2 = force the symmetric kernel (with jsplit > 0: its column-chunk length), 3 = force the MFMA multi-RHS kernel;
- * 21 / 22 (experiment switch): one / two rows per lane in the two-vector symmetric kernel.  All per context. */
+ * 21 / 22 (experiment switch): one / two rows per lane in the two-vector symmetric kernel;
+ * 31 / 32: rbl_gmres_saddle_dev applies apply_PC with the reference's sign of the force block (:601: the preconditioned
+ * operator then has eigenvalues near -1 AND +1) / with that sign restored (default; one cluster, fewer iterations, same
+ * solution).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

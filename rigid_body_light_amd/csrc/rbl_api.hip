@@ -1082,6 +1082,7 @@ int rbl_sync_check(rbl_ctx *c)
 int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
   if (!c) return RBL_ERR_ARG;
+  if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }   // GMRES: reference-sign / restored-sign PC
   if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
   c->sym_tune.chunk = (variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;
@@ -1202,7 +1203,7 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   int rc;
   if ((rc = rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, d_in, w1, m))) return rc;      // invM slip
   rbl_launch_KT_x_Lam(c->stream, lev, w1, S.N_blb, S.N_bod, f6);                                     // K^T (invM slip)
-  rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p, d_in + n3, f6, S.N_bod, d_out + n3); // U  (:601-608)
+  rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p, d_in + n3, f6, S.N_bod, d_out + n3, c->pc_fsign); // U  (:601-608)
   // Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over the factors
   rbl_launch_pc_block_lambda(c->stream, w1, (const double *)c->d_pcMK.p, d_out + n3, S.N_blb, n3, d_out);
   return RBL_OK;
@@ -1229,7 +1230,7 @@ int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
     c->dev_pc_valid = true;
   }
   rbl_launch_pc_diag_apply(c->stream, (const double *)c->d_lever.p, (const double *)c->d_invM2.p, (const double *)c->d_NL.p,
-                           S.N_blb, S.N_bod, d_in, d_out);
+                           S.N_blb, S.N_bod, d_in, d_out, c->pc_fsign);
   return RBL_OK;
 }
 
@@ -1310,8 +1311,23 @@ int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double r
   return finish_and_check(c);
 }
 
+static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                              double *resid_out);
+
+// any invertible right preconditioner leaves the solution unchanged: inside the solve the force block of apply_PC
+// takes the sign that makes A P^-1 ~ I (see rbl_ctx::pc_fsign); the bound apply_PC keeps the reference's convention
 static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
                              double *resid_out)
+{
+  const double keep = c->pc_fsign;
+  if (c->gmres_pc_sign_fix) c->pc_fsign = 1.0;
+  const int rc = gmres_saddle_core_(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
+  c->pc_fsign = keep;
+  return rc;
+}
+
+static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                              double *resid_out)
 {
   int rc = sync_bodies(c); if (rc) return rc;
   if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
                                                       const double *__restrict__ invM2,
                                                       const double *__restrict__ NL, int N_blb,
                                                       long n3, const double *__restrict__ in,
-                                                      double *__restrict__ out)
+                                                      double *__restrict__ out, double fsign)
 {
   __shared__ double s[6][BT];
   __shared__ double Ush[6];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
     const double *L = NL + 36 * (size_t)b;
     double y[6], u[6];
     for (int p = 0; p < 6; ++p) {
-      double v = -F[6 * b + p] - f[p];
+      double v = fsign * F[6 * b + p] - f[p];
       for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
       y[p] = v / L[6 * p + p];
     }
@@ -240,14 +240,14 @@ __global__ void k_pc_block_ninv(const double *__restrict__ cols /* [6][6*N_bod]:
 
 // U_b = Ninv_b^-1 (-F_b - f_b) through the 6x6 Cholesky factor (:601-608); also copies U to out
 __global__ void k_pc_block_mid(const double *__restrict__ NL, const double *__restrict__ F,
-                               const double *__restrict__ f, int N_bod, double *__restrict__ U)
+                               const double *__restrict__ f, int N_bod, double *__restrict__ U, double fsign)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= N_bod) return;
   const double *L = NL + 36 * (size_t)b;
   double y[6], u[6];
   for (int p = 0; p < 6; ++p) {
-    double v = -F[6 * b + p] - f[6 * b + p];
+    double v = fsign * F[6 * b + p] - f[6 * b + p];
     for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
     y[p] = v / L[6 * p + p];
   }
@@ -289,10 +289,10 @@ void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, d
 }
 
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
-                             double *d_U)
+                             double *d_U, double fsign)
 {
   if (N_bod <= 0) return;
-  hipLaunchKernelGGL(k_pc_block_mid, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_NL, d_F, d_f, N_bod, d_U);
+  hipLaunchKernelGGL(k_pc_block_mid, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_NL, d_F, d_f, N_bod, d_U, fsign);
 }
 
 void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
@@ -344,9 +344,9 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
 }
 
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
-                              int N_blb, int N_bod, const double *d_in, double *d_out)
+                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign)
 {
   if (N_bod <= 0) return;
   hipLaunchKernelGGL(k_pc_diag_apply, dim3(N_bod), dim3(BT), 0, st, d_lever, d_invM2, d_NL, N_blb,
-                     (long)3 * N_blb * N_bod, d_in, d_out);
+                     (long)3 * N_blb * N_bod, d_in, d_out, fsign);
 }

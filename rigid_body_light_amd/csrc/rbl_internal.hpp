@@ -88,6 +88,11 @@ struct rbl_ctx {
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
   RblCholAux chol_aux;
+  // apply_PC as the reference defines it (:601-608) answers [M -K; K^T 0] x = [slip; -F]: with the saddle operator of
+  // src/Rigid.py:73-80 the preconditioned operator then has its 6 N_bod body eigenvalues at -1 and the rest at +1.  The
+  // library's own GMRES may apply the preconditioner with the force block's sign restored (pc_fsign = +1: one cluster).
+  double pc_fsign = -1.0;
+  bool gmres_pc_sign_fix = true;
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
@@ -192,12 +197,12 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
                               const double *d_pos, int N_blb, int N_bod, double *d_invM2, double *d_NL,
                               unsigned *d_err);
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
-                              int N_blb, int N_bod, const double *d_in, double *d_out);
+                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign);
 void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err);
 void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
                                 int64_t n3, double *d_out);
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
-                             double *d_U);
+                             double *d_U, double fsign);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

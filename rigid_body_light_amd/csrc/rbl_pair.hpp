@@ -68,51 +68,57 @@ __device__ __forceinline__ double rbl_rsqrt(double x)
 // into a VGPR with a v_mov_b64 on EVERY evaluation.  A caller with registers to spare passes them in as
 // opaque VGPR-resident values (RblWallK from rbl_wall_k_resident()) and saves those two issue slots per pair.
 struct RblWallK {
-  double k1, k2, k3;   // -10/3, 70/3, 20
+  double k1, k2, k3, k4;   // -10/3, 70/3, 20, 3/2
 };
-__device__ __forceinline__ RblWallK rbl_wall_k_literal() { return RblWallK{-10.0 / 3.0, 70.0 / 3.0, 20.0}; }
+__device__ __forceinline__ RblWallK rbl_wall_k_literal() { return RblWallK{-10.0 / 3.0, 70.0 / 3.0, 20.0, 1.5}; }
 __device__ __forceinline__ RblWallK rbl_wall_k_resident()
 {
   RblWallK K = rbl_wall_k_literal();
-  asm volatile("" : "+v"(K.k1), "+v"(K.k2), "+v"(K.k3));   // opaque to the optimiser: stays in VGPRs
+  asm volatile("" : "+v"(K.k1), "+v"(K.k2), "+v"(K.k3), "+v"(K.k4));   // opaque to the optimiser: stays in VGPRs
   return K;
 }
 
 template <bool UNIT = false>
 __device__ __forceinline__ void rbl_wall_coeffs(const RblParams &P, double dz, double zi, double zj, double q,
-                                                double A, double Bc, double &cF, double &beta, double &gxz,
+                                                double r2, double A, double Bc, double &cF, double &beta, double &gxz,
                                                 double &gzx, double &mzz, const RblWallK &K = rbl_wall_k_literal())
 {
+  // Further identities that take instructions out (84 -> 75 fp64 instructions per unordered pair):
+  //   T0 = 2g - ez = (z_j - z_i)/R = -dz/R             (g never formed)
+  //   gk = z_i z_j / R^2 = (1 - r^2/R^2) / 4           (R^2 - r^2 = 4 z_i z_j)
+  //   v = ez^2 = 1 - q/R^2                             (ez itself is only needed as Rz/R inside Rz w/R^2)
+  //   gk and v only enter O(1) polynomials, so the cancellation when z_i z_j << R^2 or Rz^2 << R^2 costs an
+  //   absolute ~1e-16 there, nothing relative to the block
+  //   2 ez T0 - 4 g^2 = -T0^2 - v                      (the zz bracket: -T0^2 - v (b2 + 1) + u d1), and its -w T0^2 =
+  //   -dz^2 w/R^2 cancels the same term of Bc dz^2 = (Bc - w/R^2) dz^2 + dz^2 w/R^2:  mzz = cF + gm dz + w (u d1 - v b2p)
+  //   T1 = ez (b2 + 1 - 20/3 u^2),  b2 + 1 = 6 gk + u t2 =: b2p
+  //   fact2 ez -+ T1 enter as  gm -+ T1' (Rz w / R^2):  two FMAs on the shared product, no separate add/sub
+  //   Bc dz + T0 w / R = dz (Bc - w / R^2) = gm,  and  Bc + b2 w / R^2 = (Bc - w/R^2) + b2p w / R^2
   const double Rz = zi + zj;
   const double R2 = __builtin_fma(Rz, Rz, q);
   const double invR = rbl_rsqrt(R2);
   const double w = UNIT ? invR : P.a * invR;
-  const double ez = Rz * invR;
+  const double iR2 = invR * invR;
   const double u = w * w;
-  const double v = ez * ez;
-  const double g = zj * invR;
-  const double gk = g * (zi * invR);
+  const double v = __builtin_fma(-q, iR2, 1.0);
+  const double rr = r2 * iR2;                                                        // (r/R)^2 = 1 - 4 gk
   const double t1 = __builtin_fma(u, __builtin_fma(v, K.k1, 2.0 / 3.0), __builtin_fma(v, 2.0, -2.0 / 3.0));
-  const double b1 = __builtin_fma(u, t1, __builtin_fma(-2.0, gk, -1.0));
+  const double b1 = __builtin_fma(u, t1, __builtin_fma(0.5, rr, -K.k4));             // -1 - 2 gk + u t1
   const double t2 = __builtin_fma(u, __builtin_fma(v, K.k2, -10.0 / 3.0), __builtin_fma(v, -10.0, 2.0));
-  const double a2 = __builtin_fma(6.0, gk, -1.0);
-  const double b2 = __builtin_fma(u, t2, a2);
-  const double T0 = __builtin_fma(2.0, g, -ez);
-  const double T1 = ez * __builtin_fma(u, __builtin_fma(u, -20.0 / 3.0, t2), a2 + 1.0);
-  const double d1 = __builtin_fma(u, __builtin_fma(v, K.k3, -8.0 / 3.0), -4.0 * v);
-  const double wi = w * invR;
+  const double sixgk = __builtin_fma(-rr, K.k4, K.k4);
+  const double b2p = __builtin_fma(u, t2, sixgk);                                    // b2 + 1
+  const double uu = u * u;
+  const double T1p = __builtin_fma(uu, -20.0 / 3.0, b2p);                            // T1 / ez
+  const double w3 = w * iR2;                                                         // w / R^2
+  const double Bw = Bc - w3;
   cF = __builtin_fma(w, b1, A);
-  beta = __builtin_fma(b2, wi * invR, Bc);                         // lateral dyad: (Bc + fact2/R^2) dl dl^T
-  const double Bdz = Bc * dz;
-  const double gm = __builtin_fma(T0, wi, Bdz), gd = T1 * wi;
-  gxz = gm - gd;                                                   // M_xz = dx gxz, M_yz = dy gxz
-  gzx = gm + gd;                                                   // M_zx = dx gzx, M_zy = dy gzx
-  // zz entry beyond cF + Bc dz^2:  f2 ez^2 + (f3 + f4) ez + f5 = w [2 ez T0 - b2 ez^2 + b5]   (using
-  // ez [(f2 ez + f3) + (f2 ez + f4)] = 2 w ez T0)
-  double c = __builtin_fma(ez + ez, T0, -(b2 * v));
-  c = __builtin_fma(u, d1, c);
-  c = __builtin_fma(-4.0 * g, g, c);
-  mzz = __builtin_fma(w, c, __builtin_fma(Bdz, dz, cF));
+  beta = __builtin_fma(b2p, w3, Bw);                                                 // lateral dyad: (Bc + fact2/R^2) dl dl^T
+  const double gm = dz * Bw, gdw = Rz * w3;
+  gxz = __builtin_fma(-T1p, gdw, gm);                                                // M_xz = dx gxz, M_yz = dy gxz
+  gzx = __builtin_fma(T1p, gdw, gm);                                                 // M_zx = dx gzx, M_zy = dy gzx
+  // zz bracket  u d1 - v b2p,  d1 = u (20 v - 8/3) - 4 v:   u^2 (20 v - 8/3) - v (b2p + 4 u)
+  const double c = __builtin_fma(uu, __builtin_fma(v, K.k3, -8.0 / 3.0), -(v * __builtin_fma(4.0, u, b2p)));
+  mzz = __builtin_fma(w, c, __builtin_fma(gm, dz, cF));
 }
 
 // ---------------------------------------------------------------------------
@@ -176,7 +182,7 @@ __device__ __forceinline__ void rbl_pair_accum(const RblParams &P, double xi, do
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, r2, A, Bc, cF, beta, gxz, gzx, mzz, K);
   const double lat = __builtin_fma(beta, q2, gxz * Fz);
   ux = __builtin_fma(cF, Fx, __builtin_fma(lat, dx, ux));
   uy = __builtin_fma(cF, Fy, __builtin_fma(lat, dy, uy));
@@ -238,7 +244,7 @@ __device__ __forceinline__ void rbl_pair_sym(const RblParams &P, double xi, doub
   // Wall: coefficients for ONE direction (h = z_j); M_ji = M_ij^T exactly, so U_j += M_ij^T F_i reuses
   // them.  Vector form: 20 FMAs for both directions instead of forming nine entries.
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, r2, A, Bc, cF, beta, gxz, gzx, mzz, K);
   // U_i += M F_j
   const double pj = __builtin_fma(dy, Fjy, dx * Fjx);
   const double lj = __builtin_fma(beta, pj, gxz * Fjz);
@@ -295,7 +301,7 @@ __device__ __forceinline__ void rbl_pair_sym2(const RblParams &P, double xi, dou
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, r2, A, Bc, cF, beta, gxz, gzx, mzz, K);
   auto app = [&](const RblV3 &F, RblV3 &u, double g_lat, double g_z) {   // M F (g_lat = gxz, g_z = gzx) or M^T F (swapped)
     const double p = __builtin_fma(dy, F.y, dx * F.x);
     const double l = __builtin_fma(beta, p, g_lat * F.z);
@@ -358,7 +364,7 @@ __device__ __forceinline__ void rbl_pair_block_fast(const RblParams &P, double x
     return;
   }
   double cF, beta, gxz, gzx, mzz;
-  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, A, Bc, cF, beta, gxz, gzx, mzz, K);
+  rbl_wall_coeffs<UNIT>(P, dz, zi, zj, q, r2, A, Bc, cF, beta, gxz, gzx, mzz, K);
   const double bx = beta * dx, by = beta * dy;
   m[0] = __builtin_fma(bx, dx, cF); m[1] = bx * dy; m[2] = dx * gxz;
   m[3] = m[1]; m[4] = __builtin_fma(by, dy, cF); m[5] = dy * gxz;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build an A/B variant of librbl.so with extra compiler flags (e.g. -DRBL_SYM_UNROLL=4) next to the objects:
+#   tools/build_variant.sh u4 -DRBL_SYM_UNROLL=4   ->  rigid_body_light_amd/build/variants/librbl_u4.so
+# Select it at run time with RBL_LIBRARY=<path> (rigid_body_light_amd/_lib.py); timing comparisons must be made on ONE box.
+set -e
+name=$1; shift
+here=$(cd "$(dirname "$0")/.." && pwd)
+src=$here/rigid_body_light_amd/csrc
+out=$here/rigid_body_light_amd/build/variants
+mkdir -p $out/$name
+for f in rbl_kernels.hip rbl_dense.hip rbl_body_dev.hip rbl_api.hip rbl_host.cpp; do
+  o=$out/$name/${f%.*}.o
+  if [ "$f" = rbl_kernels.hip ] || [ ! -f $o ]; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -Wno-unused-function "$@" -c $src/$f -o $o &
+  fi
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/librbl_$name.so $out/$name/*.o
+echo built $out/librbl_$name.so
