@@ -146,6 +146,8 @@ def timestep_mode(args, dev, world=1, rank=0):
         from rigid_body_light_amd._lib import lib
         lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
+    for v in args.tune:
+        ctx.set_tuning(0, v)
     iters = 20 if args.rtol <= 0 else 200
     rtol = args.rtol if args.rtol > 0 else None
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
@@ -416,6 +418,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
+    ap.add_argument("--tune", type=int, action="append", default=[], help="rbl_set_tuning(0, V) switches for A/B runs (31/32 PC sign, "
+                    "41/42 one-kernel GMRES for small systems), repeatable")
     ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 

@@ -297,6 +297,19 @@ int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d
                              uint64_t seed, int method, int split_rand, double delta, double *d_RHS,
                              double *X_half, double *Q_half);
 
+/* ---- multi-GPU inside the library's own solvers --------------------------------------------------------------
+ * One process per GPU, every rank holds the same (replicated) body state and calls the same entry points with the
+ * same arguments.  After rbl_set_comm every FULL mobility product the library evaluates for itself -- the iterations
+ * of rbl_gmres_saddle_dev, of the Lanczos square roots, M_RFD, rbl_apply_saddle_dev, the whole-step entry points --
+ * is this rank's share of the unordered blob-tile pairs (as rbl_apply_M_sym_dev(rank, world)) followed by ONE call of
+ * `allreduce`, which must leave the sum over all ranks in d_buf[0..count) on every rank, ordered after the work already
+ * enqueued on the context's stream and before whatever is enqueued next (e.g. ncclAllReduce / torch.distributed
+ * all_reduce on that stream; a host-staged implementation synchronises the stream itself).  Returns 0 on success.
+ * All vectors of the Krylov recurrences stay replicated and bitwise identical on every rank, so the ranks take the same
+ * convergence decisions.  world == 1 (or fn == NULL) switches back to single-GPU products. */
+typedef int (*rbl_allreduce_fn)(void *user, double *d_buf, int64_t count);
+int rbl_set_comm(rbl_ctx *ctx, int rank, int world, rbl_allreduce_fn allreduce, void *user);
+
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);
 
@@ -306,7 +319,9 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 21 / 22 (experiment switch): one / two rows per lane in the two-vector symmetric kernel;
  * 31 / 32: rbl_gmres_saddle_dev applies apply_PC with the reference's sign of the force block (:601: the preconditioned
  * operator then has eigenvalues near -1 AND +1) / with that sign restored (default; one cluster, fewer iterations, same
- * solution).  All per context. */
+ * solution);
+ * 41 / 42: rbl_gmres_saddle_dev never / when it fits (default) runs the whole solve of a small system (<= 256 blobs,
+ * diagonal PC, <= 64 iterations) as ONE kernel launch on one CU.  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

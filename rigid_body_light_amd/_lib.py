@@ -62,6 +62,7 @@ def lib():
         L.rbl_set_block_refresh.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
+        L.rbl_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
         _LIB = L
     return _LIB
@@ -94,6 +95,33 @@ class DeviceContext:
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1)
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_set_config(self.h, X.ctypes.data, Q.ctypes.data, X.size // 3))
+
+    def set_comm(self, sharded):
+        """multi-GPU inside the library's solvers: `sharded` is a dist.ShardedMobility (rank, world, all_reduce_sum);
+        every full mobility product of librbl's own GMRES / Lanczos / step drivers becomes this rank's tile pairs + one
+        all-reduce through torch.distributed (RCCL on device buffers; host-staged with gloo).  None switches it off."""
+        import torch
+        if sharded is None or sharded.world == 1:
+            self._comm_cb = None
+            self._chk(self.L.rbl_set_comm(self.h, 0, 1, None, None))
+            return
+
+        class _View:   # a raw device pointer as a torch tensor (no copy)
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def _allreduce(user, ptr, count):
+            try:
+                t = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
+                sharded.all_reduce_sum(t)
+                return 0
+            except Exception as e:      # never unwind through the C caller
+                import sys
+                print("rbl all-reduce callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+
+        self._comm_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)(_allreduce)
+        self._chk(self.L.rbl_set_comm(self.h, sharded.rank, sharded.world, C.cast(self._comm_cb, C.c_void_p), None))
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.rbl_set_stream(self.h, stream_ptr))

@@ -177,6 +177,13 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   if (c->tune_variant == 1) sym = false;
   if (c->tune_variant == 2) sym = full;
   int rc;
+  if (full && c->comm_world > 1 && c->comm_fn) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
+    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, c->sym_tune)))) return rc;
+    rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
+                           c->n_cu, c->d_err, 1, c->sym_tune);
+    if (c->comm_fn(c->comm_user, d_out, 3 * nbl)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
+    return RBL_OK;
+  }
   if (sym) {
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune)))) return rc;
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
@@ -202,6 +209,18 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
   if (c->tune_variant == 3) mfma = true;
   if (c->tune_variant == 1 || c->tune_variant == 2) mfma = false;
   int rc;
+  if (c->comm_world > 1 && c->comm_fn) {   // multi-GPU: pairs of vectors through the sharded two-vector kernel, one all-reduce per pair
+    int k = 0;
+    for (; k + 2 <= nrhs; k += 2) {
+      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, c->sym_tune)))) return rc;
+      rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
+                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, c->sym_tune);
+      if (c->comm_fn(c->comm_user, d_out + (size_t)k * n3, 2 * n3)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
+    }
+    for (; k < nrhs; ++k)
+      if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
+    return RBL_OK;
+  }
   if (!mfma) {   // 1-3 vectors: pairs of vectors through the two-vector symmetric kernel, a single one alone
     int k = 0;
     const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune) <= c->sym_workspace_budget;
@@ -1072,6 +1091,13 @@ int rbl_trmv_lower_dev(rbl_ctx *c, const double *d_L, int64_t n, const double *d
   return RBL_OK;
 }
 
+int rbl_set_comm(rbl_ctx *c, int rank, int world, rbl_allreduce_fn fn, void *user)
+{
+  if (!c || world < 1 || rank < 0 || rank >= world) return rbl_fail(c, RBL_ERR_ARG, "set_comm: need 0 <= rank < world");
+  c->comm_rank = rank; c->comm_world = (fn ? world : 1); c->comm_fn = fn; c->comm_user = user;
+  return RBL_OK;
+}
+
 int rbl_sync_check(rbl_ctx *c)
 {
   if (!c) return RBL_ERR_ARG;
@@ -1082,7 +1108,8 @@ int rbl_sync_check(rbl_ctx *c)
 int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
   if (!c) return RBL_ERR_ARG;
-  if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }   // GMRES: reference-sign / restored-sign PC
+  if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
+  if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on   // GMRES: reference-sign / restored-sign PC
   if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
   c->sym_tune.chunk = (variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;
@@ -1279,11 +1306,43 @@ extern "C" {
 static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
                              double *resid_out);
 
+// Small systems (<= 256 blobs, diagonal PC): geometry, preconditioner build and the whole Arnoldi / Givens loop in ONE
+// kernel launch on one CU (rbl_small.hip) -- launch-bound otherwise (cfg 1: ~6 launches per iteration).
+static int gmres_small(rbl_ctx *c, const double *d_rhs, const double *d_x0, int max_iter, double rtol, double *d_x,
+                       int *iters_out, double *resid_out)
+{
+  int rc = ensure_xq_dev(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const size_t wd = rbl_gmres_small_work_doubles(S.N_blb, S.N_bod, max_iter);
+  if ((rc = rbl_dev_reserve(c, c->d_gm, sizeof(double) * (wd + 2)))) return rc;
+  double *work = (double *)c->d_gm.p, *scal = work + wd;
+  const double *dX = (const double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
+  rc = rbl_launch_gmres_small(c->stream, rbl_make_params(S.a, S.eta), S.wall, dX, dQ, (const double *)c->d_cfg.p, S.N_blb,
+                              S.N_bod, d_rhs, d_x0, d_x, max_iter, rtol, c->gmres_pc_sign_fix ? 1.0 : c->pc_fsign, work, scal,
+                              c->d_err);
+  if (rc) return rbl_fail(c, rc, "gmres (one-kernel solver): system does not fit");
+  double hs[2] = {0.0, 0.0};
+  RBL_HIP(c, hipMemcpyAsync(hs, scal, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  if ((rc = finish_and_check(c))) return rc;
+  int it = 0;
+  std::memcpy(&it, &hs[0], sizeof(int));
+  if (iters_out) *iters_out = it;
+  if (resid_out) *resid_out = hs[1];
+  return RBL_OK;
+}
+
 // use_x0 != 0: d_x holds an initial guess (e.g. the previous time step's solution): the solver iterates on the
 // residual b - A x0 (one extra product) and the tolerance stays relative to |b|.
 int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int use_x0,
                          int *iters_out, double *resid_out)
 {
+  {
+    int rc = need_config(c); if (rc) return rc;
+    if ((rc = rbl_dev_init(c))) return rc;
+    if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+    if (c->gmres_small && c->comm_world == 1 && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc))
+      return gmres_small(c, d_rhs, use_x0 ? d_x : nullptr, max_iter, rtol, d_x, iters_out, resid_out);
+  }
   if (!use_x0) return gmres_saddle_core(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
   int rc = sync_bodies(c); if (rc) return rc;
   if (!d_rhs || !d_x) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");

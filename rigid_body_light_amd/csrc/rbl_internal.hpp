@@ -93,6 +93,12 @@ struct rbl_ctx {
   // library's own GMRES may apply the preconditioner with the force block's sign restored (pc_fsign = +1: one cluster).
   double pc_fsign = -1.0;
   bool gmres_pc_sign_fix = true;
+  bool gmres_small = true;
+  // multi-GPU (rbl_set_comm): this context is rank comm_rank of comm_world; every full mobility product inside the
+  // library becomes this rank's share of the unordered tile pairs followed by comm_fn (sum all-reduce over the ranks)
+  int comm_rank = 0, comm_world = 1;
+  rbl_allreduce_fn comm_fn = nullptr;
+  void *comm_user = nullptr;      // systems that fit one CU: the whole solve in ONE kernel launch (rbl_small.hip)
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
@@ -185,6 +191,13 @@ void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, doub
                       const double *y, double *out);
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
                               int64_t n_blobs, const double *in, double *out);
+
+// whole GMRES solve of a small system in one kernel (rbl_small.hip)
+bool rbl_gmres_small_fits(int N_blb, int N_bod, int max_iter, bool block_pc);
+size_t rbl_gmres_small_work_doubles(int N_blb, int N_bod, int max_iter);
+int rbl_launch_gmres_small(hipStream_t st, const RblParams &P, bool wall, const double *dX, const double *dQ, const double *dcfg,
+                           int N_blb, int N_bod, const double *d_rhs, const double *d_x0, double *d_x, int max_iter, double rtol,
+                           double fsign, double *d_work, double *d_scal, unsigned *d_err);
 
 // per-body geometric operators on the device (rbl_body_dev.hip)
 void rbl_launch_body_geom(hipStream_t st, const double *dX, const double *dQ, const double *dcfg,

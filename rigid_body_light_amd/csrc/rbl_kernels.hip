@@ -236,28 +236,81 @@ __global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbo
 #endif
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-template <bool WALL, int NI>
-__global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r,
-                                                    const double *__restrict__ F,
-                                                    double *__restrict__ slabI,
-                                                    double *__restrict__ slabJ, long N, int T,
-                                                    int C, int i_first, int i_step, RblParams P,
-                                                    unsigned *err, const unsigned char *__restrict__ farmap)
+// ---- slab layout -------------------------------------------------------------------------------------------
+// A workgroup of the symmetric kernels is SW wavefronts = SW consecutive owned row super-tiles ("row group" g) x one
+// chunk c of C column tiles.  It leaves
+//   row sums     slabI[c]  : for every row blob this chunk can see, i.e. blobs [0, HI(c)),  HI(c) = 64 min((c+1) C + NI-1, T)
+//                            (a super-tile whose first tile is the chunk's last column still owns NI-1 more row tiles)
+//   column sums  slabJ[g]  : ONE set per row group (the SW waves' LDS accumulators are added in wave order before the
+//                            write), for the column blobs at or after the group's first row, [RJ(g), Npad)
+// With one rank (i_step == 1) both are stored as triangles (tri = 1): prefix offsets in closed form,
+//   offI(c) = 64 [C c (c+1) / 2 + (NI-1) c],      offJ(g) = g Npad - RJ1 g (g-1) / 2,   RJ(g) = RJ1 g,   RJ1 = 64 NI SW;
+// row shards of a multi-GPU launch own every i_step-th super-tile, their slabs stay rectangular (and are 1/i_step of
+// the single-rank size anyway).  nrhs vectors lie back to back inside a slab.  All in units of blobs (x 3 doubles).
+// SW = 4 for large systems (two rows per lane), 1 for small ones: with few tiles the lock-step of a multi-wave workgroup
+// and its coarser work units cost more than the slabs save (8 100 blobs: 0.080 ms with SW = 1, 0.108 ms with SW = 4).
+#ifndef RBL_SYM_WAVES
+#define RBL_SYM_WAVES 4
+#endif
+constexpr int SW_LARGE = RBL_SYM_WAVES;
+
+struct SymLayout {
+  long Npad;
+  int T, NI, C, nch, rowsI, rowsG, tri, nrhs, i_first, i_step, SW;
+};
+
+__host__ __device__ __forceinline__ long sym_HI(const SymLayout &L, int c)
+{
+  if (!L.tri) return L.Npad;
+  const long h = (long)(c + 1) * L.C + (L.NI - 1);
+  return (h < L.T ? h : (long)L.T) * TS;
+}
+__host__ __device__ __forceinline__ long sym_offI(const SymLayout &L, int c)
+{
+  return L.tri ? (long)TS * ((long)L.C * ((long)c * (c + 1) / 2) + (long)(L.NI - 1) * c) : (long)c * L.Npad;
+}
+__host__ __device__ __forceinline__ long sym_RJ(const SymLayout &L, int g) { return L.tri ? (long)TS * L.NI * L.SW * g : 0; }
+__host__ __device__ __forceinline__ long sym_offJ(const SymLayout &L, int g)
+{
+  return L.tri ? (long)g * L.Npad - (long)TS * L.NI * L.SW * ((long)g * (g - 1) / 2) : (long)g * L.Npad;
+}
+// doubles: address of (vector v, blob b) in chunk c's row-sum slab / group g's column-sum slab
+__device__ __forceinline__ size_t sym_idxI(const SymLayout &L, int c, int v, long b)
+{
+  return ((size_t)sym_offI(L, c) * L.nrhs + (size_t)v * sym_HI(L, c) + (size_t)b) * 3;
+}
+__device__ __forceinline__ size_t sym_idxJ(const SymLayout &L, int g, int v, long b)
+{
+  const long rj = sym_RJ(L, g);
+  return ((size_t)sym_offJ(L, g) * L.nrhs + (size_t)v * (L.Npad - rj) + (size_t)(b - rj)) * 3;
+}
+
+template <bool WALL, int NI, int SW>
+__global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict__ r,
+                                                        const double *__restrict__ F,
+                                                        double *__restrict__ slabI,
+                                                        double *__restrict__ slabJ, long N, SymLayout L, RblParams P,
+                                                        unsigned *err, const unsigned char *__restrict__ farmap)
 {
   // A lane owns NI rows (row "super-tile" I = tiles NI*I .. NI*I+NI-1): the j data read from
-  // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.
+  // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.  The SW waves of the workgroup own SW
+  // consecutive owned super-tiles and walk the same column tiles in step: ONE staged j tile, per-wave accumulators.
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS];  // (x,y) (z,fx) (fy,fz) of the j tile
-  __shared__ double sU[3][TS];                      // M_ji F_i sums for the j tile
-  const int lane = threadIdx.x;
-  const int I = sym_row_of((int)blockIdx.x, i_first, i_step);  // super-tile index
-  const int c = blockIdx.y;
-  const int It0 = NI * I;                            // first 64-row tile of this super-tile
-  if (It0 >= T) return;
+  __shared__ double sU[SW][3][TS];                  // M_ji F_i sums for the j tile, one set per wave
+  const int lane = threadIdx.x & (TS - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int T = L.T, C = L.C;
+  const int g = blockIdx.x, c = blockIdx.y;
+  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);   // first tile of the group (wave 0's)
+  if (It00 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
-  if (J0 < It0) J0 = It0;
-  if (J0 >= J1) return;
-  const long Npad = (long)T * TS;
+  if (J0 < It00) J0 = It00;
+  if (J0 >= J1) return;                                            // workgroup-uniform
+  const int e = SW * g + wave;
+  const int I = sym_row_of(e, L.i_first, L.i_step);                // this wave's super-tile
+  const bool wlive = e < L.rowsI && NI * I < T;
+  const int It0 = wlive ? NI * I : (1 << 30);                      // a wave without rows never sweeps, only keeps step
   unsigned flags = 0;
 
   // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
@@ -282,23 +335,28 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
   double xi[NI], yi[NI], zi[NI], Fix[NI], Fiy[NI], Fiz[NI], uix[NI], uiy[NI], uiz[NI];
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
-    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);
+    load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);
     uix[a] = 0.0; uiy[a] = 0.0; uiz[a] = 0.0;
   }
 
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
-    double xj, yj, zj, Fjx, Fjy, Fjz;
-    load_blob(j, xj, yj, zj, Fjx, Fjy, Fjz);
+    double xj = 0, yj = 0, zj = 0, Fjx = 0, Fjy = 0, Fjz = 0;
+    if (wave == 0) load_blob(j, xj, yj, zj, Fjx, Fjy, Fjz);
+    const bool sweeps = J >= It0;                                  // wave-uniform
     // wave-uniform: every blob of tile J is farther than 2a from every owned row (k_tile_far)
-    const bool far_tile = farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    const bool far_tile = sweeps && farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    __syncthreads();                                               // previous tile consumed, its column sums written
+    if (wave == 0) {
+      sP0[lane] = (double2_t){xj, yj};
+      sP1[lane] = (double2_t){zj, Fjx};
+      sP2[lane] = (double2_t){Fjy, Fjz};
+    }
+    sU[wave][0][lane] = 0.0; sU[wave][1][lane] = 0.0; sU[wave][2][lane] = 0.0;
     __syncthreads();
-    sP0[lane] = (double2_t){xj, yj};
-    sP1[lane] = (double2_t){zj, Fjx};
-    sP2[lane] = (double2_t){Fjy, Fjz};
-    sU[0][lane] = 0.0; sU[1][lane] = 0.0; sU[2][lane] = 0.0;
-    __syncthreads();
-    if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
+    if (!sweeps) {
+      // the tile lies before this wave's rows: pairs belong to an earlier wave
+    } else if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
       auto sweep = [&](auto nearchk) {
         unsigned off16 = (unsigned)lane * 16u;       // byte offset of column jj in the 16-B arrays, carried (jj*8 = off16/2)
 #pragma unroll RBL_SYM_UNROLL
@@ -313,9 +371,9 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
             rbl_pair_sym<WALL, true, decltype(nearchk)::value>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x,
                                                                pa.y, pb.x, pb.y, pd.x, pd.y, uix[a], uiy[a], uiz[a],
                                                                vx, vy, vz, flags, WK);
-          __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
       if (far_tile) sweep(std::false_type{});   // no pair can overlap: sweep without the per-pair test
@@ -337,24 +395,31 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
             double vx = 0.0, vy = 0.0, vz = 0.0;
             rbl_pair_sym<WALL, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x,
                                pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags, WK);
-            __hip_atomic_fetch_add(&sU[0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&sU[1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&sU[2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sU[wave][0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sU[wave][1][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sU[wave][2][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
     }
-    if (J > It0) {  // some owned row tile precedes J: column sums exist
+    if (J > It00) {  // some owned row tile of the group precedes J: column sums exist.  Waves added in fixed order.
       __syncthreads();
-      double *p = slabJ + ((size_t)blockIdx.x * (size_t)Npad + (size_t)j) * 3;
-      p[0] = sU[0][lane]; p[1] = sU[1][lane]; p[2] = sU[2][lane];
+      for (int q = threadIdx.x; q < 3 * TS; q += TS * SW) {
+        const int l = q / 3, k = q - 3 * l;
+        double sum = sU[0][k][l];
+#pragma unroll
+        for (int w = 1; w < SW; ++w) sum += sU[w][k][l];
+        slabJ[sym_idxJ(L, g, 0, (long)J * TS + l) + k] = sum;
+      }
     }
   }
+  if (wlive && c * C + C > It0) {   // this wave swept at least one tile of the chunk: its row sums (k_reduce_sym reads chunks >= It0 / C)
 #pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    if (It0 + a < T) {
-      double *p = slabI + ((size_t)c * (size_t)Npad + (size_t)(It0 + a) * TS + lane) * 3;
-      p[0] = uix[a]; p[1] = uiy[a]; p[2] = uiz[a];
+    for (int a = 0; a < NI; ++a) {
+      if (It0 + a < T) {
+        double *p = slabI + sym_idxI(L, c, 0, (long)(It0 + a) * TS + lane);
+        p[0] = uix[a]; p[1] = uiy[a]; p[2] = uiz[a];
+      }
     }
   }
   if (flags) atomicOr(err, flags);
@@ -362,27 +427,31 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym(const double *__restrict__ r
 
 // ---------------------------------------------------------------------------
 // The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
-// coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back:
-// slabI[chunk][2][Npad][3], slabJ[row][2][Npad][3].
+// coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back.
 // ---------------------------------------------------------------------------
-template <bool WALL, int NI>
-__global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
-                                                     double *__restrict__ slabI, double *__restrict__ slabJ, long N,
-                                                     int T, int C, int i_first, int i_step, RblParams P, unsigned *err,
-                                                     const unsigned char *__restrict__ farmap)
+template <bool WALL, int NI, int SW>
+__global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
+                                                         double *__restrict__ slabI, double *__restrict__ slabJ, long N,
+                                                         SymLayout L, RblParams P, unsigned *err,
+                                                         const unsigned char *__restrict__ farmap)
 {
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS], sP3[TS], sP4[TS];  // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
-  __shared__ double sU[2][3][TS];
-  const int lane = threadIdx.x;
-  const int I = sym_row_of((int)blockIdx.x, i_first, i_step);
-  const int c = blockIdx.y;
-  const int It0 = NI * I;
-  if (It0 >= T) return;
+  __shared__ double sU[SW][2][3][TS];
+  const int lane = threadIdx.x & (TS - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int T = L.T, C = L.C;
+  const int g = blockIdx.x, c = blockIdx.y;
+  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);
+  if (It00 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
-  if (J0 < It0) J0 = It0;
+  if (J0 < It00) J0 = It00;
   if (J0 >= J1) return;
-  const long Npad = (long)T * TS, n3 = 3 * N;
+  const int e = SW * g + wave;
+  const int I = sym_row_of(e, L.i_first, L.i_step);
+  const bool wlive = e < L.rowsI && NI * I < T;
+  const int It0 = wlive ? NI * I : (1 << 30);
+  const long n3 = 3 * N;
   unsigned flags = 0;
   const RblParams Pu = unit_params(P);
   const RblWallK WK = rbl_wall_k_resident();
@@ -406,25 +475,28 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ 
   RblV3 Fi0[NI], Fi1[NI], ui0[NI], ui1[NI];
 #pragma unroll
   for (int a = 0; a < NI; ++a) {
-    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
+    load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
     ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = ui0[a];
   }
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
-    double xj, yj, zj;
-    RblV3 Fj0, Fj1;
-    load_blob(j, xj, yj, zj, Fj0, Fj1);
-    const bool far_tile = farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    double xj = 0, yj = 0, zj = 0;
+    RblV3 Fj0{0, 0, 0}, Fj1{0, 0, 0};
+    if (wave == 0) load_blob(j, xj, yj, zj, Fj0, Fj1);
+    const bool sweeps = J >= It0;
+    const bool far_tile = sweeps && farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
     __syncthreads();
-    sP0[lane] = (double2_t){xj, yj};
-    sP1[lane] = (double2_t){zj, Fj0.x};
-    sP2[lane] = (double2_t){Fj0.y, Fj0.z};
-    sP3[lane] = (double2_t){Fj1.x, Fj1.y};
-    sP4[lane] = (double2_t){Fj1.z, 0.0};
+    if (wave == 0) {
+      sP0[lane] = (double2_t){xj, yj};
+      sP1[lane] = (double2_t){zj, Fj0.x};
+      sP2[lane] = (double2_t){Fj0.y, Fj0.z};
+      sP3[lane] = (double2_t){Fj1.x, Fj1.y};
+      sP4[lane] = (double2_t){Fj1.z, 0.0};
+    }
 #pragma unroll
     for (int v = 0; v < 2; ++v)
 #pragma unroll
-      for (int d = 0; d < 3; ++d) sU[v][d][lane] = 0.0;
+      for (int d = 0; d < 3; ++d) sU[wave][v][d][lane] = 0.0;
     __syncthreads();
     auto pair_step = [&](int jj, int a, auto nearchk) {
       const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj], pe = sP3[jj], pf = sP4[jj];
@@ -432,14 +504,15 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ 
       rbl_pair_sym2<WALL, true, decltype(nearchk)::value>(Pu, xi[a], yi[a], zi[a], Fi0[a], Fi1[a], pa.x, pa.y, pb.x,
                                                           RblV3{pb.y, pd.x, pd.y}, RblV3{pe.x, pe.y, pf.x}, ui0[a],
                                                           ui1[a], v0, v1, flags, WK);
-      __hip_atomic_fetch_add(&sU[0][0][jj], v0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sU[0][1][jj], v0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sU[0][2][jj], v0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sU[1][0][jj], v1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sU[1][1][jj], v1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&sU[1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][0][0][jj], v0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][0][1][jj], v0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][0][2][jj], v0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][1][0][jj], v1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][1][1][jj], v1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&sU[wave][1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    if (J >= It0 + NI) {
+    if (!sweeps) {
+    } else if (J >= It0 + NI) {
       auto sweep = [&](auto nearchk) {
 #pragma unroll 2
         for (int s = 0; s < TS; ++s) {
@@ -466,76 +539,77 @@ __global__ __launch_bounds__(TS) void k_apply_M_sym2(const double *__restrict__ 
         }
       }
     }
-    if (J > It0) {
+    if (J > It00) {
       __syncthreads();
+      const int t = threadIdx.x;
+      for (int q = t; q < 2 * 3 * TS; q += TS * SW) {
+        const int v = q / (3 * TS), rem = q - v * 3 * TS, l = rem / 3, k = rem - 3 * l;
+        double sum = sU[0][v][k][l];
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        double *p = slabJ + (((size_t)blockIdx.x * 2 + v) * (size_t)Npad + (size_t)j) * 3;
-        p[0] = sU[v][0][lane]; p[1] = sU[v][1][lane]; p[2] = sU[v][2][lane];
+        for (int w = 1; w < SW; ++w) sum += sU[w][v][k][l];
+        slabJ[sym_idxJ(L, g, v, (long)J * TS + l) + k] = sum;
       }
     }
   }
+  if (wlive && c * C + C > It0) {
 #pragma unroll
-  for (int a = 0; a < NI; ++a) {
-    if (It0 + a < T) {
-      double *p = slabI + (((size_t)c * 2) * (size_t)Npad + (size_t)(It0 + a) * TS + lane) * 3;
-      p[0] = ui0[a].x; p[1] = ui0[a].y; p[2] = ui0[a].z;
-      double *p1 = p + (size_t)Npad * 3;
-      p1[0] = ui1[a].x; p1[1] = ui1[a].y; p1[2] = ui1[a].z;
+    for (int a = 0; a < NI; ++a) {
+      if (It0 + a < T) {
+        double *p = slabI + sym_idxI(L, c, 0, (long)(It0 + a) * TS + lane);
+        p[0] = ui0[a].x; p[1] = ui0[a].y; p[2] = ui0[a].z;
+        double *p1 = slabI + sym_idxI(L, c, 1, (long)(It0 + a) * TS + lane);
+        p1[0] = ui1[a].x; p1[1] = ui1[a].y; p1[2] = ui1[a].z;
+      }
     }
   }
   if (flags) atomicOr(err, flags);
 }
 
 // Slab reduction.  Block = 64 consecutive entries of U (all in one blob tile J, since a tile is 192 entries)
-// x RG groups; group g adds the slab entries e = g, g+RG, ... (first the row-sum slabs of the chunks that
-// cover J, then the column-sum slabs of the row tiles before J), the RG partial sums are combined in LDS in
-// fixed order.  Many short independent load streams instead of one long one per entry: at 8 100 blobs the
-// one-thread-per-entry form ran 95 workgroups for 33 us on 37 MB.
+// x RG groups; group q adds the slab entries e = q, q+RG, ... (first the row-sum slabs of the chunks that
+// cover J, then the column-sum slabs of the row groups before J), the RG partial sums are combined in LDS in
+// fixed order.  Many short independent load streams instead of one long one per entry.
 constexpr int RG = 16;
 
 template <bool WALL>
 __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict__ slabI,
                                                        const double *__restrict__ slabJ,
                                                        const double *__restrict__ r,
-                                                       double *__restrict__ out, long N, int T, int C,
-                                                       int nch, int NI, int i_first, int i_step, RblParams P,
+                                                       double *__restrict__ out, long N, SymLayout L, RblParams P,
                                                        unsigned *err)
 {
-  // blockIdx.y = right-hand side (slabs of gridDim.y vectors lie back to back, out is [gridDim.y][3N])
-  const size_t Npad3v = (size_t)T * TS * 3;
-  slabI += (size_t)blockIdx.y * Npad3v;
-  slabJ += (size_t)blockIdx.y * Npad3v;
-  out += (size_t)blockIdx.y * (size_t)(3 * N);
+  // blockIdx.y = right-hand side (out is [gridDim.y][3N])
+  const int v = blockIdx.y;
+  out += (size_t)v * (size_t)(3 * N);
   __shared__ double sh[RG][64];
-  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
   const long idx = (long)blockIdx.x * 64 + tx;           // over 3*N
   const bool live = idx < 3 * N;
   const long idc = live ? idx : 3 * N - 1;
   const long j = idc / 3;
+  const int k = (int)(idc - 3 * j);
   const int J = (int)(j / TS);
+  const int NI = L.NI, C = L.C;
   const int Is = J / NI;                                 // super-tile owning row tile J
-  const size_t Npad3 = (size_t)T * TS * 3 * gridDim.y;   // distance between consecutive slabs
-  const bool owned = sym_row_owned(Is, i_first, i_step);   // this launch owned the rows of tile J
+  const bool owned = sym_row_owned(Is, L.i_first, L.i_step);   // this launch owned the rows of tile J
   const int c0 = (NI * Is) / C;
-  const int nI = owned ? nch - c0 : 0;
+  const int nI = owned ? L.nch - c0 : 0;
   const int Ilim = (J + NI - 1) / NI;                    // super-tiles I with NI*I < J
-  const int nJ = sym_rows_below(Ilim, i_first, i_step);
-  const double *pI = slabI + (size_t)c0 * Npad3 + idc;
-  const double *pJ = slabJ + idc;
+  const int nE = sym_rows_below(Ilim, L.i_first, L.i_step);   // owned ones among them
+  const int nJ = (nE + L.SW - 1) / L.SW;                 // row groups whose first super-tile precedes J
   double s = 0.0;
-  int e = g;
+  int e = q;
 #pragma unroll 4
-  for (; e < nI; e += RG) s += pI[(size_t)e * Npad3];
+  for (; e < nI; e += RG) s += slabI[sym_idxI(L, c0 + e, v, j) + k];
   e -= nI;
 #pragma unroll 4
-  for (; e < nJ; e += RG) s += pJ[(size_t)e * Npad3];
-  sh[g][tx] = s;
+  for (; e < nJ; e += RG) s += slabJ[sym_idxJ(L, e, v, j) + k];
+  sh[q][tx] = s;
   __syncthreads();
-  if (g == 0 && live) {
+  if (q == 0 && live) {
     double t = sh[0][tx];
 #pragma unroll
-    for (int q = 1; q < RG; ++q) t += sh[q][tx];
+    for (int w = 1; w < RG; ++w) t += sh[w][tx];
     double sc = P.nf;
     if (WALL) sc *= damp_of(P, r[3 * j + 2]);
     out[idx] = sc * t;
@@ -1087,9 +1161,9 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 
 // ---- symmetric variant ------------------------------------------------------
 // tune (per context, rbl_set_tuning): chunk > 0 forces the chunk length C; ni2 > 0 the rows per lane of the two-vector kernel
-static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI, int *C, int *nch, int *nrowsI, int nrhs,
-                         const RblSymTune &tune)
+static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step, int nrhs, const RblSymTune &tune)
 {
+  SymLayout L;
   const int t = (int)((n_blobs + TS - 1) / TS);
   // 2 rows per lane once there is parallelism to spare: same speed on one GPU (the kernel is
   // VALU-issue bound either way) but half the column-sum slab to write and re-read
@@ -1100,37 +1174,47 @@ static void sym_geometry(int64_t n_blobs, int n_cu, int i_step, int *T, int *NI,
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
   // wave-units balance the triangular work and hide tile-boundary latency; C = 4..16 is flat at
   // 128 400 blobs (29.8-29.9 ms vs 30.8 at C = 64), C = 2 best at 8 100.  Aim for ~8 rounds of
-  // (4 waves/SIMD x 4 SIMD x CUs) units, capped at 16 tiles.
+  // (4 waves/SIMD x 4 SIMD x CUs) wave-units, capped at 16 tiles.
   const double pairs = 0.5 * (double)rowsI * (double)t;
   const double target_units = (double)(n_cu > 0 ? n_cu : 256) * 16.0 * 8.0;
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
   if (tune.chunk > 0) c = tune.chunk;
-  *T = t; *NI = ni; *C = c; *nch = (t + c - 1) / c; *nrowsI = rowsI;
+  L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
+  L.SW = (ni == 2) ? SW_LARGE : 1;
+  L.rowsG = (rowsI + L.SW - 1) / L.SW; L.tri = (i_step == 1) ? 1 : 0; L.nrhs = nrhs; L.i_first = i_first; L.i_step = i_step;
+  return L;
+}
+
+static size_t sym_slabI_blobs(const SymLayout &L) { return (size_t)(sym_offI(L, L.nch - 1) + sym_HI(L, L.nch - 1)); }
+static size_t sym_slabJ_blobs(const SymLayout &L)
+{
+  return (size_t)(sym_offJ(L, L.rowsG - 1) + (L.Npad - sym_RJ(L, L.rowsG - 1)));
 }
 
 size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, int *NI_out, int *C_out)
 {
-  int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs, tune);
-  if (NI_out) *NI_out = NI;
-  if (C_out) *C_out = C;
+  const SymLayout L = sym_geometry(n_blobs, n_cu, 0, i_step, nrhs, tune);
+  if (NI_out) *NI_out = L.NI;
+  if (C_out) *C_out = L.C;
   // slabs + tile bounding boxes + far map (one byte per (row super-tile, tile))
-  return (((size_t)nch + (size_t)rowsI) * (size_t)T * TS * 3 * nrhs + (size_t)T * 6) * sizeof(double) + (size_t)((T + NI - 1) / NI) * (size_t)T + 64;
+  return ((sym_slabI_blobs(L) + sym_slabJ_blobs(L)) * 3 * nrhs + (size_t)L.T * 6) * sizeof(double) +
+         (size_t)((L.T + L.NI - 1) / L.NI) * (size_t)L.T + 64;
 }
 
 template <bool WALL, int NI>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
-                       int i_first, int i_step, double *d_out, double *slabI, double *slabJ, int T, int C, int nch,
-                       int rowsI, unsigned *d_err, int nrhs)
+                       double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err)
 {
-  dim3 grid((unsigned)rowsI, (unsigned)nch), block(TS);
+  constexpr int SW = (NI == 2) ? SW_LARGE : 1;
+  const int T = L.T, nrhs = L.nrhs;
+  dim3 grid((unsigned)L.rowsG, (unsigned)L.nch), block(TS * SW);
   const int64_t n = 3 * n_blobs;
   dim3 g2((unsigned)((n + 63) / 64), (unsigned)nrhs), b2(64 * RG);
   unsigned char *farmap = nullptr;
   if (NI == 2) {   // large systems only: two more tiny launches, then most tile pairs skip the overlap test
-    double *bbox = slabJ + (size_t)rowsI * (size_t)T * TS * 3 * nrhs;
+    double *bbox = slabJ + sym_slabJ_blobs(L) * 3 * nrhs;
     farmap = (unsigned char *)(bbox + (size_t)T * 6);
     const int nsup = (T + NI - 1) / NI;
     hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)T), dim3(TS), 0, st, d_r, (long)n_blobs, P.inv_a, bbox);
@@ -1138,31 +1222,29 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
                        (const double *)bbox, T, NI, farmap);
   }
   if (nrhs == 2)
-    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
-                       i_first, i_step, P, d_err, (const unsigned char *)farmap);
+    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+                       d_err, (const unsigned char *)farmap);
   else
-    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, T, C,
-                       i_first, i_step, P, d_err, (const unsigned char *)farmap);
-  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, T, C, nch, NI,
-                     i_first, i_step, P, d_err);
+    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+                       d_err, (const unsigned char *)farmap);
+  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
 }
 
-// nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...) * nrhs
+// nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...)
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,
                             double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune)
 {
   if (n_blobs <= 0) return;
-  int T, NI, C, nch, rowsI;
-  sym_geometry(n_blobs, n_cu, i_step, &T, &NI, &C, &nch, &rowsI, nrhs, tune);
+  const SymLayout L = sym_geometry(n_blobs, n_cu, i_first, i_step, nrhs, tune);
   double *slabI = d_work;
-  double *slabJ = d_work + (size_t)nch * (size_t)T * TS * 3 * nrhs;
-  if (NI == 2) {
-    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
-    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
+  double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
+  if (L.NI == 2) {
+    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
+    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
   } else {
-    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
-    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, i_first, i_step, d_out, slabI, slabJ, T, C, nch, rowsI, d_err, nrhs);
+    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
+    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
   }
 }
 

@@ -1,0 +1,384 @@
+// rbl_small.hip -- the whole right-preconditioned GMRES solve of a SMALL system in ONE kernel launch.
+//
+// moving the Krylov loop onto the device "removes per-iteration latency at small N".  At
+// BASELINE cfg 1 (10 x shell_N_12 = 120 blobs, 360 + 60 unknowns) one iteration of rbl_gmres_saddle_dev is ~6 kernel
+// launches of a few microseconds each: the solve is launch-bound (1.0 ms for 21 products).  Here one workgroup of
+// 1024 threads on one CU does everything between the right-hand side and the solution with workgroup barriers
+// instead of kernel boundaries:
+//
+//   geometry (lever arms, positions: reference :257-265, :374) -> diagonal preconditioner (diag_invM :489-543,
+//   Ninv = K^T invM K and its 6x6 Cholesky :593-594) -> [ z = P^-1 v_j  (:589-616) ; w = A z  (src/Rigid.py:73-80:
+//   M lambda - K U | K^T lambda, M by ordered pair evaluation with rbl_pair_accum, reference :641-659) ;
+//   classical Gram-Schmidt twice ; Givens update and convergence test ]* -> x = P^-1 V y.
+//
+// Vectors of the iteration live in LDS, the Krylov basis and the Hessenberg matrix in a global workspace (L2-resident:
+// 70 KB at cfg 1).  Every sum has a fixed order: results are bitwise reproducible, like the rest of the library.
+// Limits: N <= 256 blobs, 6 N_bod <= 384, diagonal preconditioner, max_iter <= 64 (checked by the launcher).
+#include "rbl_internal.hpp"
+
+namespace {
+
+constexpr int SGT = 1024;          // threads of the one workgroup
+constexpr int SG_MAXN = 256;       // blobs
+constexpr int SG_MAXB = 64;        // bodies
+constexpr int SG_MAXIT = 64;
+
+struct SmallArgs {
+  const double *X, *Q, *cfg;       // body state (device): 3 Nb, 4 Nb (scalar-first), N_blb x 3 (mean removed)
+  const double *rhs;               // nsys
+  const double *x0;                // initial guess or nullptr
+  double *x;                       // nsys
+  double *V, *H;                   // workspace: (max_iter+1) nsys | (max_iter+1) x max_iter column-major + g[max_iter+1] + cs, sn
+  int *iters_out;                  // device scalars
+  double *resid_out;
+  unsigned *err;
+  RblParams P;
+  int N_blb, N_bod, max_iter;
+  double rtol, fsign;
+};
+
+__device__ __forceinline__ void quat_rot9(const double *q, double *R)
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// sum over the wavefront, result in every lane (fixed butterfly order)
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <bool WALL>
+__global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
+{
+  extern __shared__ double sm[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int NW = SGT / 64;
+  const int nbl = A.N_blb, nb = A.N_bod, N = nbl * nb, n3 = 3 * N, nb6 = 6 * nb, nsys = n3 + nb6;
+  const int m = A.max_iter, ldh = m + 1;
+  const int Qc = SGT / N;                       // column chunks of the pair evaluation (>= 4 for N <= 256)
+  const int jlen = (N + Qc - 1) / Qc;
+  double *pos = sm;                             // 3N  positions / a
+  double *lev = pos + n3;                       // 3N  lever arms
+  double *iM = lev + n3;                        // 2N  diag_invM: (xx = yy, zz)
+  double *dmp = iM + 2 * N;                     // N   wall damping d_i (1 without the wall term)
+  double *NLs = dmp + N;                        // 36 Nb  Cholesky factors of K^T invM K
+  double *vz = NLs + 36 * nb;                   // nsys   z = P^-1 v
+  double *vw = vz + nsys;                       // nsys   w
+  double *vv = vw + nsys;                       // nsys   current basis vector / scratch
+  double *fb = vv + nsys;                       // 6 Nb   body sums
+  double *hh = fb + nb6;                        // max_iter + 2
+  double *sc = hh + (m + 2);                    // 8 scalars: [0] |b|, [1] stop flag, [2] resid, [3] iterations
+  double *part = sc + 8;                        // Qc * 3N partial row sums
+  const RblParams P = A.P;
+  const RblParams Pu = {1.0, 1.0, P.nf, 4.0, 1e-24, -0.375, 0.125, 0};
+  unsigned flags = 0;
+
+  // ---- geometry + diagonal preconditioner ---------------------------------------------------------------
+  if (t < N) {
+    const int b = t / nbl, k = t - b * nbl;
+    double R[9];
+    quat_rot9(A.Q + 4 * b, R);
+    const double c0 = A.cfg[3 * k], c1 = A.cfg[3 * k + 1], c2 = A.cfg[3 * k + 2];
+    double l0, l1, l2, p2;
+    {
+#pragma clang fp contract(off)
+      l0 = c0 * R[0] + c1 * R[1] + c2 * R[2];
+      l1 = c0 * R[3] + c1 * R[4] + c2 * R[5];
+      l2 = c0 * R[6] + c1 * R[7] + c2 * R[8];
+      lev[3 * t] = l0; lev[3 * t + 1] = l1; lev[3 * t + 2] = l2;
+      p2 = l2 + A.X[3 * b + 2];
+      pos[3 * t] = (l0 + A.X[3 * b]) * P.inv_a; pos[3 * t + 1] = (l1 + A.X[3 * b + 1]) * P.inv_a; pos[3 * t + 2] = p2 * P.inv_a;
+    }
+    double dxx = 4.0 / 3.0, dzz = 4.0 / 3.0, d = 1.0;
+    if (WALL) {  // self wall term (:98-104), h = z/a; damping (:629-633)
+      const double h = p2 / P.a;
+      if (h < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+      const double iz = 1.0 / h, iz3 = iz * iz * iz, iz5 = iz3 * iz * iz;
+      dxx += -(9 * iz - 2 * iz3 + iz5) / 12.0;
+      dzz += -(9 * iz - 4 * iz3 + iz5) / 6.0;
+      d = (p2 >= P.a) ? 1.0 : p2 / P.a;
+    }
+    const double scale = 1.0 / P.nf;
+    iM[2 * t] = scale / dxx; iM[2 * t + 1] = scale / dzz;
+    dmp[t] = d;
+  }
+  __syncthreads();
+  if (t < nb) {   // Ninv_b = sum_k K_k^T D_k K_k (lower triangle), then its 6x6 Cholesky, row-major L
+    double acc[21];
+    for (int q = 0; q < 21; ++q) acc[q] = 0.0;
+    for (int k = 0; k < nbl; ++k) {
+      const int i = t * nbl + k;
+      const double lx = lev[3 * i], ly = lev[3 * i + 1], lz = lev[3 * i + 2];
+      const double Kk[3][6] = {{1, 0, 0, 0, lz, -ly}, {0, 1, 0, -lz, 0, lx}, {0, 0, 1, ly, -lx, 0}};
+      const double D[3] = {iM[2 * i], iM[2 * i], iM[2 * i + 1]};
+      int q = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c <= r; ++c) {
+          acc[q] += Kk[0][r] * D[0] * Kk[0][c] + Kk[1][r] * D[1] * Kk[1][c] + Kk[2][r] * D[2] * Kk[2][c];
+          ++q;
+        }
+    }
+    double L[36];
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c <= r; ++c) { L[6 * r + c] = acc[q]; if (c < r) L[6 * c + r] = 0.0; ++q; }
+    bool ok = true;
+    for (int j = 0; j < 6; ++j) {
+      double dd = L[6 * j + j];
+      for (int k = 0; k < j; ++k) dd -= L[6 * j + k] * L[6 * j + k];
+      if (!(dd > 0.0)) ok = false;
+      dd = sqrt(dd);
+      L[6 * j + j] = dd;
+      for (int i = j + 1; i < 6; ++i) {
+        double v = L[6 * i + j];
+        for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+        L[6 * i + j] = v / dd;
+      }
+    }
+    if (!ok) flags |= RBL_FLAG_NOT_SPD;
+    for (int e = 0; e < 36; ++e) NLs[36 * t + e] = L[e];
+  }
+  __syncthreads();
+
+  // ---- operators on LDS vectors (every thread calls them: they contain barriers) ----------------------------
+  // out = P^-1 in   (apply_PC with the diagonal invM, :589-616; fsign: see rbl_ctx::pc_fsign)
+  auto apply_PC = [&](const double *in, double *out) {
+    if (t < nb6) {                           // f = K^T (invM slip), component c of body b
+      const int b = t / 6, c = t - 6 * b;
+      double f = 0.0;
+      for (int k = 0; k < nbl; ++k) {
+        const int i = b * nbl + k;
+        const double v0 = iM[2 * i] * in[3 * i], v1 = iM[2 * i] * in[3 * i + 1], v2 = iM[2 * i + 1] * in[3 * i + 2];
+        const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
+        f += c == 0 ? v0 : c == 1 ? v1 : c == 2 ? v2 : c == 3 ? l1 * v2 - l2 * v1 : c == 4 ? l2 * v0 - l0 * v2 : l0 * v1 - l1 * v0;
+      }
+      fb[t] = f;
+    }
+    __syncthreads();
+    if (t < nb) {                            // U = Ninv^-1 (fsign F - f) through the Cholesky factor (:601-608)
+      const double *L = NLs + 36 * t;
+      double y[6], u[6];
+      for (int p = 0; p < 6; ++p) {
+        double v = A.fsign * in[n3 + 6 * t + p] - fb[6 * t + p];
+        for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
+        y[p] = v / L[6 * p + p];
+      }
+      for (int p = 5; p >= 0; --p) {
+        double v = y[p];
+        for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
+        u[p] = v / L[6 * p + p];
+      }
+      for (int p = 0; p < 6; ++p) out[n3 + 6 * t + p] = u[p];
+    }
+    __syncthreads();
+    if (t < N) {                             // Lambda = invM (slip + K U)   (:610)
+      const int b = t / nbl;
+      const double *u = out + n3 + 6 * b;
+      const double l0 = lev[3 * t], l1 = lev[3 * t + 1], l2 = lev[3 * t + 2];
+      out[3 * t] = iM[2 * t] * (in[3 * t] + u[0] + l2 * u[4] - l1 * u[5]);
+      out[3 * t + 1] = iM[2 * t] * (in[3 * t + 1] + u[1] + l0 * u[5] - l2 * u[3]);
+      out[3 * t + 2] = iM[2 * t + 1] * (in[3 * t + 2] + u[2] + l1 * u[3] - l0 * u[4]);
+    }
+    __syncthreads();
+  };
+
+  // out = [M lambda - K U ; K^T lambda]   (src/Rigid.py:73-80; M = B Mob B with the wall term, :641-659)
+  auto apply_A = [&](const double *in, double *out) {
+    {
+      const int q = t / N, i = t - q * N;
+      if (q < Qc) {
+        const double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+        double ux = 0.0, uy = 0.0, uz = 0.0;
+        const int j0 = q * jlen, j1 = (j0 + jlen < N) ? j0 + jlen : N;
+        for (int j = j0; j < j1; ++j) {
+          const double dj = WALL ? dmp[j] : 1.0;
+          rbl_pair_accum<WALL, true, true>(Pu, xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], dj * in[3 * j],
+                                           dj * in[3 * j + 1], dj * in[3 * j + 2], j == i, ux, uy, uz, flags);
+        }
+        double *p = part + (size_t)q * n3 + 3 * i;
+        p[0] = ux; p[1] = uy; p[2] = uz;
+      }
+    }
+    __syncthreads();
+    if (t < n3) {                            // U_i = nf d_i sum_q part - (K U)_i
+      double s = 0.0;
+      for (int q = 0; q < Qc; ++q) s += part[(size_t)q * n3 + t];
+      const int i = t / 3, c = t - 3 * i, b = i / nbl;
+      if (!isfinite(s)) flags |= RBL_FLAG_NONFINITE;
+      const double *u = in + n3 + 6 * b;
+      const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
+      const double ku = c == 0 ? u[0] + l2 * u[4] - l1 * u[5] : c == 1 ? u[1] + l0 * u[5] - l2 * u[3] : u[2] + l1 * u[3] - l0 * u[4];
+      out[t] = (WALL ? P.nf * dmp[i] : P.nf) * s - ku;
+    } else if (t < n3 + nb6) {               // K^T lambda
+      const int tt = t - n3, b = tt / 6, c = tt - 6 * b;
+      double f = 0.0;
+      for (int k = 0; k < nbl; ++k) {
+        const int i = b * nbl + k;
+        const double v0 = in[3 * i], v1 = in[3 * i + 1], v2 = in[3 * i + 2];
+        const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
+        f += c == 0 ? v0 : c == 1 ? v1 : c == 2 ? v2 : c == 3 ? l1 * v2 - l2 * v1 : c == 4 ? l2 * v0 - l0 * v2 : l0 * v1 - l1 * v0;
+      }
+      out[t] = f;
+    }
+    __syncthreads();
+  };
+
+  // squared norm of an LDS vector -> hh[m+1] (every thread gets it): wave partials added in wave order
+  auto norm2 = [&](const double *v) -> double {
+    double a = 0.0;
+    for (int i = t; i < nsys; i += SGT) a = __builtin_fma(v[i], v[i], a);
+    a = wave_sum(a);
+    if (lane == 0) part[wave] = a;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < NW; ++w) s += part[w];
+    __syncthreads();
+    return s;
+  };
+
+  // ---- r0 = b - A x0 (or b), beta, V_0 --------------------------------------------------------------------
+  double bnorm;
+  {
+    for (int i = t; i < nsys; i += SGT) vw[i] = A.rhs[i];
+    __syncthreads();
+    bnorm = sqrt(norm2(vw));
+    if (A.x0) {
+      for (int i = t; i < nsys; i += SGT) vz[i] = A.x0[i];
+      __syncthreads();
+      apply_A(vz, vv);
+      for (int i = t; i < nsys; i += SGT) vw[i] -= vv[i];
+      __syncthreads();
+    }
+  }
+  const double beta = A.x0 ? sqrt(norm2(vw)) : bnorm;
+  double *Hg = A.H, *gg = A.H + (size_t)ldh * m, *cs = gg + ldh, *sn = cs + m;   // global: Hessenberg, rotated rhs, Givens
+  int used = 0;
+  double resid = (bnorm > 0.0) ? beta / bnorm : 0.0;
+  const bool trivial = !(beta > 0.0) || (A.rtol > 0.0 && resid < A.rtol);
+  if (!trivial) {
+    const double ib = 1.0 / beta;
+    for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ib; vv[i] = v; A.V[i] = v; }
+    if (t == 0) gg[0] = beta;
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      apply_PC(vv, vz);
+      apply_A(vz, vw);
+      // classical Gram-Schmidt twice against V_0..V_j: wave w takes the basis vectors w, w+NW, ...
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int k = wave; k <= j; k += NW) {
+          const double *vk = A.V + (size_t)k * nsys;
+          double a = 0.0;
+          for (int i = lane; i < nsys; i += 64) a = __builtin_fma(vk[i], vw[i], a);
+          a = wave_sum(a);
+          if (lane == 0) hh[k] = a;
+        }
+        __syncthreads();
+        for (int i = t; i < nsys; i += SGT) {
+          double a = vw[i];
+          for (int k = 0; k <= j; ++k) a = __builtin_fma(-hh[k], A.V[(size_t)k * nsys + i], a);
+          vw[i] = a;
+        }
+        if (t <= j) Hg[(size_t)j * ldh + t] = pass ? Hg[(size_t)j * ldh + t] + hh[t] : hh[t];
+        __syncthreads();
+      }
+      const double hn = sqrt(norm2(vw));
+      const double ih = hn > 1e-300 ? 1.0 / hn : 0.0;
+      double *vn = A.V + (size_t)(j + 1) * nsys;
+      for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ih; vv[i] = v; vn[i] = v; }
+      if (t == 0) {   // Givens update of column j and of the rotated right-hand side; residual estimate
+        double *col = Hg + (size_t)j * ldh;
+        col[j + 1] = hn;
+        for (int i = 0; i < j; ++i) {
+          const double a = cs[i] * col[i] + sn[i] * col[i + 1];
+          col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+          col[i] = a;
+        }
+        const double den = hypot(col[j], col[j + 1]);
+        cs[j] = den > 0.0 ? col[j] / den : 1.0;
+        sn[j] = den > 0.0 ? col[j + 1] / den : 0.0;
+        col[j] = den; col[j + 1] = 0.0;
+        gg[j + 1] = -sn[j] * gg[j];
+        gg[j] = cs[j] * gg[j];
+        sc[2] = fabs(gg[j + 1]) / bnorm;
+        sc[1] = (A.rtol > 0.0 && sc[2] < A.rtol) || !(hn > 1e-300) ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      used = j + 1;
+      resid = sc[2];
+      if (sc[1] != 0.0) break;               // workgroup-uniform
+    }
+    // y = R^-1 g (thread 0), z = V y, x = P^-1 z (+ x0)
+    if (t == 0) {
+      for (int i = used - 1; i >= 0; --i) {
+        double v = gg[i];
+        for (int k = i + 1; k < used; ++k) v -= Hg[(size_t)k * ldh + i] * hh[k];
+        const double d = Hg[(size_t)i * ldh + i];
+        hh[i] = d != 0.0 ? v / d : 0.0;
+        if (!isfinite(hh[i])) flags |= RBL_FLAG_NONFINITE;
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < nsys; i += SGT) {
+      double a = 0.0;
+      for (int k = 0; k < used; ++k) a = __builtin_fma(hh[k], A.V[(size_t)k * nsys + i], a);
+      vw[i] = a;
+    }
+    __syncthreads();
+    apply_PC(vw, vz);
+    for (int i = t; i < nsys; i += SGT) A.x[i] = A.x0 ? A.x0[i] + vz[i] : vz[i];
+  } else {
+    for (int i = t; i < nsys; i += SGT) A.x[i] = A.x0 ? A.x0[i] : 0.0;
+  }
+  if (t == 0) { *A.iters_out = used; *A.resid_out = resid; }
+  if (flags) atomicOr(A.err, flags);
+}
+
+}  // namespace
+
+static size_t small_lds_bytes(int N_blb, int N_bod, int max_iter)
+{
+  const size_t N = (size_t)N_blb * N_bod, n3 = 3 * N, nb6 = 6 * (size_t)N_bod, nsys = n3 + nb6, Qc = SGT / N;
+  return sizeof(double) * (2 * n3 + 2 * N + N + 36 * (size_t)N_bod + 3 * nsys + nb6 + (size_t)(max_iter + 2) + 8 + Qc * n3);
+}
+
+// does the one-kernel solver cover this system?
+bool rbl_gmres_small_fits(int N_blb, int N_bod, int max_iter, bool block_pc)
+{
+  const long N = (long)N_blb * N_bod;
+  if (block_pc || N < 1 || N > SG_MAXN || N_bod > SG_MAXB || max_iter < 1 || max_iter > SG_MAXIT) return false;
+  return small_lds_bytes(N_blb, N_bod, max_iter) <= 64 * 1024;
+}
+
+size_t rbl_gmres_small_work_doubles(int N_blb, int N_bod, int max_iter)
+{
+  const size_t nsys = (size_t)3 * N_blb * N_bod + (size_t)6 * N_bod;
+  return (size_t)(max_iter + 1) * nsys + (size_t)(max_iter + 1) * max_iter + (size_t)(max_iter + 1) + 2 * (size_t)max_iter + 8;
+}
+
+// d_work: rbl_gmres_small_work_doubles(...) doubles; d_scal: 2 doubles (iterations as an int in the first, residual in the second)
+int rbl_launch_gmres_small(hipStream_t st, const RblParams &P, bool wall, const double *dX, const double *dQ, const double *dcfg,
+                           int N_blb, int N_bod, const double *d_rhs, const double *d_x0, double *d_x, int max_iter, double rtol,
+                           double fsign, double *d_work, double *d_scal, unsigned *d_err)
+{
+  if (!rbl_gmres_small_fits(N_blb, N_bod, max_iter, false)) return RBL_ERR_SIZE;
+  const size_t nsys = (size_t)3 * N_blb * N_bod + (size_t)6 * N_bod;
+  const size_t lds = small_lds_bytes(N_blb, N_bod, max_iter);
+  SmallArgs A;
+  A.X = dX; A.Q = dQ; A.cfg = dcfg; A.rhs = d_rhs; A.x0 = d_x0; A.x = d_x;
+  A.V = d_work; A.H = d_work + (size_t)(max_iter + 1) * nsys;
+  A.iters_out = (int *)d_scal; A.resid_out = d_scal + 1; A.err = d_err;
+  A.P = P; A.N_blb = N_blb; A.N_bod = N_bod; A.max_iter = max_iter; A.rtol = rtol; A.fsign = fsign;
+  if (wall) hipLaunchKernelGGL(k_gmres_small<true>, dim3(1), dim3(SGT), lds, st, A);
+  else hipLaunchKernelGGL(k_gmres_small<false>, dim3(1), dim3(SGT), lds, st, A);
+  return RBL_OK;
+}

@@ -200,14 +200,19 @@ def lanczos_mhalf(apply_A, W, max_iter=100, tol=1e-3, check_every=1):
 
 
 class ShardedDeterministicStepper(DeterministicStepper):
-    """The same deterministic step on P GPUs (one process each): the mobility product inside the
-    saddle operator is tile-pair sharded (ShardedMobility.apply_M_allreduce: all-reduce of the
-    partial U), everything else -- K ops, preconditioner, Arnoldi vectors -- is O(N), replicated and
-    bitwise identical on every rank, so no other communication is needed."""
+    """The same deterministic step on P GPUs (one process each).  native=True (default): librbl's own GMRES
+    (rbl_gmres_saddle_dev) with the context switched to multi-GPU products (DeviceContext.set_comm -> rbl_set_comm):
+    every mobility product of the Arnoldi loop is this rank's share of the unordered tile pairs + ONE all-reduce of the
+    partial U; the recurrences stay on the device, the host looks at the Hessenberg matrix once per convergence test.
+    Everything else -- K ops, preconditioner, Krylov vectors -- is O(N), replicated and bitwise identical on every rank.
+    native=False keeps the torch Arnoldi loop around the same sharded product (the first implementation; tests
+    compare the two)."""
 
-    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device):
-        super().__init__(ctx, n_bodies, blobs_per_body, device, use_graph=False)
+    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device, native=True):
+        super().__init__(ctx, n_bodies, blobs_per_body, device, use_graph=False, native=native)
         self.sm = sharded
+        if native:
+            ctx.set_comm(sharded)
 
     def refresh_positions(self):
         p, n = self.ctx.positions_ptr()                 # replicated body state -> full positions on this rank
@@ -231,7 +236,8 @@ class ShardedDeterministicStepper(DeterministicStepper):
         return out
 
     def step(self, F_body, iters=20, rtol=None):
-        self.refresh_positions()
+        if not self.native:
+            self.refresh_positions()
         return super().step(F_body, iters, rtol)
 
 
@@ -328,13 +334,12 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
     replicated and bitwise identical on every rank (the noise comes from a seeded device generator)."""
 
     def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device, a, wall, kBT, dt,
-                 lanczos_tol=1e-3, lanczos_max_iter=100, precondition=True):
-        super().__init__(ctx, sharded, n_bodies, blobs_per_body, device)
+                 lanczos_tol=1e-3, lanczos_max_iter=100, precondition=True, native=True):
+        super().__init__(ctx, sharded, n_bodies, blobs_per_body, device, native=native)
         self.a, self.wall, self.kBT, self.dt = a, wall, kBT, dt
         self.ltol, self.lmax = lanczos_tol, lanczos_max_iter
         self.precondition = precondition      # block-Jacobi preconditioned square root (librbl's RBL_MHALF_LANCZOS_PC)
         self.lanczos_iterations = []
-
 
     def _product(self, r_full, v):
         """apply_M (reference :641-659) on the sharded pairs: B M B with the wall term, plain M without"""
@@ -378,6 +383,14 @@ class ShardedBrownianStepper(ShardedDeterministicStepper):
         return rhs, Xh, Qh
 
     def step(self, F_body, slip=None, W=None, seed=0, iters=20, rtol=None, split_rand=True, delta=1.0e-4):
+        if self.native:
+            # librbl's own stochastic midpoint step pieces (rbl_RHS_and_Midpoint_dev: lock-step Lanczos, M_RFD; then
+            # rbl_gmres_saddle_dev), every product sharded through the context's communicator (rbl_set_comm)
+            self.ctx.set_lanczos(self.lmax, self.ltol)
+            out = BrownianStepper.step(self, F_body, slip=slip, W=W, seed=seed, method=2 if self.precondition else 1,
+                                       iters=iters, rtol=rtol, split_rand=split_rand, delta=delta)
+            self.lanczos_iterations = [self.ctx.lanczos_report()[0]] * (2 if split_rand else 1)
+            return out
         Fb = torch.as_tensor(F_body, dtype=torch.float64, device=self.dev).reshape(-1)
         sl = (torch.zeros(self.n3, dtype=torch.float64, device=self.dev) if slip is None else
               torch.as_tensor(slip, dtype=torch.float64, device=self.dev).reshape(-1))

@@ -907,12 +907,13 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
     dt, a, eta, kBT = 0.005, 1.0, 1.0, 0.02
     dev = torch.device("cuda:0")
     out = []
-    for sharded in (False, True):
+    for sharded in (False, "torch loop", "native loop"):
         ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
         if sharded:
             st = ShardedBrownianStepper(ctx, ShardedMobility(nb, 12, device=dev, ctx=ctx), nb, 12, dev, a, wall, kBT, dt,
-                                        lanczos_tol=1e-12, lanczos_max_iter=144, precondition=precondition)
+                                        lanczos_tol=1e-12, lanczos_max_iter=144, precondition=precondition,
+                                        native=(sharded == "native loop"))
             m, resid = st.step(force, slip=slip, W=W, iters=80, rtol=1e-11)
             assert len(st.lanczos_iterations) == 2
         else:
@@ -921,8 +922,9 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
             m, resid = st.step(force, slip=slip, W=W, method=2 if precondition else 1, iters=80, rtol=1e-11)
         assert resid < 1e-11
         out.append(ctx.get_config(nb))
-    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-9)
+    for k in (1, 2):
+        np.testing.assert_allclose(out[k][0], out[0][0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out[k][1], out[0][1], rtol=0, atol=1e-9)
     assert np.linalg.norm(out[0][0] - X) > 1e-4
 
 
@@ -1009,6 +1011,40 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub, Ua) < 1e-9 and abs(ra - rb) < 1e-9 * max(ra, 1e-30) + 1e-12
     assert rb2 < 1e-11 and abs(mb - ma) <= 3            # the native loop tests convergence every 4th iteration
     assert rel(Ub2, Ua2) < 1e-8
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_one_kernel_gmres_equals_general_solver(wall):
+    """Small systems (BASELINE cfg 1: 10 x shell_N_12): rbl_gmres_saddle_dev runs the whole solve -- geometry, diagonal
+    preconditioner, Arnoldi, Givens -- as ONE kernel on one CU (rbl_small.hip).  Same iterates as the general
+    multi-launch solver: fixed work, converged, and from an initial guess; and the solution solves the saddle system."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb = 10, 12
+    c = make_config(nb, nblb, wall)
+    n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    b = torch.from_numpy(np.concatenate([0.3 * rng.standard_normal(n3), np.tile([0.1, 0, -1.0, 0.2, 0, 0.05], nb)])).to(dev)
+    x0 = torch.from_numpy(0.01 * rng.standard_normal(nsys)).to(dev)
+    res = {}
+    for variant in (41, 42):        # 41: general solver, 42: one-kernel solver
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_tuning(0, variant)
+        xa = torch.empty_like(b); ma, ra = ctx.gmres_saddle(b.data_ptr(), 20, None, xa.data_ptr())            # fixed work
+        xb = torch.empty_like(b); mb, rb_ = ctx.gmres_saddle(b.data_ptr(), 60, 1e-11, xb.data_ptr())          # converged
+        xc = x0.clone(); mc, rc_ = ctx.gmres_saddle(b.data_ptr(), 60, 1e-11, xc.data_ptr(), use_x0=True)      # from a guess
+        out = torch.empty_like(b)
+        ctx.apply_saddle(xb.data_ptr(), out.data_ptr()); ctx.sync_check()
+        assert float(torch.linalg.norm(out - b) / torch.linalg.norm(b)) < 1e-10
+        res[variant] = [v.cpu().numpy() for v in (xa, xb, xc)] + [ma, ra, mb, rb_, mc, rc_]
+    g, s_ = res[41], res[42]
+    assert g[3] == s_[3] == 20 and abs(g[4] - s_[4]) < 1e-9 * g[4] + 1e-13
+    assert rel(s_[0], g[0]) < 1e-9
+    assert s_[6] < 1e-11 and abs(s_[5] - g[5]) <= 3 and rel(s_[1], g[1]) < 1e-8
+    assert s_[8] < 1e-11 and abs(s_[7] - g[7]) <= 3 and rel(s_[2], g[2]) < 1e-8
 
 
 @pytest.mark.parametrize("wall", [False, True])

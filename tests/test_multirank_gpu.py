@@ -73,7 +73,10 @@ def _max_diff(stdout, world):
     return float(line.split("=")[1].split(",")[0])
 
 
-def test_two_rank_sharded_brownian_step_matches_single_process():
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_two_rank_sharded_brownian_step_matches_single_process(monkeypatch, native):
+    """native = 1: librbl's own Lanczos / GMRES loops with the communicator callback (rbl_set_comm); 0: the torch loops"""
+    monkeypatch.setenv("RBL_CHECK_NATIVE", native)
     p = _torchrun(2, ["tools/check_sharded_brownian.py"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10

@@ -26,6 +26,7 @@ def main():
     n3 = 3 * nb * nblb
     W = np.random.default_rng(11).standard_normal(3 * n3)
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    native = os.environ.get("RBL_CHECK_NATIVE", "1") == "1"          # librbl's own loops with rbl_set_comm (default) or the torch loops
     out = []
     for sharded in (True, False):
         ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=kBT,
@@ -36,7 +37,7 @@ def main():
             lib().rbl_set_blk_pc(ctx.h, 1)
         if sharded:
             st = ShardedBrownianStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
-                                        c["dt"], lanczos_tol=ltol, lanczos_max_iter=300)
+                                        c["dt"], lanczos_tol=ltol, lanczos_max_iter=300, native=native)
             m, resid = st.step(Fb, W=W, iters=150, rtol=gtol)
         else:
             ctx.set_lanczos(300, ltol)

@@ -52,7 +52,7 @@ def main():
     lines = open(src).read().split("\n")
     res = {}
     for i, l in enumerate(lines):
-        m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)EE\S*):", l)
+        m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)E(?:Li\d+E)?E\S*):", l)
         if not m:
             continue
         kern, wall, ni = m.group(2), m.group(3) == "1", int(m.group(4))
