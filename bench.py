@@ -66,15 +66,24 @@ def self_launch(args, argv):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
+        h.update(open(os.path.join(ROOT, "rigid_body_light_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def isa_counts(kernel):
     """executed instructions per unordered pair of `kernel` in the far-tile sweep, from the assembly of the
-    sources librbl.so was built from (tools/isa_stats.py, written by rigid_body_light_amd/build.py)"""
+    sources librbl.so was built from (tools/isa_stats.py, written by rigid_body_light_amd/build.py); ignored when the
+    kernel sources have changed since (hash recorded in the file)"""
     path = os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")
-    lib = os.path.join(ROOT, "rigid_body_light_amd", "librbl.so")
     try:
-        if os.path.getmtime(path) + 120 < os.path.getmtime(lib):
-            return None                        # stale: the library was rebuilt without its instruction counts
-        return json.load(open(path))["kernels"][kernel]["per_unordered_pair"]
+        d = json.load(open(path))
+        if d.get("kernel_source_sha256") != kernel_source_hash():
+            return None
+        return d["kernels"][kernel]["per_unordered_pair"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -82,14 +91,10 @@ def isa_counts(kernel):
 def pmc_traffic(kernel, config, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only when that
     profile was taken from the kernel sources this library was built from (hash recorded in the file)."""
-    import hashlib
     path = os.path.join(ROOT, "profiles", "r02_bench_%s_pmc.json" % config)
     try:
         d = json.load(open(path))
-        h = hashlib.sha256()
-        for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
-            h.update(open(os.path.join(ROOT, "rigid_body_light_amd", "csrc", f), "rb").read())
-        if d.get("kernel_source_sha256") != h.hexdigest() or world != 1 or d.get("kernel") != kernel:
+        if d.get("kernel_source_sha256") != kernel_source_hash() or world != 1 or d.get("kernel") != kernel:
             return None, None
         return d["hbm_bytes_per_launch"], d
     except (OSError, KeyError, ValueError):
@@ -461,6 +466,8 @@ def main():
     ctx.set_config(c["X"], c["Q"])
     if args.jsplit or args.variant:
         ctx.set_tuning(args.jsplit, args.variant)
+    for v in args.tune:
+        ctx.set_tuning(0, v)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
     nrows = sm.row1 - sm.row0
 
@@ -571,7 +578,7 @@ def main():
                 roof["traffic_source"] = tsrc.get("source")
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None,
-                         "note": "librbl.isa.json missing or older than librbl.so: run rigid_body_light_amd/build.py"})
+                         "note": "librbl.isa.json missing or not from the current kernel sources: run rigid_body_light_amd/build.py"})
         if sym_info:
             roof["launch"] = sym_info
         line = {

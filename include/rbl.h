@@ -321,7 +321,11 @@ int rbl_sync_check(rbl_ctx *ctx);
  * operator then has eigenvalues near -1 AND +1) / with that sign restored (default; one cluster, fewer iterations, same
  * solution);
  * 41 / 42: rbl_gmres_saddle_dev never / when it fits (default) runs the whole solve of a small system (<= 256 blobs,
- * diagonal PC, <= 64 iterations) as ONE kernel launch on one CU.  All per context. */
+ * diagonal PC, <= 255 iterations) as ONE kernel launch on one CU;
+ * 51 / 52: inexact-Krylov relaxation off (default) / on: once rbl_gmres_saddle_dev's residual estimate is below
+ * rtol x 1e5, its mobility products evaluate far tile pairs in packed single precision (relative product error ~1e-6,
+ * ~1.8x faster); the solution still satisfies the fp64 system to rtol (tests check the true residual);
+ * 53 / 54: test hook, every full product through that relaxed kernel off / on.  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

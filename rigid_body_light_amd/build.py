@@ -19,7 +19,7 @@ ARCH = os.environ.get("RBL_OFFLOAD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_body_dev.hip", "rbl_small.hip", "rbl_api.hip", "rbl_host.cpp"]
-HEADERS = ["rbl_internal.hpp", "rbl_pair.hpp", os.path.join("..", "..", "include", "rbl.h")]
+HEADERS = ["rbl_internal.hpp", "rbl_pair.hpp", "rbl_pair_pk.hpp", os.path.join("..", "..", "include", "rbl.h")]
 
 
 def lib_path():

@@ -179,15 +179,19 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   int rc;
   if (full && c->comm_world > 1 && c->comm_fn) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, c->sym_tune)))) return rc;
+    RblSymTune tune = c->sym_tune;
+    if (c->force_relaxed) tune.relaxed = 1;
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
-                           c->n_cu, c->d_err, 1, c->sym_tune);
+                           c->n_cu, c->d_err, 1, tune);
     if (c->comm_fn(c->comm_user, d_out, 3 * nbl)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
     return RBL_OK;
   }
   if (sym) {
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune)))) return rc;
+    RblSymTune tune = c->sym_tune;
+    if (c->force_relaxed) tune.relaxed = 1;
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
-                           c->d_err, 1, c->sym_tune);
+                           c->d_err, 1, tune);
   } else {
     int js = 1;
     const size_t pb = rbl_apply_M_part_bytes(nbl, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);
@@ -213,8 +217,10 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
     int k = 0;
     for (; k + 2 <= nrhs; k += 2) {
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, c->sym_tune)))) return rc;
+      RblSymTune tune = c->sym_tune;
+      if (c->force_relaxed) tune.relaxed = 1;
       rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
-                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, c->sym_tune);
+                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
       if (c->comm_fn(c->comm_user, d_out + (size_t)k * n3, 2 * n3)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
     }
     for (; k < nrhs; ++k)
@@ -226,8 +232,10 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
     const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune) <= c->sym_workspace_budget;
     for (; sym2 && k + 2 <= nrhs; k += 2) {
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune)))) return rc;
+      RblSymTune tune = c->sym_tune;
+      if (c->force_relaxed) tune.relaxed = 1;
       rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
-                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, c->sym_tune);
+                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
     }
     for (; k < nrhs; ++k)
       if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
@@ -785,7 +793,11 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   int m = 0;
   bool done = false;
   for (int it = 0; it < maxit && !done; ++it) {
-    if ((rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec, precond))) return rc;
+    // inexact Krylov: an estimate wanted to lanczos_tol >= 1e-4 does not notice a product error of ~1e-6
+    c->sym_tune.relaxed = (c->gmres_relax && c->lanczos_tol >= 1.0e-4) ? 1 : 0;
+    rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec, precond);
+    c->sym_tune.relaxed = 0;
+    if (rc) return rc;
     for (int v = 0; v < nvec; ++v)
       rbl_launch_lanczos_step(c->stream, n, u + (size_t)v * n, Vp(it, v), it > 0 ? Vp(it - 1, v) : nullptr,
                               it > 0 ? d_beta(v) + (it - 1) : nullptr, d_alpha(v) + it, d_beta(v) + it, Vp(it + 1, v),
@@ -1045,8 +1057,10 @@ int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_dev: need n_blobs > 0 and 0 <= i_first < i_step");
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, 1, c->sym_tune)))) return rc;
+  RblSymTune tune = c->sym_tune;
+  if (c->force_relaxed) tune.relaxed = 1;
   rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
-                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, c->sym_tune);
+                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, tune);
   return RBL_OK;
 }
 
@@ -1109,7 +1123,9 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
 {
   if (!c) return RBL_ERR_ARG;
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
-  if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on   // GMRES: reference-sign / restored-sign PC
+  if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
+  if (variant == 51 || variant == 52) { c->gmres_relax = (variant == 52); return RBL_OK; }           // inexact-Krylov relaxed products in GMRES off / on
+  if (variant == 53 || variant == 54) { c->force_relaxed = (variant == 54); return RBL_OK; }         // hook: every full product relaxed off / on   // GMRES: reference-sign / restored-sign PC
   if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
   c->sym_tune.chunk = (variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
   c->tune_jsplit = jsplit; c->tune_variant = variant;
@@ -1440,7 +1456,12 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   for (int j = 0; j < m; ++j) {
     const double *vj = V + (size_t)j * nsys;
     if ((rc = rbl_apply_PC_dev(c, vj, z))) return rc;
-    if ((rc = rbl_apply_saddle_dev(c, z, w))) return rc;
+    // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
+    // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
+    c->sym_tune.relaxed = (c->gmres_relax && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
+    rc = rbl_apply_saddle_dev(c, z, w);
+    c->sym_tune.relaxed = 0;
+    if (rc) return rc;
     double *Hcol = H + (size_t)j * ldh;
     rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 0, part);
     rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 1, part);

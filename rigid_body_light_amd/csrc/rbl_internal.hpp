@@ -56,6 +56,7 @@ struct RblDevBuf {
 struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
   int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
+  int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
 
 struct RblCholAux {        // second stream + events for the one-panel lookahead
@@ -94,6 +95,10 @@ struct rbl_ctx {
   double pc_fsign = -1.0;
   bool gmres_pc_sign_fix = true;
   bool gmres_small = true;
+  // inexact-Krylov relaxation (off by default): once GMRES's residual estimate is below rtol x 1e5 its products may carry
+  // a relative error of ~1e-6 without the solution losing accuracy -- far tile pairs then run in packed single precision
+  bool gmres_relax = false;
+  bool force_relaxed = false;   // test / benchmark hook: every full product through the relaxed kernel
   // multi-GPU (rbl_set_comm): this context is rank comm_rank of comm_world; every full mobility product inside the
   // library becomes this rank's share of the unordered tile pairs followed by comm_fn (sum all-reduce over the ranks)
   int comm_rank = 0, comm_world = 1;

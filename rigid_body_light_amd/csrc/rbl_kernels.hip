@@ -17,6 +17,7 @@
 // All fp64-VALU-bound kernels share the pair arithmetic of rbl_pair.hpp.  No float atomics on
 // global memory anywhere: every sum has a fixed order, results are bitwise reproducible.
 #include "rbl_internal.hpp"
+#include "rbl_pair_pk.hpp"
 
 #include <algorithm>
 #include <type_traits>
@@ -285,7 +286,10 @@ __device__ __forceinline__ size_t sym_idxJ(const SymLayout &L, int g, int v, lon
   return ((size_t)sym_offJ(L, g) * L.nrhs + (size_t)v * (L.Npad - rj) + (size_t)(b - rj)) * 3;
 }
 
-template <bool WALL, int NI, int SW>
+// PREC = 1 (relaxed product, two rows per lane only): tile pairs the far map proves free of overlaps are swept in packed
+// single precision (rbl_pair_sym_pk), coordinates relative to the workgroup's first row blob; their per-tile sums are
+// added to the double accumulators, so single precision only ever sums 64 x NI terms.  Diagonal / near tiles stay fp64.
+template <bool WALL, int NI, int SW, int PREC>
 __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict__ r,
                                                         const double *__restrict__ F,
                                                         double *__restrict__ slabI,
@@ -295,8 +299,10 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
   // A lane owns NI rows (row "super-tile" I = tiles NI*I .. NI*I+NI-1): the j data read from
   // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.  The SW waves of the workgroup own SW
   // consecutive owned super-tiles and walk the same column tiles in step: ONE staged j tile, per-wave accumulators.
+  static_assert(PREC == 0 || NI == 2, "the packed single-precision sweep carries the two rows of a lane");
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS];  // (x,y) (z,fx) (fy,fz) of the j tile
   __shared__ double sU[SW][3][TS];                  // M_ji F_i sums for the j tile, one set per wave
+  __shared__ float sPf[PREC ? 6 : 1][TS];           // relaxed product: the j tile in single precision, origin-relative
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
@@ -312,6 +318,11 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);                      // a wave without rows never sweeps, only keeps step
   unsigned flags = 0;
+  double ox = 0.0, oy = 0.0, oz = 0.0;                             // origin of the single-precision coordinates (radius-scaled)
+  if (PREC) {
+    const long b0 = ((long)It00 * TS < N) ? (long)It00 * TS : N - 1;
+    ox = r[3 * b0] * P.inv_a; oy = r[3 * b0 + 1] * P.inv_a; oz = r[3 * b0 + 2] * P.inv_a;
+  }
 
   // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
   // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
@@ -338,6 +349,18 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
     load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);
     uix[a] = 0.0; uiy[a] = 0.0; uiz[a] = 0.0;
   }
+  rbl_f2 xi2 = {0, 0}, yi2 = {0, 0}, zi2 = {0, 0}, Fx2 = {0, 0}, Fy2 = {0, 0}, Fz2 = {0, 0};
+  float two_z0 = 0.0f;
+  if (PREC) {
+    const int a1 = NI - 1;
+    xi2 = (rbl_f2){(float)(xi[0] - ox), (float)(xi[a1] - ox)};
+    yi2 = (rbl_f2){(float)(yi[0] - oy), (float)(yi[a1] - oy)};
+    zi2 = (rbl_f2){(float)(zi[0] - oz), (float)(zi[a1] - oz)};
+    Fx2 = (rbl_f2){(float)Fix[0], (float)Fix[a1]};
+    Fy2 = (rbl_f2){(float)Fiy[0], (float)Fiy[a1]};
+    Fz2 = (rbl_f2){(float)Fiz[0], (float)Fiz[a1]};
+    two_z0 = (float)(2.0 * oz);
+  }
 
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
@@ -351,11 +374,31 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
       sP0[lane] = (double2_t){xj, yj};
       sP1[lane] = (double2_t){zj, Fjx};
       sP2[lane] = (double2_t){Fjy, Fjz};
+      if (PREC) {
+        sPf[0][lane] = (float)(xj - ox); sPf[PREC ? 1 : 0][lane] = (float)(yj - oy); sPf[PREC ? 2 : 0][lane] = (float)(zj - oz);
+        sPf[PREC ? 3 : 0][lane] = (float)Fjx; sPf[PREC ? 4 : 0][lane] = (float)Fjy; sPf[PREC ? 5 : 0][lane] = (float)Fjz;
+      }
     }
     sU[wave][0][lane] = 0.0; sU[wave][1][lane] = 0.0; sU[wave][2][lane] = 0.0;
     __syncthreads();
     if (!sweeps) {
       // the tile lies before this wave's rows: pairs belong to an earlier wave
+    } else if (PREC && far_tile && J >= It0 + NI) {   // relaxed product: packed single precision, both rows of the lane at once
+      rbl_f2 ax = {0, 0}, ay = {0, 0}, az = {0, 0};
+#pragma unroll 2
+      for (int s = 0; s < TS; ++s) {
+        const int jj = (lane + s) & (TS - 1);
+        rbl_f2 vx = {0, 0}, vy = {0, 0}, vz = {0, 0};
+        rbl_pair_sym_pk<WALL>(xi2, yi2, zi2, Fx2, Fy2, Fz2, sPf[0][jj], sPf[PREC ? 1 : 0][jj], sPf[PREC ? 2 : 0][jj],
+                              sPf[PREC ? 3 : 0][jj], sPf[PREC ? 4 : 0][jj], sPf[PREC ? 5 : 0][jj], two_z0, ax, ay, az, vx, vy, vz);
+        // column sums in double: ds_add_f32 issues ~23x slower than ds_add_f64 on gfx950 (tools/peak_fp32pk.hip: 3.2 vs 74 G
+        // wave-instructions/s), three conversions per step are far cheaper
+        __hip_atomic_fetch_add(&sU[wave][0][jj], (double)(vx.x + vx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][1][jj], (double)(vy.x + vy.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][2][jj], (double)(vz.x + vz.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      uix[0] += (double)ax.x; uiy[0] += (double)ay.x; uiz[0] += (double)az.x;
+      uix[NI - 1] += (double)ax.y; uiy[NI - 1] += (double)ay.y; uiz[NI - 1] += (double)az.y;
     } else if (J >= It0 + NI) {  // every owned row tile lies strictly before J: fused symmetric sweep
       auto sweep = [&](auto nearchk) {
         unsigned off16 = (unsigned)lane * 16u;       // byte offset of column jj in the 16-B arrays, carried (jj*8 = off16/2)
@@ -429,14 +472,16 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
 // The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
 // coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back.
 // ---------------------------------------------------------------------------
-template <bool WALL, int NI, int SW>
+template <bool WALL, int NI, int SW, int PREC>
 __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
                                                          double *__restrict__ slabI, double *__restrict__ slabJ, long N,
                                                          SymLayout L, RblParams P, unsigned *err,
                                                          const unsigned char *__restrict__ farmap)
 {
+  static_assert(PREC == 0 || NI == 2, "the packed single-precision sweep carries the two rows of a lane");
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS], sP3[TS], sP4[TS];  // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
   __shared__ double sU[SW][2][3][TS];
+  __shared__ float sPf[PREC ? 9 : 1][TS];           // relaxed product: x y z f0 f1 in single precision, origin-relative
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
@@ -478,6 +523,20 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
     load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
     ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = ui0[a];
   }
+  double ox = 0.0, oy = 0.0, oz = 0.0;
+  rbl_f2 xi2 = {0, 0}, yi2 = {0, 0}, zi2 = {0, 0}, F0x = {0, 0}, F0y = {0, 0}, F0z = {0, 0}, F1x = {0, 0}, F1y = {0, 0}, F1z = {0, 0};
+  float two_z0 = 0.0f;
+  if (PREC) {
+    const long b0 = ((long)It00 * TS < N) ? (long)It00 * TS : N - 1;
+    ox = r[3 * b0] * P.inv_a; oy = r[3 * b0 + 1] * P.inv_a; oz = r[3 * b0 + 2] * P.inv_a;
+    const int a1 = NI - 1;
+    xi2 = (rbl_f2){(float)(xi[0] - ox), (float)(xi[a1] - ox)};
+    yi2 = (rbl_f2){(float)(yi[0] - oy), (float)(yi[a1] - oy)};
+    zi2 = (rbl_f2){(float)(zi[0] - oz), (float)(zi[a1] - oz)};
+    F0x = (rbl_f2){(float)Fi0[0].x, (float)Fi0[a1].x}; F0y = (rbl_f2){(float)Fi0[0].y, (float)Fi0[a1].y}; F0z = (rbl_f2){(float)Fi0[0].z, (float)Fi0[a1].z};
+    F1x = (rbl_f2){(float)Fi1[0].x, (float)Fi1[a1].x}; F1y = (rbl_f2){(float)Fi1[0].y, (float)Fi1[a1].y}; F1z = (rbl_f2){(float)Fi1[0].z, (float)Fi1[a1].z};
+    two_z0 = (float)(2.0 * oz);
+  }
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
     double xj = 0, yj = 0, zj = 0;
@@ -492,6 +551,11 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
       sP2[lane] = (double2_t){Fj0.y, Fj0.z};
       sP3[lane] = (double2_t){Fj1.x, Fj1.y};
       sP4[lane] = (double2_t){Fj1.z, 0.0};
+      if (PREC) {
+        sPf[0][lane] = (float)(xj - ox); sPf[PREC ? 1 : 0][lane] = (float)(yj - oy); sPf[PREC ? 2 : 0][lane] = (float)(zj - oz);
+        sPf[PREC ? 3 : 0][lane] = (float)Fj0.x; sPf[PREC ? 4 : 0][lane] = (float)Fj0.y; sPf[PREC ? 5 : 0][lane] = (float)Fj0.z;
+        sPf[PREC ? 6 : 0][lane] = (float)Fj1.x; sPf[PREC ? 7 : 0][lane] = (float)Fj1.y; sPf[PREC ? 8 : 0][lane] = (float)Fj1.z;
+      }
     }
 #pragma unroll
     for (int v = 0; v < 2; ++v)
@@ -512,6 +576,28 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
       __hip_atomic_fetch_add(&sU[wave][1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if (!sweeps) {
+    } else if (PREC && far_tile && J >= It0 + NI) {   // relaxed product: packed single precision, coefficients once for both vectors
+      rbl_f2 a0x = {0, 0}, a0y = {0, 0}, a0z = {0, 0}, a1x = {0, 0}, a1y = {0, 0}, a1z = {0, 0};
+#pragma unroll 2
+      for (int s = 0; s < TS; ++s) {
+        const int jj = (lane + s) & (TS - 1);
+        const RblPkCoef K = rbl_pk_coef<WALL>(xi2, yi2, zi2, sPf[0][jj], sPf[PREC ? 1 : 0][jj], sPf[PREC ? 2 : 0][jj], two_z0);
+        rbl_f2 v0x = {0, 0}, v0y = {0, 0}, v0z = {0, 0}, v1x = {0, 0}, v1y = {0, 0}, v1z = {0, 0};
+        rbl_pk_apply<WALL, false>(K, rbl_splat(sPf[PREC ? 3 : 0][jj]), rbl_splat(sPf[PREC ? 4 : 0][jj]), rbl_splat(sPf[PREC ? 5 : 0][jj]), a0x, a0y, a0z);
+        rbl_pk_apply<WALL, false>(K, rbl_splat(sPf[PREC ? 6 : 0][jj]), rbl_splat(sPf[PREC ? 7 : 0][jj]), rbl_splat(sPf[PREC ? 8 : 0][jj]), a1x, a1y, a1z);
+        rbl_pk_apply<WALL, true>(K, F0x, F0y, F0z, v0x, v0y, v0z);
+        rbl_pk_apply<WALL, true>(K, F1x, F1y, F1z, v1x, v1y, v1z);
+        __hip_atomic_fetch_add(&sU[wave][0][0][jj], (double)(v0x.x + v0x.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][0][1][jj], (double)(v0y.x + v0y.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][0][2][jj], (double)(v0z.x + v0z.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][1][0][jj], (double)(v1x.x + v1x.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][1][1][jj], (double)(v1y.x + v1y.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&sU[wave][1][2][jj], (double)(v1z.x + v1z.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      ui0[0].x += (double)a0x.x; ui0[0].y += (double)a0y.x; ui0[0].z += (double)a0z.x;
+      ui0[NI - 1].x += (double)a0x.y; ui0[NI - 1].y += (double)a0y.y; ui0[NI - 1].z += (double)a0z.y;
+      ui1[0].x += (double)a1x.x; ui1[0].y += (double)a1y.x; ui1[0].z += (double)a1z.x;
+      ui1[NI - 1].x += (double)a1x.y; ui1[NI - 1].y += (double)a1y.y; ui1[NI - 1].z += (double)a1z.y;
     } else if (J >= It0 + NI) {
       auto sweep = [&](auto nearchk) {
 #pragma unroll 2
@@ -1205,7 +1291,7 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
 
 template <bool WALL, int NI>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
-                       double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err)
+                       double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed)
 {
   constexpr int SW = (NI == 2) ? SW_LARGE : 1;
   const int T = L.T, nrhs = L.nrhs;
@@ -1221,11 +1307,17 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
     hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
                        (const double *)bbox, T, NI, farmap);
   }
-  if (nrhs == 2)
-    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+  if (nrhs == 2 && relaxed && NI == 2)
+    hipLaunchKernelGGL((k_apply_M_sym2<WALL, 2, SW_LARGE, 1>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+                       d_err, (const unsigned char *)farmap);
+  else if (nrhs == 2)
+    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+                       d_err, (const unsigned char *)farmap);
+  else if (relaxed && NI == 2)
+    hipLaunchKernelGGL((k_apply_M_sym<WALL, 2, SW_LARGE, 1>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap);
   else
-    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap);
   hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
 }
@@ -1239,12 +1331,13 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   const SymLayout L = sym_geometry(n_blobs, n_cu, i_first, i_step, nrhs, tune);
   double *slabI = d_work;
   double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
+  const bool relaxed = tune.relaxed != 0;
   if (L.NI == 2) {
-    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
-    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
+    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
   } else {
-    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
-    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err);
+    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
   }
 }
 

@@ -11,9 +11,12 @@
 //   M lambda - K U | K^T lambda, M by ordered pair evaluation with rbl_pair_accum, reference :641-659) ;
 //   classical Gram-Schmidt twice ; Givens update and convergence test ]* -> x = P^-1 V y.
 //
-// Vectors of the iteration live in LDS, the Krylov basis and the Hessenberg matrix in a global workspace (L2-resident:
-// 70 KB at cfg 1).  Every sum has a fixed order: results are bitwise reproducible, like the rest of the library.
-// Limits: N <= 256 blobs, 6 N_bod <= 384, diagonal preconditioner, max_iter <= 64 (checked by the launcher).
+// Vectors of the iteration, the new Hessenberg column, the Givens rotations and (up to 64 iterations) the triangular
+// factor live in LDS; so does the Krylov basis when it fits beside them in the CU's 160 KB (cfg 1: 71 KB for 21 vectors),
+// otherwise it goes to a global workspace (L2-resident).  A first version kept basis and Hessenberg matrix in global
+// memory: thread 0's Givens recurrence then was a chain of dependent L2 round trips, ~10 us per iteration.
+// Every sum has a fixed order: results are bitwise reproducible, like the rest of the library.
+// Limits: N <= 256 blobs, N_bod <= 64, diagonal preconditioner, max_iter <= 255 (checked by the launcher).
 #include "rbl_internal.hpp"
 
 namespace {
@@ -21,14 +24,16 @@ namespace {
 constexpr int SGT = 1024;          // threads of the one workgroup
 constexpr int SG_MAXN = 256;       // blobs
 constexpr int SG_MAXB = 64;        // bodies
-constexpr int SG_MAXIT = 64;
+constexpr int SG_MAXIT = 255;
+constexpr int SG_RLDS = 64;        // up to this many iterations the triangular factor R stays in LDS (packed columns)
+constexpr size_t SG_LDS_MAX = 150 * 1024;
 
 struct SmallArgs {
   const double *X, *Q, *cfg;       // body state (device): 3 Nb, 4 Nb (scalar-first), N_blb x 3 (mean removed)
   const double *rhs;               // nsys
   const double *x0;                // initial guess or nullptr
   double *x;                       // nsys
-  double *V, *H;                   // workspace: (max_iter+1) nsys | (max_iter+1) x max_iter column-major + g[max_iter+1] + cs, sn
+  double *V, *H;                   // global workspace: (max_iter+1) nsys (unused when the basis is in LDS) | packed R columns (max_iter > 64)
   int *iters_out;                  // device scalars
   double *resid_out;
   unsigned *err;
@@ -57,14 +62,14 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
-template <bool WALL>
+template <bool WALL, bool VLDS>
 __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
 {
   extern __shared__ double sm[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int NW = SGT / 64;
   const int nbl = A.N_blb, nb = A.N_bod, N = nbl * nb, n3 = 3 * N, nb6 = 6 * nb, nsys = n3 + nb6;
-  const int m = A.max_iter, ldh = m + 1;
+  const int m = A.max_iter;
   const int Qc = SGT / N;                       // column chunks of the pair evaluation (>= 4 for N <= 256)
   const int jlen = (N + Qc - 1) / Qc;
   double *pos = sm;                             // 3N  positions / a
@@ -76,9 +81,17 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
   double *vw = vz + nsys;                       // nsys   w
   double *vv = vw + nsys;                       // nsys   current basis vector / scratch
   double *fb = vv + nsys;                       // 6 Nb   body sums
-  double *hh = fb + nb6;                        // max_iter + 2
-  double *sc = hh + (m + 2);                    // 8 scalars: [0] |b|, [1] stop flag, [2] resid, [3] iterations
+  double *hh = fb + nb6;                        // max_iter + 2: Gram-Schmidt coefficients of one pass, later y
+  double *hc = hh + (m + 2);                    // max_iter + 2: the new Hessenberg column
+  double *gg = hc + (m + 2);                    // max_iter + 2: rotated right-hand side
+  double *cs = gg + (m + 2);                    // max_iter: Givens cosines
+  double *sn = cs + m;                          // max_iter: Givens sines
+  double *sc = sn + m;                          // 8 scalars: [1] stop flag, [2] residual estimate
   double *part = sc + 8;                        // Qc * 3N partial row sums
+  double *Rl = part + (size_t)Qc * n3;          // packed upper-triangular R, column j at j (j+1) / 2 (max_iter <= SG_RLDS), else global
+  const bool r_lds = m <= SG_RLDS;
+  double *Rm = r_lds ? Rl : A.H;
+  double *Vb = VLDS ? Rl + (r_lds ? (size_t)m * (m + 1) / 2 : 0) : A.V;   // Krylov basis
   const RblParams P = A.P;
   const RblParams Pu = {1.0, 1.0, P.nf, 4.0, 1e-24, -0.375, 0.125, 0};
   unsigned flags = 0;
@@ -261,13 +274,12 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
     }
   }
   const double beta = A.x0 ? sqrt(norm2(vw)) : bnorm;
-  double *Hg = A.H, *gg = A.H + (size_t)ldh * m, *cs = gg + ldh, *sn = cs + m;   // global: Hessenberg, rotated rhs, Givens
   int used = 0;
   double resid = (bnorm > 0.0) ? beta / bnorm : 0.0;
   const bool trivial = !(beta > 0.0) || (A.rtol > 0.0 && resid < A.rtol);
   if (!trivial) {
     const double ib = 1.0 / beta;
-    for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ib; vv[i] = v; A.V[i] = v; }
+    for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ib; vv[i] = v; Vb[i] = v; }
     if (t == 0) gg[0] = beta;
     __syncthreads();
     for (int j = 0; j < m; ++j) {
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
       // classical Gram-Schmidt twice against V_0..V_j: wave w takes the basis vectors w, w+NW, ...
       for (int pass = 0; pass < 2; ++pass) {
         for (int k = wave; k <= j; k += NW) {
-          const double *vk = A.V + (size_t)k * nsys;
+          const double *vk = Vb + (size_t)k * nsys;
           double a = 0.0;
           for (int i = lane; i < nsys; i += 64) a = __builtin_fma(vk[i], vw[i], a);
           a = wave_sum(a);
@@ -285,44 +297,53 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
         __syncthreads();
         for (int i = t; i < nsys; i += SGT) {
           double a = vw[i];
-          for (int k = 0; k <= j; ++k) a = __builtin_fma(-hh[k], A.V[(size_t)k * nsys + i], a);
+          for (int k = 0; k <= j; ++k) a = __builtin_fma(-hh[k], Vb[(size_t)k * nsys + i], a);
           vw[i] = a;
         }
-        if (t <= j) Hg[(size_t)j * ldh + t] = pass ? Hg[(size_t)j * ldh + t] + hh[t] : hh[t];
+        if (t <= j) hc[t] = pass ? hc[t] + hh[t] : hh[t];
         __syncthreads();
       }
       const double hn = sqrt(norm2(vw));
       const double ih = hn > 1e-300 ? 1.0 / hn : 0.0;
-      double *vn = A.V + (size_t)(j + 1) * nsys;
+      double *vn = Vb + (size_t)(j + 1) * nsys;
       for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ih; vv[i] = v; vn[i] = v; }
-      if (t == 0) {   // Givens update of column j and of the rotated right-hand side; residual estimate
-        double *col = Hg + (size_t)j * ldh;
-        col[j + 1] = hn;
+      if (t == 0) {   // Givens update of column j (in LDS) and of the rotated right-hand side; residual estimate
+        hc[j + 1] = hn;
         for (int i = 0; i < j; ++i) {
-          const double a = cs[i] * col[i] + sn[i] * col[i + 1];
-          col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
-          col[i] = a;
+          const double a = cs[i] * hc[i] + sn[i] * hc[i + 1];
+          hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1];
+          hc[i] = a;
         }
-        const double den = hypot(col[j], col[j + 1]);
-        cs[j] = den > 0.0 ? col[j] / den : 1.0;
-        sn[j] = den > 0.0 ? col[j + 1] / den : 0.0;
-        col[j] = den; col[j + 1] = 0.0;
+        const double den = hypot(hc[j], hc[j + 1]);
+        cs[j] = den > 0.0 ? hc[j] / den : 1.0;
+        sn[j] = den > 0.0 ? hc[j + 1] / den : 0.0;
+        hc[j] = den;
         gg[j + 1] = -sn[j] * gg[j];
         gg[j] = cs[j] * gg[j];
         sc[2] = fabs(gg[j + 1]) / bnorm;
         sc[1] = (A.rtol > 0.0 && sc[2] < A.rtol) || !(hn > 1e-300) ? 1.0 : 0.0;
+        double *rc = Rm + (size_t)j * (j + 1) / 2;         // column j of R, rows 0..j
+        for (int i = 0; i <= j; ++i) rc[i] = hc[i];
       }
       __syncthreads();
       used = j + 1;
       resid = sc[2];
       if (sc[1] != 0.0) break;               // workgroup-uniform
     }
-    // y = R^-1 g (thread 0), z = V y, x = P^-1 z (+ x0)
+    // y = R^-1 g (thread 0), z = V y, x = P^-1 z (+ x0).  A factor kept in global memory (max_iter > 64) is first staged
+    // into the idle partial-sum buffer: the substitution is a chain of dependent reads
+    const double *Rs = Rm;
+    const int nR = used * (used + 1) / 2;
+    if (!r_lds && nR <= Qc * n3) {
+      for (int i = t; i < nR; i += SGT) part[i] = Rm[i];
+      Rs = part;
+      __syncthreads();
+    }
     if (t == 0) {
       for (int i = used - 1; i >= 0; --i) {
         double v = gg[i];
-        for (int k = i + 1; k < used; ++k) v -= Hg[(size_t)k * ldh + i] * hh[k];
-        const double d = Hg[(size_t)i * ldh + i];
+        for (int k = i + 1; k < used; ++k) v -= Rs[(size_t)k * (k + 1) / 2 + i] * hh[k];
+        const double d = Rs[(size_t)i * (i + 1) / 2 + i];
         hh[i] = d != 0.0 ? v / d : 0.0;
         if (!isfinite(hh[i])) flags |= RBL_FLAG_NONFINITE;
       }
@@ -330,7 +351,7 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
     __syncthreads();
     for (int i = t; i < nsys; i += SGT) {
       double a = 0.0;
-      for (int k = 0; k < used; ++k) a = __builtin_fma(hh[k], A.V[(size_t)k * nsys + i], a);
+      for (int k = 0; k < used; ++k) a = __builtin_fma(hh[k], Vb[(size_t)k * nsys + i], a);
       vw[i] = a;
     }
     __syncthreads();
@@ -345,10 +366,15 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
 
 }  // namespace
 
-static size_t small_lds_bytes(int N_blb, int N_bod, int max_iter)
+static size_t small_lds_base_bytes(int N_blb, int N_bod, int max_iter)
 {
-  const size_t N = (size_t)N_blb * N_bod, n3 = 3 * N, nb6 = 6 * (size_t)N_bod, nsys = n3 + nb6, Qc = SGT / N;
-  return sizeof(double) * (2 * n3 + 2 * N + N + 36 * (size_t)N_bod + 3 * nsys + nb6 + (size_t)(max_iter + 2) + 8 + Qc * n3);
+  const size_t N = (size_t)N_blb * N_bod, n3 = 3 * N, nb6 = 6 * (size_t)N_bod, nsys = n3 + nb6, Qc = SGT / N, m = (size_t)max_iter;
+  return sizeof(double) * (2 * n3 + 2 * N + N + 36 * (size_t)N_bod + 3 * nsys + nb6 + 3 * (m + 2) + 2 * m + 8 + Qc * n3 +
+                           (max_iter <= SG_RLDS ? m * (m + 1) / 2 : 0));
+}
+static size_t small_basis_bytes(int N_blb, int N_bod, int max_iter)
+{
+  return sizeof(double) * (size_t)(max_iter + 1) * ((size_t)3 * N_blb * N_bod + (size_t)6 * N_bod);
 }
 
 // does the one-kernel solver cover this system?
@@ -356,13 +382,13 @@ bool rbl_gmres_small_fits(int N_blb, int N_bod, int max_iter, bool block_pc)
 {
   const long N = (long)N_blb * N_bod;
   if (block_pc || N < 1 || N > SG_MAXN || N_bod > SG_MAXB || max_iter < 1 || max_iter > SG_MAXIT) return false;
-  return small_lds_bytes(N_blb, N_bod, max_iter) <= 64 * 1024;
+  return small_lds_base_bytes(N_blb, N_bod, max_iter) <= 64 * 1024;
 }
 
 size_t rbl_gmres_small_work_doubles(int N_blb, int N_bod, int max_iter)
 {
   const size_t nsys = (size_t)3 * N_blb * N_bod + (size_t)6 * N_bod;
-  return (size_t)(max_iter + 1) * nsys + (size_t)(max_iter + 1) * max_iter + (size_t)(max_iter + 1) + 2 * (size_t)max_iter + 8;
+  return (size_t)(max_iter + 1) * nsys + (size_t)max_iter * (max_iter + 1) / 2 + 8;
 }
 
 // d_work: rbl_gmres_small_work_doubles(...) doubles; d_scal: 2 doubles (iterations as an int in the first, residual in the second)
@@ -372,13 +398,25 @@ int rbl_launch_gmres_small(hipStream_t st, const RblParams &P, bool wall, const 
 {
   if (!rbl_gmres_small_fits(N_blb, N_bod, max_iter, false)) return RBL_ERR_SIZE;
   const size_t nsys = (size_t)3 * N_blb * N_bod + (size_t)6 * N_bod;
-  const size_t lds = small_lds_bytes(N_blb, N_bod, max_iter);
+  size_t lds = small_lds_base_bytes(N_blb, N_bod, max_iter);
+  bool vlds = lds + small_basis_bytes(N_blb, N_bod, max_iter) <= SG_LDS_MAX;     // the Krylov basis beside the vectors in LDS?
   SmallArgs A;
   A.X = dX; A.Q = dQ; A.cfg = dcfg; A.rhs = d_rhs; A.x0 = d_x0; A.x = d_x;
   A.V = d_work; A.H = d_work + (size_t)(max_iter + 1) * nsys;
   A.iters_out = (int *)d_scal; A.resid_out = d_scal + 1; A.err = d_err;
   A.P = P; A.N_blb = N_blb; A.N_bod = N_bod; A.max_iter = max_iter; A.rtol = rtol; A.fsign = fsign;
-  if (wall) hipLaunchKernelGGL(k_gmres_small<true>, dim3(1), dim3(SGT), lds, st, A);
-  else hipLaunchKernelGGL(k_gmres_small<false>, dim3(1), dim3(SGT), lds, st, A);
+  if (vlds) {   // more than 64 KB of dynamic LDS needs the attribute; if the runtime refuses, fall back to the global basis
+    const size_t big = lds + small_basis_bytes(N_blb, N_bod, max_iter);
+    const void *fn = wall ? (const void *)k_gmres_small<true, true> : (const void *)k_gmres_small<false, true>;
+    if (big <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big) == hipSuccess) lds = big;
+    else { (void)hipGetLastError(); vlds = false; }
+  }
+  if (vlds) {
+    if (wall) hipLaunchKernelGGL((k_gmres_small<true, true>), dim3(1), dim3(SGT), lds, st, A);
+    else hipLaunchKernelGGL((k_gmres_small<false, true>), dim3(1), dim3(SGT), lds, st, A);
+  } else {
+    if (wall) hipLaunchKernelGGL((k_gmres_small<true, false>), dim3(1), dim3(SGT), lds, st, A);
+    else hipLaunchKernelGGL((k_gmres_small<false, false>), dim3(1), dim3(SGT), lds, st, A);
+  }
   return RBL_OK;
 }

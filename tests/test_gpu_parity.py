@@ -1013,6 +1013,83 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub2, Ua2) < 1e-8
 
 
+@pytest.mark.parametrize("nb,nblb,wall", [(60, 162, True), (60, 162, False), (200, 642, True)])
+def test_relaxed_product_accuracy(nb, nblb, wall):
+    """The RELAXED product (rbl_set_tuning 54 forces it; far tile pairs in packed single precision, origin-relative
+    coordinates, per-tile sums added in double) against the fp64 product: ~1e-6 relative -- what an inexact Krylov
+    iteration may use once its residual is small.  Never the default."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    c = make_config(nb, nblb, wall)
+    if wall:
+        c["X"][:3, 2] = 1.0 + 0.4 * c["a"]          # some blobs in the damping zone
+    N = nb * nblb
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    x = torch.from_numpy(np.random.default_rng(12).standard_normal(3 * N)).to(dev)
+    ref = torch.empty_like(x); rel_ = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
+    ctx.set_tuning(0, 54)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, rel_.data_ptr())
+    ctx.set_tuning(0, 53)
+    again = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, again.data_ptr())
+    ctx.sync_check()
+    assert torch.equal(again, ref)                                   # the switch is transient and exact when off
+    err = float(torch.linalg.norm(rel_ - ref) / torch.linalg.norm(ref))
+    rows = (rel_ - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
+    assert 0.0 < err < 3e-6 and float(rows.max()) < 3e-5, (err, float(rows.max()))
+    # the two-vector kernel (lock-step Lanczos) has the same relaxed form
+    X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
+    R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
+    ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, R2.data_ptr())
+    ctx.set_tuning(0, 54)
+    ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, S2.data_ptr())
+    ctx.set_tuning(0, 53)
+    ctx.sync_check()
+    assert float(torch.linalg.norm(R2[0] - ref) / torch.linalg.norm(ref)) < 1e-13
+    for k in range(2):
+        e2 = float(torch.linalg.norm(S2[k] - R2[k]) / torch.linalg.norm(R2[k]))
+        assert 0.0 < e2 < 3e-6, (k, e2)
+    ctx.close()
+
+
+def test_relaxed_gmres_reaches_the_fp64_tolerance():
+    """Inexact Krylov (rbl_set_tuning 52): GMRES with the block-diagonal PC to 1e-8 on a 9 720-blob wall system, products
+    relaxed once the residual estimate is below 1e-3.  The solution must satisfy the fp64 saddle system to the same
+    tolerance (TRUE residual, evaluated with the fp64 operator) and agree with the all-fp64 solve."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, nblb, wall = 60, 162, True
+    c = make_config(nb, nblb, wall)
+    n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    b = torch.from_numpy(np.concatenate([rng.standard_normal(n3), np.tile([0.0, 0, -1.0, 0, 0, 0], nb)])).to(dev)
+    sol = {}
+    for variant in (51, 52):
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_tuning(0, variant)
+        x = torch.empty_like(b)
+        m, res = ctx.gmres_saddle(b.data_ptr(), 100, 1e-8, x.data_ptr())
+        ctx.set_tuning(0, 51)
+        out = torch.empty_like(b)
+        ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
+        true_res = float(torch.linalg.norm(out - b) / torch.linalg.norm(b))
+        assert res < 1e-8 and true_res < 2e-8, (variant, m, res, true_res)
+        sol[variant] = (x.cpu().numpy(), m)
+        ctx.close()
+    assert abs(sol[52][1] - sol[51][1]) <= 2
+    assert rel(sol[52][0], sol[51][0]) < 1e-6
+
+
 @pytest.mark.parametrize("wall", [False, True])
 def test_one_kernel_gmres_equals_general_solver(wall):
     """Small systems (BASELINE cfg 1: 10 x shell_N_12): rbl_gmres_saddle_dev runs the whole solve -- geometry, diagonal

@@ -52,12 +52,36 @@ def main():
     lines = open(src).read().split("\n")
     res = {}
     for i, l in enumerate(lines):
-        m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)E(?:Li\d+E)?E\S*):", l)
+        m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)E((?:Li\d+E)*)E\S*):", l)
         if not m:
             continue
         kern, wall, ni = m.group(2), m.group(3) == "1", int(m.group(4))
+        extra = [int(x) for x in re.findall(r"Li(\d+)E", m.group(5))]      # SW [, PREC]
+        relaxed = len(extra) >= 2 and extra[1] == 1
         end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
         best = None
+        if relaxed:      # the packed single-precision sweep: v_rsq_f32 + ds_add_f32, two pairs per packed instruction
+            for name, ops in blocks_of(lines, i, end):
+                g = lambda pred: sum(v for k, v in ops.items() if pred(k))
+                rsq32 = g(lambda k: k.startswith("v_rsq_f32"))
+                if rsq32 == 0 or g(lambda k: k.startswith("ds_add_f32")) == 0 or g(lambda k: k.startswith("v_rsq_f64")):
+                    continue
+                if best is None or rsq32 > best[1]:
+                    best = (name, rsq32, ops)
+            if best is None:
+                continue
+            ops = best[2]
+            g = lambda pred: sum(v for k, v in ops.items() if pred(k))
+            pairs = best[1] / (2.0 if wall else 1.0)
+            pk_fma, pk_mul, pk_add = g(lambda k: k.startswith("v_pk_fma_f32")), g(lambda k: k.startswith("v_pk_mul_f32")), g(lambda k: k.startswith("v_pk_add_f32"))
+            f32 = g(lambda k: k.startswith(("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32")))
+            valu = g(lambda k: k.startswith("v_"))
+            res["%s<%s,%d,relaxed>" % (kern, "true" if wall else "false", ni)] = {
+                "block": best[0], "unordered_pairs_per_trip": pairs,
+                "per_unordered_pair": {"valu": valu / pairs, "pk_fma": pk_fma / pairs, "pk_mul": pk_mul / pairs, "pk_add": pk_add / pairs,
+                                       "rsq_f32": best[1] / pairs, "f32_scalar": f32 / pairs, "lds": g(lambda k: k.startswith("ds_")) / pairs,
+                                       "flop": (4 * pk_fma + 2 * pk_mul + 2 * pk_add + f32 + best[1]) / pairs}}
+            continue
         for name, ops in blocks_of(lines, i, end):
             c = classify(ops)
             if c["rsq"] == 0 or c["ds_add"] == 0 or c["div"] or c["trans"] != c["rsq"]:
@@ -72,10 +96,20 @@ def main():
         per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]   # a transcendental counted as ONE flop
         res["%s<%s,%d>" % (kern, "true" if wall else "false", ni)] = {
             "block": best[0], "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rigid_body_light_amd", "csrc")
+    for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
     json.dump({"source": "hipcc -S --offload-device-only of csrc/rbl_kernels.hip (same flags as librbl.so)",
-               "kernels": res}, open(dst, "w"), indent=1, sort_keys=True)
+               "kernel_source_sha256": h.hexdigest(), "kernels": res}, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
         p = v["per_unordered_pair"]
+        if "pk_fma" in p:
+            print("%-28s %s: %.1f VALU (%.1f pk_fma %.1f pk_mul %.1f pk_add %.1f rsq_f32) %.1f LDS / unordered pair"
+                  % (k, v["block"], p["valu"], p["pk_fma"], p["pk_mul"], p["pk_add"], p["rsq_f32"], p["lds"]))
+            continue
         print("%-28s %s: %.1f VALU (%.1f f64: %.1f fma %.1f mul %.1f add %.1f trans) %.1f LDS -> %.0f flop / unordered pair"
               % (k, v["block"], p["valu"], p["f64"], p["fma"], p["mul"], p["add"], p["trans"], p["lds"], p["flop"]))
 
