@@ -361,11 +361,13 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         out["converged"] = d
     # stochastic midpoint step, converged: BASELINE configs[3] (on N GPUs: `--mode timestep --kBT 1 --gpus N`)
     bro = {}
-    for ltol in (1e-3, 1e-6):
+    for ltol, relaxed in ((1e-3, False), (1e-6, False), (1e-3, True)):
         bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
         lib().rbl_set_blk_pc(bctx.h, 1)
         bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(200, ltol)
         bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
+        if relaxed:                    # inexact Krylov (rbl_set_tuning 52): see the `relaxation` note below
+            bctx.set_tuning(0, 52)
         if world > 1:
             from rigid_body_light_amd.dist import ShardedMobility
             bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
@@ -378,10 +380,15 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             lz = lambda: [bctx.lanczos_report()[0]]
         one(0)
         d = timed(one, 1)
-        d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz()})
-        bro["lanczos_%g" % ltol] = d
+        d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz(), "relaxed_products": relaxed})
+        bro["lanczos_%g%s" % (ltol, "_relaxed" if relaxed else "")] = d
         del bst, bctx
     bro.update({"kBT": 1.0, "rtol": 1e-8, "initial_guess": "zero (fresh noise every step)",
+                "relaxation": "the *_relaxed entry is opt-in (rbl_set_tuning 52), everything else is fp64 throughout: an inexact Krylov "
+                              "iteration tolerates a relative product error of (tolerance / current residual), so GMRES iterations whose "
+                              "residual estimate is below 1e-3 and the Lanczos iterations (tolerance 1e-3) evaluate far tile pairs in packed "
+                              "single precision (product error ~1e-6, 1.8x faster); the solution still satisfies the fp64 system to 1e-8 "
+                              "(true residual checked in tests/test_gpu_parity.py::test_relaxed_gmres_reaches_the_fp64_tolerance)",
                 "definition": "stochastic midpoint step: 2 M^{1/2}W (block-Jacobi preconditioned Lanczos, two vectors in lock step) + "
                               "M_RFD (2 apply_M) + Kinv at q^n, GMRES with the block-diagonal PC to 1e-8 at the predictor "
                               "configuration, update from q^n"})
