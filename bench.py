@@ -46,8 +46,11 @@ N_SIMD = 1024                                 # 256 CUs x 4 SIMDs; one wave64 fp
 
 
 def self_launch(args, argv):
-    """`python bench.py --gpus N` without torchrun: start the N-rank job as a CHILD process (one rank per GPU,
-    RCCL) before this process has touched the GPU, relay its output and exit with its status."""
+    """`python bench.py --gpus N` without torchrun: start the N-rank job as CHILD processes (one rank per GPU, RCCL)
+    before this process has touched the GPU, print the ONE line and exit with the job's status.  Two phases, so that the
+    headline line survives whatever happens to the (much longer) time-step part: phase `main` times the hot path and
+    produces the line; phase `timestep` (apply_M mode with --timestep-steps > 0 only) runs the time-step variants as a
+    second job under a time limit and its result -- or the reason it is missing -- is merged into the line."""
     import socket
     import subprocess
     ndev = torch.cuda.device_count()          # counts devices without initialising HIP on this image
@@ -56,14 +59,40 @@ def self_launch(args, argv):
                          "ranks on one GPU)" % (args.gpus, args.gpus, ndev))
     if ndev < 1:
         raise SystemExit("bench.py: no GPU visible")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+    def run(phase, timeout):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", RBL_BENCH_PHASE=phase)
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired as e:
+            return 124, (e.stdout or ""), "timed out after %d s" % timeout
+        return p.returncode, p.stdout, None
+
+    two_phase = args.mode == "apply_M" and args.timestep_steps > 0
+    rc, out, why = run("main" if two_phase else "all", 3000)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc != 0 or not lines:
+        sys.stdout.write(out)
+        raise SystemExit(rc or 1)
+    if not two_phase:
+        sys.stdout.write(out)
+        raise SystemExit(0)
+    line = json.loads(lines[-1])
+    rc2, out2, why2 = run("timestep", 1500)
+    l2 = [l for l in out2.splitlines() if l.startswith("{")]
+    if rc2 == 0 and l2:
+        line["timestep"] = json.loads(l2[-1])
+    else:
+        line["timestep"] = {"error": "the time-step job did not finish (%s); the headline line above it is unaffected"
+                                     % (why2 or ("exit status %d" % rc2))}
+    print(json.dumps(line), flush=True)
+    raise SystemExit(0)
 
 
 def kernel_source_hash():
@@ -541,9 +570,22 @@ def main():
         got = (U_part[3 * b0:3 * b0 + 24] if use_sym else U_local[3 * (b0 - sm.row0):3 * (b0 - sm.row0) + 24]).cpu().numpy()
         np.savez("%s.rank%d.npz" % (args.dump_check, rank), row0=b0, values=got, world=world, rank=rank)
 
-    tstep = None
-    if args.timestep_steps > 0:
+    phase = os.environ.get("RBL_BENCH_PHASE", "all")       # set by self_launch: main | timestep | all
+    if phase == "timestep":                                  # second job of a self-launched N-rank run: only the time steps
         tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
+        if rank == 0:
+            print(json.dumps(tstep), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    tstep = None
+    if args.timestep_steps > 0 and phase != "main":
+        try:
+            tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
+        except Exception as e:                               # the hot-path line must not be lost to the time-step part
+            if world > 1:
+                raise
+            tstep = {"error": repr(e)}
 
     if rank == 0:
         sec_per_step = elapsed / args.steps

@@ -52,20 +52,28 @@ def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
         assert np.linalg.norm(z["values"] - Uo) / np.linalg.norm(Uo) < 1e-11
 
 
-def test_bench_self_launches_two_ranks():
+@pytest.mark.parametrize("timestep_steps", ["0", "1"])
+def test_bench_self_launches_two_ranks(timestep_steps):
     """`python bench.py --gpus 2` WITHOUT torchrun (the way the driver calls it): bench.py starts the two ranks itself
-    (a child torchrun, before touching the GPU) and the line it prints says n_gpus = 2."""
+    (a child torchrun, before touching the GPU) and the ONE line it prints says n_gpus = 2.  With time steps requested they
+    run as a second 2-rank job (native sharded GMRES / Lanczos through rbl_set_comm) whose result is merged into the line."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RBL_BENCH_PHASE"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3",
-                        "--warmup", "1", "--cpu-budget", "0", "--timestep-steps", "0"], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=300)
+                        "--warmup", "1", "--cpu-budget", "0", "--timestep-steps", timestep_steps], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"]
     assert 0.0 < d["roofline"]["frac"] <= 1.0
+    if timestep_steps != "0":
+        t = d["timestep"]
+        assert "error" not in t and t["apply_M_per_timestep"] == 21
+        assert t["brownian_converged"]["lanczos_0.001"]["gmres_residual_max"] < 1e-8
 
 
 def _max_diff(stdout, world):
