@@ -248,8 +248,11 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 //   offI(c) = 64 [C c (c+1) / 2 + (NI-1) c],      offJ(g) = g Npad - RJ1 g (g-1) / 2,   RJ(g) = RJ1 g,   RJ1 = 64 NI SW;
 // row shards of a multi-GPU launch own every i_step-th super-tile, their slabs stay rectangular (and are 1/i_step of
 // the single-rank size anyway).  nrhs vectors lie back to back inside a slab.  All in units of blobs (x 3 doubles).
-// SW = 4 for large systems (two rows per lane), 1 for small ones: with few tiles the lock-step of a multi-wave workgroup
-// and its coarser work units cost more than the slabs save (8 100 blobs: 0.080 ms with SW = 1, 0.108 ms with SW = 4).
+// SW = 4 for large single-rank systems (two rows per lane), 1 otherwise: with few tiles the lock-step of a multi-wave
+// workgroup and its coarser work units cost more than the slabs save (8 100 blobs: 0.080 ms with SW = 1, 0.108 ms with
+// SW = 4), and the strided rows of a multi-GPU shard (every i_step-th super-tile) put the four waves of a group up to
+// 8 i_step tiles apart (cfg 3 at 8 ranks: 2.7 ms per rank with SW = 1, 4.8 ms with SW = 4; the shards' slabs are
+// 1/i_step of the single-rank ones anyway).
 #ifndef RBL_SYM_WAVES
 #define RBL_SYM_WAVES 4
 #endif
@@ -306,7 +309,9 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
-  const int g = blockIdx.x, c = blockIdx.y;
+  // workgroups go to the 8 XCDs round-robin in launch order: rotate the row group with the chunk, or a group count that
+  // is a multiple of 8 pins every group (and its triangular share of the work) to one XCD for the whole launch
+  const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
   const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);   // first tile of the group (wave 0's)
   if (It00 >= T) return;
   int J0 = c * C;
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
-  const int g = blockIdx.x, c = blockIdx.y;
+  const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // see k_apply_M_sym
   const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);
   if (It00 >= T) return;
   int J0 = c * C;
@@ -1268,7 +1273,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   if (c > 16) c = 16;
   if (tune.chunk > 0) c = tune.chunk;
   L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
-  L.SW = (ni == 2) ? SW_LARGE : 1;
+  L.SW = (ni == 2 && i_step == 1) ? SW_LARGE : 1;
   L.rowsG = (rowsI + L.SW - 1) / L.SW; L.tri = (i_step == 1) ? 1 : 0; L.nrhs = nrhs; L.i_first = i_first; L.i_step = i_step;
   return L;
 }
@@ -1289,11 +1294,10 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
          (size_t)((L.T + L.NI - 1) / L.NI) * (size_t)L.T + 64;
 }
 
-template <bool WALL, int NI>
+template <bool WALL, int NI, int SW>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
                        double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed)
 {
-  constexpr int SW = (NI == 2) ? SW_LARGE : 1;
   const int T = L.T, nrhs = L.nrhs;
   dim3 grid((unsigned)L.rowsG, (unsigned)L.nch), block(TS * SW);
   const int64_t n = 3 * n_blobs;
@@ -1307,14 +1311,15 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
     hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
                        (const double *)bbox, T, NI, farmap);
   }
+  constexpr int PR = (NI == 2) ? 1 : 0;      // the relaxed form exists for two rows per lane
   if (nrhs == 2 && relaxed && NI == 2)
-    hipLaunchKernelGGL((k_apply_M_sym2<WALL, 2, SW_LARGE, 1>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+    hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW, PR>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap);
   else if (nrhs == 2)
     hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap);
   else if (relaxed && NI == 2)
-    hipLaunchKernelGGL((k_apply_M_sym<WALL, 2, SW_LARGE, 1>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
+    hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, PR>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap);
   else
     hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
@@ -1332,12 +1337,15 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   double *slabI = d_work;
   double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
   const bool relaxed = tune.relaxed != 0;
-  if (L.NI == 2) {
-    if (wall) launch_sym<true, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
-    else launch_sym<false, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+  if (L.NI == 2 && L.SW == SW_LARGE) {
+    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+  } else if (L.NI == 2) {
+    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
   } else {
-    if (wall) launch_sym<true, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
-    else launch_sym<false, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
   }
 }
 

@@ -21,6 +21,8 @@ U = torch.empty_like(F)
 full = None
 REPS = 10
 WORLDS = [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]
+if os.environ.get("CHUNK"):                      # force the chunk length C of the symmetric kernel (tuning experiments)
+    ctx.set_tuning(int(os.environ["CHUNK"]), 2)
 for world in WORLDS:
     ts = []; acc = torch.zeros_like(F)
     for rank in range(world):

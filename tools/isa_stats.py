@@ -60,11 +60,11 @@ def main():
         relaxed = len(extra) >= 2 and extra[1] == 1
         end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
         best = None
-        if relaxed:      # the packed single-precision sweep: v_rsq_f32 + ds_add_f32, two pairs per packed instruction
+        if relaxed:      # the packed single-precision sweep: v_rsq_f32, two pairs per packed instruction, column sums by ds_add_f64
             for name, ops in blocks_of(lines, i, end):
                 g = lambda pred: sum(v for k, v in ops.items() if pred(k))
                 rsq32 = g(lambda k: k.startswith("v_rsq_f32"))
-                if rsq32 == 0 or g(lambda k: k.startswith("ds_add_f32")) == 0 or g(lambda k: k.startswith("v_rsq_f64")):
+                if rsq32 == 0 or g(lambda k: k.startswith("ds_add_f")) == 0 or g(lambda k: k.startswith("v_rsq_f64")):
                     continue
                 if best is None or rsq32 > best[1]:
                     best = (name, rsq32, ops)
