@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,3 +43,23 @@ def test_context_lifecycle_and_loud_failure_without_device():
         rc = lib.rbl_apply_M(h, buf, buf, 6, buf)
         assert rc == 5 and b"no CPU fallback" in lib.rbl_last_error(h)  # RBL_ERR_NO_DEVICE
     lib.rbl_destroy(h)
+
+
+def test_isa_counts_match_the_kernel_sources():
+    """bench.py prices its roofline with per-pair instruction counts taken from the assembly of the SAME kernel sources the
+    library is built from (tools/isa_stats.py, run by rigid_body_light_amd/build.py): the file exists, belongs to the
+    current sources (hash) and holds the kernels the default benchmark launches."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "rigid_body_light_amd", "librbl.isa.json")))
+    h = hashlib.sha256()
+    for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
+        h.update(open(os.path.join(root, "rigid_body_light_amd", "csrc", f), "rb").read())
+    assert d["kernel_source_sha256"] == h.hexdigest(), "run rigid_body_light_amd/build.py"
+    for k in ("k_apply_M_sym<true,2>", "k_apply_M_sym<false,2>", "k_apply_M_sym<true,1>", "k_apply_M_sym2<true,2>"):
+        p = d["kernels"][k]["per_unordered_pair"]
+        assert 30 < p["valu"] < 130 and p["flop"] <= 2 * p["valu"] and p["fma"] > p["mul"]
+    sys.path.insert(0, root)
+    import bench
+    assert bench.isa_counts("k_apply_M_sym<true,2>")["flop"] == d["kernels"]["k_apply_M_sym<true,2>"]["per_unordered_pair"]["flop"]

@@ -1058,14 +1058,17 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     ctx.close()
 
 
-def test_relaxed_gmres_reaches_the_fp64_tolerance():
-    """Inexact Krylov (rbl_set_tuning 52): GMRES with the block-diagonal PC to 1e-8 on a 9 720-blob wall system, products
-    relaxed once the residual estimate is below 1e-3.  The solution must satisfy the fp64 saddle system to the same
-    tolerance (TRUE residual, evaluated with the fp64 operator) and agree with the all-fp64 solve."""
+@pytest.mark.parametrize("nb,nblb", [(60, 162), (200, 642)])
+def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
+    """Inexact Krylov (rbl_set_tuning 52): GMRES with the block-diagonal PC to 1e-8 on a wall system (9 720 blobs and
+    cfg 3's 128 400), products relaxed once the residual estimate is below 1e-3.  The solution must satisfy the fp64 saddle
+    system to the same tolerance (TRUE residual, evaluated with the fp64 operator) and agree with the all-fp64 solve.
+    (Iterative refinement around all-relaxed inner solves was tried: 2 fp64 + 18 relaxed products instead of 6 + 11 --
+    the restart costs what the cheaper products save, so the single run stayed.)"""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext, lib
-    nb, nblb, wall = 60, 162, True
+    wall = True
     c = make_config(nb, nblb, wall)
     n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
     dev = torch.device("cuda:0")
@@ -1086,7 +1089,7 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance():
         assert res < 1e-8 and true_res < 2e-8, (variant, m, res, true_res)
         sol[variant] = (x.cpu().numpy(), m)
         ctx.close()
-    assert abs(sol[52][1] - sol[51][1]) <= 2
+    assert abs(sol[52][1] - sol[51][1]) <= 3
     assert rel(sol[52][0], sol[51][0]) < 1e-6
 
 
