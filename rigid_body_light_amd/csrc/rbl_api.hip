@@ -1336,7 +1336,8 @@ static int gmres_small(rbl_ctx *c, const double *d_rhs, const double *d_x0, int 
   rc = rbl_launch_gmres_small(c->stream, rbl_make_params(S.a, S.eta), S.wall, dX, dQ, (const double *)c->d_cfg.p, S.N_blb,
                               S.N_bod, d_rhs, d_x0, d_x, max_iter, rtol, c->gmres_pc_sign_fix ? 1.0 : c->pc_fsign, work, scal,
                               c->d_err);
-  if (rc) return rbl_fail(c, rc, "gmres (one-kernel solver): system does not fit");
+  if (rc == RBL_ERR_SIZE) return rc;       // the caller falls back to the general solver
+  if (rc) return rbl_fail(c, rc, "gmres (one-kernel solver): launch failed");
   double hs[2] = {0.0, 0.0};
   RBL_HIP(c, hipMemcpyAsync(hs, scal, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
   if ((rc = finish_and_check(c))) return rc;
@@ -1356,8 +1357,11 @@ int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double r
     int rc = need_config(c); if (rc) return rc;
     if ((rc = rbl_dev_init(c))) return rc;
     if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
-    if (c->gmres_small && c->comm_world == 1 && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc))
-      return gmres_small(c, d_rhs, use_x0 ? d_x : nullptr, max_iter, rtol, d_x, iters_out, resid_out);
+    if (c->gmres_small && c->comm_world == 1 && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc)) {
+      rc = gmres_small(c, d_rhs, use_x0 ? d_x : nullptr, max_iter, rtol, d_x, iters_out, resid_out);
+      if (rc != RBL_ERR_SIZE) return rc;
+      c->gmres_small = false;                // this runtime does not grant the LDS the one-kernel solver needs
+    }
   }
   if (!use_x0) return gmres_saddle_core(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
   int rc = sync_bodies(c); if (rc) return rc;

@@ -54,12 +54,27 @@ __device__ __forceinline__ void quat_rot9(const double *q, double *R)
   R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
-// sum over the wavefront, result in every lane (fixed butterfly order)
+// sum over the wavefront, result in every lane, fixed order.  Inside the 16-lane rows by DPP moves (quad_perm, half-row
+// and row mirrors: a few cycles each; the __shfl_xor butterfly is six dependent ds_bpermute round trips, ~800 cycles, and
+// this kernel pays it on every dot product), across the four rows through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);     // row_half_mirror
+  v += dpp_move<0x140>(v);     // row_mirror: every lane holds its row's sum
+  return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 
 template <bool WALL, bool VLDS>
@@ -70,13 +85,11 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
   constexpr int NW = SGT / 64;
   const int nbl = A.N_blb, nb = A.N_bod, N = nbl * nb, n3 = 3 * N, nb6 = 6 * nb, nsys = n3 + nb6;
   const int m = A.max_iter;
-  const int Qc = SGT / N;                       // column chunks of the pair evaluation (>= 4 for N <= 256)
-  const int jlen = (N + Qc - 1) / Qc;
   double *pos = sm;                             // 3N  positions / a
   double *lev = pos + n3;                       // 3N  lever arms
   double *iM = lev + n3;                        // 2N  diag_invM: (xx = yy, zz)
   double *dmp = iM + 2 * N;                     // N   wall damping d_i (1 without the wall term)
-  double *NLs = dmp + N;                        // 36 Nb  Cholesky factors of K^T invM K
+  double *NLs = dmp + N;                        // 36 Nb  (K^T invM K)^-1, row-major 6x6 per body
   double *vz = NLs + 36 * nb;                   // nsys   z = P^-1 v
   double *vw = vz + nsys;                       // nsys   w
   double *vv = vw + nsys;                       // nsys   current basis vector / scratch
@@ -86,9 +99,11 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
   double *gg = hc + (m + 2);                    // max_iter + 2: rotated right-hand side
   double *cs = gg + (m + 2);                    // max_iter: Givens cosines
   double *sn = cs + m;                          // max_iter: Givens sines
-  double *sc = sn + m;                          // 8 scalars: [1] stop flag, [2] residual estimate
-  double *part = sc + 8;                        // Qc * 3N partial row sums
-  double *Rl = part + (size_t)Qc * n3;          // packed upper-triangular R, column j at j (j+1) / 2 (max_iter <= SG_RLDS), else global
+  double *sc = sn + m;                          // 8 scalars: [1] stop flag, [2] residual estimate, [3] |w|^2 before Gram-Schmidt
+  double *part = sc + 8;                        // NW x 3N: one accumulator set per wavefront for the symmetric pair sweep (also scratch)
+  double *su = part + (size_t)NW * n3;          // 3N  self terms
+  double *kt = su + n3;                         // 6N  per-blob terms of K^T lambda
+  double *Rl = kt + 6 * N;                      // packed upper-triangular R, column j at j (j+1) / 2 (max_iter <= SG_RLDS), else global
   const bool r_lds = m <= SG_RLDS;
   double *Rm = r_lds ? Rl : A.H;
   double *Vb = VLDS ? Rl + (r_lds ? (size_t)m * (m + 1) / 2 : 0) : A.V;   // Krylov basis
@@ -159,39 +174,50 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
       }
     }
     if (!ok) flags |= RBL_FLAG_NOT_SPD;
-    for (int e = 0; e < 36; ++e) NLs[36 * t + e] = L[e];
+    // the explicit inverse (L L^T)^-1, column by column: every application is then a 6x6 product spread over six
+    // threads instead of one thread's chain of two triangular solves with twelve divisions
+    for (int col = 0; col < 6; ++col) {
+      double y[6], u[6];
+      for (int p = 0; p < 6; ++p) {
+        double v = (p == col) ? 1.0 : 0.0;
+        for (int q2 = 0; q2 < p; ++q2) v -= L[6 * p + q2] * y[q2];
+        y[p] = v / L[6 * p + p];
+      }
+      for (int p = 5; p >= 0; --p) {
+        double v = y[p];
+        for (int q2 = p + 1; q2 < 6; ++q2) v -= L[6 * q2 + p] * u[q2];
+        u[p] = v / L[6 * p + p];
+      }
+      for (int p = 0; p < 6; ++p) NLs[36 * t + 6 * p + col] = u[p];
+    }
   }
   __syncthreads();
 
   // ---- operators on LDS vectors (every thread calls them: they contain barriers) ----------------------------
   // out = P^-1 in   (apply_PC with the diagonal invM, :589-616; fsign: see rbl_ctx::pc_fsign)
   auto apply_PC = [&](const double *in, double *out) {
-    if (t < nb6) {                           // f = K^T (invM slip), component c of body b
-      const int b = t / 6, c = t - 6 * b;
-      double f = 0.0;
-      for (int k = 0; k < nbl; ++k) {
-        const int i = b * nbl + k;
-        const double v0 = iM[2 * i] * in[3 * i], v1 = iM[2 * i] * in[3 * i + 1], v2 = iM[2 * i + 1] * in[3 * i + 2];
-        const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
-        f += c == 0 ? v0 : c == 1 ? v1 : c == 2 ? v2 : c == 3 ? l1 * v2 - l2 * v1 : c == 4 ? l2 * v0 - l0 * v2 : l0 * v1 - l1 * v0;
-      }
-      fb[t] = f;
+    if (t < N) {                             // per-blob terms of K^T (invM slip) -> part[c][blob]
+      const double v0 = iM[2 * t] * in[3 * t], v1 = iM[2 * t] * in[3 * t + 1], v2 = iM[2 * t + 1] * in[3 * t + 2];
+      const double l0 = lev[3 * t], l1 = lev[3 * t + 1], l2 = lev[3 * t + 2];
+      part[t] = v0; part[N + t] = v1; part[2 * N + t] = v2;
+      part[3 * N + t] = l1 * v2 - l2 * v1; part[4 * N + t] = l2 * v0 - l0 * v2; part[5 * N + t] = l0 * v1 - l1 * v0;
     }
     __syncthreads();
-    if (t < nb) {                            // U = Ninv^-1 (fsign F - f) through the Cholesky factor (:601-608)
-      const double *L = NLs + 36 * t;
-      double y[6], u[6];
-      for (int p = 0; p < 6; ++p) {
-        double v = A.fsign * in[n3 + 6 * t + p] - fb[6 * t + p];
-        for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
-        y[p] = v / L[6 * p + p];
-      }
-      for (int p = 5; p >= 0; --p) {
-        double v = y[p];
-        for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
-        u[p] = v / L[6 * p + p];
-      }
-      for (int p = 0; p < 6; ++p) out[n3 + 6 * t + p] = u[p];
+    if (t < nb6) {                           // fsign F - K^T (invM slip), component c of body b (blobs added in order)
+      const int b = t / 6, c = t - 6 * b;
+      const double *p = part + (size_t)c * N + (size_t)b * nbl;
+      double f = 0.0;
+      for (int k = 0; k < nbl; ++k) f += p[k];
+      fb[t] = A.fsign * in[n3 + t] - f;
+    }
+    __syncthreads();
+    if (t < nb6) {                           // U = Ninv^-1 (fsign F - f)   (:601-608), explicit 6x6 inverse
+      const int b = t / 6, c = t - 6 * b;
+      const double *Nm = NLs + 36 * b + 6 * c, *rh = fb + 6 * b;
+      double u = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) u = __builtin_fma(Nm[d], rh[d], u);
+      out[n3 + t] = u;
     }
     __syncthreads();
     if (t < N) {                             // Lambda = invM (slip + K U)   (:610)
@@ -206,41 +232,61 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
   };
 
   // out = [M lambda - K U ; K^T lambda]   (src/Rigid.py:73-80; M = B Mob B with the wall term, :641-659)
+  // Every unordered pair once (M_ji = M_ij^T, rbl_pair_sym): step (s, rb) pairs the rows i = 64 rb + lane with the columns
+  // j = i + s (mod N), s = 1 .. N/2 (for even N the offset N/2 only from the lower half), so the 64 lanes of a wavefront
+  // touch 64 different rows and 64 different columns per step; the steps are dealt round-robin to the 16 wavefronts, each
+  // adding into its OWN accumulator set (fixed order inside a wave), and the sets are added in wave order afterwards.
   auto apply_A = [&](const double *in, double *out) {
+    for (int idx = t; idx < NW * n3; idx += SGT) part[idx] = 0.0;
+    if (t < N) {                             // self blocks (:40-46, :98-104) and the per-blob terms of K^T lambda
+      const double di = WALL ? dmp[t] : 1.0;
+      double ux = 0.0, uy = 0.0, uz = 0.0;
+      rbl_pair_accum<WALL, true, true>(Pu, pos[3 * t], pos[3 * t + 1], pos[3 * t + 2], pos[3 * t], pos[3 * t + 1], pos[3 * t + 2],
+                                       di * in[3 * t], di * in[3 * t + 1], di * in[3 * t + 2], true, ux, uy, uz, flags);
+      su[3 * t] = ux; su[3 * t + 1] = uy; su[3 * t + 2] = uz;
+      const double v0 = in[3 * t], v1 = in[3 * t + 1], v2 = in[3 * t + 2];
+      const double l0 = lev[3 * t], l1 = lev[3 * t + 1], l2 = lev[3 * t + 2];
+      kt[t] = v0; kt[N + t] = v1; kt[2 * N + t] = v2;
+      kt[3 * N + t] = l1 * v2 - l2 * v1; kt[4 * N + t] = l2 * v0 - l0 * v2; kt[5 * N + t] = l0 * v1 - l1 * v0;
+    }
+    __syncthreads();
     {
-      const int q = t / N, i = t - q * N;
-      if (q < Qc) {
-        const double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-        double ux = 0.0, uy = 0.0, uz = 0.0;
-        const int j0 = q * jlen, j1 = (j0 + jlen < N) ? j0 + jlen : N;
-        for (int j = j0; j < j1; ++j) {
-          const double dj = WALL ? dmp[j] : 1.0;
-          rbl_pair_accum<WALL, true, true>(Pu, xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], dj * in[3 * j],
-                                           dj * in[3 * j + 1], dj * in[3 * j + 2], j == i, ux, uy, uz, flags);
+      const int RB = (N + 63) / 64, nsteps = (N / 2) * RB;
+      double *acc = part + (size_t)wave * n3;
+      for (int q = wave; q < nsteps; q += NW) {
+        const int s_ = q / RB + 1, i = (q - (s_ - 1) * RB) * 64 + lane;
+        if (i < N && (2 * s_ != N || 2 * i < N)) {
+          int j = i + s_;
+          if (j >= N) j -= N;
+          const double di = WALL ? dmp[i] : 1.0, dj = WALL ? dmp[j] : 1.0;
+          double uix = 0.0, uiy = 0.0, uiz = 0.0, ujx = 0.0, ujy = 0.0, ujz = 0.0;
+          rbl_pair_sym<WALL, true, true>(Pu, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], di * in[3 * i], di * in[3 * i + 1],
+                                         di * in[3 * i + 2], pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], dj * in[3 * j],
+                                         dj * in[3 * j + 1], dj * in[3 * j + 2], uix, uiy, uiz, ujx, ujy, ujz, flags);
+          __hip_atomic_fetch_add(&acc[3 * i], uix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc[3 * i + 1], uiy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc[3 * i + 2], uiz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc[3 * j], ujx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc[3 * j + 1], ujy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc[3 * j + 2], ujz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        double *p = part + (size_t)q * n3 + 3 * i;
-        p[0] = ux; p[1] = uy; p[2] = uz;
       }
     }
     __syncthreads();
-    if (t < n3) {                            // U_i = nf d_i sum_q part - (K U)_i
-      double s = 0.0;
-      for (int q = 0; q < Qc; ++q) s += part[(size_t)q * n3 + t];
+    if (t < n3) {                            // U_i = nf d_i (self + sum over the waves' sets) - (K U)_i
+      double s = su[t];
+      for (int w = 0; w < NW; ++w) s += part[(size_t)w * n3 + t];
       const int i = t / 3, c = t - 3 * i, b = i / nbl;
       if (!isfinite(s)) flags |= RBL_FLAG_NONFINITE;
       const double *u = in + n3 + 6 * b;
       const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
       const double ku = c == 0 ? u[0] + l2 * u[4] - l1 * u[5] : c == 1 ? u[1] + l0 * u[5] - l2 * u[3] : u[2] + l1 * u[3] - l0 * u[4];
       out[t] = (WALL ? P.nf * dmp[i] : P.nf) * s - ku;
-    } else if (t < n3 + nb6) {               // K^T lambda
+    } else if (t < n3 + nb6) {               // K^T lambda: blobs of the body added in order
       const int tt = t - n3, b = tt / 6, c = tt - 6 * b;
+      const double *p = kt + (size_t)c * N + (size_t)b * nbl;
       double f = 0.0;
-      for (int k = 0; k < nbl; ++k) {
-        const int i = b * nbl + k;
-        const double v0 = in[3 * i], v1 = in[3 * i + 1], v2 = in[3 * i + 2];
-        const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
-        f += c == 0 ? v0 : c == 1 ? v1 : c == 2 ? v2 : c == 3 ? l1 * v2 - l2 * v1 : c == 4 ? l2 * v0 - l0 * v2 : l0 * v1 - l1 * v0;
-      }
+      for (int k = 0; k < nbl; ++k) f += p[k];
       out[t] = f;
     }
     __syncthreads();
@@ -275,6 +321,7 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
   }
   const double beta = A.x0 ? sqrt(norm2(vw)) : bnorm;
   int used = 0;
+  const double ibn = (bnorm > 0.0) ? 1.0 / bnorm : 0.0;
   double resid = (bnorm > 0.0) ? beta / bnorm : 0.0;
   const bool trivial = !(beta > 0.0) || (A.rtol > 0.0 && resid < A.rtol);
   if (!trivial) {
@@ -282,59 +329,94 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
     for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ib; vv[i] = v; Vb[i] = v; }
     if (t == 0) gg[0] = beta;
     __syncthreads();
+#ifdef RBL_SMALL_PROF
+    long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+#define RBL_STAMP(k) do { t1 = clock64(); tp[k] += t1 - t0; t0 = t1; } while (0)
+#else
+#define RBL_STAMP(k) do { } while (0)
+#endif
     for (int j = 0; j < m; ++j) {
+      RBL_STAMP(5);
       apply_PC(vv, vz);
+      RBL_STAMP(0);
       apply_A(vz, vw);
-      // classical Gram-Schmidt twice against V_0..V_j: wave w takes the basis vectors w, w+NW, ...
+      RBL_STAMP(1);
+      // Classical Gram-Schmidt against V_0..V_j (wave w takes the basis vectors w, w+NW, ...), repeated only when the
+      // first pass cancelled more than a factor 10 of |w| (the "twice is enough" test of Daniel-Gragg-Kaufman-Stewart
+      // with eta = 0.1: the orthogonality error of a single pass is ~eps |w_before| / |w_after|).  Every update sweep
+      // also gathers |w|^2, wave 0's first dot-product sweep gathers |w_before|^2: no separate norm passes.
+      double hn2 = 0.0;
       for (int pass = 0; pass < 2; ++pass) {
         for (int k = wave; k <= j; k += NW) {
           const double *vk = Vb + (size_t)k * nsys;
-          double a = 0.0;
-          for (int i = lane; i < nsys; i += 64) a = __builtin_fma(vk[i], vw[i], a);
+          double a = 0.0, w0 = 0.0;
+          for (int i = lane; i < nsys; i += 64) {
+            const double wi = vw[i];
+            a = __builtin_fma(vk[i], wi, a);
+            if (k == 0 && pass == 0) w0 = __builtin_fma(wi, wi, w0);
+          }
           a = wave_sum(a);
-          if (lane == 0) hh[k] = a;
+          if (k == 0 && pass == 0) w0 = wave_sum(w0);
+          if (lane == 0) { hh[k] = a; if (k == 0 && pass == 0) sc[3] = w0; }
         }
         __syncthreads();
+        double wsq = 0.0;
         for (int i = t; i < nsys; i += SGT) {
           double a = vw[i];
           for (int k = 0; k <= j; ++k) a = __builtin_fma(-hh[k], Vb[(size_t)k * nsys + i], a);
           vw[i] = a;
+          wsq = __builtin_fma(a, a, wsq);
         }
         if (t <= j) hc[t] = pass ? hc[t] + hh[t] : hh[t];
+        wsq = wave_sum(wsq);
+        if (lane == 0) part[wave] = wsq;
         __syncthreads();
+        hn2 = 0.0;
+        for (int w = 0; w < NW; ++w) hn2 += part[w];
+        if (hn2 >= 0.01 * sc[3]) break;      // workgroup-uniform: every thread adds the same 16 numbers in the same order
+        __syncthreads();                     // part / hh are rewritten by the second pass
       }
-      const double hn = sqrt(norm2(vw));
+      RBL_STAMP(2);
+      const double hn = sqrt(hn2);
+      RBL_STAMP(3);
       const double ih = hn > 1e-300 ? 1.0 / hn : 0.0;
       double *vn = Vb + (size_t)(j + 1) * nsys;
       for (int i = t; i < nsys; i += SGT) { const double v = vw[i] * ih; vv[i] = v; vn[i] = v; }
       if (t == 0) {   // Givens update of column j (in LDS) and of the rotated right-hand side; residual estimate
-        hc[j + 1] = hn;
-        for (int i = 0; i < j; ++i) {
-          const double a = cs[i] * hc[i] + sn[i] * hc[i + 1];
-          hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1];
-          hc[i] = a;
+        double cur = hc[0];                  // the running entry stays in a register: the chain is two FMAs per rotation,
+        for (int i = 0; i < j; ++i) {        // the LDS reads of cs, sn and the next entry do not depend on it
+          const double nxt = hc[i + 1], ci = cs[i], si = sn[i];
+          hc[i] = __builtin_fma(ci, cur, si * nxt);
+          cur = __builtin_fma(-si, cur, ci * nxt);
         }
-        const double den = hypot(hc[j], hc[j + 1]);
-        cs[j] = den > 0.0 ? hc[j] / den : 1.0;
-        sn[j] = den > 0.0 ? hc[j + 1] / den : 0.0;
+        hc[j] = cur; hc[j + 1] = hn;
+        const double den = sqrt(__builtin_fma(hc[j], hc[j], hc[j + 1] * hc[j + 1]));   // entries are O(|A P^-1|): no scaling needed
+        const double rden = den > 0.0 ? 1.0 / den : 0.0;
+        cs[j] = den > 0.0 ? hc[j] * rden : 1.0;
+        sn[j] = hc[j + 1] * rden;
         hc[j] = den;
         gg[j + 1] = -sn[j] * gg[j];
         gg[j] = cs[j] * gg[j];
-        sc[2] = fabs(gg[j + 1]) / bnorm;
+        sc[2] = fabs(gg[j + 1]) * ibn;
         sc[1] = (A.rtol > 0.0 && sc[2] < A.rtol) || !(hn > 1e-300) ? 1.0 : 0.0;
         double *rc = Rm + (size_t)j * (j + 1) / 2;         // column j of R, rows 0..j
         for (int i = 0; i <= j; ++i) rc[i] = hc[i];
       }
       __syncthreads();
+      RBL_STAMP(4);
       used = j + 1;
       resid = sc[2];
       if (sc[1] != 0.0) break;               // workgroup-uniform
     }
+#ifdef RBL_SMALL_PROF
+    if (t == 0) printf("k_gmres_small cycles (s_memtime, 100 MHz ticks?) over %d iterations: PC %lld  A %lld  CGS2 %lld  norm %lld  normalise+Givens %lld  other %lld\n",
+                       used, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5]);
+#endif
     // y = R^-1 g (thread 0), z = V y, x = P^-1 z (+ x0).  A factor kept in global memory (max_iter > 64) is first staged
     // into the idle partial-sum buffer: the substitution is a chain of dependent reads
     const double *Rs = Rm;
     const int nR = used * (used + 1) / 2;
-    if (!r_lds && nR <= Qc * n3) {
+    if (!r_lds && nR <= NW * n3) {
       for (int i = t; i < nR; i += SGT) part[i] = Rm[i];
       Rs = part;
       __syncthreads();
@@ -368,8 +450,8 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
 
 static size_t small_lds_base_bytes(int N_blb, int N_bod, int max_iter)
 {
-  const size_t N = (size_t)N_blb * N_bod, n3 = 3 * N, nb6 = 6 * (size_t)N_bod, nsys = n3 + nb6, Qc = SGT / N, m = (size_t)max_iter;
-  return sizeof(double) * (2 * n3 + 2 * N + N + 36 * (size_t)N_bod + 3 * nsys + nb6 + 3 * (m + 2) + 2 * m + 8 + Qc * n3 +
+  const size_t N = (size_t)N_blb * N_bod, n3 = 3 * N, nb6 = 6 * (size_t)N_bod, nsys = n3 + nb6, m = (size_t)max_iter;
+  return sizeof(double) * (2 * n3 + 2 * N + N + 36 * (size_t)N_bod + 3 * nsys + nb6 + 3 * (m + 2) + 2 * m + 8 + (SGT / 64) * n3 + n3 + 6 * N +
                            (max_iter <= SG_RLDS ? m * (m + 1) / 2 : 0));
 }
 static size_t small_basis_bytes(int N_blb, int N_bod, int max_iter)
@@ -382,7 +464,7 @@ bool rbl_gmres_small_fits(int N_blb, int N_bod, int max_iter, bool block_pc)
 {
   const long N = (long)N_blb * N_bod;
   if (block_pc || N < 1 || N > SG_MAXN || N_bod > SG_MAXB || max_iter < 1 || max_iter > SG_MAXIT) return false;
-  return small_lds_base_bytes(N_blb, N_bod, max_iter) <= 64 * 1024;
+  return small_lds_base_bytes(N_blb, N_bod, max_iter) <= SG_LDS_MAX;
 }
 
 size_t rbl_gmres_small_work_doubles(int N_blb, int N_bod, int max_iter)
@@ -405,11 +487,20 @@ int rbl_launch_gmres_small(hipStream_t st, const RblParams &P, bool wall, const 
   A.V = d_work; A.H = d_work + (size_t)(max_iter + 1) * nsys;
   A.iters_out = (int *)d_scal; A.resid_out = d_scal + 1; A.err = d_err;
   A.P = P; A.N_blb = N_blb; A.N_bod = N_bod; A.max_iter = max_iter; A.rtol = rtol; A.fsign = fsign;
-  if (vlds) {   // more than 64 KB of dynamic LDS needs the attribute; if the runtime refuses, fall back to the global basis
-    const size_t big = lds + small_basis_bytes(N_blb, N_bod, max_iter);
-    const void *fn = wall ? (const void *)k_gmres_small<true, true> : (const void *)k_gmres_small<false, true>;
-    if (big <= 64 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big) == hipSuccess) lds = big;
-    else { (void)hipGetLastError(); vlds = false; }
+  // more than 64 KB of dynamic LDS needs the attribute (gfx950: 160 KB per CU).  If the runtime refuses the basis goes to
+  // global memory; if even the vectors do not fit the caller falls back to the general solver (RBL_ERR_SIZE).
+  auto allow = [&](bool v, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    const void *fn = wall ? (v ? (const void *)k_gmres_small<true, true> : (const void *)k_gmres_small<true, false>)
+                          : (v ? (const void *)k_gmres_small<false, true> : (const void *)k_gmres_small<false, false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+  };
+  if (vlds && allow(true, lds + small_basis_bytes(N_blb, N_bod, max_iter))) lds += small_basis_bytes(N_blb, N_bod, max_iter);
+  else {
+    vlds = false;
+    if (!allow(false, lds)) return RBL_ERR_SIZE;
   }
   if (vlds) {
     if (wall) hipLaunchKernelGGL((k_gmres_small<true, true>), dim3(1), dim3(SGT), lds, st, A);

@@ -10,7 +10,7 @@ out=$here/rigid_body_light_amd/build/variants
 mkdir -p $out/$name
 for f in rbl_kernels.hip rbl_dense.hip rbl_body_dev.hip rbl_small.hip rbl_api.hip rbl_host.cpp; do
   o=$out/$name/${f%.*}.o
-  if [ "$f" = rbl_kernels.hip ] || [ ! -f $o ]; then
+  if true; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -Wno-unused-function "$@" -c $src/$f -o $o &
   fi
 done
