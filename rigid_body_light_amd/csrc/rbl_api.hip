@@ -165,6 +165,24 @@ static RblParams ctx_params(const rbl_ctx *c)
   return P;
 }
 
+// ---- multi-GPU (rbl_set_comm): this rank's bodies (contiguous split, sizes differ by at most one -- the partition of
+// rigid_body_light_amd/dist.py) and the caller's sum all-reduce.  Per-body work (Cholesky factors, substitutions) is done for
+// the own bodies only, written into a zeroed full-length vector and completed by the all-reduce (an all-gather by sums).
+static bool comm_on(const rbl_ctx *c) { return c->comm_world > 1 && c->comm_fn != nullptr; }
+
+static void comm_body_range(const rbl_ctx *c, int *b0, int *b1)
+{
+  const int nb = c->S.N_bod, base = nb / c->comm_world, rem = nb % c->comm_world, r = c->comm_rank;
+  *b0 = r * base + (r < rem ? r : rem);
+  *b1 = *b0 + base + (r < rem ? 1 : 0);
+}
+
+static int comm_allreduce(rbl_ctx *c, double *d_buf, int64_t count)
+{
+  if (c->comm_fn(c->comm_user, d_buf, count)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
+  return RBL_OK;
+}
+
 static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
                            int64_t row_begin, int64_t row_end, double *d_out)
 {
@@ -719,6 +737,24 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
     const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
     int rc;
+    if (comm_on(c)) {   // every rank substitutes through ITS bodies' factors only; sums complete the vectors
+      int b0, b1; comm_body_range(c, &b0, &b1);
+      const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
+      const double *Lo = L + (size_t)b0 * (size_t)msz, *Lio = Li + (size_t)b0 * lstride;
+      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
+      if (b1 > b0 && (rc = rbl_launch_block_solve_multi(c->stream, Lo, m, b1 - b0, msz, Lio, d_x + off, d_tmp + off, m, nvec, n, 2)))
+        return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+      if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
+      c->no_damp = true;
+      rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
+      c->no_damp = false;
+      if (rc) return rc;
+      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
+      if (b1 > b0 && (rc = rbl_launch_block_solve_multi(c->stream, Lo, m, b1 - b0, msz, Lio, d_y + off, d_tmp + off, m, nvec, n, 1))) return rc;
+      if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
+      RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, sizeof(double) * (size_t)nvec * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+      return RBL_OK;
+    }
     if ((rc = rbl_launch_block_solve_multi(c->stream, L, m, c->S.N_bod, msz, Li, d_x, d_tmp, m, nvec, n, 2)))   // both vectors in one pass over L
       return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
     c->no_damp = true;
@@ -847,9 +883,15 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, d_out + (size_t)v * n, (int64_t)nvec * n);
   if (precond) {   // x = B (L y)
     const int64_t mb = 3 * (int64_t)c->S.N_blb;
+    int b0 = 0, b1 = c->S.N_bod;
+    if (comm_on(c)) comm_body_range(c, &b0, &b1);
+    const size_t off = (size_t)b0 * (size_t)mb;
     for (int v = 0; v < nvec; ++v) {
       double *o = d_out + (size_t)v * n;
-      if ((rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_blkL.p, mb, c->S.N_bod, mb * mb, o, tmp, mb))) return rc;
+      if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)n, c->stream));
+      if (b1 > b0 && (rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)(mb * mb), mb, b1 - b0,
+                                                 mb * mb, o + off, tmp + off, mb))) return rc;
+      if (comm_on(c) && (rc = comm_allreduce(c, tmp, n))) return rc;
       rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, tmp, o);
     }
   }
@@ -869,7 +911,9 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
       if (!c->S.cfg_set || nbl != (int64_t)c->S.N_bod * c->S.N_blb)
         return rbl_fail(c, RBL_ERR_SIZE, "M_half_W (preconditioned Lanczos) works on the object's own configuration only");
       if ((rc = sync_bodies(c))) return rc;
-      if ((rc = pc_block_factors(c))) return rc;
+      int b0 = 0, b1 = -1;
+      if (comm_on(c)) comm_body_range(c, &b0, &b1);
+      if (b1 != b0 && (rc = pc_block_factors(c, b0, b1))) return rc;
     }
     int v = 0;   // pairs of vectors in lock step (shared pair coefficients), a single one alone
     for (; v + 2 <= nvec; v += 2)
@@ -1213,8 +1257,12 @@ static int pc_block_build(rbl_ctx *c)
 {
   const RblBodyState &S = c->S;
   const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  int b0 = 0, b1 = S.N_bod;                              // multi-GPU: this rank's bodies only (rbl_set_comm)
+  if (comm_on(c)) comm_body_range(c, &b0, &b1);
+  const int nbo = b1 - b0;
+  const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
   int rc;
-  if ((rc = pc_block_factors(c))) return rc;
+  if (nbo > 0 && (rc = pc_block_factors(c, b0, b1))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
@@ -1227,13 +1275,15 @@ static int pc_block_build(rbl_ctx *c)
     rbl_launch_unit_U(c->stream, S.N_bod, cc, Uunit);
     rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Uunit, S.N_blb, N, MK + (size_t)cc * n3, nullptr, 0.0);
   }
+  if (nbo <= 0) return RBL_OK;
   // ... solved in place, three per pass over the factors (the sweeps are latency chains: 6 single solves cost 10 ms at cfg 3)
-  if ((rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p, m, S.N_bod, msz, (const double *)c->d_blkLinv.p,
-                                         MK, MK, m, 6, n3, 0)))
+  if ((rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)msz, m, nbo, msz,
+                                         (const double *)c->d_blkLinv.p + (size_t)b0 * lstride, MK + off, MK + off, m, 6, n3, 0)))
     return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
   for (int cc = 0; cc < 6; ++cc)
-    rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, MK + (size_t)cc * n3, S.N_blb, S.N_bod, cols + (size_t)cc * 6 * S.N_bod);
-  rbl_launch_pc_block_ninv(c->stream, cols, S.N_bod, (double *)c->d_NL.p, c->d_err);
+    rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p + off, MK + (size_t)cc * n3 + off, S.N_blb, nbo,
+                        cols + (size_t)cc * 6 * S.N_bod + (size_t)6 * b0);
+  rbl_launch_pc_block_ninv(c->stream, cols, S.N_bod, (double *)c->d_NL.p, c->d_err, b0, b1);
   return RBL_OK;
 }
 
@@ -1243,12 +1293,24 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *f6 = w2 + n3 + 36 * (size_t)S.N_bod + 6 * (size_t)S.N_bod;
   const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p, *lev = (const double *)c->d_lever.p;
+  int b0 = 0, b1 = S.N_bod;
+  const bool shard = comm_on(c);                         // own bodies only, completed by one all-reduce of the result
+  if (shard) comm_body_range(c, &b0, &b1);
+  const int nbo = b1 - b0;
+  const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
   int rc;
-  if ((rc = rbl_launch_block_solve(c->stream, L, m, S.N_bod, msz, Li, d_in, w1, m))) return rc;      // invM slip
-  rbl_launch_KT_x_Lam(c->stream, lev, w1, S.N_blb, S.N_bod, f6);                                     // K^T (invM slip)
-  rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p, d_in + n3, f6, S.N_bod, d_out + n3, c->pc_fsign); // U  (:601-608)
-  // Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over the factors
-  rbl_launch_pc_block_lambda(c->stream, w1, (const double *)c->d_pcMK.p, d_out + n3, S.N_blb, n3, d_out);
+  if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
+  if (nbo > 0) {
+    if ((rc = rbl_launch_block_solve(c->stream, L + (size_t)b0 * (size_t)msz, m, nbo, msz, Li + (size_t)b0 * lstride, d_in + off,
+                                     w1 + off, m))) return rc;                                          // invM slip
+    rbl_launch_KT_x_Lam(c->stream, lev + off, w1 + off, S.N_blb, nbo, f6 + (size_t)6 * b0);              // K^T (invM slip)
+    rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p + (size_t)36 * b0, d_in + n3 + (size_t)6 * b0, f6 + (size_t)6 * b0,
+                            nbo, d_out + n3 + (size_t)6 * b0, c->pc_fsign);                              // U  (:601-608)
+    // Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over the factors
+    rbl_launch_pc_block_lambda(c->stream, w1 + off, (const double *)c->d_pcMK.p + off, d_out + n3 + (size_t)6 * b0, S.N_blb,
+                               (int64_t)m * nbo, n3, d_out + off);
+  }
+  if (shard) return comm_allreduce(c, d_out, n3 + (int64_t)6 * S.N_bod);
   return RBL_OK;
 }
 

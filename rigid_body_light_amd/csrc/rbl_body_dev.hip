@@ -213,10 +213,10 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
 
 // block-diagonal PC: assemble Ninv_b = K_b^T invM_b K_b from its six columns and factor it (6x6)
 __global__ void k_pc_block_ninv(const double *__restrict__ cols /* [6][6*N_bod]: column c of every body */,
-                                int N_bod, double *__restrict__ NL, unsigned *err)
+                                int N_bod, int b_begin, int b_end, double *__restrict__ NL, unsigned *err)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= N_bod) return;
+  const int b = b_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);   // bodies [b_begin, b_end) of N_bod
+  if (b >= b_end) return;
   double L[36];
   for (int c = 0; c < 6; ++c)
     for (int p = 0; p < 6; ++p) L[6 * p + c] = cols[(size_t)c * 6 * N_bod + 6 * b + p];
@@ -262,15 +262,16 @@ __global__ void k_pc_block_mid(const double *__restrict__ NL, const double *__re
 // Lambda = invM (slip + K U) = invM slip + (invM K) U  (:610): the first term is the vector the
 // preconditioner already solved for, invM K (six columns per body) is kept from the build -- no second
 // pass over the Cholesky factors.  MK: [6][n3], column c of every body stacked.
+// (count entries starting at the pointers given; `stride` = distance between the six MK columns = 3 N of the whole system)
 __global__ void k_pc_block_lambda(const double *__restrict__ y1, const double *__restrict__ MK,
-                                  const double *__restrict__ U, int N_blb, long n3, double *__restrict__ out)
+                                  const double *__restrict__ U, int N_blb, long count, long stride, double *__restrict__ out)
 {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n3) return;
+  if (i >= count) return;
   const long b = (i / 3) / N_blb;
   double acc = y1[i];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * n3 + i], U[6 * b + c], acc);
+  for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * stride + i], U[6 * b + c], acc);
   out[i] = acc;
 }
 
@@ -282,10 +283,13 @@ __global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
 
 }  // namespace
 
-void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err)
+void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err, int b_begin,
+                              int b_end)
 {
-  if (N_bod <= 0) return;
-  hipLaunchKernelGGL(k_pc_block_ninv, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_cols, N_bod, d_NL, d_err);
+  if (b_end < 0) b_end = N_bod;
+  if (b_end <= b_begin) return;
+  hipLaunchKernelGGL(k_pc_block_ninv, dim3((b_end - b_begin + 63) / 64), dim3(64), 0, st, d_cols, N_bod, b_begin, b_end, d_NL,
+                     d_err);
 }
 
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
@@ -296,11 +300,11 @@ void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d
 }
 
 void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
-                                int64_t n3, double *d_out)
+                                int64_t count, int64_t stride, double *d_out)
 {
-  if (n3 <= 0) return;
-  hipLaunchKernelGGL(k_pc_block_lambda, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, d_y1, d_MK, d_U, N_blb,
-                     (long)n3, d_out);
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_pc_block_lambda, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_y1, d_MK, d_U, N_blb,
+                     (long)count, (long)stride, d_out);
 }
 
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)

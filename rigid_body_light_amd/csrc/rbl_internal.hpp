@@ -216,9 +216,10 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
                               unsigned *d_err);
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
                               int N_blb, int N_bod, const double *d_in, double *d_out, double fsign);
-void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err);
+void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err, int b_begin = 0,
+                              int b_end = -1);
 void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
-                                int64_t n3, double *d_out);
+                                int64_t count, int64_t stride, double *d_out);
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
                              double *d_U, double fsign);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);

@@ -90,9 +90,12 @@ def test_two_rank_sharded_brownian_step_matches_single_process(monkeypatch, nati
     assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10
 
 
-def test_three_rank_uneven_split_brownian_step(monkeypatch):
-    """7 bodies over 3 ranks (3 + 2 + 2): padded all-gathers, per-rank body ranges of the block factors"""
+@pytest.mark.parametrize("block_pc", ["0", "1"])
+def test_three_rank_uneven_split_brownian_step(monkeypatch, block_pc):
+    """7 bodies over 3 ranks (3 + 2 + 2): per-rank body ranges of the block factors -- of the preconditioned square root
+    and (block_pc = 1) of the block-diagonal preconditioner, each rank substituting through its own bodies only"""
     monkeypatch.setenv("RBL_CHECK_BODIES", "7")
+    monkeypatch.setenv("RBL_CHECK_BLOCK_PC", block_pc)
     p = _torchrun(3, ["tools/check_sharded_brownian.py"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "world 3" in p.stdout and _max_diff(p.stdout, 3) < 1e-10
