@@ -1043,6 +1043,16 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     err = float(torch.linalg.norm(rel_ - ref) / torch.linalg.norm(ref))
     rows = (rel_ - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
     assert 0.0 < err < 3e-6 and float(rows.max()) < 3e-5, (err, float(rows.max()))
+    # multi-GPU shards (one wave per workgroup, every i_step-th row super-tile) have it too: three relaxed shards add up
+    ctx.set_tuning(0, 54)
+    acc = torch.zeros_like(x)
+    for first in range(3):
+        pshard = torch.empty_like(x)
+        ctx.apply_M_sym(x.data_ptr(), r.data_ptr(), N, first, 3, pshard.data_ptr())
+        acc += pshard
+    ctx.set_tuning(0, 53)
+    ctx.sync_check()
+    assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 3e-6
     # the two-vector kernel (lock-step Lanczos) has the same relaxed form
     X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
     R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
