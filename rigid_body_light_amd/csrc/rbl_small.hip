@@ -282,12 +282,13 @@ __global__ __launch_bounds__(SGT) void k_gmres_small(SmallArgs A)
       const double l0 = lev[3 * i], l1 = lev[3 * i + 1], l2 = lev[3 * i + 2];
       const double ku = c == 0 ? u[0] + l2 * u[4] - l1 * u[5] : c == 1 ? u[1] + l0 * u[5] - l2 * u[3] : u[2] + l1 * u[3] - l0 * u[4];
       out[t] = (WALL ? P.nf * dmp[i] : P.nf) * s - ku;
-    } else if (t < n3 + nb6) {               // K^T lambda: blobs of the body added in order
-      const int tt = t - n3, b = tt / 6, c = tt - 6 * b;
+    }
+    if (t < nb6) {                           // K^T lambda: blobs of the body added in order (3N + 6 N_bod may exceed the
+      const int b = t / 6, c = t - 6 * b;    // thread count, so this is not an else-branch of the rows above)
       const double *p = kt + (size_t)c * N + (size_t)b * nbl;
       double f = 0.0;
       for (int k = 0; k < nbl; ++k) f += p[k];
-      out[t] = f;
+      out[n3 + t] = f;
     }
     __syncthreads();
   };

@@ -1103,16 +1103,21 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
     assert rel(sol[52][0], sol[51][0]) < 1e-6
 
 
+@pytest.mark.parametrize("nb,nblb", [(10, 12), (3, 42), (1, 162), (40, 4)])
 @pytest.mark.parametrize("wall", [False, True])
-def test_one_kernel_gmres_equals_general_solver(wall):
-    """Small systems (BASELINE cfg 1: 10 x shell_N_12): rbl_gmres_saddle_dev runs the whole solve -- geometry, diagonal
-    preconditioner, Arnoldi, Givens -- as ONE kernel on one CU (rbl_small.hip).  Same iterates as the general
-    multi-launch solver: fixed work, converged, and from an initial guess; and the solution solves the saddle system."""
+def test_one_kernel_gmres_equals_general_solver(wall, nb, nblb):
+    """Small systems (BASELINE cfg 1: 10 x shell_N_12; also 3 x 42, one body of 162 blobs, 40 four-blob bodies):
+    rbl_gmres_saddle_dev runs the whole solve -- geometry, diagonal preconditioner, Arnoldi, Givens -- as ONE kernel on
+    one CU (rbl_small.hip).  Same iterates as the general multi-launch solver: fixed work, converged, and from an initial
+    guess; and the solution solves the saddle system."""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
-    nb, nblb = 10, 12
-    c = make_config(nb, nblb, wall)
+    if nblb == 4:                     # a tetrahedron of four touching blobs (no shell file of that size)
+        c = make_config(nb, 12, wall)
+        c["cfg"] = np.array([[1.0, 1.0, 1.0], [1.0, -1.0, -1.0], [-1.0, 1.0, -1.0], [-1.0, -1.0, 1.0]]) * (c["a"] / np.sqrt(2.0))
+    else:
+        c = make_config(nb, nblb, wall)
     n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(31)
@@ -1124,15 +1129,16 @@ def test_one_kernel_gmres_equals_general_solver(wall):
         ctx.set_config(c["X"], c["Q"])
         ctx.set_tuning(0, variant)
         xa = torch.empty_like(b); ma, ra = ctx.gmres_saddle(b.data_ptr(), 20, None, xa.data_ptr())            # fixed work
-        xb = torch.empty_like(b); mb, rb_ = ctx.gmres_saddle(b.data_ptr(), 60, 1e-11, xb.data_ptr())          # converged
-        xc = x0.clone(); mc, rc_ = ctx.gmres_saddle(b.data_ptr(), 60, 1e-11, xc.data_ptr(), use_x0=True)      # from a guess
+        xb = torch.empty_like(b); mb, rb_ = ctx.gmres_saddle(b.data_ptr(), 200, 1e-11, xb.data_ptr())         # converged
+        xc = x0.clone(); mc, rc_ = ctx.gmres_saddle(b.data_ptr(), 200, 1e-11, xc.data_ptr(), use_x0=True)     # from a guess
         out = torch.empty_like(b)
         ctx.apply_saddle(xb.data_ptr(), out.data_ptr()); ctx.sync_check()
         assert float(torch.linalg.norm(out - b) / torch.linalg.norm(b)) < 1e-10
         res[variant] = [v.cpu().numpy() for v in (xa, xb, xc)] + [ma, ra, mb, rb_, mc, rc_]
     g, s_ = res[41], res[42]
-    assert g[3] == s_[3] == 20 and abs(g[4] - s_[4]) < 1e-9 * g[4] + 1e-13
-    assert rel(s_[0], g[0]) < 1e-9
+    # (the one-kernel solver re-orthogonalises only when needed, the general one always: unconverged iterates agree to ~1e-8)
+    assert g[3] == s_[3] == 20 and abs(g[4] - s_[4]) < 1e-7 * g[4] + 1e-13
+    assert rel(s_[0], g[0]) < 1e-7
     assert s_[6] < 1e-11 and abs(s_[5] - g[5]) <= 3 and rel(s_[1], g[1]) < 1e-8
     assert s_[8] < 1e-11 and abs(s_[7] - g[7]) <= 3 and rel(s_[2], g[2]) < 1e-8
 
