@@ -1013,6 +1013,42 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub2, Ua2) < 1e-8
 
 
+@pytest.mark.parametrize("wall", [False, True])
+def test_apply_M_four_wave_path_ragged_vs_oracle(orc, wall):
+    """8 262 blobs = 130 tiles (the last one ragged) = 65 row super-tiles = 17 four-wave row groups, the last with ONE live
+    wave: the smallest system on the two-rows-per-lane / four-waves-per-workgroup / triangular-slab path, against the
+    oracle on rows of the first, a middle and the last (partly empty) group; the relaxed form on the same layout."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb = 51, 162
+    c = make_config(nb, nblb, wall)
+    if wall:
+        c["X"][:2, 2] = 1.0 + 0.4 * c["a"]
+    N = nb * nblb
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    assert ctx.apply_M_sym_info(N)[0] == 2                      # two rows per lane -> the four-wave kernel
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    x = torch.from_numpy(np.random.default_rng(21).standard_normal(3 * N)).to(dev)
+    out = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())
+    ctx.sync_check()
+    rh, xh, oh = r.cpu().numpy(), x.cpu().numpy(), out.cpu().numpy()
+    for b0 in (0, 100, 4100, 8192 - 30, N - 70):                # incl. rows of the last row group and the ragged tile
+        Uo = orc.apply_M_rows(xh, rh, b0, b0 + 70, c["a"], c["eta"], wall, nthreads=8)
+        assert rel(oh[3 * b0:3 * b0 + 210], Uo) < 1e-12, b0
+    ctx.set_tuning(0, 54)
+    rlx = torch.empty_like(x)
+    ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, rlx.data_ptr())
+    ctx.set_tuning(0, 53)
+    ctx.sync_check()
+    assert float(torch.linalg.norm(rlx - out) / torch.linalg.norm(out)) < 3e-6
+    ctx.close()
+
+
 @pytest.mark.parametrize("nb,nblb,wall", [(60, 162, True), (60, 162, False), (200, 642, True)])
 def test_relaxed_product_accuracy(nb, nblb, wall):
     """The RELAXED product (rbl_set_tuning 54 forces it; far tile pairs in packed single precision, origin-relative
