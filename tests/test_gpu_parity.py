@@ -1014,6 +1014,47 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
 
 
 @pytest.mark.parametrize("wall", [False, True])
+def test_symmetric_kernel_equals_ordered_kernel_over_sizes(wall):
+    """Cross-kernel sweep over blob counts around every layout switch of the symmetric kernel (tiles of 64, one / two rows
+    per lane at 128 tiles, one / four waves per workgroup, chunk lengths 1 .. 16, triangular slabs, ragged last tile /
+    super-tile / row group) and over chunk-length overrides: the symmetric product (every unordered pair once, slabs) and
+    the ordered-rows kernel (no slabs at all) must agree to rounding, and so must 2- and 3-way shard sums."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    dev = torch.device("cuda:0")
+    a, eta = 0.3, 1.1
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 700, 4095, 8127, 8128, 8129, 8191, 8192, 8193, 8255, 8256, 8257, 8320, 8449,
+             12345, 16384, 16385, 20001]
+    ctx = DeviceContext(a, eta, wall, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    for N in sizes:
+        side = max(4.0, (N * 8.0) ** (1.0 / 3.0))                      # ~8 a^3-cubes per blob: some overlaps (r < 2a), most far
+        pos = rng.uniform(0.0, side, (N, 3)) * a
+        if wall:
+            pos[:, 2] += 0.05 * a
+        r = torch.from_numpy(pos.reshape(-1)).to(dev)
+        x = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
+        ref = torch.empty_like(x); out = torch.empty_like(x)
+        ctx.set_tuning(0, 1)                                           # ordered rows
+        ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
+        for chunk in ((0,) if N < 8000 else (0, 1, 3, 7)):
+            ctx.set_tuning(chunk, 2)                                   # symmetric, heuristic or forced chunk length
+            ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())
+            ctx.sync_check()
+            assert float(torch.linalg.norm(out - ref) / torch.linalg.norm(ref)) < 1e-12, (N, chunk)
+        ctx.set_tuning(0, 0)
+        for world in (2, 3):
+            acc = torch.zeros_like(x)
+            for first in range(world):
+                p = torch.empty_like(x)
+                ctx.apply_M_sym(x.data_ptr(), r.data_ptr(), N, first, world, p.data_ptr())
+                acc += p
+            ctx.sync_check()
+            assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 1e-12, (N, world)
+    ctx.close()
+
+
+@pytest.mark.parametrize("wall", [False, True])
 def test_apply_M_four_wave_path_ragged_vs_oracle(orc, wall):
     """8 262 blobs = 130 tiles (the last one ragged) = 65 row super-tiles = 17 four-wave row groups, the last with ONE live
     wave: the smallest system on the two-rows-per-lane / four-waves-per-workgroup / triangular-slab path, against the
