@@ -283,7 +283,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -727,6 +727,40 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 static int sync_bodies(rbl_ctx *c);
 static int pc_block_factors(rbl_ctx *c, int b0 = 0, int b1 = -1);
 
+// op(L_b) applied to bodies [b0, b0 + nbo) of nv vectors `pitch` doubles apart (in / out: the FULL vectors, body 0 first);
+// mode 0: (L L^T)^-1, 1: L^-1, 2: L^-T.  Small bodies go through their explicit inverses (two matrix-vector products
+// instead of two chains of substitution steps), the others through the substitution kernel.  In place is fine.
+static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode)
+{
+  if (nbo <= 0) return RBL_OK;
+  const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
+  const size_t off = (size_t)b0 * (size_t)m;
+  if (c->blk_inv_valid) {
+    const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
+    int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
+    const double *X = (const double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)msz;
+    double *tmp = (double *)c->d_blkTmp.p;
+    for (int v0 = 0; v0 < nv; v0 += 3) {              // groups of three vectors share the scratch
+      const int g = nv - v0 >= 3 ? 3 : nv - v0;
+      const double *pi = in + (size_t)v0 * (size_t)pitch + off;
+      double *po = out + (size_t)v0 * (size_t)pitch + off;
+      if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, 0, tmp + off);
+      else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, mode, nullptr);
+      else {                                          // in place: through the scratch
+        rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr);
+        for (int v = 0; v < g && !rc; ++v)
+          RBL_HIP(c, hipMemcpyAsync(po + (size_t)v * (size_t)pitch, tmp + off + (size_t)v * (size_t)pitch,
+                                    sizeof(double) * (size_t)m * (size_t)nbo, hipMemcpyDeviceToDevice, c->stream));
+      }
+      if (rc) return rc;
+    }
+    return RBL_OK;
+  }
+  const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
+  return rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)msz, m, nbo, msz,
+                                      (const double *)c->d_blkLinv.p + (size_t)b0 * lstride, in + off, out + off, m, nv, pitch, mode);
+}
+
 // y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
 // precond: y_v = L^-1 M L^-T x_v with the per-body Cholesky factors L L^T = M_body (block Jacobi), M undamped
 static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
@@ -734,15 +768,11 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
 {
   const int64_t n = 3 * nbl;
   if (precond) {
-    const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
-    const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p;
     int rc;
     if (comm_on(c)) {   // every rank substitutes through ITS bodies' factors only; sums complete the vectors
       int b0, b1; comm_body_range(c, &b0, &b1);
-      const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
-      const double *Lo = L + (size_t)b0 * (size_t)msz, *Lio = Li + (size_t)b0 * lstride;
       RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
-      if (b1 > b0 && (rc = rbl_launch_block_solve_multi(c->stream, Lo, m, b1 - b0, msz, Lio, d_x + off, d_tmp + off, m, nvec, n, 2)))
+      if ((rc = blk_solve(c, b0, b1 - b0, d_x, d_tmp, nvec, n, 2)))
         return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       c->no_damp = true;
@@ -750,18 +780,23 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       c->no_damp = false;
       if (rc) return rc;
       RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
-      if (b1 > b0 && (rc = rbl_launch_block_solve_multi(c->stream, Lo, m, b1 - b0, msz, Lio, d_y + off, d_tmp + off, m, nvec, n, 1))) return rc;
+      if ((rc = blk_solve(c, b0, b1 - b0, d_y, d_tmp, nvec, n, 1))) return rc;
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, sizeof(double) * (size_t)nvec * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
       return RBL_OK;
     }
-    if ((rc = rbl_launch_block_solve_multi(c->stream, L, m, c->S.N_bod, msz, Li, d_x, d_tmp, m, nvec, n, 2)))   // both vectors in one pass over L
+    if ((rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2)))   // both vectors in one pass over L
       return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+    double *prod = d_y;                                // explicit inverses do not work in place: product into their scratch
+    if (c->blk_inv_valid) {
+      if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n))) return rc;
+      prod = (double *)c->d_blkTmp.p;
+    }
     c->no_damp = true;
-    rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
+    rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, prod);
     c->no_damp = false;
     if (rc) return rc;
-    return rbl_launch_block_solve_multi(c->stream, L, m, c->S.N_bod, msz, Li, d_y, d_y, m, nvec, n, 1);
+    return blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1);
   }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
@@ -1048,14 +1083,12 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
   if (body_end < 0) body_end = c->S.N_bod;
   if ((rc = pc_block_factors(c, body_begin, body_end))) return rc;
   const int64_t m = 3 * (int64_t)c->S.N_blb;
-  const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
   const double *L = (const double *)c->d_blkL.p + (size_t)body_begin * (size_t)(m * m);
-  const double *Li = (const double *)c->d_blkLinv.p + (size_t)body_begin * lstride;
   const double *in = d_in + (size_t)body_begin * (size_t)m;
   double *out = d_out + (size_t)body_begin * (size_t)m;
   const int nb = body_end - body_begin;
   rc = mode == 3 ? rbl_launch_block_trmv(c->stream, L, m, nb, m * m, in, out, m)
-                 : rbl_launch_block_solve(c->stream, L, m, nb, m * m, Li, in, out, m, mode);
+                 : blk_solve(c, body_begin, nb, d_in, d_out, 1, 0, mode);
   if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
   return RBL_OK;
 }
@@ -1168,6 +1201,7 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (!c) return RBL_ERR_ARG;
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
   if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
+  if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
   if (variant == 51 || variant == 52) { c->gmres_relax = (variant == 52); return RBL_OK; }           // inexact-Krylov relaxed products in GMRES off / on
   if (variant == 53 || variant == 54) { c->force_relaxed = (variant == 54); return RBL_OK; }         // hook: every full product relaxed off / on   // GMRES: reference-sign / restored-sign PC
   if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
@@ -1249,6 +1283,14 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
                              msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
+  c->blk_inv_valid = false;
+  if (c->blk_explicit && rbl_block_inverse_fits(m)) {     // small bodies: explicit L^-1, sweeps become matrix-vector products
+    if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;
+    if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, b1 - b0, msz, (const double *)c->d_blkLinv.p + (size_t)b0 * lstride,
+                                       (double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)msz)))
+      return rbl_fail(c, rc, "block inverse launch failed");
+    c->blk_inv_valid = true;
+  }
   c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1; c->blk_age = 0;
   return RBL_OK;
 }
@@ -1256,11 +1298,11 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
 static int pc_block_build(rbl_ctx *c)
 {
   const RblBodyState &S = c->S;
-  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  const int64_t m = 3 * (int64_t)S.N_blb, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   int b0 = 0, b1 = S.N_bod;                              // multi-GPU: this rank's bodies only (rbl_set_comm)
   if (comm_on(c)) comm_body_range(c, &b0, &b1);
   const int nbo = b1 - b0;
-  const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
+  const size_t off = (size_t)b0 * (size_t)m;
   int rc;
   if (nbo > 0 && (rc = pc_block_factors(c, b0, b1))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
@@ -1277,8 +1319,7 @@ static int pc_block_build(rbl_ctx *c)
   }
   if (nbo <= 0) return RBL_OK;
   // ... solved in place, three per pass over the factors (the sweeps are latency chains: 6 single solves cost 10 ms at cfg 3)
-  if ((rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)msz, m, nbo, msz,
-                                         (const double *)c->d_blkLinv.p + (size_t)b0 * lstride, MK + off, MK + off, m, 6, n3, 0)))
+  if ((rc = blk_solve(c, b0, nbo, MK, MK, 6, n3, 0)))
     return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
   for (int cc = 0; cc < 6; ++cc)
     rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p + off, MK + (size_t)cc * n3 + off, S.N_blb, nbo,
@@ -1290,19 +1331,18 @@ static int pc_block_build(rbl_ctx *c)
 static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
 {
   const RblBodyState &S = c->S;
-  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  const int64_t m = 3 * (int64_t)S.N_blb, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *f6 = w2 + n3 + 36 * (size_t)S.N_bod + 6 * (size_t)S.N_bod;
-  const double *L = (const double *)c->d_blkL.p, *Li = (const double *)c->d_blkLinv.p, *lev = (const double *)c->d_lever.p;
+  const double *lev = (const double *)c->d_lever.p;
   int b0 = 0, b1 = S.N_bod;
   const bool shard = comm_on(c);                         // own bodies only, completed by one all-reduce of the result
   if (shard) comm_body_range(c, &b0, &b1);
   const int nbo = b1 - b0;
-  const size_t off = (size_t)b0 * (size_t)m, lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
+  const size_t off = (size_t)b0 * (size_t)m;
   int rc;
   if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
   if (nbo > 0) {
-    if ((rc = rbl_launch_block_solve(c->stream, L + (size_t)b0 * (size_t)msz, m, nbo, msz, Li + (size_t)b0 * lstride, d_in + off,
-                                     w1 + off, m))) return rc;                                          // invM slip
+    if ((rc = blk_solve(c, b0, nbo, d_in, w1, 1, 0, 0))) return rc;                                      // invM slip
     rbl_launch_KT_x_Lam(c->stream, lev + off, w1 + off, S.N_blb, nbo, f6 + (size_t)6 * b0);              // K^T (invM slip)
     rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p + (size_t)36 * b0, d_in + n3 + (size_t)6 * b0, f6 + (size_t)6 * b0,
                             nbo, d_out + n3 + (size_t)6 * b0, c->pc_fsign);                              // U  (:601-608)

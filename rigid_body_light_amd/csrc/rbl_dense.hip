@@ -883,7 +883,378 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * n + e];
   }
 }
+
+// The same sweeps for bodies of order n <= BSS_T (shell_N_12 / 42 / 162: n = 36 / 126 / 486), where a sweep is a chain of
+// n / IB dependent steps and nothing else: thread t owns row t (forward) / column t (backward) for the whole solve and
+// the IB factor entries it needs for step s + 1 are already on their way to registers while step s runs (double
+// buffered), as is the next diagonal inverse -- so a step costs its two barriers and 2 x IB multiply-adds instead of a
+// round trip to L2 / HBM (n = 486: 147 -> ~40 us for both sweeps).  Same operation order per row as k_block_solve.
+constexpr int BSS_T = 512;
+
+template <int NV>
+__global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__restrict__ L, long n, long strideA,
+                                                             const double *__restrict__ Linv, long strideL,
+                                                             const double *in, double *out, long vec_stride, long rhs_pitch,
+                                                             int mode /* 0: L L^T, 1: L only, 2: L^T only */)
+{
+  extern __shared__ double y[];                      // NV x n doubles + NV x IB scratch
+  double *tbuf = y + (size_t)NV * n;                 // tbuf[v * IB + m]
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double *Lb = L + (size_t)b * (size_t)strideA;
+  const double *Lib = Linv + (size_t)b * (size_t)strideL;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    if (t < n) y[(size_t)v * n + t] = vin[t];
+  }
+  const int nsteps = (int)((n + IB - 1) / IB);
+  const bool diag = t < IB * NV;                     // threads 0 .. NV*IB-1: (vector, row of the diagonal block)
+  const int tv = diag ? t / IB : 0, tt = t % IB;
+  double li[IB], la[IB], lb[IB];
+
+  if (mode != 2) {                                   // ---- forward: L y' = v
+    auto load_panel = [&](int s, double (&dst)[IB]) {            // L[t][k + m], rows below block s (a full block, or none)
+      const long k = (long)s * IB;
+      if (t >= k + IB && t < n) {
+        const double *col = Lb + (size_t)k * (size_t)n + t;
+#pragma unroll
+        for (int m = 0; m < IB; ++m) dst[m] = col[(size_t)m * n];
+      }
+    };
+    auto load_diag = [&](int s) {                                // row tt of Linv_kk
+      if (diag) {
+        const double *Li = Lib + (size_t)s * IB * IB + tt * IB;
+#pragma unroll
+        for (int m = 0; m < IB; ++m) li[m] = Li[m];
+      }
+    };
+    auto step = [&](int s, double (&cur)[IB], double (&nxt)[IB]) {
+      const long k = (long)s * IB;
+      const int nb = (int)((n - k < IB) ? n - k : IB);
+      if (s + 1 < nsteps) load_panel(s + 1, nxt);
+      if (diag) {
+        const double *yv = y + (size_t)tv * n + k;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < IB; ++m)
+          if (m <= tt && tt < nb) acc = __builtin_fma(li[m], yv[m], acc);
+        tbuf[t] = acc;
+      }
+      if (s + 1 < nsteps) load_diag(s + 1);
+      __syncthreads();
+      if (diag && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
+      if (t >= k + IB && t < n) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double a0 = y[(size_t)v * n + t], a1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < IB; m += 2) {
+            a0 = __builtin_fma(-cur[m], tbuf[v * IB + m], a0);
+            a1 = __builtin_fma(-cur[m + 1], tbuf[v * IB + m + 1], a1);
+          }
+          y[(size_t)v * n + t] = a0 + a1;
+        }
+      }
+      __syncthreads();
+    };
+    load_diag(0);
+    load_panel(0, la);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+      step(s, la, lb);
+      if (s + 1 < nsteps) step(s + 1, lb, la);
+    }
+  } else {
+    __syncthreads();
+  }
+
+  if (mode != 1) {                                   // ---- backward: L^T x = y'
+    auto load_panel = [&](int s, double (&dst)[IB]) {            // L[k + m][t], columns before block s
+      const long k = (long)s * IB;
+      const int nb = (int)((n - k < IB) ? n - k : IB);
+      if (t < k) {
+        const double *row = Lb + (size_t)t * (size_t)n + k;
+#pragma unroll
+        for (int m = 0; m < IB; ++m) dst[m] = m < nb ? row[m] : 0.0;
+      }
+    };
+    auto load_diag = [&](int s) {                                // column tt of Linv_kk
+      if (diag) {
+        const double *Li = Lib + (size_t)s * IB * IB + tt;
+#pragma unroll
+        for (int m = 0; m < IB; ++m) li[m] = Li[m * IB];
+      }
+    };
+    auto step = [&](int s, double (&cur)[IB], double (&nxt)[IB]) {
+      const long k = (long)s * IB;
+      const int nb = (int)((n - k < IB) ? n - k : IB);
+      if (s > 0) load_panel(s - 1, nxt);
+      if (diag) {
+        const double *yv = y + (size_t)tv * n + k;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < IB; ++m)
+          if (m >= tt && m < nb) acc = __builtin_fma(li[m], yv[m], acc);
+        tbuf[t] = acc;                                           // 0 for rows beyond a ragged last block
+      }
+      if (s > 0) load_diag(s - 1);
+      __syncthreads();
+      if (diag && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
+      if (t < k) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double a0 = y[(size_t)v * n + t], a1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < IB; m += 2) {
+            a0 = __builtin_fma(-cur[m], tbuf[v * IB + m], a0);
+            a1 = __builtin_fma(-cur[m + 1], tbuf[v * IB + m + 1], a1);
+          }
+          y[(size_t)v * n + t] = a0 + a1;
+        }
+      }
+      __syncthreads();
+    };
+    load_diag(nsteps - 1);
+    load_panel(nsteps - 1, la);
+    for (int s = nsteps - 1; s >= 0; s -= 2) {
+      step(s, la, lb);
+      if (s - 1 >= 0) step(s - 1, lb, la);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    if (t < n) o[t] = y[(size_t)v * n + t];
+  }
+}
+
+// ---- explicit per-body inverses X = L^-1 for small bodies (n <= BSS_T) ---------------------------------------------
+// A substitution sweep is a chain of n / IB dependent steps whatever is prefetched (n = 486: ~60 us a sweep, 50 bodies or
+// 5000); with X at hand a sweep is one triangular matrix-vector product, every output independent.  X costs n^3 / 3
+// flops per body and factorisation, the same as the factorisation itself.
+//   k_trtri_small : workgroup (block column j, body): forward substitution of the IB unit vectors of block j through L,
+//                   a wave keeps 64 rows of X[:, block j] in MFMA accumulators (rank-IB updates on the matrix cores; a
+//                   VALU form with the T operand broadcast from LDS was LDS-bandwidth-bound, 709 us at 50 x 486), the
+//                   IB x IB diagonal products go through LDS; stores X twice: XL column-major (X[r][c] at c n + r) and XU row-major (r n + c), so that
+//                   X v and X^T v both read consecutive addresses across a wavefront.
+//   k_block_inv_apply : workgroup = 64 outputs x 8 waves, each wave an eighth of the sum (interleaved), fixed-order LDS
+//                   reduction; out = X v (upper = 0) or X^T v (upper = 1).
+__global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict__ L, long n, long strideA,
+                                                       const double *__restrict__ Linv, long strideL, double *__restrict__ X)
+{
+  __shared__ double sY[IB][IB + 1], sLi[IB][IB + 1], sT[IB][IB + 1];
+  const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const int wave = t >> 6, lane = t & 63, l15 = lane & 15, l4 = lane >> 4;
+  const long k0 = (long)j * IB;
+  const int nbj = (int)((n - k0 < IB) ? n - k0 : IB);
+  const int nsteps = (int)((n + IB - 1) / IB);
+  const double *Lb = L + (size_t)b * (size_t)strideA;
+  const double *Lib = Linv + (size_t)b * (size_t)strideL;
+  double *XL = X + (size_t)b * 2 * (size_t)(n * n), *XU = XL + (size_t)(n * n);
+  // a wave owns 64 rows of X[:, block j] as 4 x 2 transposed MFMA tiles: acc[ti][tc][v] = Y[i][c],
+  // c = 16 tc + l4 + 4 v, i = rbase + 16 ti + l15  (the C/D layout of v_mfma_f64_16x16x4_f64, as in k_trsm_tall)
+  const long rbase = 64L * wave;
+  double4_t acc[4][2];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) acc[ti][tc] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  constexpr int LP = IB * IB / 128;                  // Linv entries per thread at the smallest workgroup (128 threads)
+  double bq[4][IB / 4], lip[LP];
+
+  auto load_panel = [&](int s) {                     // B operands: L[i][k + 4 ks + l4] for the tiles below block s
+    const long k = (long)s * IB;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const long i = rbase + 16 * ti + l15;
+      const bool on = rbase + 16 * ti >= k + IB && i < n;
+      const double *p = Lb + (size_t)(k + l4) * (size_t)n + (on ? i : 0);
+#pragma unroll
+      for (int ks = 0; ks < IB / 4; ++ks) bq[ti][ks] = on ? p[(size_t)(4 * ks) * (size_t)n] : 0.0;
+    }
+  };
+  auto load_diag = [&](int s) {
+    const double *Li = Lib + (size_t)s * IB * IB;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { const int e = t + i * nt; if (e < IB * IB) lip[i] = Li[e]; }
+  };
+  auto stage_rows = [&](double4_t (&y0)[2], double4_t (&y1)[2]) {       // the two tiles of block s -> sY[m][c]
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        sY[l15][16 * tc + l4 + 4 * v] = y0[tc][v];
+        sY[16 + l15][16 * tc + l4 + 4 * v] = y1[tc][v];
+      }
+  };
+  auto take_rows = [&](double4_t (&y0)[2], double4_t (&y1)[2]) {        // rows of block s are final: X = T
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        y0[tc][v] = sT[l15][16 * tc + l4 + 4 * v];
+        y1[tc][v] = sT[16 + l15][16 * tc + l4 + 4 * v];
+      }
+  };
+  load_diag(j);
+  load_panel(j);
+  for (int s = j; s < nsteps; ++s) {
+    const long k = (long)s * IB;
+    const int wo = (int)(k >> 6), hi = (int)((k >> 5) & 1);              // owner wave of block s, which pair of its tiles
+    if (s == j) {                                                        // Y = E_j: the block is the identity
+      for (int e = t; e < IB * IB; e += nt) sY[e / IB][e % IB] = (e / IB == e % IB) ? 1.0 : 0.0;
+    } else if (wave == wo) {
+      if (hi) stage_rows(acc[2], acc[3]); else stage_rows(acc[0], acc[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { const int e = t + i * nt; if (e < IB * IB) sLi[e / IB][e % IB] = lip[i]; }
+    __syncthreads();
+    if (s + 1 < nsteps) load_diag(s + 1);
+    for (int e = t; e < IB * IB; e += nt) {                              // T = Linv_ss Y_s
+      const int a = e / IB, c = e % IB;
+      double sum = 0.0;
+#pragma unroll
+      for (int m = 0; m < IB; ++m)
+        if (m <= a) sum = __builtin_fma(sLi[a][m], sY[m][c], sum);
+      sT[a][c] = sum;
+    }
+    __syncthreads();
+    if (wave == wo) {
+      if (hi) take_rows(acc[2], acc[3]); else take_rows(acc[0], acc[1]);
+    }
+    if (rbase + 63 >= k + IB && s + 1 < nsteps) {                         // Y[i][:] -= L[i][k-block] T on the matrix cores
+      double ta[2][IB / 4];
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int ks = 0; ks < IB / 4; ++ks) ta[tc][ks] = -sT[4 * ks + l4][16 * tc + l15];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+        if (rbase + 16 * ti >= k + IB) {
+#pragma unroll
+          for (int ks = 0; ks < IB / 4; ++ks) {
+            acc[ti][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[0][ks], bq[ti][ks], acc[ti][0], 0, 0, 0);
+            acc[ti][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[1][ks], bq[ti][ks], acc[ti][1], 0, 0, 0);
+          }
+        }
+    }
+    if (s + 1 < nsteps) load_panel(s + 1);                               // in flight during the next diagonal product
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const long i = rbase + 16 * ti + l15;
+    if (i >= k0 && i < n) {
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = 16 * tc + l4 + 4 * v;
+          if (c < nbj) {
+            XL[(size_t)(k0 + c) * (size_t)n + i] = acc[ti][tc][v];
+            XU[(size_t)i * (size_t)n + k0 + c] = acc[ti][tc][v];
+          }
+        }
+    }
+  }
+}
+
+constexpr int BIA_W = 8;      // waves per workgroup of k_block_inv_apply: 64 outputs, each wave an eighth of every sum
+
+template <int NV>
+__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__restrict__ X, long n, const double *in, double *out,
+                                                         long vec_stride, long rhs_pitch, int upper)
+{
+  extern __shared__ double v[];                      // NV x n vector, then BIA_W x 64 x NV partial sums
+  double *red = v + (size_t)NV * n;
+  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const double *A = X + (size_t)b * 2 * (size_t)(n * n) + (upper ? (size_t)(n * n) : 0);
+#pragma unroll
+  for (int vv = 0; vv < NV; ++vv) {
+    const double *vin = in + (size_t)vv * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    for (long q = t; q < n; q += 64 * BIA_W) v[(size_t)vv * n + q] = vin[q];
+  }
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * 64, e = e0 + lane, ec = e < n ? e : n - 1;
+  // X v: columns q <= e (the wave's range ends with its last row);  X^T v: rows q >= e
+  const long qlo = upper ? e0 : 0, qhi = upper ? n : ((e0 + 64 < n) ? e0 + 64 : n);
+  double acc[NV];
+#pragma unroll
+  for (int vv = 0; vv < NV; ++vv) acc[vv] = 0.0;
+  constexpr int U = 32;                              // loads in flight per lane: the whole sum is latency, not bandwidth
+  for (long q0 = qlo + w; q0 < qhi; q0 += BIA_W * U) {
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long q = q0 + BIA_W * u;
+      a[u] = q < qhi ? A[(size_t)q * (size_t)n + ec] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long q = q0 + BIA_W * u;
+      const bool ok = q < qhi && (upper ? q >= e : q <= e);
+      const double av = ok ? a[u] : 0.0;
+      const long qc = q < qhi ? q : qhi - 1;
+#pragma unroll
+      for (int vv = 0; vv < NV; ++vv) acc[vv] = __builtin_fma(av, v[(size_t)vv * n + qc], acc[vv]);
+    }
+  }
+#pragma unroll
+  for (int vv = 0; vv < NV; ++vv) red[(w * 64 + lane) * NV + vv] = acc[vv];
+  __syncthreads();
+  if (w == 0 && e < n) {
+#pragma unroll
+    for (int vv = 0; vv < NV; ++vv) {
+      double r = red[lane * NV + vv];
+#pragma unroll
+      for (int ww = 1; ww < BIA_W; ++ww) r += red[(ww * 64 + lane) * NV + vv];          // fixed order
+      out[(size_t)vv * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride + e] = r;
+    }
+  }
+}
 }  // namespace
+
+// measured (tools/bench_block_solve.py, both sweeps): n = 486 x 50 bodies 124 -> 43 us; n = 126 x 400 and n = 36 x 2000 are
+// chains of 4 and 2 steps only, where the substitution kernel (23 us) beats two matrix-vector launches
+bool rbl_block_inverse_fits(int64_t n) { return n > 192 && n <= BSS_T; }
+size_t rbl_block_inverse_bytes(int64_t n, int batch) { return sizeof(double) * 2 * (size_t)(n * n) * (size_t)batch; }
+
+// X_b = L_b^-1 for `batch` factored bodies (d_L, d_Linv as left by rbl_launch_cholesky_batched); d_X: 2 n^2 doubles a body
+int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
+                             double *d_X)
+{
+  if (n > BSS_T) return RBL_ERR_SIZE;
+  const int64_t nsteps = (n + IB - 1) / IB;
+  const int th = (int)(n <= 128 ? 128 : ((n + 63) / 64) * 64);
+  hipLaunchKernelGGL(k_trtri_small, dim3((unsigned)nsteps, batch), dim3(th), 0, st, d_L, (long)n, (long)strideA, d_Linv,
+                     (long)(nsteps * IB * IB), d_X);
+  return RBL_OK;
+}
+
+// mode 0: x = X^T X v ;  1: x = X v ;  2: x = X^T v  (= (L L^T)^-1 v, L^-1 v, L^-T v).  d_tmp: nv vectors of
+// tmp_pitch doubles (mode 0 only; laid out like d_out).  In place is fine for mode 0, not for 1 / 2.
+int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
+                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp)
+{
+  if (n > BSS_T) return RBL_ERR_SIZE;
+  if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
+  if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
+  const dim3 grid((unsigned)((n + 63) / 64), batch);
+  auto pass = [&](const double *in, double *out, int upper) {
+    for (int v0 = 0; v0 < nv;) {
+      const int g = nv - v0 >= 3 ? 3 : nv - v0;
+      const size_t lds = sizeof(double) * ((size_t)g * (size_t)n + 64 * BIA_W * (size_t)g);
+      const double *pi = in + (size_t)v0 * (size_t)rhs_pitch;
+      double *po = out + (size_t)v0 * (size_t)rhs_pitch;
+      if (g == 3) hipLaunchKernelGGL(k_block_inv_apply<3>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
+      else if (g == 2) hipLaunchKernelGGL(k_block_inv_apply<2>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
+      else hipLaunchKernelGGL(k_block_inv_apply<1>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
+      v0 += g;
+    }
+  };
+  if (mode == 0) { pass(d_in, d_tmp, 0); pass(d_tmp, d_out, 1); }
+  else pass(d_in, d_out, mode == 1 ? 0 : 1);
+  return RBL_OK;
+}
 
 // y_b = L_b x_b for every matrix of the batch (lower-triangular product): one workgroup per matrix, x in LDS,
 // column sweep with rows spread over the threads.
@@ -935,6 +1306,20 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     const size_t lds = sizeof(double) * (size_t)g * (size_t)(n + IB);
     const double *in = d_in + (size_t)v0 * (size_t)rhs_pitch;
     double *out = d_out + (size_t)v0 * (size_t)rhs_pitch;
+    if (n <= BSS_T) {          // small bodies: one row per thread, factor entries prefetched a step ahead
+      const int th = (int)(n <= 128 ? 128 : ((n + 63) / 64) * 64);
+      if (g == 3)
+        hipLaunchKernelGGL(k_block_solve_small<3>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                           out, (long)vec_stride, (long)rhs_pitch, mode);
+      else if (g == 2)
+        hipLaunchKernelGGL(k_block_solve_small<2>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                           out, (long)vec_stride, (long)rhs_pitch, mode);
+      else
+        hipLaunchKernelGGL(k_block_solve_small<1>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                           out, (long)vec_stride, (long)rhs_pitch, mode);
+      v0 += g;
+      continue;
+    }
     if (g == 3)
       hipLaunchKernelGGL(k_block_solve<3>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
                          (long)vec_stride, (long)rhs_pitch, mode);

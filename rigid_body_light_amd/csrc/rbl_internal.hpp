@@ -75,6 +75,8 @@ struct rbl_ctx {
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
+  RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 of small bodies (two layouts), scratch of their application
+  bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
   RblDevBuf d_step;                                 // time-step entry points: solution, rhs, slip, force
@@ -173,6 +175,13 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
                                  int64_t rhs_pitch, int mode);
 int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                           double *d_out, int64_t vec_stride);
+// explicit per-body inverses for small bodies (3 N_blb <= 512): substitution sweeps become triangular matrix-vector products
+bool rbl_block_inverse_fits(int64_t n);
+size_t rbl_block_inverse_bytes(int64_t n, int batch);
+int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
+                             double *d_X);
+int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
+                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
                            double *d_out, double *d_part);
 size_t rbl_trmv_part_bytes(int64_t n);

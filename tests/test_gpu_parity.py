@@ -973,6 +973,56 @@ def test_block_solve_body_ranges(orc, shell12, wall):
     assert rel(full[0].cpu().numpy(), ref) < 1e-11
 
 
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("nblb", [42, 65, 75, 86, 162, 170])
+def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
+    """Bodies of order 192 < 3 N_blb <= 512 apply (L L^T)^-1, L^-1, L^-T through explicit inverses X = L^-1 (k_trtri_small
+    + k_block_inv_apply) instead of substitution chains: every mode against the substitution kernels (rbl_set_tuning 61)
+    and against dense numpy factors, on full and ragged 32-blocks and 64-row tiles (n = 195, 225, 258, 486, 510; 126 is
+    below the switch and takes the substitution path both times), body ranges and in place."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    nb = 5
+    rng = np.random.default_rng(nblb)
+    kk = np.arange(nblb) + 0.5                                 # Fibonacci shell, neighbours ~2.5 a apart
+    th, ph = np.arccos(1.0 - 2.0 * kk / nblb), np.pi * (1.0 + 5.0 ** 0.5) * kk
+    cfg = 0.7 * np.sqrt(nblb) * np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1)
+    R = float(np.linalg.norm(cfg, axis=1).max()) + 1.5
+    X = np.array([[3.0 * R * b, 0.5 * b, R + 0.3 * b] for b in range(nb)])
+    Q = rng.standard_normal((nb, 4)); Q /= np.linalg.norm(Q, axis=1)[:, None]
+    dev = torch.device("cuda:0")
+    m = 3 * nblb
+    v = torch.from_numpy(rng.standard_normal(m * nb)).to(dev)
+    res = {}
+    for variant in (61, 62):
+        ctx = DeviceContext(1.0, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        ctx.set_tuning(0, variant)
+        for mode in (0, 1, 2):
+            o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
+            res[(variant, mode)] = o
+            part = torch.full_like(v, 7.5)
+            ctx.block_solve(v.data_ptr(), part.data_ptr(), mode, 1, 4); ctx.sync_check()
+            assert torch.equal(part[m:4 * m], o[m:4 * m]) and torch.all(part[:m] == 7.5) and torch.all(part[4 * m:] == 7.5)
+            w = v.clone(); ctx.block_solve(w.data_ptr(), w.data_ptr(), mode); ctx.sync_check()       # in place
+            assert torch.equal(w, o)
+        rt = torch.empty(m * nb, dtype=torch.float64, device=dev)
+        ctx.blob_positions(0, nb, rt.data_ptr()); ctx.sync_check()
+        ctx.close()
+    M = orc.rotne_prager_tensor(rt.cpu().numpy(), 1.0, 1.0, wall)
+    vh = v.cpu().numpy()
+    for mode in (0, 1, 2):
+        ref = np.empty(m * nb)
+        for b in range(nb):
+            sl = slice(m * b, m * (b + 1))
+            Lb = np.linalg.cholesky(M[sl, sl])
+            ref[sl] = (np.linalg.solve(M[sl, sl], vh[sl]) if mode == 0 else
+                       np.linalg.solve(Lb, vh[sl]) if mode == 1 else np.linalg.solve(Lb.T, vh[sl]))
+        for variant in (61, 62):
+            assert rel(res[(variant, mode)].cpu().numpy(), ref) < 1e-10, (variant, mode)
+        assert rel(res[(62, mode)].cpu().numpy(), res[(61, mode)].cpu().numpy()) < 1e-11
+
+
 @pytest.mark.parametrize("block", [False, True])
 def test_native_gmres_equals_torch_gmres(shell12, block):
     """rbl_gmres_saddle_dev (librbl's own right-preconditioned GMRES) == the torch Arnoldi driver, fixed work and
