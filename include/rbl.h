@@ -325,7 +325,9 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 51 / 52: inexact-Krylov relaxation off (default) / on: once rbl_gmres_saddle_dev's residual estimate is below
  * rtol x 1e5, its mobility products evaluate far tile pairs in packed single precision (relative product error ~1e-6,
  * ~1.8x faster); the solution still satisfies the fp64 system to rtol (tests check the true residual);
- * 53 / 54: test hook, every full product through that relaxed kernel off / on.  All per context. */
+ * 53 / 54: test hook, every full product through that relaxed kernel off / on;
+ * 61 / 62: per-body factors of bodies with 65..170 blobs applied by substitution / through explicit inverses L^-1
+ * (default; built with the factors, a sweep becomes one triangular matrix-vector product).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

@@ -737,7 +737,7 @@ size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
 int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
                                 unsigned *d_err, double *d_Linv)
 {
-  constexpr int NBB = 512;   // outer panel of the batched factorisation: rank-512 trailing updates
+  constexpr int NBB = 512;   // outer panel of the batched factorisation: rank-512 trailing updates (n = 486: 256 same, 128 / 64 slower)
   const int64_t nsteps = (n + IB - 1) / IB;
   const long strideL = (long)(nsteps * IB * IB);
   for (int64_t k = 0; k < n; k += NBB) {
