@@ -31,6 +31,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // Cholesky update of row r, for the high half it is forward substitution -- so L_kk^-1 (needed by
 // the MFMA triangular solves) comes out of the same instruction stream for free.  Pivots by
 // v_rsq_f64 + Newton (no sqrt/div chain).  Leaves Linv (IB x IB, row-major [c][m]) in Y.
+// (Round 2, measured and dropped: multipliers of columns c + 3.. through LDS -- one write, broadcast reads -- instead of
+// two v_readlane each: 1.5x SLOWER, 50 x 486 batch 0.58 -> 0.90 ms and n = 24 300 50.7 -> 46 TFLOP/s; the LDS round
+// trip lands on the pivot chain, the v_readlane pairs do not.)
 // t = lane (0..63).  Returns true when a pivot was not positive.
 __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 {
