@@ -118,12 +118,17 @@ def isa_counts(kernel):
 
 
 def pmc_traffic(kernel, config, world):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only when that
-    profile was taken from the kernel sources this library was built from (hash recorded in the file)."""
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only while the built
+    library holds the same kernel code as the profiled one: the file records the sha256 of the profiled instance's
+    instruction text, tools/isa_stats.py computes the same for every build (librbl.isa.json)."""
     path = os.path.join(ROOT, "profiles", "r02_bench_%s_pmc.json" % config)
     try:
         d = json.load(open(path))
-        if d.get("kernel_source_sha256") != kernel_source_hash() or world != 1 or d.get("kernel") != kernel:
+        isa = json.load(open(os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")))
+        if isa.get("kernel_source_sha256") != kernel_source_hash():       # stale assembly analysis: nothing to compare with
+            return None, None
+        same = d.get("kernel_isa_sha256") and d["kernel_isa_sha256"] == isa["instance_isa_sha256"].get(d.get("kernel_instance"))
+        if not same or world != 1 or d.get("kernel") != kernel:
             return None, None
         return d["hbm_bytes_per_launch"], d
     except (OSError, KeyError, ValueError):

@@ -283,7 +283,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -1341,15 +1341,21 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   const size_t off = (size_t)b0 * (size_t)m;
   int rc;
   if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
+  c->ktl_of = nullptr;
   if (nbo > 0) {
     if ((rc = blk_solve(c, b0, nbo, d_in, w1, 1, 0, 0))) return rc;                                      // invM slip
-    rbl_launch_KT_x_Lam(c->stream, lev + off, w1 + off, S.N_blb, nbo, f6 + (size_t)6 * b0);              // K^T (invM slip)
-    rbl_launch_pc_block_mid(c->stream, (const double *)c->d_NL.p + (size_t)36 * b0, d_in + n3 + (size_t)6 * b0, f6 + (size_t)6 * b0,
-                            nbo, d_out + n3 + (size_t)6 * b0, c->pc_fsign);                              // U  (:601-608)
-    // Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over the factors
-    rbl_launch_pc_block_lambda(c->stream, w1 + off, (const double *)c->d_pcMK.p + off, d_out + n3 + (size_t)6 * b0, S.N_blb,
-                               (int64_t)m * nbo, n3, d_out + off);
+    // K^T (invM slip);  U (:601-608);  Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over
+    // the factors -- one launch (k_pc_block_tail); inside GMRES it also leaves K^T Lambda for the saddle product
+    double *ktl = nullptr;
+    if (c->ktl_arm && !shard) {
+      if ((rc = rbl_dev_reserve(c, c->d_ktl, sizeof(double) * 6 * (size_t)S.N_bod))) return rc;
+      ktl = (double *)c->d_ktl.p;
+    }
+    rbl_launch_pc_block_tail(c->stream, lev, w1, (const double *)c->d_pcMK.p, n3, (const double *)c->d_NL.p, d_in + n3, S.N_blb,
+                             b0, nbo, c->pc_fsign, d_out + n3, d_out, ktl);
+    if (ktl) c->ktl_of = d_out;
   }
+  (void)f6; (void)off;
   if (shard) return comm_allreduce(c, d_out, n3 + (int64_t)6 * S.N_bod);
   return RBL_OK;
 }
@@ -1406,6 +1412,11 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
   const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3))) return rc;
   if ((rc = apply_M_enqueue(c, S.wall, d_x, (const double *)c->d_pos.p, N, 0, N, (double *)c->d_sad.p))) return rc;
+  if (c->ktl_arm && c->ktl_of == d_x) {      // GMRES: d_x came out of the block preconditioner together with its K^T Lambda
+    rbl_launch_saddle_tail(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, S.N_bod, d_out,
+                           (const double *)c->d_sad.p, (const double *)c->d_ktl.p);
+    return RBL_OK;
+  }
   rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, d_out, (const double *)c->d_sad.p, -1.0);
   rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, d_x, S.N_blb, S.N_bod, d_out + n3);
   return RBL_OK;
@@ -1561,17 +1572,18 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   };
   for (int j = 0; j < m; ++j) {
     const double *vj = V + (size_t)j * nsys;
-    if ((rc = rbl_apply_PC_dev(c, vj, z))) return rc;
+    c->ktl_arm = true;                                 // the PC's K^T Lambda by-product feeds the product that follows
+    if ((rc = rbl_apply_PC_dev(c, vj, z))) { c->ktl_arm = false; return rc; }
     // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
     // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
     c->sym_tune.relaxed = (c->gmres_relax && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
     rc = rbl_apply_saddle_dev(c, z, w);
     c->sym_tune.relaxed = 0;
+    c->ktl_arm = false; c->ktl_of = nullptr;
     if (rc) return rc;
     double *Hcol = H + (size_t)j * ldh;
-    rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 0, part);
-    rbl_launch_cgs_pass(c->stream, V, nsys, j + 1, w, Hcol, 1, part);
-    rbl_launch_lanczos_init(c->stream, nsys, w, Hcol + j + 1, V + (size_t)(j + 1) * nsys, part2);   // H[j+1][j] = |w|, V_{j+1}
+    // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches
+    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
     used = j + 1;
     if (rtol > 0.0 && (used % check_every == 0 || used == m)) {
       RBL_HIP(c, hipMemcpyAsync(Hh.data(), H, sizeof(double) * Hh.size(), hipMemcpyDeviceToHost, c->stream));

@@ -275,6 +275,85 @@ __global__ void k_pc_block_lambda(const double *__restrict__ y1, const double *_
   out[i] = acc;
 }
 
+// The three steps of a block-preconditioner application after invM slip (y1) in ONE launch, one workgroup per body:
+// f = K^T y1 (k_KT_x_Lam), U = Ninv^-1 (fsign F - f) (k_pc_block_mid), Lambda = y1 + (invM K) U (k_pc_block_lambda) --
+// and, for the saddle product that follows inside GMRES, K^T Lambda (ktl, may be NULL).  Bodies b_begin .. b_begin + gridDim.x.
+__global__ __launch_bounds__(BT) void k_pc_block_tail(const double *__restrict__ lever, const double *__restrict__ y1,
+                                                      const double *__restrict__ MK, long stride,
+                                                      const double *__restrict__ NL, const double *__restrict__ F, int N_blb,
+                                                      int b_begin, double fsign, double *__restrict__ U,
+                                                      double *__restrict__ lam, double *__restrict__ ktl)
+{
+  __shared__ double s[6][BT];
+  __shared__ double us[6];
+  const int b = b_begin + blockIdx.x, t = threadIdx.x;
+  double f[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = t; k < N_blb; k += BT) {
+    const size_t idx = 3 * ((size_t)b * N_blb + k);
+    const double *l = lever + idx, *v = y1 + idx;
+    f[0] += v[0]; f[1] += v[1]; f[2] += v[2];
+    f[3] += l[1] * v[2] - l[2] * v[1];
+    f[4] += l[2] * v[0] - l[0] * v[2];
+    f[5] += l[0] * v[1] - l[1] * v[0];
+  }
+  block_reduce<6>(f, s, t);
+  if (t == 0) {
+    const double *L = NL + 36 * (size_t)b;
+    double y[6], u[6];
+    for (int p = 0; p < 6; ++p) {
+      double v = fsign * F[6 * b + p] - f[p];
+      for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
+      y[p] = v / L[6 * p + p];
+    }
+    for (int p = 5; p >= 0; --p) {
+      double v = y[p];
+      for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
+      u[p] = v / L[6 * p + p];
+    }
+    for (int p = 0; p < 6; ++p) { U[6 * b + p] = u[p]; us[p] = u[p]; }
+  }
+  __syncthreads();
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = t; k < N_blb; k += BT) {
+    const size_t idx = 3 * ((size_t)b * N_blb + k);
+    double v[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double acc = y1[idx + d];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * stride + idx + d], us[c], acc);
+      v[d] = acc;
+      lam[idx + d] = acc;
+    }
+    const double *l = lever + idx;
+    g[0] += v[0]; g[1] += v[1]; g[2] += v[2];
+    g[3] += l[1] * v[2] - l[2] * v[1];
+    g[4] += l[2] * v[0] - l[0] * v[2];
+    g[5] += l[0] * v[1] - l[1] * v[0];
+  }
+  if (ktl) {
+    block_reduce<6>(g, s, t);
+    if (t < 6) ktl[6 * b + t] = g[t];
+  }
+}
+
+// saddle epilogue in one launch: out_top = sub - K U (k_K_x_U with alpha = -1) and out_bot = ktl (K^T lambda, computed
+// by k_pc_block_tail when the vector came out of the preconditioner)
+__global__ void k_saddle_tail(const double *__restrict__ lever, const double *__restrict__ U, int N_blb, long N,
+                              double *__restrict__ out, const double *__restrict__ sub, const double *__restrict__ ktl,
+                              int nb6)
+{
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < nb6) out[3 * N + idx] = ktl[idx];
+  if (idx >= N) return;
+  const int b = (int)(idx / N_blb);
+  const double *u = U + 6 * b, *om = u + 3, *l = lever + 3 * idx;
+  const double k0 = u[0] + l[2] * om[1] - l[1] * om[2];
+  const double k1 = u[1] + l[0] * om[2] - l[2] * om[0];
+  const double k2 = u[2] + l[1] * om[0] - l[0] * om[1];
+  out[3 * idx] = sub[3 * idx] - k0; out[3 * idx + 1] = sub[3 * idx + 1] - k1; out[3 * idx + 2] = sub[3 * idx + 2] - k2;
+}
+
 __global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,6 +384,23 @@ void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double
   if (count <= 0) return;
   hipLaunchKernelGGL(k_pc_block_lambda, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_y1, d_MK, d_U, N_blb,
                      (long)count, (long)stride, d_out);
+}
+
+void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,
+                              const double *d_NL, const double *d_F, int N_blb, int b_begin, int b_count, double fsign,
+                              double *d_U, double *d_lam, double *d_ktl)
+{
+  if (b_count <= 0) return;
+  hipLaunchKernelGGL(k_pc_block_tail, dim3(b_count), dim3(BT), 0, st, d_lever, d_y1, d_MK, (long)stride, d_NL, d_F, N_blb,
+                     b_begin, fsign, d_U, d_lam, d_ktl);
+}
+
+void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N, int N_bod,
+                            double *d_out, const double *d_sub, const double *d_ktl)
+{
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_saddle_tail, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_lever, d_U, N_blb, (long)N, d_out,
+                     d_sub, d_ktl, 6 * N_bod);
 }
 
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)

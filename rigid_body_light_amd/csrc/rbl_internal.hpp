@@ -76,6 +76,8 @@ struct rbl_ctx {
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 of small bodies (two layouts), scratch of their application
+  RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
+  bool ktl_arm = false; const double *ktl_of = nullptr;   // armed by the GMRES loop only; ktl_of = the vector d_ktl belongs to
   bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
@@ -191,6 +193,8 @@ void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const dou
                      int64_t n, double *d_out2);  // out[0]=x.y out[1]=x.z (z may be null)
 int rbl_gmres_max_vectors(void);
 size_t rbl_gmres_part_doubles(void);
+void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
+                             double *part);
 void rbl_launch_cgs_pass(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, int accumulate,
                          double *part);
 size_t rbl_lanczos_part_doubles(void);
@@ -231,6 +235,11 @@ void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double
                                 int64_t count, int64_t stride, double *d_out);
 void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
                              double *d_U, double fsign);
+void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,
+                              const double *d_NL, const double *d_F, int N_blb, int b_begin, int b_count, double fsign,
+                              double *d_U, double *d_lam, double *d_ktl);
+void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N, int N_bod,
+                            double *d_out, const double *d_sub, const double *d_ktl);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

@@ -63,3 +63,8 @@ def test_isa_counts_match_the_kernel_sources():
     sys.path.insert(0, root)
     import bench
     assert bench.isa_counts("k_apply_M_sym<true,2>")["flop"] == d["kernels"]["k_apply_M_sym<true,2>"]["per_unordered_pair"]["flop"]
+    # the HBM-traffic figure of the bench line comes from PMC passes under profiles/: they must have been taken from the
+    # kernel code this build holds (instruction-text hash of the profiled instance) -- re-profile after a kernel change
+    pmc = json.load(open(os.path.join(root, "profiles", "r02_bench_cfg3_pmc.json")))
+    assert pmc["kernel_isa_sha256"] == d["instance_isa_sha256"][pmc["kernel_instance"]], "re-run the PMC passes (profiles/README.md)"
+    assert bench.pmc_traffic("k_apply_M_sym<true,2>", "cfg3", 1)[0] == pmc["hbm_bytes_per_launch"]

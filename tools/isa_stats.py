@@ -47,10 +47,25 @@ def classify(ops):
             "rsq": g(lambda k: k.startswith("v_rsq_f64")), "ds_add": g(lambda k: k.startswith("ds_add_f64"))}
 
 
+def isa_hash(lines, start, end):
+    """sha256 of the instruction text of one function: comments and directives dropped, basic-block labels renumbered
+    without the function's index in the file -- unrelated edits elsewhere in the source leave it unchanged"""
+    import hashlib
+    h = hashlib.sha256()
+    for l in lines[start + 1:end]:
+        t = l.split(";")[0].strip()
+        if not t or (t.startswith(".") and not t.startswith(".LBB")):
+            continue
+        h.update(re.sub(r"\.LBB\d+_(\d+)", r".LBB_\1", " ".join(t.split())).encode())
+        h.update(b"\n")
+    return h.hexdigest()
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     lines = open(src).read().split("\n")
     res = {}
+    instances = {}
     for i, l in enumerate(lines):
         m = re.match(r"^(_ZN\S*?(k_apply_M_sym\d?)ILb([01])ELi(\d)E((?:Li\d+E)*)E\S*):", l)
         if not m:
@@ -59,6 +74,7 @@ def main():
         extra = [int(x) for x in re.findall(r"Li(\d+)E", m.group(5))]      # SW [, PREC]
         relaxed = len(extra) >= 2 and extra[1] == 1
         end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        instances["%s<%s,%d%s>" % (kern, "true" if wall else "false", ni, "".join(",%d" % x for x in extra))] = isa_hash(lines, i, end)
         best = None
         if relaxed:      # the packed single-precision sweep: v_rsq_f32, two pairs per packed instruction, column sums by ds_add_f64
             for name, ops in blocks_of(lines, i, end):
@@ -103,7 +119,8 @@ def main():
     for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
         h.update(open(os.path.join(csrc, f), "rb").read())
     json.dump({"source": "hipcc -S --offload-device-only of csrc/rbl_kernels.hip (same flags as librbl.so)",
-               "kernel_source_sha256": h.hexdigest(), "kernels": res}, open(dst, "w"), indent=1, sort_keys=True)
+               "kernel_source_sha256": h.hexdigest(), "kernels": res, "instance_isa_sha256": instances},
+              open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
         p = v["per_unordered_pair"]
         if "pk_fma" in p:

@@ -25,7 +25,14 @@ avg = {k: sum(v) / len(v) for k, v in agg.items()}
 h = hashlib.sha256()
 for f in ("rbl_kernels.hip", "rbl_pair.hpp"):
     h.update(open(os.path.join(ROOT, "rigid_body_light_amd", "csrc", f), "rb").read())
+inst = key.replace(" ", "")
+inst = inst if inst.endswith(">") else inst + ">"
+try:   # instruction-text hash of the profiled instance (tools/isa_stats.py via the build): what bench.py compares
+    isa_sha = json.load(open(os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")))["instance_isa_sha256"].get(inst)
+except (OSError, KeyError, ValueError):
+    isa_sha = None
 doc = {"kernel": None, "kernel_match": key, "config": config, "kernel_source_sha256": h.hexdigest(),
+       "kernel_instance": inst, "kernel_isa_sha256": isa_sha,
        "counters_avg_per_dispatch": avg, "dispatches": {k: len(v) for k, v in agg.items()},
        "source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py (separate passes), averaged per dispatch by tools/pmc_to_json.py"}
 if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
