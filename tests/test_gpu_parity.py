@@ -1225,6 +1225,16 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
         true_res = float(torch.linalg.norm(out - b) / torch.linalg.norm(b))
         assert res < 1e-8 and true_res < 2e-8, (variant, m, res, true_res)
         sol[variant] = (x.cpu().numpy(), m)
+        # warm start (a time step's extrapolated guess): the right-hand side moves by 1e-5, GMRES solves the correction
+        # equation to 1e-8 |b| -- with the relaxation on, EVERY product of the iteration may be relaxed (the residual
+        # to reduce is already < 1e-3 of the tolerance scale); only b - A x0 stays fp64.  True residual as above.
+        b2 = b + 1e-5 * torch.from_numpy(rng.standard_normal(nsys)).to(dev) * torch.linalg.norm(b) / np.sqrt(nsys)
+        ctx.set_tuning(0, variant)
+        m2, res2 = ctx.gmres_saddle(b2.data_ptr(), 100, 1e-8, x.data_ptr(), use_x0=True)
+        ctx.set_tuning(0, 51)
+        ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
+        true2 = float(torch.linalg.norm(out - b2) / torch.linalg.norm(b2))
+        assert res2 < 1e-8 and true2 < 2e-8 and m2 < m, (variant, m2, res2, true2)
         ctx.close()
     assert abs(sol[52][1] - sol[51][1]) <= 3
     assert rel(sol[52][0], sol[51][0]) < 1e-6
