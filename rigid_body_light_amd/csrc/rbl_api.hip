@@ -283,7 +283,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -320,6 +320,7 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   S.params_set = true;
   S.M_scale = 1.0;
   c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
+  c->bf_valid = false;                                 // the body-frame factor belongs to (a, eta, cfg)
   return RBL_OK;
 }
 
@@ -730,11 +731,84 @@ static int pc_block_factors(rbl_ctx *c, int b0 = 0, int b1 = -1);
 // op(L_b) applied to bodies [b0, b0 + nbo) of nv vectors `pitch` doubles apart (in / out: the FULL vectors, body 0 first);
 // mode 0: (L L^T)^-1, 1: L^-1, 2: L^-T.  Small bodies go through their explicit inverses (two matrix-vector products
 // instead of two chains of substitution steps), the others through the substitution kernel.  In place is fine.
+// Free space (no wall term in M): every body's mobility is the SAME body-frame matrix seen through the body's rotation,
+// M_b = (I x R_b) M_body (I x R_b)^T (the RPY block of a pair depends on the separation vector only, which rotates with the
+// body).  So there is nothing to factor per configuration: M_body = L L^T once per rbl_set_parameters, and the factor used
+// for body b is G_b = (I x R_b) L  (G G^T = M_b; not triangular, which nothing here needs):
+//   (G G^T)^-1 v = R (L L^T)^-1 R^T v,   G^-1 v = L^-1 R^T v,   G^-T v = R L^-T v,   G x = R L x.
+// One matrix for all bodies also means the factor is read from cache instead of HBM.
+static bool bf_on(const rbl_ctx *c) { return c->blk_bodyframe && !c->S.wall; }
+
+static int bf_build(rbl_ctx *c)
+{
+  if (c->bf_valid) return RBL_OK;
+  const RblBodyState &S = c->S;
+  const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m;
+  int rc = ensure_xq_dev(c); if (rc) return rc;         // d_cfg: the blob positions in the body frame
+  if ((rc = rbl_dev_reserve(c, c->d_bfL, sizeof(double) * (size_t)msz))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_bfLinv, rbl_cholesky_batched_work_bytes(m, 1)))) return rc;
+  double *Lb = (double *)c->d_bfL.p;
+  rbl_launch_build_M_batched(c->stream, rbl_make_params(S.a, S.eta), false, (const double *)c->d_cfg.p, S.N_blb, 1, Lb, msz, c->d_err);
+  if ((rc = rbl_launch_cholesky_batched(c->stream, Lb, m, 1, msz, c->d_err, (double *)c->d_bfLinv.p)))
+    return rbl_fail(c, rc, "body-frame cholesky launch failed");
+  c->bf_inv = false;
+  if (c->blk_explicit && rbl_block_inverse_fits(m)) {
+    if ((rc = rbl_dev_reserve(c, c->d_bfX, rbl_block_inverse_bytes(m, 1)))) return rc;
+    if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, 1, msz, (const double *)c->d_bfLinv.p, (double *)c->d_bfX.p)))
+      return rbl_fail(c, rc, "body-frame inverse launch failed");
+    c->bf_inv = true;
+  }
+  c->bf_valid = true;
+  return RBL_OK;
+}
+
+// the factors the block operations below work with: body-frame (free space) or per-configuration Cholesky (wall)
+static int blk_prepare(rbl_ctx *c, int b0, int b1)
+{
+  const int hi = b1 < 0 ? c->S.N_bod : b1;
+  if (b0 < 0 || b0 >= hi || hi > c->S.N_bod) return rbl_fail(c, RBL_ERR_ARG, "block factors: need 0 <= body_begin < body_end <= N_bodies");
+  if (bf_on(c)) return bf_build(c);
+  return pc_block_factors(c, b0, b1);
+}
+
 static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode)
 {
   if (nbo <= 0) return RBL_OK;
   const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
   const size_t off = (size_t)b0 * (size_t)m;
+  if (bf_on(c)) {
+    const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
+    int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
+    double *tmp = (double *)c->d_blkTmp.p;
+    const double *dQ = (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0;
+    for (int v0 = 0; v0 < nv; v0 += 3) {
+      const int g = nv - v0 >= 3 ? 3 : nv - v0;
+      const double *pi = in + (size_t)v0 * (size_t)pitch + off;
+      double *po = out + (size_t)v0 * (size_t)pitch + off;
+      if (c->bf_inv) {                                  // small bodies: X = L^-1 explicit, rotations fused into the products
+        if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, 0, tmp + off, dQ);
+        else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, mode, nullptr, dQ);
+        else {
+          rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr, dQ);
+          for (int v = 0; v < g && !rc; ++v)
+            RBL_HIP(c, hipMemcpyAsync(po + (size_t)v * (size_t)pitch, tmp + off + (size_t)v * (size_t)pitch,
+                                      sizeof(double) * (size_t)m * (size_t)nbo, hipMemcpyDeviceToDevice, c->stream));
+        }
+      } else {                                          // substitution through the ONE shared factor (batch stride 0)
+        const double *src = pi;
+        if (mode != 2) {                                // R^T first (scratch laid out like the vectors)
+          rbl_launch_rotate_bodies(c->stream, dQ, pi, tmp + off, c->S.N_blb, nbo, g, pitch, 1);
+          src = tmp + off;
+        }
+        double *dst = (mode == 1) ? po : tmp + off;
+        rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, (const double *)c->d_bfLinv.p, src, dst, m, g,
+                                          pitch, mode | 0x100);
+        if (!rc && mode != 1) rbl_launch_rotate_bodies(c->stream, dQ, dst, po, c->S.N_blb, nbo, g, pitch, 0);
+      }
+      if (rc) return rc;
+    }
+    return RBL_OK;
+  }
   if (c->blk_inv_valid) {
     const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
     int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
@@ -759,6 +833,23 @@ static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out,
   const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
   return rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)msz, m, nbo, msz,
                                       (const double *)c->d_blkLinv.p + (size_t)b0 * lstride, in + off, out + off, m, nv, pitch, mode);
+}
+
+// out = G_b in for bodies [b0, b0 + nbo) of ONE vector (in / out: the full vectors; not in place)
+static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
+{
+  if (nbo <= 0) return RBL_OK;
+  const int64_t m = 3 * (int64_t)c->S.N_blb;
+  const size_t off = (size_t)b0 * (size_t)m;
+  if (bf_on(c)) {                                       // G x = R (L x)
+    int rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, in + off, out + off, m);
+    if (rc) return rc;
+    const double *dQ = (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0;
+    rbl_launch_rotate_bodies(c->stream, dQ, out + off, out + off, c->S.N_blb, nbo, 1, 0, 0);
+    return RBL_OK;
+  }
+  return rbl_launch_block_trmv(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)(m * m), m, nbo, m * m, in + off,
+                               out + off, m);
 }
 
 // y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
@@ -917,15 +1008,12 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   for (int v = 0; v < nvec; ++v)
     rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, d_out + (size_t)v * n, (int64_t)nvec * n);
   if (precond) {   // x = B (L y)
-    const int64_t mb = 3 * (int64_t)c->S.N_blb;
     int b0 = 0, b1 = c->S.N_bod;
     if (comm_on(c)) comm_body_range(c, &b0, &b1);
-    const size_t off = (size_t)b0 * (size_t)mb;
     for (int v = 0; v < nvec; ++v) {
       double *o = d_out + (size_t)v * n;
       if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)n, c->stream));
-      if (b1 > b0 && (rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)(mb * mb), mb, b1 - b0,
-                                                 mb * mb, o + off, tmp + off, mb))) return rc;
+      if ((rc = blk_trmv(c, b0, b1 - b0, o, tmp))) return rc;
       if (comm_on(c) && (rc = comm_allreduce(c, tmp, n))) return rc;
       rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, tmp, o);
     }
@@ -948,7 +1036,7 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
       if ((rc = sync_bodies(c))) return rc;
       int b0 = 0, b1 = -1;
       if (comm_on(c)) comm_body_range(c, &b0, &b1);
-      if (b1 != b0 && (rc = pc_block_factors(c, b0, b1))) return rc;
+      if (b1 != b0 && (rc = blk_prepare(c, b0, b1))) return rc;
     }
     int v = 0;   // pairs of vectors in lock step (shared pair coefficients), a single one alone
     for (; v + 2 <= nvec; v += 2)
@@ -1081,14 +1169,10 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
   int rc = sync_bodies(c); if (rc) return rc;
   if (mode < 0 || mode > 3 || !d_in || !d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x");
   if (body_end < 0) body_end = c->S.N_bod;
-  if ((rc = pc_block_factors(c, body_begin, body_end))) return rc;
-  const int64_t m = 3 * (int64_t)c->S.N_blb;
-  const double *L = (const double *)c->d_blkL.p + (size_t)body_begin * (size_t)(m * m);
-  const double *in = d_in + (size_t)body_begin * (size_t)m;
-  double *out = d_out + (size_t)body_begin * (size_t)m;
+  if ((rc = blk_prepare(c, body_begin, body_end))) return rc;
   const int nb = body_end - body_begin;
-  rc = mode == 3 ? rbl_launch_block_trmv(c->stream, L, m, nb, m * m, in, out, m)
-                 : blk_solve(c, body_begin, nb, d_in, d_out, 1, 0, mode);
+  if (mode == 3 && d_in == d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 3 does not work in place");
+  rc = mode == 3 ? blk_trmv(c, body_begin, nb, d_in, d_out) : blk_solve(c, body_begin, nb, d_in, d_out, 1, 0, mode);
   if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
   return RBL_OK;
 }
@@ -1201,7 +1285,8 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (!c) return RBL_ERR_ARG;
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
   if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
-  if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
+  if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
+  if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
   if (variant == 51 || variant == 52) { c->gmres_relax = (variant == 52); return RBL_OK; }           // inexact-Krylov relaxed products in GMRES off / on
   if (variant == 53 || variant == 54) { c->force_relaxed = (variant == 54); return RBL_OK; }         // hook: every full product relaxed off / on   // GMRES: reference-sign / restored-sign PC
   if (variant == 21 || variant == 22) { c->sym_tune.ni2 = variant - 20; return RBL_OK; }   // experiment: rows per lane of the 2-vector kernel
@@ -1304,7 +1389,7 @@ static int pc_block_build(rbl_ctx *c)
   const int nbo = b1 - b0;
   const size_t off = (size_t)b0 * (size_t)m;
   int rc;
-  if (nbo > 0 && (rc = pc_block_factors(c, b0, b1))) return rc;
+  if (nbo > 0 && (rc = blk_prepare(c, b0, b1))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__res
 //                   VALU form with the T operand broadcast from LDS was LDS-bandwidth-bound, 709 us at 50 x 486), the
 //                   IB x IB diagonal products go through LDS; stores X twice: XL column-major (X[r][c] at c n + r) and XU row-major (r n + c), so that
 //                   X v and X^T v both read consecutive addresses across a wavefront.
-//   k_block_inv_apply : workgroup = 64 outputs x 8 waves, each wave an eighth of the sum (interleaved), fixed-order LDS
+//   k_block_inv_apply : workgroup = 63 outputs (21 blobs) x 8 waves, each wave an eighth of the sum (interleaved), fixed-order LDS
 //                   reduction; out = X v (upper = 0) or X^T v (upper = 1).
 __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict__ L, long n, long strideA,
                                                        const double *__restrict__ Linv, long strideL, double *__restrict__ X)
@@ -1161,25 +1161,53 @@ __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict_
   }
 }
 
-constexpr int BIA_W = 8;      // waves per workgroup of k_block_inv_apply: 64 outputs, each wave an eighth of every sum
+constexpr int BIA_W = 8;      // waves per workgroup of k_block_inv_apply: BIA_R outputs, each wave an eighth of every sum
+constexpr int BIA_R = 63;     // outputs per workgroup: 21 whole blobs (the optional output rotation needs whole blobs)
 
+__device__ __forceinline__ void quat_rot_d(const double *q, double *R)      // R(Q), scalar-first unit quaternion
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// mstride: doubles between the matrices of consecutive bodies (2 n^2; 0 = ONE body-frame matrix shared by all bodies, see
+// the body-frame factors in rbl_api.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
+// blob), rot & 2: the output is rotated back (x_k <- R_b x_k); Q: quaternions of the bodies (4 per body, relative to b = 0).
 template <int NV>
-__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__restrict__ X, long n, const double *in, double *out,
-                                                         long vec_stride, long rhs_pitch, int upper)
+__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__restrict__ X, long n, long mstride,
+                                                                const double *in, double *out, long vec_stride, long rhs_pitch,
+                                                                int upper, const double *__restrict__ Q, int rot)
 {
   extern __shared__ double v[];                      // NV x n vector, then BIA_W x 64 x NV partial sums
   double *red = v + (size_t)NV * n;
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const double *A = X + (size_t)b * 2 * (size_t)(n * n) + (upper ? (size_t)(n * n) : 0);
+  const double *A = X + (size_t)b * (size_t)mstride + (upper ? (size_t)(n * n) : 0);
+  double R[9];
+  if (rot) quat_rot_d(Q + 4 * (size_t)b, R);
 #pragma unroll
   for (int vv = 0; vv < NV; ++vv) {
     const double *vin = in + (size_t)vv * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-    for (long q = t; q < n; q += 64 * BIA_W) v[(size_t)vv * n + q] = vin[q];
+    for (long k = t; 3 * k < n; k += 64 * BIA_W) {   // one blob (three entries) per thread
+      const double a0 = vin[3 * k], a1 = vin[3 * k + 1], a2 = vin[3 * k + 2];
+      double *d = v + (size_t)vv * n + 3 * k;
+      if (rot & 1) {                                 // R^T a
+        d[0] = R[0] * a0 + R[3] * a1 + R[6] * a2;
+        d[1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
+        d[2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
+      } else { d[0] = a0; d[1] = a1; d[2] = a2; }
+    }
   }
   __syncthreads();
-  const long e0 = (long)blockIdx.x * 64, e = e0 + lane, ec = e < n ? e : n - 1;
+  const long e0 = (long)blockIdx.x * BIA_R, e = e0 + lane, ec = e < n ? e : n - 1;
+  const long eend = (e0 + BIA_R < n) ? e0 + BIA_R : n;
   // X v: columns q <= e (the wave's range ends with its last row);  X^T v: rows q >= e
-  const long qlo = upper ? e0 : 0, qhi = upper ? n : ((e0 + 64 < n) ? e0 + 64 : n);
+  const long qlo = upper ? e0 : 0, qhi = upper ? n : eend;
   double acc[NV];
 #pragma unroll
   for (int vv = 0; vv < NV; ++vv) acc[vv] = 0.0;
@@ -1204,14 +1232,54 @@ __global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__
 #pragma unroll
   for (int vv = 0; vv < NV; ++vv) red[(w * 64 + lane) * NV + vv] = acc[vv];
   __syncthreads();
-  if (w == 0 && e < n) {
+  double r[NV];
+  if (w == 0) {
 #pragma unroll
     for (int vv = 0; vv < NV; ++vv) {
-      double r = red[lane * NV + vv];
+      double sum = red[lane * NV + vv];
 #pragma unroll
-      for (int ww = 1; ww < BIA_W; ++ww) r += red[(ww * 64 + lane) * NV + vv];          // fixed order
-      out[(size_t)vv * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride + e] = r;
+      for (int ww = 1; ww < BIA_W; ++ww) sum += red[(ww * 64 + lane) * NV + vv];        // fixed order
+      r[vv] = sum;
     }
+  }
+  if (rot & 2) {                                     // whole blobs of this workgroup: x_k <- R x_k
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int vv = 0; vv < NV; ++vv) red[vv * 64 + lane] = r[vv];
+    }
+    __syncthreads();
+    if (w == 0) {
+      const int k3 = 3 * (lane / 3), d = lane % 3;
+#pragma unroll
+      for (int vv = 0; vv < NV; ++vv) {
+        const double *x = red + vv * 64 + k3;
+        r[vv] = R[3 * d] * x[0] + R[3 * d + 1] * x[1] + R[3 * d + 2] * x[2];
+      }
+    }
+  }
+  if (w == 0 && lane < BIA_R && e < n) {
+#pragma unroll
+    for (int vv = 0; vv < NV; ++vv) out[(size_t)vv * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride + e] = r[vv];
+  }
+}
+
+// v_k <- R_b v_k (transpose = 0) or R_b^T v_k (1) for every blob k of bodies 0 .. (pointers relative to the first body)
+__global__ void k_rotate_bodies(const double *__restrict__ Q, const double *in, double *out, int N_blb, long nblobs,
+                                long rhs_pitch, int transpose)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nblobs) return;
+  double R[9];
+  quat_rot_d(Q + 4 * (k / N_blb), R);
+  const size_t o = (size_t)blockIdx.y * (size_t)rhs_pitch + 3 * (size_t)k;
+  const double a0 = in[o], a1 = in[o + 1], a2 = in[o + 2];
+  if (transpose) {
+    out[o] = R[0] * a0 + R[3] * a1 + R[6] * a2; out[o + 1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
+    out[o + 2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
+  } else {
+    out[o] = R[0] * a0 + R[1] * a1 + R[2] * a2; out[o + 1] = R[3] * a0 + R[4] * a1 + R[5] * a2;
+    out[o + 2] = R[6] * a0 + R[7] * a1 + R[8] * a2;
   }
 }
 }  // namespace
@@ -1234,29 +1302,44 @@ int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int b
 }
 
 // mode 0: x = X^T X v ;  1: x = X v ;  2: x = X^T v  (= (L L^T)^-1 v, L^-1 v, L^-T v).  d_tmp: nv vectors of
-// tmp_pitch doubles (mode 0 only; laid out like d_out).  In place is fine for mode 0, not for 1 / 2.
+// rhs_pitch doubles (mode 0 only; laid out like d_out).  In place is fine for mode 0, not for 1 / 2.
+// d_Q != NULL: d_X is ONE body-frame inverse shared by all bodies and the factor meant is G_b = R_b L (G G^T = M_b):
+// G^-1 v = X R^T v, G^-T v = R X^T v, (G G^T)^-1 v = R X^T X R^T v  (d_Q: the bodies' quaternions, first body first).
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
-                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp)
+                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q)
 {
   if (n > BSS_T) return RBL_ERR_SIZE;
   if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
   if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
-  const dim3 grid((unsigned)((n + 63) / 64), batch);
+  const dim3 grid((unsigned)((n + BIA_R - 1) / BIA_R), batch);
+  const long mstride = d_Q ? 0 : 2 * (long)(n * n);
   auto pass = [&](const double *in, double *out, int upper) {
+    const int rot = d_Q ? (upper ? 2 : 1) : 0;
     for (int v0 = 0; v0 < nv;) {
       const int g = nv - v0 >= 3 ? 3 : nv - v0;
       const size_t lds = sizeof(double) * ((size_t)g * (size_t)n + 64 * BIA_W * (size_t)g);
       const double *pi = in + (size_t)v0 * (size_t)rhs_pitch;
       double *po = out + (size_t)v0 * (size_t)rhs_pitch;
-      if (g == 3) hipLaunchKernelGGL(k_block_inv_apply<3>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
-      else if (g == 2) hipLaunchKernelGGL(k_block_inv_apply<2>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
-      else hipLaunchKernelGGL(k_block_inv_apply<1>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, pi, po, (long)vec_stride, (long)rhs_pitch, upper);
+      if (g == 3) hipLaunchKernelGGL(k_block_inv_apply<3>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+      else if (g == 2) hipLaunchKernelGGL(k_block_inv_apply<2>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+      else hipLaunchKernelGGL(k_block_inv_apply<1>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
       v0 += g;
     }
   };
   if (mode == 0) { pass(d_in, d_tmp, 0); pass(d_tmp, d_out, 1); }
   else pass(d_in, d_out, mode == 1 ? 0 : 1);
   return RBL_OK;
+}
+
+// nv vectors (rhs_pitch apart) of `batch` bodies with N_blb blobs each: every blob's three entries rotated by its body's
+// R (transpose = 0) or R^T (1).  In place is fine.
+void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,
+                              int64_t rhs_pitch, int transpose)
+{
+  const long nblobs = (long)N_blb * batch;
+  if (nblobs <= 0 || nv <= 0) return;
+  hipLaunchKernelGGL(k_rotate_bodies, dim3((unsigned)((nblobs + 255) / 256), nv), dim3(256), 0, st, d_Q, d_in, d_out, N_blb,
+                     nblobs, (long)rhs_pitch, transpose);
 }
 
 // y_b = L_b x_b for every matrix of the batch (lower-triangular product): one workgroup per matrix, x in LDS,
@@ -1294,7 +1377,7 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
   return RBL_OK;
 }
 
-// mode 0: x = (L L^T)^-1 v ;  1: x = L^-1 v ;  2: x = L^-T v.  nv vectors per matrix, rhs_pitch doubles apart: up to three
+// mode 0: x = (L L^T)^-1 v ;  1: x = L^-1 v ;  2: x = L^-T v  (| 0x100: ONE factor shared by the whole batch).  nv vectors per matrix, rhs_pitch doubles apart: up to three
 // share one pass over L (LDS: nv (n + 32) doubles <= 64 KB), more are done in groups.  In place (d_out == d_in) is fine.
 int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
                                  const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
@@ -1302,7 +1385,9 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
 {
   if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
-  const long strideL = (long)(nsteps * IB * IB);
+  const bool shared = (mode & 0x100) != 0;           // one factor for every body of the batch (strideA = 0 by the caller)
+  mode &= 0xff;
+  const long strideL = shared ? 0 : (long)(nsteps * IB * IB);
   for (int v0 = 0; v0 < nv;) {
     int g = nv - v0 >= 3 ? 3 : nv - v0;
     while (g > 1 && (size_t)g * (size_t)(n + IB) * sizeof(double) > 65536) --g;

@@ -76,6 +76,10 @@ struct rbl_ctx {
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 of small bodies (two layouts), scratch of their application
+  // free space: M_b = (I x R_b) M_body (I x R_b)^T with ONE body-frame matrix for all bodies and all time: its factor
+  // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
+  RblDevBuf d_bfL, d_bfLinv, d_bfX;
+  bool blk_bodyframe = true, bf_valid = false, bf_inv = false;   // rbl_set_tuning 71 / 72
   RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
   bool ktl_arm = false; const double *ktl_of = nullptr;   // armed by the GMRES loop only; ktl_of = the vector d_ktl belongs to
   bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
@@ -183,7 +187,10 @@ size_t rbl_block_inverse_bytes(int64_t n, int batch);
 int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
                              double *d_X);
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
-                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp);
+                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp,
+                               const double *d_Q = nullptr);
+void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,
+                              int64_t rhs_pitch, int transpose);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
                            double *d_out, double *d_part);
 size_t rbl_trmv_part_bytes(int64_t n);

@@ -997,6 +997,7 @@ def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     for variant in (61, 62):
         ctx = DeviceContext(1.0, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
+        ctx.set_tuning(0, 71)                    # per-configuration Cholesky factors (the body-frame form has its own test)
         ctx.set_tuning(0, variant)
         for mode in (0, 1, 2):
             o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
@@ -1021,6 +1022,62 @@ def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
         for variant in (61, 62):
             assert rel(res[(variant, mode)].cpu().numpy(), ref) < 1e-10, (variant, mode)
         assert rel(res[(62, mode)].cpu().numpy(), res[(61, mode)].cpu().numpy()) < 1e-11
+
+
+@pytest.mark.parametrize("nblb", [12, 42, 86, 162, 200])
+def test_free_space_body_frame_factors(orc, nblb):
+    """Without the wall term every body's mobility is one body-frame matrix seen through the body's rotation, so the block
+    operations factor that matrix ONCE (rbl_set_parameters) and use G_b = (I x R_b) L for body b (G G^T = M_b; not
+    triangular).  Whatever the factor, the four operations must satisfy, against the dense per-body mobility M_b of the
+    oracle:  mode 0 = M_b^-1 v;  mode 1 (G^-1) after mode 3 (G x) = identity;  mode 2 (G^-T): G^-1 M_b G^-T = identity;
+    mode 3: G G^T v = M_b v with G^T v = M_b (G^-T ... ) -- checked as mode3(mode1(M_b v)) = M_b v and
+    mode1(M_b mode2(v)) = v.  Sizes: substitution (n = 36, 126, 600) and explicit-inverse (258, 486) forms, body ranges, in
+    place; and mode 0 equals the per-configuration Cholesky path (rbl_set_tuning 71) to rounding."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    nb = 5
+    rng = np.random.default_rng(100 + nblb)
+    kk = np.arange(nblb) + 0.5
+    th, ph = np.arccos(1.0 - 2.0 * kk / nblb), np.pi * (1.0 + 5.0 ** 0.5) * kk
+    cfg = 0.7 * np.sqrt(nblb) * np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1)
+    R = float(np.linalg.norm(cfg, axis=1).max()) + 1.5
+    X = np.array([[3.0 * R * b, 0.5 * b, R + 0.3 * b] for b in range(nb)])
+    Q = rng.standard_normal((nb, 4)); Q /= np.linalg.norm(Q, axis=1)[:, None]
+    dev = torch.device("cuda:0")
+    m = 3 * nblb
+    v = torch.from_numpy(rng.standard_normal(m * nb)).to(dev)
+    ctx = DeviceContext(1.0, 1.0, False, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    rt = torch.empty(m * nb, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, rt.data_ptr()); ctx.sync_check()
+    M = orc.rotne_prager_tensor(rt.cpu().numpy(), 1.0, 1.0, False)
+    Mb = [torch.from_numpy(M[m * b:m * (b + 1), m * b:m * (b + 1)].copy()).to(dev) for b in range(nb)]
+
+    def blockmul(x):
+        return torch.cat([Mb[b] @ x[m * b:m * (b + 1)] for b in range(nb)])
+
+    def bs(x, mode, b0=0, b1=-1):
+        o = torch.full_like(x, 7.5)
+        ctx.block_solve(x.contiguous().data_ptr(), o.data_ptr(), mode, b0, b1); ctx.sync_check()
+        return o
+
+    x0 = bs(v, 0)
+    ref0 = torch.cat([torch.linalg.solve(Mb[b], v[m * b:m * (b + 1)]) for b in range(nb)])
+    assert float(torch.linalg.norm(x0 - ref0) / torch.linalg.norm(ref0)) < 1e-10
+    Mv = blockmul(v)
+    assert float(torch.linalg.norm(bs(bs(Mv, 1), 3) - Mv) / torch.linalg.norm(Mv)) < 1e-10          # G G^-1 = I
+    assert float(torch.linalg.norm(bs(blockmul(bs(v, 2)), 1) - v) / torch.linalg.norm(v)) < 1e-10   # G^-1 M G^-T = I
+    assert float(torch.linalg.norm(bs(bs(v, 1), 2) - ref0) / torch.linalg.norm(ref0)) < 1e-10       # G^-T G^-1 = M^-1
+    for mode in (0, 1, 2, 3):
+        full = bs(v, mode)
+        part = bs(v, mode, 1, 4)
+        assert torch.equal(part[m:4 * m], full[m:4 * m]) and torch.all(part[:m] == 7.5) and torch.all(part[4 * m:] == 7.5)
+        if mode != 3:
+            w = v.clone(); ctx.block_solve(w.data_ptr(), w.data_ptr(), mode); ctx.sync_check()
+            assert torch.equal(w, full)
+    ctx.set_tuning(0, 71)                                    # per-configuration factors: the same inverse
+    assert float(torch.linalg.norm(bs(v, 0) - x0) / torch.linalg.norm(x0)) < 1e-11
+    ctx.close()
 
 
 @pytest.mark.parametrize("block", [False, True])
@@ -1282,7 +1339,8 @@ def test_one_kernel_gmres_equals_general_solver(wall, nb, nblb):
 
 @pytest.mark.parametrize("wall", [False, True])
 def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
-    """method 'lanczos_pc': x = B L S^{1/2} W with S = L^-1 M L^-T (L L^T = per-body mobility) -- against the same
+    """method 'lanczos_pc': x = B L S^{1/2} W with S = L^-1 M L^-T (L L^T = per-body mobility: the Cholesky factor of the
+    wall-corrected block, or in free space the body-frame Cholesky factor rotated with the body) -- against the same
     expression assembled from the oracle's dense matrix; and its covariance factor is exact: (B L S^1/2)(...)^T = B M B."""
     from oracle import oracle as onp
     nb = 5
@@ -1300,9 +1358,20 @@ def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
     M = orc.rotne_prager_tensor(r, 1.0, 1.0, wall)
     B = orc.damp(r, 1.0)
     L = np.zeros_like(M)
-    for b in range(nb):
-        sl = slice(36 * b, 36 * (b + 1))
-        L[sl, sl] = np.linalg.cholesky(M[sl, sl])
+    if wall:                                    # per-configuration Cholesky factors of the wall-corrected blocks
+        for b in range(nb):
+            sl = slice(36 * b, 36 * (b + 1))
+            L[sl, sl] = np.linalg.cholesky(M[sl, sl])
+    else:                                       # free space: ONE body-frame factor, rotated with each body: G_b = (I x R_b) L_body
+        from scipy.spatial.transform import Rotation
+        c0 = np.asarray(shell12, dtype=np.float64) - np.asarray(shell12, dtype=np.float64).mean(axis=0)
+        Lbody = np.linalg.cholesky(orc.rotne_prager_tensor(c0.reshape(-1), 1.0, 1.0, False))
+        Qn = np.asarray(Q, dtype=np.float64).reshape(nb, 4); Qn = Qn / np.linalg.norm(Qn, axis=1)[:, None]
+        for b in range(nb):
+            sl = slice(36 * b, 36 * (b + 1))
+            Rb = Rotation.from_quat([Qn[b, 1], Qn[b, 2], Qn[b, 3], Qn[b, 0]]).as_matrix()
+            L[sl, sl] = np.kron(np.eye(12), Rb) @ Lbody
+            assert np.linalg.norm(L[sl, sl] @ L[sl, sl].T - M[sl, sl]) < 1e-12 * np.linalg.norm(M[sl, sl])   # a factor of M_b
     Li = np.linalg.inv(L)
     S = Li @ M @ Li.T
     lam, Z = np.linalg.eigh(0.5 * (S + S.T))
