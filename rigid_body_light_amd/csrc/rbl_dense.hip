@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__res
 //                   VALU form with the T operand broadcast from LDS was LDS-bandwidth-bound, 709 us at 50 x 486), the
 //                   IB x IB diagonal products go through LDS; stores X twice: XL column-major (X[r][c] at c n + r) and XU row-major (r n + c), so that
 //                   X v and X^T v both read consecutive addresses across a wavefront.
-//   k_block_inv_apply : workgroup = 63 outputs (21 blobs) x 8 waves, each wave an eighth of the sum (interleaved), fixed-order LDS
+//   k_block_inv_apply : workgroup = 63 outputs (21 blobs) x 4 waves, each wave a quarter of the sum (interleaved), fixed-order LDS
 //                   reduction; out = X v (upper = 0) or X^T v (upper = 1).
 __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict__ L, long n, long strideA,
                                                        const double *__restrict__ Linv, long strideL, double *__restrict__ X)
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict_
   }
 }
 
-constexpr int BIA_W = 8;      // waves per workgroup of k_block_inv_apply: BIA_R outputs, each wave an eighth of every sum
+constexpr int BIA_W = 4;      // waves per workgroup of k_block_inv_apply: BIA_R outputs, each wave a quarter of every sum (measured at 50 x 486: 2 waves 27 us, 4 waves 15.8, 8 waves 18.2)
 constexpr int BIA_R = 63;     // outputs per workgroup: 21 whole blobs (the optional output rotation needs whole blobs)
 
 __device__ __forceinline__ void quat_rot_d(const double *q, double *R)      // R(Q), scalar-first unit quaternion
