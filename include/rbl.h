@@ -252,9 +252,13 @@ int rbl_K_x_U_dev(rbl_ctx *ctx, const double *d_U, double *d_out);            /*
 int rbl_KT_x_Lam_dev(rbl_ctx *ctx, const double *d_lambda, double *d_out);    /* KT_x_Lam :410 */
 int rbl_apply_PC_dev(rbl_ctx *ctx, const double *d_in, double *d_out);        /* apply_PC :589, diagonal PC */
 int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /* src/Rigid.py:73-80 */
-/* Per-body Cholesky factors L L^T = M_body of the object's own configuration (wall term per wall_PC, undamped;
- * the block-diagonal preconditioner's factors), applied to a blob vector d_in[n3] -> d_out[n3]:
- * mode 0: (L L^T)^-1 x, 1: L^-1 x, 2: L^-T x, 3: L x.  rbl_set_no_damp(ctx, 1) makes the matvec entry points
+/* Per-body factors L L^T = M_body of the object's own configuration (wall term per wall_PC, undamped; the
+ * block-diagonal preconditioner's factors), applied to a blob vector d_in[n3] -> d_out[n3]:
+ * mode 0: (L L^T)^-1 x, 1: L^-1 x, 2: L^-T x, 3: L x (mode 3 not in place).  With the wall term L is the lower Cholesky
+ * factor of the body's block, rebuilt per configuration.  In free space every body's block is ONE body-frame matrix seen
+ * through the body's rotation, M_b = (I x R_b) M_body (I x R_b)^T, so the factor is L = (I x R_b) chol(M_body): built once per
+ * rbl_set_parameters, exact for every configuration, not triangular (mode 0 is the same operator either way;
+ * rbl_set_tuning(ctx, 0, 71) restores per-configuration Cholesky factors).  rbl_set_no_damp(ctx, 1) makes the matvec entry points
  * apply the plain wall-corrected M (no damping B) until switched off again: together they let a caller compose
  * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product. */
 int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode);
@@ -327,7 +331,9 @@ int rbl_sync_check(rbl_ctx *ctx);
  * ~1.8x faster); the solution still satisfies the fp64 system to rtol (tests check the true residual);
  * 53 / 54: test hook, every full product through that relaxed kernel off / on;
  * 61 / 62: per-body factors of bodies with 65..170 blobs applied by substitution / through explicit inverses L^-1
- * (default; built with the factors, a sweep becomes one triangular matrix-vector product).  All per context. */
+ * (default; built with the factors, a sweep becomes one triangular matrix-vector product);
+ * 71 / 72: free space only: per-configuration Cholesky factors of every body / one body-frame factor rotated with each
+ * body (default; see rbl_block_solve_dev).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

@@ -794,7 +794,10 @@ static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out,
             RBL_HIP(c, hipMemcpyAsync(po + (size_t)v * (size_t)pitch, tmp + off + (size_t)v * (size_t)pitch,
                                       sizeof(double) * (size_t)m * (size_t)nbo, hipMemcpyDeviceToDevice, c->stream));
         }
-      } else {                                          // substitution through the ONE shared factor (batch stride 0)
+      } else if (m <= 512) {                            // short chains: substitution through the ONE shared factor, rotations fused
+        rc = rbl_launch_block_solve_multi(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, (const double *)c->d_bfLinv.p, pi, po, m, g,
+                                          pitch, mode | 0x100, dQ);
+      } else {                                          // large bodies: rotate, substitute (batch stride 0), rotate back
         const double *src = pi;
         if (mode != 2) {                                // R^T first (scratch laid out like the vectors)
           rbl_launch_rotate_bodies(c->stream, dQ, pi, tmp + off, c->S.N_blb, nbo, g, pitch, 1);

@@ -894,21 +894,47 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
 // round trip to L2 / HBM (n = 486: 147 -> ~40 us for both sweeps).  Same operation order per row as k_block_solve.
 constexpr int BSS_T = 512;
 
+__device__ __forceinline__ void quat_rot_d(const double *q, double *R)      // R(Q), scalar-first unit quaternion
+{
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+
 template <int NV>
 __global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__restrict__ L, long n, long strideA,
                                                              const double *__restrict__ Linv, long strideL,
                                                              const double *in, double *out, long vec_stride, long rhs_pitch,
-                                                             int mode /* 0: L L^T, 1: L only, 2: L^T only */)
+                                                             int mode /* 0: L L^T, 1: L only, 2: L^T only */,
+                                                             const double *__restrict__ Q, int rot)
 {
+  // Q, rot: body-frame factor shared by all bodies (strideA = strideL = 0): rot & 1 rotates the input into the body frame
+  // (v_k <- R_b^T v_k per blob), rot & 2 the result back (x_k <- R_b x_k) -- see bf_build in rbl_api.hip
   extern __shared__ double y[];                      // NV x n doubles + NV x IB scratch
   double *tbuf = y + (size_t)NV * n;                 // tbuf[v * IB + m]
   const int b = blockIdx.x, t = threadIdx.x;
   const double *Lb = L + (size_t)b * (size_t)strideA;
   const double *Lib = Linv + (size_t)b * (size_t)strideL;
+  double R[9];
+  if (rot) quat_rot_d(Q + 4 * (size_t)b, R);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-    if (t < n) y[(size_t)v * n + t] = vin[t];
+    if (3 * t < n) {                                 // one blob (three entries) per thread
+      const double a0 = vin[3 * t], a1 = vin[3 * t + 1], a2 = vin[3 * t + 2];
+      double *d = y + (size_t)v * n + 3 * t;
+      if (rot & 1) {
+        d[0] = R[0] * a0 + R[3] * a1 + R[6] * a2;
+        d[1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
+        d[2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
+      } else { d[0] = a0; d[1] = a1; d[2] = a2; }
+    }
   }
   const int nsteps = (int)((n + IB - 1) / IB);
   const bool diag = t < IB * NV;                     // threads 0 .. NV*IB-1: (vector, row of the diagonal block)
@@ -1027,7 +1053,14 @@ __global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__res
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-    if (t < n) o[t] = y[(size_t)v * n + t];
+    if (3 * t < n) {
+      const double *x = y + (size_t)v * n + 3 * t;
+      if (rot & 2) {
+        o[3 * t] = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+        o[3 * t + 1] = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+        o[3 * t + 2] = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+      } else { o[3 * t] = x[0]; o[3 * t + 1] = x[1]; o[3 * t + 2] = x[2]; }
+    }
   }
 }
 
@@ -1163,18 +1196,6 @@ __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict_
 
 constexpr int BIA_W = 4;      // waves per workgroup of k_block_inv_apply: BIA_R outputs, each wave a quarter of every sum (measured at 50 x 486: 2 waves 27 us, 4 waves 15.8, 8 waves 18.2)
 constexpr int BIA_R = 63;     // outputs per workgroup: 21 whole blobs (the optional output rotation needs whole blobs)
-
-__device__ __forceinline__ void quat_rot_d(const double *q, double *R)      // R(Q), scalar-first unit quaternion
-{
-  const double w = q[0], x = q[1], y = q[2], z = q[3];
-  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const double twx = tx * w, twy = ty * w, twz = tz * w;
-  const double txx = tx * x, txy = ty * x, txz = tz * x;
-  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
-  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
-}
 
 // mstride: doubles between the matrices of consecutive bodies (2 n^2; 0 = ONE body-frame matrix shared by all bodies, see
 // the body-frame factors in rbl_api.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
@@ -1381,8 +1402,9 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
 // share one pass over L (LDS: nv (n + 32) doubles <= 64 KB), more are done in groups.  In place (d_out == d_in) is fine.
 int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
                                  const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
-                                 int64_t rhs_pitch, int mode)
+                                 int64_t rhs_pitch, int mode, const double *d_Q)
 {
+  // d_Q (with | 0x100 and n <= 512 only): the shared factor is a body-frame one, G_b = R_b L -- rotations fused into the sweep
   if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
   const bool shared = (mode & 0x100) != 0;           // one factor for every body of the batch (strideA = 0 by the caller)
@@ -1394,17 +1416,19 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     const size_t lds = sizeof(double) * (size_t)g * (size_t)(n + IB);
     const double *in = d_in + (size_t)v0 * (size_t)rhs_pitch;
     double *out = d_out + (size_t)v0 * (size_t)rhs_pitch;
+    if (d_Q && !(shared && n <= BSS_T)) return RBL_ERR_ARG;
     if (n <= BSS_T) {          // small bodies: one row per thread, factor entries prefetched a step ahead
       const int th = (int)(n <= 128 ? 128 : ((n + 63) / 64) * 64);
+      const int rot = d_Q ? ((mode != 2 ? 1 : 0) | (mode != 1 ? 2 : 0)) : 0;
       if (g == 3)
         hipLaunchKernelGGL(k_block_solve_small<3>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
-                           out, (long)vec_stride, (long)rhs_pitch, mode);
+                           out, (long)vec_stride, (long)rhs_pitch, mode, d_Q, rot);
       else if (g == 2)
         hipLaunchKernelGGL(k_block_solve_small<2>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
-                           out, (long)vec_stride, (long)rhs_pitch, mode);
+                           out, (long)vec_stride, (long)rhs_pitch, mode, d_Q, rot);
       else
         hipLaunchKernelGGL(k_block_solve_small<1>, dim3(batch), dim3(th), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
-                           out, (long)vec_stride, (long)rhs_pitch, mode);
+                           out, (long)vec_stride, (long)rhs_pitch, mode, d_Q, rot);
       v0 += g;
       continue;
     }

@@ -178,7 +178,7 @@ int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int bat
                            const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode = 0);
 int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
                                  const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
-                                 int64_t rhs_pitch, int mode);
+                                 int64_t rhs_pitch, int mode, const double *d_Q = nullptr);
 int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                           double *d_out, int64_t vec_stride);
 // explicit per-body inverses for small bodies (3 N_blb <= 512): substitution sweeps become triangular matrix-vector products

@@ -29,3 +29,16 @@ for variant, name in ((61, "substitution"), (62, "explicit inverse")):
         line += " mode %d %.1f us" % (mode, e0.elapsed_time(e1) * 1e3 / 200)
     print(line, flush=True)
     ctx.close()
+# per-configuration factors (what a wall-corrected system needs) for comparison
+ctx = DeviceContext(c["a"], c["eta"], False, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+ctx.set_config(c["X"], c["Q"]); ctx.set_tuning(0, 71)
+ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); torch.cuda.synchronize()
+line = "per-configuration Cholesky (tuning 71):"
+for mode in (0, 1, 2):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ctx.block_solve(v.data_ptr(), o.data_ptr(), mode)
+    e1.record(); torch.cuda.synchronize()
+    line += " mode %d %.1f us" % (mode, e0.elapsed_time(e1) * 1e3 / 50)
+print(line, flush=True)
