@@ -333,7 +333,10 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 61 / 62: per-body factors of bodies with 65..170 blobs applied by substitution / through explicit inverses L^-1
  * (default; built with the factors, a sweep becomes one triangular matrix-vector product);
  * 71 / 72: free space only: per-configuration Cholesky factors of every body / one body-frame factor rotated with each
- * body (default; see rbl_block_solve_dev).  All per context. */
+ * body (default; see rbl_block_solve_dev);
+ * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an
+ * approximate block factor (no factorisation, 29.7 MB instead of 5.9 GB at cfg 3; one or two more GMRES iterations --
+ * measured level in time at cfg 3, so not the default).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

@@ -737,7 +737,7 @@ static int pc_block_factors(rbl_ctx *c, int b0 = 0, int b1 = -1);
 // for body b is G_b = (I x R_b) L  (G G^T = M_b; not triangular, which nothing here needs):
 //   (G G^T)^-1 v = R (L L^T)^-1 R^T v,   G^-1 v = L^-1 R^T v,   G^-T v = R L^-T v,   G x = R L x.
 // One matrix for all bodies also means the factor is read from cache instead of HBM.
-static bool bf_on(const rbl_ctx *c) { return c->blk_bodyframe && !c->S.wall; }
+static bool bf_on(const rbl_ctx *c) { return c->blk_bodyframe && (!c->S.wall || c->bf_wall_approx); }
 
 static int bf_build(rbl_ctx *c)
 {
@@ -1288,6 +1288,7 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (!c) return RBL_ERR_ARG;
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
   if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
+  if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
   if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
   if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
   if (variant == 51 || variant == 52) { c->gmres_relax = (variant == 52); return RBL_OK; }           // inexact-Krylov relaxed products in GMRES off / on

@@ -80,6 +80,7 @@ struct rbl_ctx {
   // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
   RblDevBuf d_bfL, d_bfLinv, d_bfX;
   bool blk_bodyframe = true, bf_valid = false, bf_inv = false;   // rbl_set_tuning 71 / 72
+  bool bf_wall_approx = false;                                   // rbl_set_tuning 73 / 74 (experiment)
   RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
   bool ktl_arm = false; const double *ktl_of = nullptr;   // armed by the GMRES loop only; ktl_of = the vector d_ktl belongs to
   bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
