@@ -283,7 +283,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -757,6 +757,11 @@ static int bf_build(rbl_ctx *c)
     if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, 1, msz, (const double *)c->d_bfLinv.p, (double *)c->d_bfX.p)))
       return rbl_fail(c, rc, "body-frame inverse launch failed");
     c->bf_inv = true;
+    // tables of the whole block preconditioner in the body frame: M_body^-1, M_body^-1 K_body, chol(K_body^T M_body^-1 K_body)
+    if ((rc = rbl_dev_reserve(c, c->d_bfPC, sizeof(double) * ((size_t)msz + 6 * (size_t)m + 36)))) return rc;
+    double *Minv = (double *)c->d_bfPC.p;
+    rbl_launch_bf_tables(c->stream, (const double *)c->d_bfX.p + (size_t)msz, (const double *)c->d_cfg.p, m, Minv, Minv + (size_t)msz,
+                         Minv + (size_t)msz + 6 * (size_t)m, c->d_err);
   }
   c->bf_valid = true;
   return RBL_OK;
@@ -1394,6 +1399,7 @@ static int pc_block_build(rbl_ctx *c)
   const size_t off = (size_t)b0 * (size_t)m;
   int rc;
   if (nbo > 0 && (rc = blk_prepare(c, b0, b1))) return rc;
+  if (bf_on(c) && c->bf_inv) return RBL_OK;              // free space, small bodies: everything was built with the body-frame factor
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
@@ -1431,6 +1437,22 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   int rc;
   if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
   c->ktl_of = nullptr;
+  if (bf_on(c) && c->bf_inv) {                           // the whole application in the body frame, one launch
+    if (nbo > 0) {
+      double *ktl = nullptr;
+      if (c->ktl_arm && !shard) {
+        if ((rc = rbl_dev_reserve(c, c->d_ktl, sizeof(double) * 6 * (size_t)S.N_bod))) return rc;
+        ktl = (double *)c->d_ktl.p;
+      }
+      const double *T = (const double *)c->d_bfPC.p;
+      if ((rc = rbl_launch_pc_bodyframe(c->stream, T, T + (size_t)(m * m), T + (size_t)(m * m) + 6 * (size_t)m, (const double *)c->d_cfg.p,
+                                        (const double *)c->d_XQ.p + 3 * (size_t)S.N_bod, m, b0, nbo, d_in, n3, c->pc_fsign, d_out, ktl)))
+        return rbl_fail(c, rc, "body-frame preconditioner launch failed");
+      if (ktl) c->ktl_of = d_out;
+    }
+    if (shard) return comm_allreduce(c, d_out, n3 + (int64_t)6 * S.N_bod);
+    return RBL_OK;
+  }
   if (nbo > 0) {
     if ((rc = blk_solve(c, b0, nbo, d_in, w1, 1, 0, 0))) return rc;                                      // invM slip
     // K^T (invM slip);  U (:601-608);  Lambda = invM (slip + K U) (:610) = invM slip + (invM K) U: no second pass over

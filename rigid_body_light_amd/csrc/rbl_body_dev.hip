@@ -354,6 +354,189 @@ __global__ void k_saddle_tail(const double *__restrict__ lever, const double *__
   out[3 * idx] = sub[3 * idx] - k0; out[3 * idx + 1] = sub[3 * idx + 1] - k1; out[3 * idx + 2] = sub[3 * idx + 2] - k2;
 }
 
+// ---- free space, small bodies: the WHOLE block preconditioner in the body frame (see bf_build in rbl_api.hip) ----------
+// M_b = (I x R) M_body (I x R)^T and K_b = (I x R) K_body blkdiag(R^T, R^T), so with s' = R^T slip, F' = (R^T F, R^T T):
+//   y1' = M_body^-1 s',  f' = K_body^T y1',  U' = N_body^-1 (fsign F' - f'),  Lambda' = y1' + (M_body^-1 K_body) U',
+//   Lambda = R Lambda',  U = (R U'_lin, R U'_ang),  K^T Lambda = (R, R) K_body^T Lambda'
+// with M_body^-1 (n x n), M_body^-1 K_body (n x 6) and chol(N_body) built ONCE per rbl_set_parameters:
+// one launch per application, nothing to build per configuration.
+__global__ void k_bf_minv(const double *__restrict__ XU, long n, double *__restrict__ Minv)   // Minv = X^T X, X row-major lower
+{
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (e >= n) return;
+  double acc = 0.0;
+  for (long r = (e > q ? e : q); r < n; ++r) acc = __builtin_fma(XU[(size_t)r * n + e], XU[(size_t)r * n + q], acc);
+  Minv[(size_t)q * n + e] = acc;
+}
+
+__global__ void k_bf_mk(const double *__restrict__ Minv, const double *__restrict__ cfg, long n, double *__restrict__ MK)
+{
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long k = 0; 3 * k < n; ++k) {
+    const double c0 = cfg[3 * k], c1 = cfg[3 * k + 1], c2 = cfg[3 * k + 2];
+    const double m0 = Minv[(size_t)(3 * k) * n + e], m1 = Minv[(size_t)(3 * k + 1) * n + e], m2 = Minv[(size_t)(3 * k + 2) * n + e];
+    acc[0] += m0; acc[1] += m1; acc[2] += m2;                 // K U = U_lin + om x c_k
+    acc[3] += m2 * c1 - m1 * c2;                               // om_x: (0, -c2, c1)
+    acc[4] += m0 * c2 - m2 * c0;                               // om_y: (c2, 0, -c0)
+    acc[5] += m1 * c0 - m0 * c1;                               // om_z: (-c1, c0, 0)
+  }
+  for (int c = 0; c < 6; ++c) MK[(size_t)c * n + e] = acc[c];
+}
+
+__global__ void k_bf_nl(const double *__restrict__ MK, const double *__restrict__ cfg, long n, double *__restrict__ NL, unsigned *err)
+{
+  __shared__ double N[36];
+  const int t = threadIdx.x;
+  if (t < 36) {                                                // N[p][c] = sum_rows K_body[row][p] MK[c][row]
+    const int p = t / 6, c = t % 6;
+    const double *col = MK + (size_t)c * n;
+    double acc = 0.0;
+    for (long k = 0; 3 * k < n; ++k) {
+      const double c0 = cfg[3 * k], c1 = cfg[3 * k + 1], c2 = cfg[3 * k + 2];
+      const double v0 = col[3 * k], v1 = col[3 * k + 1], v2 = col[3 * k + 2];
+      acc += p == 0 ? v0 : p == 1 ? v1 : p == 2 ? v2 : p == 3 ? c1 * v2 - c2 * v1 : p == 4 ? c2 * v0 - c0 * v2 : c0 * v1 - c1 * v0;
+    }
+    N[6 * p + c] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double L[36];
+    for (int e = 0; e < 36; ++e) L[e] = N[e];
+    bool ok = true;
+    for (int j = 0; j < 6; ++j) {
+      double d = L[6 * j + j];
+      for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+      if (!(d > 0.0)) ok = false;
+      d = sqrt(d);
+      L[6 * j + j] = d;
+      for (int i = j + 1; i < 6; ++i) {
+        double v = L[6 * i + j];
+        for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+        L[6 * i + j] = v / d;
+      }
+      for (int i = 0; i < j; ++i) L[6 * i + j] = 0.0;
+    }
+    if (!ok) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+    for (int e = 0; e < 36; ++e) NL[e] = L[e];
+  }
+}
+
+constexpr int BFT = 512;
+__device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], double *res, int t)
+{
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+  }
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) red[t >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (t < 6) {
+    double a = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += red[w][t];
+    res[t] = a;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__ Minv, const double *__restrict__ MK,
+                                                      const double *__restrict__ NL, const double *__restrict__ cfg,
+                                                      const double *__restrict__ Q, long n, int b_begin, const double *in,
+                                                      long n3, double fsign, double *out, double *__restrict__ ktl)
+{
+  extern __shared__ double sm[];                     // s[n] | y[n]
+  __shared__ double red[BFT / 64][6], f6[6], us[6];
+  double *sv = sm, *yv = sm + n;
+  const int b = b_begin + blockIdx.x, t = threadIdx.x;
+  double R[9];
+  quat_rot(Q + 4 * (size_t)b, R);
+  const double *slip = in + (size_t)b * (size_t)n;
+  if (3 * t < n) {                                   // s' = R^T slip, one blob per thread
+    const double a0 = slip[3 * t], a1 = slip[3 * t + 1], a2 = slip[3 * t + 2];
+    sv[3 * t] = R[0] * a0 + R[3] * a1 + R[6] * a2;
+    sv[3 * t + 1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
+    sv[3 * t + 2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
+  }
+  __syncthreads();
+  if (t < n) {                                       // y1' = M_body^-1 s'  (symmetric: column e read along its rows)
+    double a0 = 0.0, a1 = 0.0;
+    const double *col = Minv + t;
+    long q = 0;
+    for (; q + 8 <= n; q += 8) {
+      double m[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m[u] = col[(size_t)(q + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        a0 = __builtin_fma(m[u], sv[q + u], a0);
+        a1 = __builtin_fma(m[u + 1], sv[q + u + 1], a1);
+      }
+    }
+    for (; q < n; ++q) a0 = __builtin_fma(col[(size_t)q * n], sv[q], a0);
+    yv[t] = a0 + a1;
+  }
+  __syncthreads();
+  double f[6] = {0, 0, 0, 0, 0, 0};
+  if (3 * t < n) {                                   // f' = K_body^T y1'
+    const double c0 = cfg[3 * t], c1 = cfg[3 * t + 1], c2 = cfg[3 * t + 2];
+    const double v0 = yv[3 * t], v1 = yv[3 * t + 1], v2 = yv[3 * t + 2];
+    f[0] = v0; f[1] = v1; f[2] = v2;
+    f[3] = c1 * v2 - c2 * v1; f[4] = c2 * v0 - c0 * v2; f[5] = c0 * v1 - c1 * v0;
+  }
+  bf_reduce6(f, red, f6, t);
+  if (t == 0) {                                      // U' = N_body^-1 (fsign F' - f'), U = (R U'_lin, R U'_ang)
+    const double *F = in + n3 + 6 * (size_t)b;
+    double Fb[6], y[6], u[6];
+    for (int h = 0; h < 2; ++h)
+      for (int d = 0; d < 3; ++d) Fb[3 * h + d] = R[d] * F[3 * h] + R[3 + d] * F[3 * h + 1] + R[6 + d] * F[3 * h + 2];   // R^T
+    for (int p = 0; p < 6; ++p) {
+      double v = fsign * Fb[p] - f6[p];
+      for (int q = 0; q < p; ++q) v -= NL[6 * p + q] * y[q];
+      y[p] = v / NL[6 * p + p];
+    }
+    for (int p = 5; p >= 0; --p) {
+      double v = y[p];
+      for (int q = p + 1; q < 6; ++q) v -= NL[6 * q + p] * u[q];
+      u[p] = v / NL[6 * p + p];
+    }
+    for (int p = 0; p < 6; ++p) us[p] = u[p];
+    double *Uo = out + n3 + 6 * (size_t)b;
+    for (int h = 0; h < 2; ++h)
+      for (int d = 0; d < 3; ++d) Uo[3 * h + d] = R[3 * d] * u[3 * h] + R[3 * d + 1] * u[3 * h + 1] + R[3 * d + 2] * u[3 * h + 2];
+  }
+  __syncthreads();
+  if (t < n) {                                       // Lambda' = y1' + (M_body^-1 K_body) U'
+    double acc = yv[t];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * n + t], us[c], acc);
+    sv[t] = acc;
+  }
+  __syncthreads();
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  if (3 * t < n) {                                   // Lambda = R Lambda';  K_body^T Lambda'
+    const double v0 = sv[3 * t], v1 = sv[3 * t + 1], v2 = sv[3 * t + 2];
+    double *lam = out + (size_t)b * (size_t)n + 3 * t;
+    lam[0] = R[0] * v0 + R[1] * v1 + R[2] * v2;
+    lam[1] = R[3] * v0 + R[4] * v1 + R[5] * v2;
+    lam[2] = R[6] * v0 + R[7] * v1 + R[8] * v2;
+    const double c0 = cfg[3 * t], c1 = cfg[3 * t + 1], c2 = cfg[3 * t + 2];
+    g[0] = v0; g[1] = v1; g[2] = v2;
+    g[3] = c1 * v2 - c2 * v1; g[4] = c2 * v0 - c0 * v2; g[5] = c0 * v1 - c1 * v0;
+  }
+  if (ktl) {
+    bf_reduce6(g, red, f6, t);
+    if (t < 6) {
+      const int h = t / 3, d = t % 3;
+      ktl[6 * (size_t)b + t] = R[3 * d] * f6[3 * h] + R[3 * d + 1] * f6[3 * h + 1] + R[3 * d + 2] * f6[3 * h + 2];
+    }
+  }
+}
+
 __global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,6 +584,28 @@ void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double 
   if (N <= 0) return;
   hipLaunchKernelGGL(k_saddle_tail, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_lever, d_U, N_blb, (long)N, d_out,
                      d_sub, d_ktl, 6 * N_bod);
+}
+
+// body-frame preconditioner of small bodies: one-time tables from X = L_body^-1 (row-major copy d_XU) ...
+void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cfg, int64_t n, double *d_Minv, double *d_MK,
+                          double *d_NL, unsigned *d_err)
+{
+  hipLaunchKernelGGL(k_bf_minv, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, st, d_XU, (long)n, d_Minv);
+  hipLaunchKernelGGL(k_bf_mk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double *)d_Minv, d_cfg, (long)n, d_MK);
+  hipLaunchKernelGGL(k_bf_nl, dim3(1), dim3(64), 0, st, (const double *)d_MK, d_cfg, (long)n, d_NL, d_err);
+}
+
+// ... and the application to bodies [b_begin, b_begin + b_count): d_in = [slip ; F] -> d_out = [Lambda ; U] (full vectors)
+int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
+                            const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
+                            double *d_out, double *d_ktl)
+{
+  if (n > BFT) return RBL_ERR_SIZE;
+  if (b_count <= 0) return RBL_OK;
+  const int th = (int)(n <= 64 ? 64 : ((n + 63) / 64) * 64);
+  hipLaunchKernelGGL(k_pc_bodyframe, dim3(b_count), dim3(th), sizeof(double) * 2 * (size_t)n, st, d_Minv, d_MK, d_NL, d_cfg, d_Q,
+                     (long)n, b_begin, d_in, (long)n3, fsign, d_out, d_ktl);
+  return RBL_OK;
 }
 
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)

@@ -79,6 +79,7 @@ struct rbl_ctx {
   // free space: M_b = (I x R_b) M_body (I x R_b)^T with ONE body-frame matrix for all bodies and all time: its factor
   // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
   RblDevBuf d_bfL, d_bfLinv, d_bfX;
+  RblDevBuf d_bfPC;                                 // small bodies: M_body^-1 (n^2) | M_body^-1 K_body (6 n) | chol(N_body) (36)
   bool blk_bodyframe = true, bf_valid = false, bf_inv = false;   // rbl_set_tuning 71 / 72
   bool bf_wall_approx = false;                                   // rbl_set_tuning 73 / 74 (experiment)
   RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
@@ -248,6 +249,11 @@ void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const doubl
                               double *d_U, double *d_lam, double *d_ktl);
 void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N, int N_bod,
                             double *d_out, const double *d_sub, const double *d_ktl);
+void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cfg, int64_t n, double *d_Minv, double *d_MK,
+                          double *d_NL, unsigned *d_err);
+int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
+                            const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
+                            double *d_out, double *d_ktl);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

@@ -1075,8 +1075,20 @@ def test_free_space_body_frame_factors(orc, nblb):
         if mode != 3:
             w = v.clone(); ctx.block_solve(w.data_ptr(), w.data_ptr(), mode); ctx.sync_check()
             assert torch.equal(w, full)
-    ctx.set_tuning(0, 71)                                    # per-configuration factors: the same inverse
-    assert float(torch.linalg.norm(bs(v, 0) - x0) / torch.linalg.norm(x0)) < 1e-11
+    # the block preconditioner (for 65..170 blobs per body ONE body-frame launch, k_pc_bodyframe): same operator as with
+    # per-configuration factors, and P^-1 really inverts the block-diagonal saddle matrix [M_b -K_b; -K_b^T 0] body by body
+    from rigid_body_light_amd._lib import lib
+    lib().rbl_set_blk_pc(ctx.h, 1)
+    zin = torch.from_numpy(rng.standard_normal(m * nb + 6 * nb)).to(dev)
+    zo = {}
+    for variant in (72, 71):
+        ctx.set_tuning(0, variant)
+        o = torch.empty_like(zin); ctx.apply_PC(zin.data_ptr(), o.data_ptr()); ctx.sync_check()
+        zo[variant] = o
+        w = zin.clone(); ctx.apply_PC(w.data_ptr(), w.data_ptr()); ctx.sync_check()                # in place
+        assert torch.equal(w, o)
+    assert float(torch.linalg.norm(zo[72] - zo[71]) / torch.linalg.norm(zo[71])) < 1e-10
+    assert float(torch.linalg.norm(bs(v, 0) - x0) / torch.linalg.norm(x0)) < 1e-11               # (tuning 71 is on here)
     ctx.close()
 
 
