@@ -752,7 +752,7 @@ static int bf_build(rbl_ctx *c)
   if ((rc = rbl_launch_cholesky_batched(c->stream, Lb, m, 1, msz, c->d_err, (double *)c->d_bfLinv.p)))
     return rbl_fail(c, rc, "body-frame cholesky launch failed");
   c->bf_inv = false;
-  if (c->blk_explicit && rbl_block_inverse_fits(m)) {
+  if (c->blk_explicit && m <= 512) {      // (every size the inversion kernel takes: the one-launch preconditioner pays at any of them)
     if ((rc = rbl_dev_reserve(c, c->d_bfX, rbl_block_inverse_bytes(m, 1)))) return rc;
     if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, 1, msz, (const double *)c->d_bfLinv.p, (double *)c->d_bfX.p)))
       return rbl_fail(c, rc, "body-frame inverse launch failed");
