@@ -1373,8 +1373,9 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
   if ((rc = rbl_dev_reserve(c, c->d_blkLinv, rbl_cholesky_batched_work_bytes(m, S.N_bod)))) return rc;
   const RblParams P = rbl_make_params(S.a, S.eta);
   double *Lb = (double *)c->d_blkL.p + (size_t)b0 * (size_t)msz;
-  rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p + (size_t)b0 * (size_t)m, S.N_blb, b1 - b0, Lb,
-                             msz, c->d_err);
+  for (int q0 = b0; q0 < b1; q0 += 65535)               // bodies ride in gridDim.z
+    rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p + (size_t)q0 * (size_t)m, S.N_blb,
+                               (b1 - q0 < 65535) ? b1 - q0 : 65535, Lb + (size_t)(q0 - b0) * (size_t)msz, msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
   c->blk_inv_valid = false;

@@ -740,6 +740,17 @@ size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch)
 int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
                                 unsigned *d_err, double *d_Linv)
 {
+  constexpr int GRID_YZ_MAX = 65535;                 // bodies ride in gridDim.y / .z: more than that go in several rounds
+  if (batch > GRID_YZ_MAX) {
+    const size_t lstride = rbl_cholesky_batched_work_bytes(n, 1) / sizeof(double);
+    for (int b0 = 0; b0 < batch; b0 += GRID_YZ_MAX) {
+      const int nb = batch - b0 < GRID_YZ_MAX ? batch - b0 : GRID_YZ_MAX;
+      const int rc = rbl_launch_cholesky_batched(st, d_M + (size_t)b0 * (size_t)strideA, n, nb, strideA, d_err,
+                                                 d_Linv + (size_t)b0 * lstride);
+      if (rc) return rc;
+    }
+    return RBL_OK;
+  }
   constexpr int NBB = 512;   // outer panel of the batched factorisation: rank-512 trailing updates (n = 486: 256 same, 128 / 64 slower)
   const int64_t nsteps = (n + IB - 1) / IB;
   const long strideL = (long)(nsteps * IB * IB);
@@ -1317,8 +1328,12 @@ int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int b
   if (n > BSS_T) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
   const int th = (int)(n <= 128 ? 128 : ((n + 63) / 64) * 64);
-  hipLaunchKernelGGL(k_trtri_small, dim3((unsigned)nsteps, batch), dim3(th), 0, st, d_L, (long)n, (long)strideA, d_Linv,
-                     (long)(nsteps * IB * IB), d_X);
+  for (int b0 = 0; b0 < batch; b0 += 65535) {        // bodies ride in gridDim.y
+    const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    hipLaunchKernelGGL(k_trtri_small, dim3((unsigned)nsteps, nb), dim3(th), 0, st, d_L + (size_t)b0 * (size_t)strideA, (long)n,
+                       (long)strideA, d_Linv + (size_t)b0 * (size_t)(nsteps * IB * IB), (long)(nsteps * IB * IB),
+                       d_X + (size_t)b0 * 2 * (size_t)(n * n));
+  }
   return RBL_OK;
 }
 
@@ -1332,6 +1347,17 @@ int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int
   if (n > BSS_T) return RBL_ERR_SIZE;
   if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
   if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
+  if (batch > 65535) {                               // bodies ride in gridDim.y: more than that go in several rounds
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+      const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+      const size_t vo = (size_t)b0 * (size_t)vec_stride;
+      const int rc = rbl_launch_block_inv_apply(st, d_Q ? d_X : d_X + (size_t)b0 * 2 * (size_t)(n * n), n, nb, d_in + vo, d_out + vo,
+                                                vec_stride, nv, rhs_pitch, mode, d_tmp ? d_tmp + vo : nullptr,
+                                                d_Q ? d_Q + 4 * (size_t)b0 : nullptr);
+      if (rc) return rc;
+    }
+    return RBL_OK;
+  }
   const dim3 grid((unsigned)((n + BIA_R - 1) / BIA_R), batch);
   const long mstride = d_Q ? 0 : 2 * (long)(n * n);
   auto pass = [&](const double *in, double *out, int upper) {
