@@ -849,6 +849,11 @@ static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
   if (nbo <= 0) return RBL_OK;
   const int64_t m = 3 * (int64_t)c->S.N_blb;
   const size_t off = (size_t)b0 * (size_t)m;
+  const double *dQ0 = bf_on(c) ? (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0 : nullptr;
+  if (m <= 512)                                         // small bodies: every row independent, rotation fused
+    return bf_on(c) ? rbl_launch_block_trmv_small(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, in + off, out + off, m, dQ0)
+                    : rbl_launch_block_trmv_small(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)(m * m), m, nbo, m * m,
+                                                  in + off, out + off, m, nullptr);
   if (bf_on(c)) {                                       // G x = R (L x)
     int rc = rbl_launch_block_trmv(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, in + off, out + off, m);
     if (rc) return rc;
@@ -968,10 +973,9 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec, precond);
     c->sym_tune.relaxed = 0;
     if (rc) return rc;
-    for (int v = 0; v < nvec; ++v)
-      rbl_launch_lanczos_step(c->stream, n, u + (size_t)v * n, Vp(it, v), it > 0 ? Vp(it - 1, v) : nullptr,
-                              it > 0 ? d_beta(v) + (it - 1) : nullptr, d_alpha(v) + it, d_beta(v) + it, Vp(it + 1, v),
-                              d_part);
+    // both recurrences of a pair in the same three launches (vectors n apart, their scalars nsc apart)
+    rbl_launch_lanczos_step(c->stream, n, u, Vp(it, 0), it > 0 ? Vp(it - 1, 0) : nullptr, it > 0 ? d_beta(0) + (it - 1) : nullptr,
+                            d_alpha(0) + it, d_beta(0) + it, Vp(it + 1, 0), d_part, nvec, n, (int64_t)nsc);
     m = it + 1;
     if (m % check_every != 0 && m != maxit) continue;
     RBL_HIP(c, hipMemcpyAsync(hs.data(), sc, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));

@@ -1378,6 +1378,23 @@ int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int
   return RBL_OK;
 }
 
+// y_b = L_b x_b for small bodies (n <= 512) as a triangular matrix-vector product with every row independent (the kernel of
+// the inverse applications on the factor itself; k_block_trmv walks the columns in one workgroup per body: 50 us at
+// n = 486).  strideA = 0: one shared body-frame factor, then d_Q rotates the result (y_b = R_b L x_b).  Not in place.
+int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
+                                double *d_out, int64_t vec_stride, const double *d_Q)
+{
+  if (n > BSS_T || d_in == d_out) return RBL_ERR_ARG;
+  for (int b0 = 0; b0 < batch; b0 += 65535) {
+    const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+    const size_t vo = (size_t)b0 * (size_t)vec_stride;
+    hipLaunchKernelGGL(k_block_inv_apply<1>, dim3((unsigned)((n + BIA_R - 1) / BIA_R), nb), dim3(64 * BIA_W),
+                       sizeof(double) * ((size_t)n + 64 * BIA_W), st, d_L + (size_t)b0 * (size_t)strideA, (long)n, (long)strideA,
+                       d_in + vo, d_out + vo, (long)vec_stride, 0L, 0, d_Q ? d_Q + 4 * (size_t)b0 : nullptr, d_Q ? 2 : 0);
+  }
+  return RBL_OK;
+}
+
 // nv vectors (rhs_pitch apart) of `batch` bodies with N_blb blobs each: every blob's three entries rotated by its body's
 // R (transpose = 0) or R^T (1).  In place is fine.
 void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,

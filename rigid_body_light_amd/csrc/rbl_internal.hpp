@@ -191,6 +191,8 @@ int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int b
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
                                int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp,
                                const double *d_Q = nullptr);
+int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
+                                double *d_out, int64_t vec_stride, const double *d_Q);
 void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,
                               int64_t rhs_pitch, int transpose);
 void rbl_launch_trmv_lower(hipStream_t st, const double *d_L, int64_t n, const double *d_W,
@@ -211,7 +213,7 @@ void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, doubl
                              double *part);
 void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
                              const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
-                             double *part);
+                             double *part, int nvec = 1, int64_t vec_stride = 0, int64_t scal_stride = 0);
 void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
                                 double *out, int64_t stride = 0);
 void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,

@@ -1075,11 +1075,14 @@ __device__ __forceinline__ double lz_sum_parts(const double *__restrict__ part, 
 }
 
 // u -= beta_prev * vprev (when vprev != null);  partA[block] = sum v_i u_i
+// (blockIdx.y = vector of a lock-step pair: vectors vs doubles apart, their scalars ss, their partial sums ps)
 __global__ __launch_bounds__(256) void k_lz_a(long n, double *__restrict__ u, const double *__restrict__ v,
                                               const double *__restrict__ vprev, const double *__restrict__ bprev,
-                                              double *__restrict__ partA)
+                                              double *__restrict__ partA, long vs, long ss, long ps)
 {
   __shared__ double sh[256];
+  u += blockIdx.y * vs; v += blockIdx.y * vs; partA += blockIdx.y * ps;
+  if (vprev) { vprev += blockIdx.y * vs; bprev += blockIdx.y * ss; }
   const double b = vprev ? *bprev : 0.0;
   double a = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -1094,9 +1097,10 @@ __global__ __launch_bounds__(256) void k_lz_a(long n, double *__restrict__ u, co
 // alpha = sum(partA);  u -= alpha v;  partB[block] = sum u_i^2
 __global__ __launch_bounds__(256) void k_lz_b(long n, double *__restrict__ u, const double *__restrict__ v,
                                               const double *__restrict__ partA, int np,
-                                              double *__restrict__ alpha_out, double *__restrict__ partB)
+                                              double *__restrict__ alpha_out, double *__restrict__ partB, long vs, long ss, long ps)
 {
   __shared__ double sh[256];
+  u += blockIdx.y * vs; v += blockIdx.y * vs; partA += blockIdx.y * ps; partB += blockIdx.y * ps; alpha_out += blockIdx.y * ss;
   const double al = lz_sum_parts(partA, np, sh);
   if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = al;
   double a = 0.0;
@@ -1112,9 +1116,10 @@ __global__ __launch_bounds__(256) void k_lz_b(long n, double *__restrict__ u, co
 // beta = sqrt(sum(partB));  vnext = u / beta   (zeros on breakdown)
 __global__ __launch_bounds__(256) void k_lz_c(long n, const double *__restrict__ u,
                                               const double *__restrict__ partB, int np,
-                                              double *__restrict__ beta_out, double *__restrict__ vnext)
+                                              double *__restrict__ beta_out, double *__restrict__ vnext, long vs, long ss, long ps)
 {
   __shared__ double sh[256];
+  u += blockIdx.y * vs; vnext += blockIdx.y * vs; partB += blockIdx.y * ps; beta_out += blockIdx.y * ss;
   const double be = sqrt(lz_sum_parts(partB, np, sh));
   if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = be;
   const double inv = (be > 1e-300) ? 1.0 / be : 0.0;
@@ -1517,7 +1522,7 @@ static int lz_grid(int64_t n)
   return g < 1 ? 1 : g;
 }
 
-size_t rbl_lanczos_part_doubles(void) { return 2 * (size_t)LZ_BLOCKS; }
+size_t rbl_lanczos_part_doubles(void) { return 4 * (size_t)LZ_BLOCKS; }      // two partial-sum arrays for each vector of a pair
 
 // V0 = W / |W|, *wnorm_out = |W|
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
@@ -1525,21 +1530,24 @@ void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, doubl
 {
   const int g = lz_grid(n);
   hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, const_cast<double *>(d_W), d_W,
-                     (const double *)nullptr, (const double *)nullptr, part);
-  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0);
+                     (const double *)nullptr, (const double *)nullptr, part, 0L, 0L, 0L);
+  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0, 0L, 0L, 0L);
 }
 
 // one Lanczos step after u = A v:  u -= beta_prev vprev; alpha = v.u; u -= alpha v; beta = |u|; vnext = u/beta
+// nvec (1 or 2) recurrences in lock step, one launch each: vector k of u / v / vprev / vnext is k * vec_stride doubles
+// further, its scalars (beta_prev, alpha_out, beta_out) k * scal_stride
 void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
                              const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
-                             double *part)
+                             double *part, int nvec, int64_t vec_stride, int64_t scal_stride)
 {
   const int g = lz_grid(n);
   double *pA = part, *pB = part + LZ_BLOCKS;
-  hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, u, v, vprev, beta_prev, pA);
-  hipLaunchKernelGGL(k_lz_b, dim3(g), dim3(256), 0, st, (long)n, u, v, (const double *)pA, g, alpha_out, pB);
-  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, (const double *)u, (const double *)pB, g,
-                     beta_out, vnext);
+  const long vs = (long)vec_stride, ss = (long)scal_stride, ps = 2L * LZ_BLOCKS;
+  hipLaunchKernelGGL(k_lz_a, dim3(g, nvec), dim3(256), 0, st, (long)n, u, v, vprev, beta_prev, pA, vs, ss, ps);
+  hipLaunchKernelGGL(k_lz_b, dim3(g, nvec), dim3(256), 0, st, (long)n, u, v, (const double *)pA, g, alpha_out, pB, vs, ss, ps);
+  hipLaunchKernelGGL(k_lz_c, dim3(g, nvec), dim3(256), 0, st, (long)n, (const double *)u, (const double *)pB, g,
+                     beta_out, vnext, vs, ss, ps);
 }
 
 // out = sum_p coef[p] V_p, consecutive basis vectors `stride` doubles apart (0: contiguous, = n)
@@ -1570,7 +1578,7 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
   hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p1, nb, Hcol, p2);
   hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn);
   hipLaunchKernelGGL(k_lz_c, dim3(lz_grid(n)), dim3(256), 0, st, (long)n, (const double *)w, (const double *)pn, g, Hcol + k,
-                     vnext);
+                     vnext, 0L, 0L, 0L);
 }
 
 // one classical Gram-Schmidt pass of w against V[0..k): Hcol (+)= V^T w ; w -= V (V^T w)
