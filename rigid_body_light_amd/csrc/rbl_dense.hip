@@ -42,6 +42,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
   return __hiloint2double(hi, lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v)      // DPP move of both halves of a double (controls within a 16-lane row)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ bool potf2_wave(double *__restrict__ A, long n, long k, int nb,
                                            double (*Y)[IB + 1], int t)
 {
@@ -861,21 +869,40 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     }
     __syncthreads();
     if (t < IB * NV && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
-    if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r  (256 B contiguous per lane)
-      for (long c = t; c < k; c += BS_T) {
-        const double *row = Lb + (size_t)c * (size_t)n + k;
-        double lv[IB];
+    if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
+      // The 32 entries of a column are one 256-byte run.  Sixteen lanes share a column (16 bytes = two rows each), so a
+      // wave's load instruction covers four whole runs -- eight cache lines for 1 KB, as coalesced as the forward sweep --
+      // and the 32-term sum closes with four DPP steps inside the 16-lane row.  (One column per lane, the round-1 form,
+      // touched 64 lines per instruction: the backward sweep took twice the forward one, 1.23 vs 0.61 ms at cfg 3.)
+      const int lane = t & 63, wv = t >> 6, sub = lane >> 4, h = lane & 15;
+      double x0[NV], x1[NV];
 #pragma unroll
-        for (int m = 0; m < IB; ++m) lv[m] = row[m];
+      for (int v = 0; v < NV; ++v) { x0[v] = tbuf[v * IB + 2 * h]; x1[v] = tbuf[v * IB + 2 * h + 1]; }
+      constexpr int UB = 8, CS = 4 * (BS_T / 64);                  // UB loads in flight per lane (16 spill: 128 VGPRs at 1024 threads)
+      for (long cb = 4 * wv; cb < k; cb += (long)UB * CS) {
+        double l0[UB], l1[UB];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          double a0 = y[(size_t)v * n + c], a1 = 0.0;
-#pragma unroll
-          for (int m = 0; m < IB; m += 2) {
-            a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
-            a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
+        for (int q = 0; q < UB; ++q) {
+          const long c = cb + (long)q * CS + sub;                  // k is a multiple of 32: c0 + 3 < k whenever c0 < k
+          if (cb + (long)q * CS < k) {
+            const double *p = Lb + (size_t)c * (size_t)n + k + 2 * h;
+            l0[q] = p[0]; l1[q] = p[1];
           }
-          y[(size_t)v * n + c] = a0 + a1;
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q) {
+          const long c = cb + (long)q * CS + sub;
+          if (cb + (long)q * CS < k) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              double a = __builtin_fma(l0[q], x0[v], l1[q] * x1[v]);
+              a += dpp_row<0xB1>(a);                               // quad_perm [1,0,3,2]
+              a += dpp_row<0x4E>(a);                               // quad_perm [2,3,0,1]
+              a += dpp_row<0x141>(a);                              // row_half_mirror
+              a += dpp_row<0x140>(a);                              // row_mirror: every lane of the row holds the sum
+              if (h == 0) y[(size_t)v * n + c] -= a;
+            }
+          }
         }
       }
     } else {
