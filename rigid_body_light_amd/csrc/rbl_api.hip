@@ -1648,8 +1648,9 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   const size_t need = vb * (size_t)(m + 3) + sizeof(double) * ((size_t)ldh * m + 1 + m + rbl_gmres_part_doubles() +
                                                                rbl_lanczos_part_doubles());
   if ((rc = rbl_dev_reserve(c, c->d_gm, need))) return rc;
-  double *V = (double *)c->d_gm.p, *w = V + (size_t)(m + 1) * nsys, *z = w + nsys, *H = z + nsys,
-         *d_beta = H + (size_t)ldh * m, *d_y = d_beta + 1, *part = d_y + m, *part2 = part + rbl_gmres_part_doubles();
+  // (beta sits in FRONT of H: a convergence test reads back 1 + ldh * used doubles, not the whole ldh x m array)
+  double *V = (double *)c->d_gm.p, *w = V + (size_t)(m + 1) * nsys, *z = w + nsys, *d_beta = z + nsys, *H = d_beta + 1,
+         *d_y = H + (size_t)ldh * m, *part = d_y + m, *part2 = part + rbl_gmres_part_doubles();
   RBL_HIP(c, hipMemsetAsync(H, 0, sizeof(double) * (size_t)ldh * m, c->stream));
   rbl_launch_lanczos_init(c->stream, nsys, d_rhs, d_beta, V, part2);                    // V_0 = b/|b|, beta = |b|
   std::vector<double> Hh((size_t)ldh * m + 1), y;
@@ -1659,8 +1660,8 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   double resid = 1.0;
   // least squares min |beta e1 - H_k y| by Givens rotations on a host copy; returns the residual estimate
   auto solve_ls = [&](int k, std::vector<double> &yout) -> double {
-    std::vector<double> R(Hh.begin(), Hh.begin() + (size_t)ldh * m), g((size_t)k + 1, 0.0);
-    const double beta = Hh[(size_t)ldh * m];
+    std::vector<double> R(Hh.begin() + 1, Hh.begin() + 1 + (size_t)ldh * k), g((size_t)k + 1, 0.0);
+    const double beta = Hh[0];
     g[0] = beta;
     std::vector<double> cs((size_t)k), sn((size_t)k);
     for (int j = 0; j < k; ++j) {
@@ -1702,7 +1703,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
     used = j + 1;
     if (rtol > 0.0 && (used % check_every == 0 || used == m)) {
-      RBL_HIP(c, hipMemcpyAsync(Hh.data(), H, sizeof(double) * Hh.size(), hipMemcpyDeviceToHost, c->stream));
+      RBL_HIP(c, hipMemcpyAsync(Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used), hipMemcpyDeviceToHost, c->stream));
       RBL_HIP(c, hipStreamSynchronize(c->stream));
       // the test may only have become true somewhere in the last 4 iterations: take the first k that passes
       int k0 = used - (check_every - 1) < 1 ? 1 : used - (check_every - 1), hit = 0;
@@ -1714,7 +1715,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     }
   }
   if (!(rtol > 0.0) || y.size() != (size_t)used) {
-    RBL_HIP(c, hipMemcpyAsync(Hh.data(), H, sizeof(double) * Hh.size(), hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipMemcpyAsync(Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used), hipMemcpyDeviceToHost, c->stream));
     RBL_HIP(c, hipStreamSynchronize(c->stream));
     resid = solve_ls(used, y);
   }
