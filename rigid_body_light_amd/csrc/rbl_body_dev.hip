@@ -238,45 +238,9 @@ __global__ void k_pc_block_ninv(const double *__restrict__ cols /* [6][6*N_bod]:
   for (int e = 0; e < 36; ++e) NL[36 * (size_t)b + e] = L[e];
 }
 
-// U_b = Ninv_b^-1 (-F_b - f_b) through the 6x6 Cholesky factor (:601-608); also copies U to out
-__global__ void k_pc_block_mid(const double *__restrict__ NL, const double *__restrict__ F,
-                               const double *__restrict__ f, int N_bod, double *__restrict__ U, double fsign)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= N_bod) return;
-  const double *L = NL + 36 * (size_t)b;
-  double y[6], u[6];
-  for (int p = 0; p < 6; ++p) {
-    double v = fsign * F[6 * b + p] - f[6 * b + p];
-    for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
-    y[p] = v / L[6 * p + p];
-  }
-  for (int p = 5; p >= 0; --p) {
-    double v = y[p];
-    for (int q = p + 1; q < 6; ++q) v -= L[6 * q + p] * u[q];
-    u[p] = v / L[6 * p + p];
-  }
-  for (int p = 0; p < 6; ++p) U[6 * b + p] = u[p];
-}
-
-// Lambda = invM (slip + K U) = invM slip + (invM K) U  (:610): the first term is the vector the
-// preconditioner already solved for, invM K (six columns per body) is kept from the build -- no second
-// pass over the Cholesky factors.  MK: [6][n3], column c of every body stacked.
-// (count entries starting at the pointers given; `stride` = distance between the six MK columns = 3 N of the whole system)
-__global__ void k_pc_block_lambda(const double *__restrict__ y1, const double *__restrict__ MK,
-                                  const double *__restrict__ U, int N_blb, long count, long stride, double *__restrict__ out)
-{
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const long b = (i / 3) / N_blb;
-  double acc = y1[i];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * stride + i], U[6 * b + c], acc);
-  out[i] = acc;
-}
-
 // The three steps of a block-preconditioner application after invM slip (y1) in ONE launch, one workgroup per body:
-// f = K^T y1 (k_KT_x_Lam), U = Ninv^-1 (fsign F - f) (k_pc_block_mid), Lambda = y1 + (invM K) U (k_pc_block_lambda) --
+// f = K^T y1 (k_KT_x_Lam), U = Ninv^-1 (fsign F - f) through the 6x6 Cholesky factor (:601-608), Lambda = invM (slip + K U)
+// = y1 + (invM K) U (:610; invM K: six columns per body kept from the build, no second pass over the factors) --
 // and, for the saddle product that follows inside GMRES, K^T Lambda (ktl, may be NULL).  Bodies b_begin .. b_begin + gridDim.x.
 __global__ __launch_bounds__(BT) void k_pc_block_tail(const double *__restrict__ lever, const double *__restrict__ y1,
                                                       const double *__restrict__ MK, long stride,
@@ -552,21 +516,6 @@ void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, d
   if (b_end <= b_begin) return;
   hipLaunchKernelGGL(k_pc_block_ninv, dim3((b_end - b_begin + 63) / 64), dim3(64), 0, st, d_cols, N_bod, b_begin, b_end, d_NL,
                      d_err);
-}
-
-void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
-                             double *d_U, double fsign)
-{
-  if (N_bod <= 0) return;
-  hipLaunchKernelGGL(k_pc_block_mid, dim3((N_bod + 63) / 64), dim3(64), 0, st, d_NL, d_F, d_f, N_bod, d_U, fsign);
-}
-
-void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
-                                int64_t count, int64_t stride, double *d_out)
-{
-  if (count <= 0) return;
-  hipLaunchKernelGGL(k_pc_block_lambda, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_y1, d_MK, d_U, N_blb,
-                     (long)count, (long)stride, d_out);
 }
 
 void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,

@@ -1516,12 +1516,6 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
   return RBL_OK;
 }
 
-int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
-                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode)
-{
-  return rbl_launch_block_solve_multi(st, d_L, n, batch, strideA, d_Linv, d_in, d_out, vec_stride, 1, 0, mode);
-}
-
 size_t rbl_trmv_part_bytes(int64_t n)
 {
   const int64_t nch = (n + TR_COLS - 1) / TR_COLS;

@@ -176,8 +176,6 @@ size_t rbl_cholesky_work_bytes(int64_t n);
 size_t rbl_cholesky_batched_work_bytes(int64_t n, int batch);
 int rbl_launch_cholesky_batched(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA,
                                 unsigned *d_err, double *d_Linv);
-int rbl_launch_block_solve(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
-                           const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int mode = 0);
 int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA,
                                  const double *d_Linv, const double *d_in, double *d_out, int64_t vec_stride, int nv,
                                  int64_t rhs_pitch, int mode, const double *d_Q = nullptr);
@@ -206,8 +204,6 @@ int rbl_gmres_max_vectors(void);
 size_t rbl_gmres_part_doubles(void);
 void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
                              double *part);
-void rbl_launch_cgs_pass(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, int accumulate,
-                         double *part);
 size_t rbl_lanczos_part_doubles(void);
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
                              double *part);
@@ -242,10 +238,6 @@ void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const doubl
                               int N_blb, int N_bod, const double *d_in, double *d_out, double fsign);
 void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err, int b_begin = 0,
                               int b_end = -1);
-void rbl_launch_pc_block_lambda(hipStream_t st, const double *d_y1, const double *d_MK, const double *d_U, int N_blb,
-                                int64_t count, int64_t stride, double *d_out);
-void rbl_launch_pc_block_mid(hipStream_t st, const double *d_NL, const double *d_F, const double *d_f, int N_bod,
-                             double *d_U, double fsign);
 void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,
                               const double *d_NL, const double *d_F, int N_blb, int b_begin, int b_count, double fsign,
                               double *d_U, double *d_lam, double *d_ktl);

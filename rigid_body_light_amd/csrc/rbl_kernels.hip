@@ -1151,27 +1151,7 @@ __global__ __launch_bounds__(256) void k_mdot_partial(const double *__restrict__
   if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = a;
 }
 
-// w -= V[0..k) h with h_v = sum of the partials (identical in every block); block 0 adds h to Hcol (+= on
-// the second Gram-Schmidt pass).  k <= RBL_GMRES_MAXK.
-constexpr int GM_MAXK = 256;
-__global__ __launch_bounds__(256) void k_maxpy(const double *__restrict__ V, long n, int k, double *__restrict__ w,
-                                               const double *__restrict__ part, int np, double *__restrict__ Hcol,
-                                               int accumulate)
-{
-  __shared__ double h[GM_MAXK];
-  for (int v = threadIdx.x; v < k; v += 256) {
-    double a = 0.0;
-    for (int b = 0; b < np; ++b) a += part[(size_t)v * np + b];
-    h[v] = a;
-    if (blockIdx.x == 0) Hcol[v] = accumulate ? Hcol[v] + a : a;
-  }
-  __syncthreads();
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    double a = w[i];
-    for (int v = 0; v < k; ++v) a = __builtin_fma(-h[v], V[(size_t)v * n + i], a);
-    w[i] = a;
-  }
-}
+constexpr int GM_MAXK = 256;     // basis vectors an Arnoldi step can orthogonalise against (no restart)
 
 // The two Gram-Schmidt passes and the normalisation of an Arnoldi step in four launches instead of six (a launch
 // costs ~4.7 us of stream time whatever it does; at 8 100 blobs that was a third of an iteration):
@@ -1579,18 +1559,6 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
   hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn);
   hipLaunchKernelGGL(k_lz_c, dim3(lz_grid(n)), dim3(256), 0, st, (long)n, (const double *)w, (const double *)pn, g, Hcol + k,
                      vnext, 0L, 0L, 0L);
-}
-
-// one classical Gram-Schmidt pass of w against V[0..k): Hcol (+)= V^T w ; w -= V (V^T w)
-void rbl_launch_cgs_pass(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, int accumulate,
-                         double *part)
-{
-  if (k <= 0 || n <= 0) return;
-  int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, part);
-  const int g = lz_grid(n);
-  hipLaunchKernelGGL(k_maxpy, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)part, nb, Hcol, accumulate);
 }
 
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
