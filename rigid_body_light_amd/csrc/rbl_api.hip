@@ -1450,8 +1450,10 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
         ktl = (double *)c->d_ktl.p;
       }
       const double *T = (const double *)c->d_bfPC.p;
+      if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n3))) return rc;
       if ((rc = rbl_launch_pc_bodyframe(c->stream, T, T + (size_t)(m * m), T + (size_t)(m * m) + 6 * (size_t)m, (const double *)c->d_cfg.p,
-                                        (const double *)c->d_XQ.p + 3 * (size_t)S.N_bod, m, b0, nbo, d_in, n3, c->pc_fsign, d_out, ktl)))
+                                        (const double *)c->d_XQ.p + 3 * (size_t)S.N_bod, m, b0, nbo, d_in, n3, c->pc_fsign, d_out, ktl,
+                                        (double *)c->d_blkTmp.p)))
         return rbl_fail(c, rc, "body-frame preconditioner launch failed");
       if (ktl) c->ktl_of = d_out;
     }

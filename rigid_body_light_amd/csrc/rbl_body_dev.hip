@@ -388,16 +388,34 @@ __global__ void k_bf_nl(const double *__restrict__ MK, const double *__restrict_
 }
 
 constexpr int BFT = 512;
+template <int CTRL>
+__device__ __forceinline__ double bf_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], double *res, int t)
 {
+  // row sums by DPP (a __shfl_xor butterfly on doubles is twelve dependent ds_bpermute round trips per value), the four
+  // rows of a wave and the waves of the block through LDS
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+    v[q] += bf_dpp<0xB1>(v[q]);      // quad_perm [1,0,3,2]
+    v[q] += bf_dpp<0x4E>(v[q]);      // quad_perm [2,3,0,1]
+    v[q] += bf_dpp<0x141>(v[q]);     // row_half_mirror
+    v[q] += bf_dpp<0x140>(v[q]);     // row_mirror
   }
-  if ((t & 63) == 0) {
+  __shared__ double rows[BFT / 16][6];
+  if ((t & 15) == 0) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) red[t >> 6][q] = v[q];
+    for (int q = 0; q < 6; ++q) rows[t >> 4][q] = v[q];
+  }
+  __syncthreads();
+  if ((t & 63) == 0) {
+    const int r0 = t >> 4;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) red[t >> 6][q] = (rows[r0][q] + rows[r0 + 1][q]) + (rows[r0 + 2][q] + rows[r0 + 3][q]);
   }
   __syncthreads();
   if (t < 6) {
@@ -408,42 +426,57 @@ __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], dou
   __syncthreads();
 }
 
-__global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__ Minv, const double *__restrict__ MK,
-                                                      const double *__restrict__ NL, const double *__restrict__ cfg,
-                                                      const double *__restrict__ Q, long n, int b_begin, const double *in,
-                                                      long n3, double fsign, double *out, double *__restrict__ ktl)
+// y1' = M_body^-1 R^T slip, 128 outputs per workgroup: a body's product spread over ceil(n / 128) CUs (one workgroup per
+// body pulled the whole 1.9 MB table through ONE CU's 64 B/clk port: 14 of that kernel's 35 us at n = 486)
+constexpr int BFG = 128;
+__global__ __launch_bounds__(BFG) void k_bf_gemv(const double *__restrict__ Minv, const double *__restrict__ Q, long n,
+                                                 int b_begin, const double *__restrict__ in, double *__restrict__ y1)
 {
-  extern __shared__ double sm[];                     // s[n] | y[n]
-  __shared__ double red[BFT / 64][6], f6[6], us[6];
-  double *sv = sm, *yv = sm + n;
-  const int b = b_begin + blockIdx.x, t = threadIdx.x;
+  extern __shared__ double sv[];                     // s'[n]
+  const int b = b_begin + blockIdx.y, t = threadIdx.x;
   double R[9];
   quat_rot(Q + 4 * (size_t)b, R);
   const double *slip = in + (size_t)b * (size_t)n;
-  if (3 * t < n) {                                   // s' = R^T slip, one blob per thread
-    const double a0 = slip[3 * t], a1 = slip[3 * t + 1], a2 = slip[3 * t + 2];
-    sv[3 * t] = R[0] * a0 + R[3] * a1 + R[6] * a2;
-    sv[3 * t + 1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
-    sv[3 * t + 2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
+  for (long k = t; 3 * k < n; k += BFG) {            // s' = R^T slip, one blob per thread and pass
+    const double a0 = slip[3 * k], a1 = slip[3 * k + 1], a2 = slip[3 * k + 2];
+    sv[3 * k] = R[0] * a0 + R[3] * a1 + R[6] * a2;
+    sv[3 * k + 1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
+    sv[3 * k + 2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
   }
   __syncthreads();
-  if (t < n) {                                       // y1' = M_body^-1 s'  (symmetric: column e read along its rows)
+  const long e = (long)blockIdx.x * BFG + t;
+  if (e < n) {                                       // symmetric table: column e read along its rows, coalesced over e
     double a0 = 0.0, a1 = 0.0;
-    const double *col = Minv + t;
+    const double *col = Minv + e;
     long q = 0;
-    for (; q + 8 <= n; q += 8) {
-      double m[8];
+    constexpr int UQ = 32;                           // loads in flight per lane
+    for (; q + UQ <= n; q += UQ) {
+      double m[UQ];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) m[u] = col[(size_t)(q + u) * n];
+      for (int u = 0; u < UQ; ++u) m[u] = col[(size_t)(q + u) * n];
 #pragma unroll
-      for (int u = 0; u < 8; u += 2) {
+      for (int u = 0; u < UQ; u += 2) {
         a0 = __builtin_fma(m[u], sv[q + u], a0);
         a1 = __builtin_fma(m[u + 1], sv[q + u + 1], a1);
       }
     }
     for (; q < n; ++q) a0 = __builtin_fma(col[(size_t)q * n], sv[q], a0);
-    yv[t] = a0 + a1;
+    y1[(size_t)b * (size_t)n + e] = a0 + a1;
   }
+}
+
+__global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__ y1, const double *__restrict__ MK,
+                                                      const double *__restrict__ NL, const double *__restrict__ cfg,
+                                                      const double *__restrict__ Q, long n, int b_begin, const double *in,
+                                                      long n3, double fsign, double *out, double *__restrict__ ktl)
+{
+  extern __shared__ double sm[];                     // Lambda'[n] | y1'[n]
+  __shared__ double red[BFT / 64][6], f6[6], us[6];
+  double *sv = sm, *yv = sm + n;
+  const int b = b_begin + blockIdx.x, t = threadIdx.x;
+  double R[9];
+  quat_rot(Q + 4 * (size_t)b, R);
+  if (t < n) yv[t] = y1[(size_t)b * (size_t)n + t];  // y1' = M_body^-1 R^T slip (k_bf_gemv)
   __syncthreads();
   double f[6] = {0, 0, 0, 0, 0, 0};
   if (3 * t < n) {                                   // f' = K_body^T y1'
@@ -545,15 +578,21 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
 }
 
 // ... and the application to bodies [b_begin, b_begin + b_count): d_in = [slip ; F] -> d_out = [Lambda ; U] (full vectors)
+// d_y1: scratch, n doubles per body (laid out like the blob vector)
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl)
+                            double *d_out, double *d_ktl, double *d_y1)
 {
-  if (n > BFT) return RBL_ERR_SIZE;
+  if (n > BFT || !d_y1) return RBL_ERR_SIZE;
   if (b_count <= 0) return RBL_OK;
+  for (int q0 = 0; q0 < b_count; q0 += 65535) {      // bodies ride in gridDim.y
+    const int nb = b_count - q0 < 65535 ? b_count - q0 : 65535;
+    hipLaunchKernelGGL(k_bf_gemv, dim3((unsigned)((n + BFG - 1) / BFG), nb), dim3(BFG), sizeof(double) * (size_t)n, st, d_Minv, d_Q,
+                       (long)n, b_begin + q0, d_in, d_y1);
+  }
   const int th = (int)(n <= 64 ? 64 : ((n + 63) / 64) * 64);
-  hipLaunchKernelGGL(k_pc_bodyframe, dim3(b_count), dim3(th), sizeof(double) * 2 * (size_t)n, st, d_Minv, d_MK, d_NL, d_cfg, d_Q,
-                     (long)n, b_begin, d_in, (long)n3, fsign, d_out, d_ktl);
+  hipLaunchKernelGGL(k_pc_bodyframe, dim3(b_count), dim3(th), sizeof(double) * 2 * (size_t)n, st, (const double *)d_y1, d_MK, d_NL,
+                     d_cfg, d_Q, (long)n, b_begin, d_in, (long)n3, fsign, d_out, d_ktl);
   return RBL_OK;
 }
 

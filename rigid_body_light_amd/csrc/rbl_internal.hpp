@@ -247,7 +247,7 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
                           double *d_NL, unsigned *d_err);
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl);
+                            double *d_out, double *d_ktl, double *d_y1);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);
