@@ -1160,43 +1160,117 @@ constexpr int GM_MAXK = 256;     // basis vectors an Arnoldi step can orthogonal
 //                             the partials of h2 = V^T w (second pass) over them
 //   k_arnoldi_upd<true>       w -= V h2, Hcol += h2; partials of |w|^2
 //   k_lz_c                    H[j+1][j] = |w|, V_{j+1} = w / |w|
+template <int CTRL>
+__device__ __forceinline__ double ar_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// A thread owns up to AR_EPT elements (the launcher sizes the grid for that) and keeps them in registers; the basis is
+// read eight vectors at a time with all loads issued before the first multiply-add (a loop of load -> fma over a
+// run-time number of vectors is one memory round trip per vector: 16 us at 16 vectors for a 25 000-entry system).
+constexpr int AR_EPT = 4;
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ V, long n, int k, double *__restrict__ w,
                                                      const double *__restrict__ pin, int npin, double *__restrict__ Hcol,
                                                      double *__restrict__ pout)
 {
   __shared__ double h[GM_MAXK];
-  __shared__ double sw[4][GM_MAXK];
+  __shared__ double sw[16][GM_MAXK];                 // per 16-lane row of the block
   __shared__ double sh[256];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int v = t; v < k; v += 256) {
+  const int t = threadIdx.x;
+  // h_v = sum of the previous kernel's partials: a 16-lane row per vector (one thread per vector walked npin dependent
+  // loads: at 97 partials that prologue WAS the kernel)
+  for (int v = t >> 4; v < k; v += 16) {
     double a = 0.0;
-    for (int b = 0; b < npin; ++b) a += pin[(size_t)v * npin + b];
-    h[v] = a;
-    if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
+    for (int b = t & 15; b < npin; b += 16) a += pin[(size_t)v * npin + b];
+    a += ar_dpp<0xB1>(a);
+    a += ar_dpp<0x4E>(a);
+    a += ar_dpp<0x141>(a);
+    a += ar_dpp<0x140>(a);
+    if ((t & 15) == 0) {
+      h[v] = a;
+      if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
+    }
   }
   __syncthreads();
+  const long stride = (long)gridDim.x * 256, i0 = (long)blockIdx.x * 256 + t;
+  const long span = stride * AR_EPT;                 // elements one pass of the grid covers
+  const int nchunk = (int)((n + span - 1) / span);   // 1 unless the system has more than AR_BLOCKS x 256 x AR_EPT entries
+  double x[AR_EPT];
   double nrm = 0.0;
-  for (long i = (long)blockIdx.x * 256 + t; i < n; i += (long)gridDim.x * 256) {
-    double a = w[i];
-    for (int v = 0; v < k; ++v) a = __builtin_fma(-h[v], V[(size_t)v * n + i], a);
-    w[i] = a;
-    nrm = __builtin_fma(a, a, nrm);
+  for (int c = 0; c < nchunk; ++c) {                 // w -= V h
+    const long ic = i0 + (long)c * span;
+#pragma unroll
+    for (int e = 0; e < AR_EPT; ++e) { const long i = ic + e * stride; x[e] = i < n ? w[i] : 0.0; }
+    for (int v0 = 0; v0 < k; v0 += 8) {
+      double m[8][AR_EPT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < AR_EPT; ++e) {
+          const long i = ic + e * stride;
+          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * n + i] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double hv = v0 + u < k ? h[v0 + u] : 0.0;
+#pragma unroll
+        for (int e = 0; e < AR_EPT; ++e) x[e] = __builtin_fma(-hv, m[u][e], x[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < AR_EPT; ++e) {
+      const long i = ic + e * stride;
+      if (i < n) w[i] = x[e];
+      nrm = __builtin_fma(x[e], x[e], nrm);          // (elements beyond n are zero)
+    }
   }
   if (LAST) {
     nrm = lz_block_sum(nrm, sh);
     if (t == 0) pout[blockIdx.x] = nrm;
     return;
   }
-  for (int v = 0; v < k; ++v) {                      // this block's share of V_v . w (its own elements, just written)
-    double a = 0.0;
-    for (long i = (long)blockIdx.x * 256 + t; i < n; i += (long)gridDim.x * 256) a = __builtin_fma(V[(size_t)v * n + i], w[i], a);
+  for (int v0 = 0; v0 < k; v0 += 8) {                // this block's share of V_v . w over its own elements
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < nchunk; ++c) {
+      const long ic = i0 + (long)c * span;
+      if (nchunk > 1) {                              // (one chunk: the updated entries are still in registers)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) sw[wave][v] = a;
+        for (int e = 0; e < AR_EPT; ++e) { const long i = ic + e * stride; x[e] = i < n ? w[i] : 0.0; }
+      }
+      double m[8][AR_EPT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < AR_EPT; ++e) {
+          const long i = ic + e * stride;
+          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * n + i] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < AR_EPT; ++e) a[u] = __builtin_fma(m[u][e], x[e], a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      double r = a[u];
+      r += ar_dpp<0xB1>(r);                          // sums inside the 16-lane rows by DPP
+      r += ar_dpp<0x4E>(r);
+      r += ar_dpp<0x141>(r);
+      r += ar_dpp<0x140>(r);
+      if ((t & 15) == 0 && v0 + u < k) sw[t >> 4][v0 + u] = r;
+    }
   }
   __syncthreads();
-  for (int v = t; v < k; v += 256) pout[(size_t)v * gridDim.x + blockIdx.x] = (sw[0][v] + sw[1][v]) + (sw[2][v] + sw[3][v]);
+  for (int v = t; v < k; v += 256) {
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += sw[r][v];      // fixed order
+    pout[(size_t)v * gridDim.x + blockIdx.x] = a;
+  }
 }
 
 __global__ void k_scale_by_damp(RblParams P, const double *__restrict__ r, long n_blobs,
@@ -1540,7 +1614,7 @@ void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, cons
 }
 
 int rbl_gmres_max_vectors(void) { return GM_MAXK; }
-constexpr int AR_BLOCKS = 256;
+constexpr int AR_BLOCKS = 1024;
 size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * 128 + (size_t)GM_MAXK * AR_BLOCKS + AR_BLOCKS; }
 
 // one Arnoldi step after w = A P^-1 v_j: classical Gram-Schmidt twice against V[0..k), then Hcol[k] = |w| and
@@ -1551,8 +1625,9 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
   if (k <= 0 || n <= 0) return;
   int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
   if (nb < 1) nb = 1;
-  int g = (int)std::min<int64_t>(AR_BLOCKS, (n + 511) / 512);
-  if (g < 1) g = 1;
+  const int64_t gneed = (n + 256 * AR_EPT - 1) / (256 * AR_EPT);          // AR_EPT entries per thread ...
+  int g = (int)std::max<int64_t>(gneed, std::min<int64_t>(256, (n + 255) / 256));    // ... fewer in small systems: more blocks
+  if (g > AR_BLOCKS) g = AR_BLOCKS;                                        // beyond 1 048 576 entries the kernels take several passes
   double *p1 = part, *p2 = part + (size_t)GM_MAXK * 128, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
   hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, p1);
   hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p1, nb, Hcol, p2);
