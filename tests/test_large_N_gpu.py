@@ -155,3 +155,30 @@ def test_more_bodies_than_a_grid_dimension(orc, wall):
         assert float(torch.linalg.norm(p1 - p2) / torch.linalg.norm(p2)) < 1e-10
     ctx.close()
 
+
+def test_gmres_beyond_one_pass_of_the_arnoldi_kernels():
+    """545 x shell_N_642 = 349 890 blobs: the saddle system has 1 052 940 unknowns, more than one pass of the Arnoldi
+    update kernels covers (1 048 576 = 1024 blocks x 256 threads x 4 entries), so they walk their entries in two chunks.
+    Six GMRES iterations (diagonal PC): the residual the solver reports (from its Hessenberg least squares) must be the
+    true residual of the returned iterate -- that holds only if the basis is orthonormal and H = V^T A P^-1 V."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb, wall = 545, 642, False
+    c = make_config(nb, nblb, wall)
+    dev = torch.device("cuda:0")
+    n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
+    assert nsys > 1024 * 256 * 4
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    rng = np.random.default_rng(12)
+    b = torch.from_numpy(np.concatenate([rng.standard_normal(n3), np.tile([0.0, 0, -1.0, 0, 0, 0], nb)])).to(dev)
+    x = torch.empty_like(b)
+    m, res = ctx.gmres_saddle(b.data_ptr(), 6, 0.0, x.data_ptr())
+    out = torch.empty_like(b)
+    ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
+    true_res = float(torch.linalg.norm(out - b) / torch.linalg.norm(b))
+    assert m == 6 and 0.0 < res < 1.0
+    assert abs(true_res - res) < 1e-6 * max(res, 1e-3), (res, true_res)
+    ctx.close()
+
