@@ -1092,6 +1092,50 @@ def test_free_space_body_frame_factors(orc, nblb):
     ctx.close()
 
 
+def test_wall_system_with_the_free_space_body_frame_factor(orc):
+    """rbl_set_tuning 74 (opt-in): with the wall term the blocks differ from body to body, but the free-space body-frame
+    factor is still an invertible block factor, so both of its uses stay exact: the block-preconditioned GMRES reaches the
+    same solution (a few more iterations), and B G (G^-1 M G^-T)^{1/2} W is a square root of B M B -- checked through the
+    factor-independent identity G^-1 B^-1 x = S^{1/2} W  =>  |S^{1/2} W|^2 = (G^-T W) . M (G^-T W)."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, nblb, wall = 12, 162, True
+    c = make_config(nb, nblb, wall)
+    dev = torch.device("cuda:0")
+    n3 = 3 * nb * nblb; nsys = n3 + 6 * nb
+    rng = np.random.default_rng(31)
+    b = torch.from_numpy(np.concatenate([rng.standard_normal(n3), np.tile([0.0, 0, -1.0, 0, 0, 0], nb)])).to(dev)
+    W = torch.from_numpy(rng.standard_normal(n3)).to(dev)
+    sol = {}
+    for variant in (73, 74):
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_tuning(0, variant)
+        x = torch.empty_like(b)
+        m, res = ctx.gmres_saddle(b.data_ptr(), 200, 1e-10, x.data_ptr())
+        assert res < 1e-10
+        sol[variant] = (x, m)
+        if variant == 74:
+            r = torch.empty(n3, dtype=torch.float64, device=dev)
+            ctx.blob_positions(0, nb, r.data_ptr())
+            ctx.set_lanczos(300, 1e-12)
+            xr = torch.empty_like(W)
+            ctx.M_half_W(r.data_ptr(), nb * nblb, W.data_ptr(), "lanczos_pc", xr.data_ptr()); ctx.sync_check()
+            M = torch.from_numpy(orc.rotne_prager_tensor(r.cpu().numpy(), c["a"], c["eta"], wall)).to(dev)
+            z = r.view(-1, 3)[:, 2]
+            B = torch.where(z >= c["a"], torch.ones_like(z), z / c["a"]).repeat_interleave(3)
+            s_ = torch.empty_like(W); v_ = torch.empty_like(W)
+            ctx.block_solve((xr / B).contiguous().data_ptr(), s_.data_ptr(), 1)        # G^-1 B^-1 x = S^{1/2} W
+            ctx.block_solve(W.data_ptr(), v_.data_ptr(), 2); ctx.sync_check()         # G^-T W
+            lhs, rhs = float(s_ @ s_), float(v_ @ (M @ v_))
+            assert abs(lhs - rhs) < 1e-8 * rhs
+        ctx.close()
+    assert rel(sol[74][0].cpu().numpy(), sol[73][0].cpu().numpy()) < 1e-8
+    assert sol[73][1] <= sol[74][1] <= sol[73][1] + 8
+
+
 @pytest.mark.parametrize("block", [False, True])
 def test_native_gmres_equals_torch_gmres(shell12, block):
     """rbl_gmres_saddle_dev (librbl's own right-preconditioned GMRES) == the torch Arnoldi driver, fixed work and
