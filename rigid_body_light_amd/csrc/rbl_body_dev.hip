@@ -427,41 +427,61 @@ __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], dou
 }
 
 // y1' = M_body^-1 R^T slip, 128 outputs per workgroup: a body's product spread over ceil(n / 128) CUs (one workgroup per
-// body pulled the whole 1.9 MB table through ONE CU's 64 B/clk port: 14 of that kernel's 35 us at n = 486)
-constexpr int BFG = 128;
-__global__ __launch_bounds__(BFG) void k_bf_gemv(const double *__restrict__ Minv, const double *__restrict__ Q, long n,
-                                                 int b_begin, const double *__restrict__ in, double *__restrict__ y1)
+// body pulled the whole 1.9 MB table through ONE CU: 14 of that kernel's 35 us at n = 486).  Four waves split the sum
+// (interleaved, fixed-order LDS reduction), a lane owns TWO adjacent outputs and reads them with one 16-byte load: the
+// vector-memory pipe takes 16 cycles per wave instruction whatever its width, and this kernel is nothing but loads.
+constexpr int BFG = 128;                             // outputs per workgroup
+constexpr int BFW = 4;                               // waves per workgroup
+template <bool PAIR>
+__global__ __launch_bounds__(64 * BFW) void k_bf_gemv(const double *__restrict__ Minv, const double *__restrict__ Q, long n,
+                                                      int b_begin, const double *__restrict__ in, double *__restrict__ y1)
 {
-  extern __shared__ double sv[];                     // s'[n]
-  const int b = b_begin + blockIdx.y, t = threadIdx.x;
+  extern __shared__ double sv[];                     // s'[n] | partial sums [BFW][128]
+  double *red = sv + n;
+  const int b = b_begin + blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
   double R[9];
   quat_rot(Q + 4 * (size_t)b, R);
   const double *slip = in + (size_t)b * (size_t)n;
-  for (long k = t; 3 * k < n; k += BFG) {            // s' = R^T slip, one blob per thread and pass
+  for (long k = t; 3 * k < n; k += 64 * BFW) {       // s' = R^T slip, one blob per thread and pass
     const double a0 = slip[3 * k], a1 = slip[3 * k + 1], a2 = slip[3 * k + 2];
     sv[3 * k] = R[0] * a0 + R[3] * a1 + R[6] * a2;
     sv[3 * k + 1] = R[1] * a0 + R[4] * a1 + R[7] * a2;
     sv[3 * k + 2] = R[2] * a0 + R[5] * a1 + R[8] * a2;
   }
   __syncthreads();
-  const long e = (long)blockIdx.x * BFG + t;
-  if (e < n) {                                       // symmetric table: column e read along its rows, coalesced over e
-    double a0 = 0.0, a1 = 0.0;
-    const double *col = Minv + e;
-    long q = 0;
-    constexpr int UQ = 32;                           // loads in flight per lane
-    for (; q + UQ <= n; q += UQ) {
-      double m[UQ];
+  // symmetric table: row q holds the q-th term of every output, consecutive outputs are adjacent in memory
+  const long e0 = (long)blockIdx.x * BFG + 2 * lane;                 // outputs e0, e0 + 1
+  const long ec = e0 + 1 < n ? e0 : (n >= 2 ? n - 2 : 0);
+  double a0 = 0.0, a1 = 0.0;
+  constexpr int UQ = 16;                             // loads in flight per lane
+  for (long q0 = w; q0 < n; q0 += (long)BFW * UQ) {
+    double m0[UQ], m1[UQ];
 #pragma unroll
-      for (int u = 0; u < UQ; ++u) m[u] = col[(size_t)(q + u) * n];
-#pragma unroll
-      for (int u = 0; u < UQ; u += 2) {
-        a0 = __builtin_fma(m[u], sv[q + u], a0);
-        a1 = __builtin_fma(m[u + 1], sv[q + u + 1], a1);
-      }
+    for (int u = 0; u < UQ; ++u) {
+      const long q = q0 + (long)BFW * u;
+      if (q < n) {
+        const double *p = Minv + (size_t)q * (size_t)n + ec;
+        if (PAIR) { const double2 mm = *reinterpret_cast<const double2 *>(p); m0[u] = mm.x; m1[u] = mm.y; }
+        else { m0[u] = p[0]; m1[u] = p[1]; }
+      } else { m0[u] = 0.0; m1[u] = 0.0; }
     }
-    for (; q < n; ++q) a0 = __builtin_fma(col[(size_t)q * n], sv[q], a0);
-    y1[(size_t)b * (size_t)n + e] = a0 + a1;
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+      const long q = q0 + (long)BFW * u;
+      const double s = sv[q < n ? q : n - 1];
+      a0 = __builtin_fma(m0[u], s, a0);
+      a1 = __builtin_fma(m1[u], s, a1);
+    }
+  }
+  red[(w * 64 + lane) * 2] = a0; red[(w * 64 + lane) * 2 + 1] = a1;
+  __syncthreads();
+  if (w == 0) {
+    double r0 = red[lane * 2], r1 = red[lane * 2 + 1];
+#pragma unroll
+    for (int ww = 1; ww < BFW; ++ww) { r0 += red[(ww * 64 + lane) * 2]; r1 += red[(ww * 64 + lane) * 2 + 1]; }
+    double *o = y1 + (size_t)b * (size_t)n;
+    if (ec == e0) { if (e0 < n) o[e0] = r0; if (e0 + 1 < n) o[e0 + 1] = r1; }
+    else if (e0 < n) o[e0] = (e0 == ec + 1) ? r1 : r0;      // last odd entry: the clamped pair (n - 2, n - 1) holds it second
   }
 }
 
@@ -587,8 +607,12 @@ int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *
   if (b_count <= 0) return RBL_OK;
   for (int q0 = 0; q0 < b_count; q0 += 65535) {      // bodies ride in gridDim.y
     const int nb = b_count - q0 < 65535 ? b_count - q0 : 65535;
-    hipLaunchKernelGGL(k_bf_gemv, dim3((unsigned)((n + BFG - 1) / BFG), nb), dim3(BFG), sizeof(double) * (size_t)n, st, d_Minv, d_Q,
-                       (long)n, b_begin + q0, d_in, d_y1);
+    const dim3 grid((unsigned)((n + BFG - 1) / BFG), nb);
+    const size_t lds = sizeof(double) * ((size_t)n + 2 * 64 * BFW);
+    if (n % 2 == 0 && (reinterpret_cast<uintptr_t>(d_Minv) & 15) == 0)     // rows start 16-byte aligned: one load per output pair
+      hipLaunchKernelGGL(k_bf_gemv<true>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1);
+    else
+      hipLaunchKernelGGL(k_bf_gemv<false>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1);
   }
   const int th = (int)(n <= 64 ? 64 : ((n + 63) / 64) * 64);
   hipLaunchKernelGGL(k_pc_bodyframe, dim3(b_count), dim3(th), sizeof(double) * 2 * (size_t)n, st, (const double *)d_y1, d_MK, d_NL,
