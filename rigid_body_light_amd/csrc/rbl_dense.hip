@@ -928,8 +928,10 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
 // The same sweeps for bodies of order n <= BSS_T (shell_N_12 / 42 / 162: n = 36 / 126 / 486), where a sweep is a chain of
 // n / IB dependent steps and nothing else: thread t owns row t (forward) / column t (backward) for the whole solve and
 // the IB factor entries it needs for step s + 1 are already on their way to registers while step s runs (double
-// buffered), as is the next diagonal inverse -- so a step costs its two barriers and 2 x IB multiply-adds instead of a
-// round trip to L2 / HBM (n = 486: 147 -> ~40 us for both sweeps).  Same operation order per row as k_block_solve.
+// buffered), as is the next diagonal inverse -- so a step no longer waits for a round trip to L2 / HBM.  Measured at
+// n = 486: 147 -> 123 us for both sweeps only (the chain of 2 x 16 steps with two barriers each remains), which is why
+// bodies of 65..170 blobs use explicit inverses instead (below) and this kernel serves the short chains (n <= 192) and
+// the shared body-frame factor of free-space systems (rotations fused: Q, rot).  Same operation order per row as k_block_solve.
 constexpr int BSS_T = 512;
 
 __device__ __forceinline__ void quat_rot_d(const double *q, double *R)      // R(Q), scalar-first unit quaternion
