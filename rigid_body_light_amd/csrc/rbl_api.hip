@@ -783,7 +783,8 @@ static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out,
   const size_t off = (size_t)b0 * (size_t)m;
   if (bf_on(c)) {
     const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
-    int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
+    int rc = ensure_xq_dev(c); if (rc) return rc;       // the rotations read the quaternions on the device: current ones (M_RFD displaces them)
+    if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn))) return rc;
     double *tmp = (double *)c->d_blkTmp.p;
     const double *dQ = (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0;
     for (int v0 = 0; v0 < nv; v0 += 3) {
@@ -849,6 +850,7 @@ static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
   if (nbo <= 0) return RBL_OK;
   const int64_t m = 3 * (int64_t)c->S.N_blb;
   const size_t off = (size_t)b0 * (size_t)m;
+  if (bf_on(c)) { const int rc = ensure_xq_dev(c); if (rc) return rc; }
   const double *dQ0 = bf_on(c) ? (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0 : nullptr;
   if (m <= 512)                                         // small bodies: every row independent, rotation fused
     return bf_on(c) ? rbl_launch_block_trmv_small(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, in + off, out + off, m, dQ0)
@@ -1443,6 +1445,7 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
   c->ktl_of = nullptr;
   if (bf_on(c) && c->bf_inv) {                           // the whole application in the body frame, one launch
+    if ((rc = ensure_xq_dev(c))) return rc;
     if (nbo > 0) {
       double *ktl = nullptr;
       if (c->ktl_arm && !shard) {

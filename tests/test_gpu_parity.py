@@ -1064,6 +1064,15 @@ def test_free_space_body_frame_factors(orc, nblb):
     x0 = bs(v, 0)
     ref0 = torch.cat([torch.linalg.solve(Mb[b], v[m * b:m * (b + 1)]) for b in range(nb)])
     assert float(torch.linalg.norm(x0 - ref0) / torch.linalg.norm(ref0)) < 1e-10
+    # M_RFD evaluates products at two displaced configurations and restores the object's own: the rotations of the
+    # body-frame factor must be the restored ones afterwards (bit-identical result)
+    import ctypes as C
+    from rigid_body_light_amd._lib import lib
+    L_ = lib()
+    L_.rbl_M_RFD.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_void_p]; L_.rbl_M_RFD.restype = C.c_int
+    rfd = np.empty(m * nb)
+    assert L_.rbl_M_RFD(ctx.h, None, 5, 1.0e-2, rfd.ctypes.data) == 0 and np.isfinite(rfd).all()
+    assert torch.equal(bs(v, 0), x0)
     Mv = blockmul(v)
     assert float(torch.linalg.norm(bs(bs(Mv, 1), 3) - Mv) / torch.linalg.norm(Mv)) < 1e-10          # G G^-1 = I
     assert float(torch.linalg.norm(bs(blockmul(bs(v, 2)), 1) - v) / torch.linalg.norm(v)) < 1e-10   # G^-1 M G^-T = I
