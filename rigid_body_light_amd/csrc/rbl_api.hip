@@ -119,6 +119,22 @@ static int stage_ready(rbl_ctx *c)
   return RBL_OK;
 }
 
+// Krylov coefficients (<= 512 doubles, slot 0 or 1) to the device through a pinned buffer of the context: a true
+// asynchronous copy, so the stream is not drained for it (a pageable source would have to outlive the copy).  The slot is
+// written again one solve later at the earliest, behind that solve's own synchronisations.
+static int upload_coef(rbl_ctx *c, double *d_dst, const double *src, int count, int slot)
+{
+  if (count > 512 || slot < 0 || slot > 1) {
+    RBL_HIP(c, hipMemcpyAsync(d_dst, src, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    return RBL_OK;
+  }
+  if (!c->h_coef) RBL_HIP(c, hipHostMalloc((void **)&c->h_coef, sizeof(double) * 1024, hipHostMallocDefault));
+  std::memcpy(c->h_coef + 512 * slot, src, sizeof(double) * (size_t)count);
+  RBL_HIP(c, hipMemcpyAsync(d_dst, c->h_coef + 512 * slot, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+  return RBL_OK;
+}
+
 static int copy_h2d(rbl_ctx *c, void *dst, const void *src, size_t bytes)
 {
   if (bytes <= (64u << 10)) { RBL_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); return RBL_OK; }
@@ -295,6 +311,7 @@ void rbl_destroy(rbl_ctx *c)
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_coef) (void)hipHostFree(c->h_coef);
   }
   delete c;
 }
@@ -1016,9 +1033,8 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   // d_out_v = V_v[:, :m] y_v
   for (int v = 0; v < nvec; ++v) {
     if ((int)y_cur[v].size() < m) y_cur[v].resize(m, 0.0);
-    RBL_HIP(c, hipMemcpyAsync(d_coef(v), y_cur[v].data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_coef(c, d_coef(v), y_cur[v].data(), m, v))) return rc;
   }
-  RBL_HIP(c, hipStreamSynchronize(c->stream));            // y_cur is pageable host memory
   for (int v = 0; v < nvec; ++v)
     rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, d_out + (size_t)v * n, (int64_t)nvec * n);
   if (precond) {   // x = B (L y)
@@ -1726,8 +1742,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   }
   for (int k = 0; k < used; ++k)
     if (!std::isfinite(y[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "gmres: non-finite Hessenberg solve");
-  RBL_HIP(c, hipMemcpyAsync(d_y, y.data(), sizeof(double) * (size_t)used, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = upload_coef(c, d_y, y.data(), used, 0))) return rc;
   rbl_launch_lanczos_combine(c->stream, nsys, V, d_y, used, z);                        // z = V y
   if ((rc = rbl_apply_PC_dev(c, z, d_x))) return rc;                                   // x = P^-1 z
   if (iters_out) *iters_out = used;
