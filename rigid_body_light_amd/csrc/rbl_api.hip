@@ -338,6 +338,7 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   S.M_scale = 1.0;
   c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->dev_xq_valid = false;
   c->bf_valid = false;                                 // the body-frame factor belongs to (a, eta, cfg)
+  c->dev_cfg_valid = false;
   return RBL_OK;
 }
 
@@ -433,12 +434,16 @@ static int ensure_xq_dev(rbl_ctx *c)
   RblBodyState &S = c->S;
   int rc = rbl_dev_reserve(c, c->d_XQ, sizeof(double) * 7 * (size_t)S.N_bod); if (rc) return rc;
   rc = rbl_dev_reserve(c, c->d_cfg, sizeof(double) * 3 * (size_t)S.N_blb); if (rc) return rc;
-  double *dX = (double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
-  RBL_HIP(c, hipMemcpyAsync(dX, S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipMemcpyAsync(dQ, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
-  RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
+  double *dX = (double *)c->d_XQ.p;
+  // one copy for [X | Q] (a time step uploads the configuration four times), the reference shape only when it changed
+  c->h_xq.resize(7 * (size_t)S.N_bod);
+  std::memcpy(c->h_xq.data(), S.X.data(), sizeof(double) * 3 * (size_t)S.N_bod);
+  std::memcpy(c->h_xq.data() + 3 * (size_t)S.N_bod, S.Q.data(), sizeof(double) * 4 * (size_t)S.N_bod);
+  RBL_HIP(c, hipMemcpyAsync(dX, c->h_xq.data(), sizeof(double) * 7 * (size_t)S.N_bod, hipMemcpyHostToDevice, c->stream));
+  if (!c->dev_cfg_valid)
+    RBL_HIP(c, hipMemcpyAsync(c->d_cfg.p, S.ref_cfg.data(), sizeof(double) * 3 * (size_t)S.N_blb, hipMemcpyHostToDevice, c->stream));
   RBL_HIP(c, hipStreamSynchronize(c->stream));
-  c->dev_xq_valid = true;
+  c->dev_xq_valid = true; c->dev_cfg_valid = true;
   return RBL_OK;
 }
 

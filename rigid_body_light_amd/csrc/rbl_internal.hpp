@@ -98,6 +98,8 @@ struct rbl_ctx {
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
+  std::vector<double> h_xq;   // [X | Q] packed for one upload
+  bool dev_cfg_valid = false; // d_cfg holds the current reference configuration
   double *h_coef = nullptr;   // pinned, 2 x 512 doubles: Krylov coefficients go up without draining the stream (the next write is a solve later)
   RblCholAux chol_aux;
   // apply_PC as the reference defines it (:601-608) answers [M -K; K^T 0] x = [slip; -F]: with the saddle operator of
