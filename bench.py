@@ -17,6 +17,9 @@ process per GPU, torch.distributed / RCCL all-gather), total work fixed -> "stro
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline`
 (dominant kernel k_apply_M timed with events on its own stream) and `cpu_baseline`
 (the CPU oracle -- a port of the reference algorithm -- on a bounded row sample).
+At N = 1 the line also carries `configs`: every other BASELINE.json configuration timed in the same run (cfg 1 / cfg 2
+products and converged time steps, cfg 5's dense build / Cholesky / L W), each priced against the roofline that bounds it.
+At N > 1 it carries `per_rank`: where each rank's time went (kernel min / max, all-gather, all-reduce, per-body work).
 """
 import argparse
 import json
@@ -41,8 +44,31 @@ CONFIGS = {
 }
 FLOPS_PER_PAIR = {False: 59.0, True: 204.0}   # reference arithmetic per ordered pair
 PEAK_FP64_TFLOPS = 78.6                       # MI355X fp64 vector == fp64 matrix peak
+PEAK_HBM_GBS = 8000.0                         # HBM3E, MI355X_MICROARCH.md
 PEAK_CLOCK_GHZ = 2.4                          # the clock that peak is quoted at
 N_SIMD = 1024                                 # 256 CUs x 4 SIMDs; one wave64 fp64 VALU instruction occupies a SIMD for 4 cycles
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of a self-launched job must not
+    initialise the GPU before it starts its ranks): GPU nodes of the KFD topology, cut down by the *_VISIBLE_DEVICES lists."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(base, d, "properties")) if len(l.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(args, argv):
@@ -50,10 +76,12 @@ def self_launch(args, argv):
     before this process has touched the GPU, print the ONE line and exit with the job's status.  Two phases, so that the
     headline line survives whatever happens to the (much longer) time-step part: phase `main` times the hot path and
     produces the line; phase `timestep` (apply_M mode with --timestep-steps > 0 only) runs the time-step variants as a
-    second job under a time limit and its result -- or the reason it is missing -- is merged into the line."""
-    import socket
+    second job under a time limit and its result -- or the reason it is missing -- is merged into the line; a missing
+    time-step part makes the exit status non-zero (the line is still printed).  Every job runs in its own session: on a
+    time-out the whole process group is terminated, then killed, so no rank outlives bench.py holding a GPU."""
+    import signal
     import subprocess
-    ndev = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    ndev = visible_gpus()
     if args.backend == "nccl" and ndev < args.gpus:
         raise SystemExit("bench.py: --gpus %d needs %d visible GPUs, found %d (use --backend gloo to rehearse several "
                          "ranks on one GPU)" % (args.gpus, args.gpus, ndev))
@@ -61,18 +89,28 @@ def self_launch(args, argv):
         raise SystemExit("bench.py: no GPU visible")
 
     def run(phase, timeout):
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", RBL_BENCH_PHASE=phase)
         env.setdefault("OMP_NUM_THREADS", "4")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        # --standalone: torchrun picks (and holds) a free rendezvous port itself -- no bind-then-close race
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + argv
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-        except subprocess.TimeoutExpired as e:
-            return 124, (e.stdout or ""), "timed out after %d s" % timeout
-        return p.returncode, p.stdout, None
+            out, _ = p.communicate(timeout=timeout)
+            return p.returncode, out, None
+        except subprocess.TimeoutExpired:
+            killed = "terminated"
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+                try:
+                    out, _ = p.communicate(timeout=20)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)
+                    killed = "killed"
+                    out, _ = p.communicate()
+            except ProcessLookupError:
+                out, _ = p.communicate()
+            return 124, (out or ""), "timed out after %d s, ranks %s" % (timeout, killed)
 
     two_phase = args.mode == "apply_M" and args.timestep_steps > 0
     rc, out, why = run("main" if two_phase else "all", 3000)
@@ -86,13 +124,13 @@ def self_launch(args, argv):
     line = json.loads(lines[-1])
     rc2, out2, why2 = run("timestep", 1500)
     l2 = [l for l in out2.splitlines() if l.startswith("{")]
-    if rc2 == 0 and l2:
+    ok = rc2 == 0 and bool(l2)
+    if ok:
         line["timestep"] = json.loads(l2[-1])
     else:
-        line["timestep"] = {"error": "the time-step job did not finish (%s); the headline line above it is unaffected"
-                                     % (why2 or ("exit status %d" % rc2))}
+        line["timestep"] = {"error": "the time-step job did not finish (%s)" % (why2 or ("exit status %d" % rc2))}
     print(json.dumps(line), flush=True)
-    raise SystemExit(0)
+    raise SystemExit(0 if ok else 3)
 
 
 def kernel_source_hash():
@@ -121,18 +159,20 @@ def pmc_traffic(kernel, config, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only while the built
     library holds the same kernel code as the profiled one: the file records the sha256 of the profiled instance's
     instruction text, tools/isa_stats.py computes the same for every build (librbl.isa.json)."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_%s_pmc.json" % config)
-    try:
-        d = json.load(open(path))
-        isa = json.load(open(os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")))
-        if isa.get("kernel_source_sha256") != kernel_source_hash():       # stale assembly analysis: nothing to compare with
-            return None, None
-        same = d.get("kernel_isa_sha256") and d["kernel_isa_sha256"] == isa["instance_isa_sha256"].get(d.get("kernel_instance"))
-        if not same or world != 1 or d.get("kernel") != kernel:
-            return None, None
-        return d["hbm_bytes_per_launch"], d
-    except (OSError, KeyError, ValueError):
-        return None, None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_bench_%s_pmc.json" % (rnd, config))
+        try:
+            d = json.load(open(path))
+            isa = json.load(open(os.path.join(ROOT, "rigid_body_light_amd", "librbl.isa.json")))
+            if isa.get("kernel_source_sha256") != kernel_source_hash():       # stale assembly analysis: nothing to compare with
+                return None, None
+            same = d.get("kernel_isa_sha256") and d["kernel_isa_sha256"] == isa["instance_isa_sha256"].get(d.get("kernel_instance"))
+            if not same or world != 1 or d.get("kernel") != kernel:
+                continue
+            return d["hbm_bytes_per_launch"], d
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(c, nb, nblb, wall, budget_s):
@@ -168,13 +208,77 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
     return out
 
 
+def gather_ranks(values, dev, world):
+    """values: list of floats of this rank -> (world, len) numpy array on every rank"""
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    if world == 1:
+        return t.cpu().numpy()[None, :]
+    buf = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(buf, t)
+    return torch.stack(buf).cpu().numpy()
+
+
+def phase_block(ctx, steps, dev, world):
+    """per-rank, per-time-step GPU milliseconds of librbl's phases (rbl_get_timings) -> {phase: {min, max, per_rank}}"""
+    tm = ctx.timings()
+    names = list(ctx.TIMING_PHASES)
+    arr = gather_ranks([tm[k][0] / max(steps, 1) for k in names], dev, world)
+    out = {}
+    for i, k in enumerate(names):
+        out[k + "_ms"] = {"min": float(arr[:, i].min()), "max": float(arr[:, i].max()), "per_rank": [round(float(x), 4) for x in arr[:, i]]}
+    out["note"] = ("GPU milliseconds per time step and rank between hipEvents on the context's stream (rbl_get_timings): product = pair "
+                   "kernels + slab reduction of this rank's tile pairs; per_body = applications of the rank's own per-body factors; factor "
+                   "= their build; collective = the all-reduce callback incl. the wait for the slowest rank; total = the solver calls "
+                   "(what it holds beyond the others is Krylov vector work, K operators, launch gaps, host convergence tests)")
+    return out
+
+
+def root_identity_error(ctx, nb, nblb, a, dev):
+    """MEASURED accuracy of the preconditioned Lanczos root G = B L Sp^{1/2} (Sp = L^-1 M L^-T) at the context's current
+    tolerance, outside any timed region: with s = Sp^{1/2} W = L^-1 B^-1 (G W) and v = L^-T W an exact root satisfies
+    G s = B M v (one extra mobility product); returns |G s - B M v| / |B M v|.  The reference's factor is exact
+    (c_rigid_obj.cpp:670-672); an iterative replacement must state its error."""
+    N = nb * nblb
+    n = 3 * N
+    r = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    z = r.view(-1, 3)[:, 2]
+    B = torch.where(z >= a, torch.ones_like(z), z / a).repeat_interleave(3)            # make_damp_mat :618-639
+    W = torch.from_numpy(np.random.default_rng(33).standard_normal(n)).to(dev)
+
+    def root(vec):
+        out = torch.empty_like(vec)
+        ctx.M_half_W(r.data_ptr(), N, vec.contiguous().data_ptr(), "lanczos_pc", out.data_ptr())
+        return out
+
+    def bsolve(vec, mode):
+        out = torch.empty_like(vec)
+        ctx.block_solve(vec.contiguous().data_ptr(), out.data_ptr(), mode)
+        return out
+
+    x = root(W)
+    s_ = bsolve(x / B, 1)
+    v = bsolve(W, 2)
+    Mv = torch.empty_like(v)
+    ctx.set_no_damp(True)
+    try:
+        ctx.apply_M(v.data_ptr(), r.data_ptr(), N, 0, N, Mv.data_ptr())
+    finally:
+        ctx.set_no_damp(False)
+    ref = B * Mv
+    e = float(torch.linalg.norm(root(s_) - ref) / torch.linalg.norm(ref))
+    ctx.sync_check()
+    return e
+
+
 def timestep_mode(args, dev, world=1, rank=0):
-    """1 step = one deterministic time step, all operators on the GPU(s); with N > 1 the mobility
-    product of every GMRES iteration is tile-pair sharded (one all-reduce per iteration)."""
+    """1 step = one time step, all operators on the GPU(s), every loop inside librbl; with N > 1 the mobility
+    product of every Krylov iteration is tile-pair sharded (one all-reduce per iteration)."""
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
     from rigid_body_light_amd.dist import ShardedMobility
-    from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper
+    from rigid_body_light_amd.krylov import (BrownianStepper, DeterministicStepper, ShardedBrownianStepper,
+                                             ShardedDeterministicStepper)
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb
@@ -192,26 +296,24 @@ def timestep_mode(args, dev, world=1, rank=0):
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
     lanczos_its = None
     if brownian:   # stochastic midpoint step: 2 M^{1/2}W + M_RFD + Kinv, then the saddle solve at q^{n+1/2}
-        from rigid_body_light_amd.krylov import BrownianStepper, ShardedBrownianStepper
         method = {"cholesky": 0, "lanczos": 1, "lanczos_pc": 2}[args.mhalf]
         if world > 1 or args.sharded_driver:
             if method == 0:
                 raise SystemExit("the sharded Brownian step uses the Lanczos square root")
             bst = ShardedBrownianStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall,
-                                         args.kBT, c["dt"], lanczos_tol=1e-3)
+                                         args.kBT, c["dt"], lanczos_tol=args.lanczos_tol, precondition=(method == 2))
             stp_step = lambda k: bst.step(Fb, seed=k, iters=iters, rtol=rtol)
             lanczos_its = lambda: list(bst.lanczos_iterations)
         else:
-            ctx.set_lanczos(100, 1e-3)
-            bst = BrownianStepper(ctx, nb, nblb, dev, native=(not args.graph and (args.native or args.solver == "native")))
+            ctx.set_lanczos(200, args.lanczos_tol)
+            bst = BrownianStepper(ctx, nb, nblb, dev)
             stp_step = lambda k: bst.step(Fb, seed=k, method=method, iters=iters, rtol=rtol)
             lanczos_its = (lambda: [ctx.lanczos_report()[0]]) if method != 0 else None
     else:
         if world > 1:
             stp = ShardedDeterministicStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev)
         else:
-            solver = "graph" if args.graph else ("native" if args.native else args.solver)
-        stp = DeterministicStepper(ctx, nb, nblb, dev, use_graph=(solver == "graph"), native=(solver == "native"))
+            stp = DeterministicStepper(ctx, nb, nblb, dev)
         stp.warm_start = args.warm_start or args.extrapolate > 0
         if args.block_refresh > 1:
             ctx.set_block_refresh(args.block_refresh)
@@ -223,6 +325,7 @@ def timestep_mode(args, dev, world=1, rank=0):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    ctx.set_timing(True); ctx.reset_timings()
     t0 = time.perf_counter()
     for k in range(args.steps):
         m_used, r_last = stp_step(args.warmup + k)
@@ -231,6 +334,8 @@ def timestep_mode(args, dev, world=1, rank=0):
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    phases = phase_block(ctx, args.steps, dev, world)
+    ctx.set_timing(False)
     sec_t = torch.tensor([(t1 - t0) / args.steps], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(sec_t, op=dist.ReduceOp.MAX)
@@ -257,65 +362,34 @@ def timestep_mode(args, dev, world=1, rank=0):
         "data": "synthetic", "config": {"workload": args.config, "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall},
         "mf_gflops": extra.get("apply_M_per_step", iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used,
         "block_refresh": args.block_refresh, "initial_guess": (["previous solution", "2 x_n - x_{n-1}", "3 x_n - 3 x_{n-1} + x_{n-2}"][args.extrapolate]
-                          if (args.warm_start or args.extrapolate) and not brownian else "zero"), **extra}), flush=True)
+                          if (args.warm_start or args.extrapolate) and not brownian else "zero"),
+        "phases": phases, **extra}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def brownian_mode(args, dev, world, rank):
-    """BASELINE cfg 4: wall-corrected + Brownian on N GPUs.  1 step = one Brownian increment M^{1/2} W by
-    Lanczos (tol 1e-3) on the tile-pair-sharded product (all-gather once, one all-reduce per iteration)."""
+    """BASELINE cfg 4: wall-corrected + Brownian on N GPUs.  1 step = one Brownian increment M^{1/2} W by librbl's
+    Lanczos (block-Jacobi preconditioned by default) on the tile-pair-sharded product (rbl_set_comm: one all-reduce per
+    product)."""
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
     from rigid_body_light_amd.dist import ShardedMobility
-    from rigid_body_light_amd.krylov import lanczos_mhalf, lanczos_mhalf_multi
     nb, nblb, wall = CONFIGS[args.config]
     c = make_config(nb, nblb, wall)
     N = nb * nblb
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
-    r_local = torch.empty(3 * (sm.row1 - sm.row0), dtype=torch.float64, device=dev)
-    ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
-    sm.set_positions_local(r_local)
-    W = torch.from_numpy(np.random.default_rng(3).standard_normal(3 * N)).to(dev)   # identical on every rank
-
-    def A(v):    # wall=True: the kernel applies B M B; vectors are replicated, only this product communicates
-        part = torch.empty(3 * N, dtype=torch.float64, device=dev)
-        ctx.apply_M_sym(v.contiguous().data_ptr(), sm.r_full.data_ptr(), N, rank, world, part.data_ptr())
-        return sm.all_reduce_sum(part)
-
-    if args.nvec > 1:   # k increments at once: every Lanczos iteration is one multi-vector product (MFMA for k >= 4)
-        if world != 1:
-            raise SystemExit("--nvec > 1 is a single-GPU mode")
-        Wk = torch.from_numpy(np.random.default_rng(3).standard_normal((args.nvec, 3 * N))).to(dev)
-
-        def Ak(Vk):
-            out = torch.empty_like(Vk)
-            ctx.apply_M_multi(Vk.data_ptr(), sm.r_full.data_ptr(), N, args.nvec, out.data_ptr())
-            return out
-
-        for _ in range(args.warmup):
-            lanczos_mhalf_multi(Ak, Wk, 100, 1e-3)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(args.steps):
-            Y, its, ch = lanczos_mhalf_multi(Ak, Wk, 100, 1e-3)
-        torch.cuda.synchronize(); sec = (time.perf_counter() - t0) / args.steps
-        ctx.sync_check()
-        print(json.dumps({
-            "metric": "Brownian increments/sec (%d independent M^{1/2} W by lock-step Lanczos to 1e-3, %d iterations, multi-RHS "
-                      "product on the fp64 matrix cores), %d x shell_N_%d, %s, fp64" % (args.nvec, its, nb, nblb, "wall-corrected, B M B" if wall else "free-space M without damping"),
-            "value": args.nvec / sec, "unit": "increments/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "config": {"workload": args.config, "n_blobs": N, "wall": wall, "nvec": args.nvec},
-            "lanczos_iterations": its, "mf_gflops": args.nvec * its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
-        return
-    its = 0
-    from rigid_body_light_amd.krylov import sharded_mhalf_W
-    pc = args.mhalf == "lanczos_pc"       # block-Jacobi preconditioned square root (default) or plain Lanczos
+    ctx.set_comm(sm)
     if args.mhalf == "cholesky":
         raise SystemExit("--mode brownian measures the matrix-free square roots (--mhalf lanczos_pc | lanczos)")
-    one = lambda: sharded_mhalf_W(ctx, sm, sm.r_full, W[None, :], c["a"], wall, 1e-3, 100, pc)
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(3 * N)).to(dev)   # identical on every rank
+    out = torch.empty_like(W)
+    ctx.set_lanczos(200, args.lanczos_tol)
+    one = lambda: ctx.M_half_W(r.data_ptr(), N, W.data_ptr(), args.mhalf, out.data_ptr())
     for _ in range(args.warmup):
         one()
     torch.cuda.synchronize()
@@ -323,7 +397,7 @@ def brownian_mode(args, dev, world, rank):
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        y, its = one()
+        one()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -331,17 +405,20 @@ def brownian_mode(args, dev, world, rank):
     if world > 1:
         dist.all_reduce(sec, op=dist.ReduceOp.MAX)
     ctx.sync_check()
+    its, est = ctx.lanczos_report()
     if rank == 0:
         sec = float(sec.item())
+        pc = args.mhalf == "lanczos_pc"
         print(json.dumps({
-            "metric": "Brownian increments/sec (M^{1/2} W by %s to 1e-3, %d iterations), %d x shell_N_%d, %s, fp64"
-                      % ("block-Jacobi preconditioned Lanczos" if pc else "Lanczos", its, nb, nblb, "wall-corrected" if wall else "free-space"),
+            "metric": "Brownian increments/sec (M^{1/2} W by %s to %g, %d iterations), %d x shell_N_%d, %s, fp64"
+                      % ("block-Jacobi preconditioned Lanczos" if pc else "Lanczos", args.lanczos_tol, its, nb, nblb,
+                         "wall-corrected" if wall else "free-space"),
             "value": 1.0 / sec, "unit": "increments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": {"workload": "BASELINE.json configs[3]" if args.config == "cfg3" else args.config,
                                             "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
                                             "parallelism": "tile-pair-sharded x%d, all-reduce(U) per Lanczos iteration" % world},
-            "lanczos_iterations": its, "mf_gflops": its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
+            "lanczos_iterations": its, "lanczos_error_estimate": est, "mf_gflops": its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -358,7 +435,9 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
     K = args.timestep_steps
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
 
-    def timed(step_fn, k0=0):
+    def timed(step_fn, k0=0, tctx=None):
+        if tctx is not None:
+            tctx.set_timing(True); tctx.reset_timings()
         barrier(); t0 = time.perf_counter()
         its, res = [], []
         for k in range(K):
@@ -369,13 +448,17 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         if world > 1:
             dist.all_reduce(tv, op=dist.ReduceOp.MAX)
         t = float(tv.item())
-        return {"timesteps_per_sec": 1.0 / t, "ms_per_timestep": t * 1e3, "steps_timed": K, "gmres_iterations": its,
-                "gmres_residual_max": max(res), "gmres_residual_last": res[-1]}
+        d = {"timesteps_per_sec": 1.0 / t, "ms_per_timestep": t * 1e3, "steps_timed": K, "gmres_iterations": its,
+             "gmres_residual_max": max(res), "gmres_residual_last": res[-1]}
+        if tctx is not None:
+            d["phases"] = phase_block(tctx, K, dev, world)
+            tctx.set_timing(False)
+        return d
 
     out = {}
-    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev, native=True))
+    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
     stp.step(Fb, 20)
-    d = timed(lambda k: stp.step(Fb, 20))
+    d = timed(lambda k: stp.step(Fb, 20), tctx=ctx)
     d.update({"apply_M_per_timestep": 21, "definition": "deterministic fixed-work step (SURVEY.md 8d): 20 GMRES iterations on the saddle "
               "operator, diagonal PC, + evolve; NOT converged (see gmres_residual_max)"})
     out["deterministic_fixed"] = d
@@ -407,6 +490,8 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         lib().rbl_set_blk_pc(bctx.h, 1)
         bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(200, ltol)
         bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
+        for v in args.tune:
+            bctx.set_tuning(0, v)
         if relaxed:                    # inexact Krylov (rbl_set_tuning 52): see the `relaxation` note below
             bctx.set_tuning(0, 52)
         if world > 1:
@@ -416,15 +501,20 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             one = lambda k: bst.step(Fb, seed=k, iters=200, rtol=1e-8)
             lz = lambda: list(bst.lanczos_iterations)
         else:
-            bst = BrownianStepper(bctx, nb, nblb, dev, native=True)
+            bst = BrownianStepper(bctx, nb, nblb, dev)
             one = lambda k: bst.step(Fb, seed=k, method=2, iters=200, rtol=1e-8)
             lz = lambda: [bctx.lanczos_report()[0]]
         one(0)
-        d = timed(one, 1)
-        d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz(), "relaxed_products": relaxed})
+        d = timed(one, 1, tctx=bctx)
+        d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz(), "lanczos_error_estimate_last_step": bctx.lanczos_report()[1],
+                  "relaxed_products": relaxed})
+        if world == 1:                 # measured, outside the timed region: one more pair of roots + one product
+            d["root_identity_error"] = root_identity_error(bctx, nb, nblb, c["a"], dev)
         bro["lanczos_%g%s" % (ltol, "_relaxed" if relaxed else "")] = d
         del bst, bctx
     bro.update({"kBT": 1.0, "rtol": 1e-8, "initial_guess": "zero (fresh noise every step)",
+                "root_identity_error": "|G s - B M v| / |B M v| with s = L^-1 B^-1 (G W), v = L^-T W for the root G = B L (L^-1 M L^-T)^{1/2} "
+                                       "the step uses, measured after the timed steps at the entry's Lanczos tolerance (zero for an exact root)",
                 "relaxation": "the *_relaxed entry is opt-in (rbl_set_tuning 52), everything else is fp64 throughout: an inexact Krylov "
                               "iteration tolerates a relative product error of (tolerance / current residual), so GMRES iterations whose "
                               "residual estimate is below 1e-3 and the Lanczos iterations (tolerance 1e-3) evaluate far tile pairs in packed "
@@ -434,6 +524,125 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
                               "M_RFD (2 apply_M) + Kinv at q^n, GMRES with the block-diagonal PC to 1e-8 at the predictor "
                               "configuration, update from q^n"})
     out["brownian_converged"] = bro
+    return out
+
+
+def other_configs(dev, stream):
+    """The other BASELINE.json configurations, timed in the default N = 1 run (device-resident inputs, wall clock around
+    stream-synchronised loops): each entry says what bounds it and how close it gets."""
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    from rigid_body_light_amd.krylov import BrownianStepper, DeterministicStepper
+    out = {}
+
+    def wall_time(fn, reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def product_entry(name, kBT):
+        nb, nblb, wall = CONFIGS[name]
+        c = make_config(nb, nblb, wall)
+        N = nb * nblb
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=kBT, stream_ptr=stream.cuda_stream)
+        ctx.set_config(c["X"], c["Q"])
+        r = torch.empty(3 * N, dtype=torch.float64, device=dev)
+        ctx.blob_positions(0, nb, r.data_ptr())
+        F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev)
+        U = torch.empty_like(F)
+        one = lambda: ctx.apply_M(F.data_ptr(), r.data_ptr(), N, 0, N, U.data_ptr())
+        for _ in range(5):
+            one()
+        ctx.sync_check()
+        t = wall_time(one, 200)
+        ni, _, _ = ctx.apply_M_sym_info(N, 1, 1)
+        kname = "k_apply_M_sym<%s,%d>" % ("true" if wall else "false", ni)
+        isa = isa_counts(kname)
+        d = {"workload": "%d x shell_N_%d, %s" % (nb, nblb, "wall-corrected" if wall else "free-space"),
+             "apply_M_us": t * 1e6, "mf_gflops": 18.0 * float(N) ** 2 / t / 1e9}
+        if isa is not None:
+            ach = isa["flop"] * 0.5 * float(N) * float(N) / t / 1e12
+            d["roofline"] = {"bound": "fp64-valu" if N >= 4096 else "launch latency (one wave's sweep; 14 400 pairs)", "kernel": kname,
+                             "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
+                             "timed": "wall clock over 200 back-to-back launches incl. the slab reduction"}
+        return ctx, c, nb, nblb, d
+
+    # cfg 1: 10 x shell_N_12, free space, deterministic (the reference's own CPU-runnable case)
+    ctx, c, nb, nblb, d = product_entry("cfg1", 0.0)
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    st = DeterministicStepper(ctx, nb, nblb, dev)
+    res, its = [], []
+    st.step(Fb, 200, 1e-8)
+    def s1():
+        m, r_ = st.step(Fb, 200, 1e-8); its.append(m); res.append(r_)
+    t = wall_time(s1, 20)
+    d["deterministic_converged"] = {"ms_per_timestep": t * 1e3, "timesteps_per_sec": 1.0 / t, "rtol": 1e-8, "gmres_iterations": its[-5:],
+                                    "gmres_residual_max": max(res), "solver": "whole solve in ONE kernel launch on one CU (rbl_small.hip), diagonal PC"}
+    out["cfg1"] = d
+    ctx.close()
+
+    # cfg 2: 50 x shell_N_162, free space + Brownian noise
+    ctx, c, nb, nblb, d = product_entry("cfg2", 1.0)
+    lib().rbl_set_blk_pc(ctx.h, 1)
+    ctx.set_lanczos(200, 1e-3)
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    bst = BrownianStepper(ctx, nb, nblb, dev)
+    res, its, lz = [], [], []
+    bst.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)
+    seeds = iter(range(1, 1000))
+    def s2():
+        m, r_ = bst.step(Fb, seed=next(seeds), method=2, iters=200, rtol=1e-8); its.append(m); res.append(r_); lz.append(ctx.lanczos_report()[0])
+    ctx.set_timing(True); ctx.reset_timings()
+    t = wall_time(s2, 20)
+    tm = ctx.timings(); ctx.set_timing(False)
+    d["brownian_converged"] = {"ms_per_timestep": t * 1e3, "timesteps_per_sec": 1.0 / t, "rtol": 1e-8, "lanczos_tol": 1e-3,
+                               "gmres_iterations": its, "lanczos_iterations": lz, "gmres_residual_max": max(res),
+                               "root_identity_error": root_identity_error(ctx, nb, nblb, c["a"], dev),
+                               "phases_ms_per_step": {k: tm[k][0] / 20.0 for k in tm},
+                               "preconditioner": "block-diagonal in the body frame (free space: one factor for all bodies and all time)"}
+    out["cfg2"] = d
+    ctx.close()
+
+    # cfg 5: 20 x shell_N_2562, dense 3N x 3N mobility + Cholesky (189 GB of the card's 288)
+    nb, nblb, wall = CONFIGS["cfg5"]
+    N = nb * nblb; n = 3 * N
+    need = 8 * n * n
+    free = torch.cuda.mem_get_info()[0]
+    if free < need + (8 << 30):
+        out["cfg5"] = {"skipped": "the dense matrix needs %.1f GB, %.1f GB of device memory are free" % (need / 1e9, free / 1e9)}
+        return out
+    c = make_config(nb, nblb, wall)
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=stream.cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.blob_positions(0, nb, r.data_ptr())
+    W = torch.from_numpy(np.random.default_rng(3).standard_normal(n)).to(dev)
+    o = torch.empty_like(W)
+    M = torch.empty(n * n, dtype=torch.float64, device=dev)
+    build = lambda: ctx.build_M(r.data_ptr(), N, True, M.data_ptr())
+    build(); ctx.sync_check()
+    tb = wall_time(build, 2)
+    tc = wall_time(lambda: ctx.cholesky(M.data_ptr(), n, False), 1)
+    ctx.sync_check()                                                   # (a non-SPD pivot would be reported here)
+    trmv = lambda: ctx.trmv_lower(M.data_ptr(), n, W.data_ptr(), o.data_ptr())
+    trmv()
+    tt = wall_time(trmv, 3)
+    ctx.sync_check()
+    out["cfg5"] = {
+        "workload": "%d x shell_N_%d, free space, dense B M B (n = %d, %.1f GB) -> in-place Cholesky -> L W (reference M_half_W, "
+                    "c_rigid_obj.cpp:661-675)" % (nb, nblb, n, need / 1e9),
+        "k_build_M": {"ms": tb * 1e3, "roofline": {"bound": "hbm", "achieved": need / tb / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                   "frac": need / tb / 1e9 / PEAK_HBM_GBS, "algorithmic": "8 (3N)^2 bytes written once"}},
+        "cholesky": {"ms": tc * 1e3, "roofline": {"bound": "mfma", "achieved": n ** 3 / 3.0 / tc / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": n ** 3 / 3.0 / tc / 1e12 / PEAK_FP64_TFLOPS, "algorithmic": "(3N)^3 / 3 flop"}},
+        "L_W": {"ms": tt * 1e3, "roofline": {"bound": "hbm", "achieved": 4.0 * n * n / tt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                             "frac": 4.0 * n * n / tt / 1e9 / PEAK_HBM_GBS, "algorithmic": "4 (3N)^2 bytes read (lower triangle)"}},
+        "M_half_W_ms": (tb + tc + tt) * 1e3}
+    del M
+    ctx.close()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -449,30 +658,26 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path with several ranks on ONE GPU)")
     ap.add_argument("--mode", default="apply_M", choices=["apply_M", "timestep", "brownian"],
-                    help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one deterministic time step "
-                         "(SURVEY.md 8d fixed-work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve), 1 GPU")
+                    help="apply_M: 1 step = one M.F pass (default).  timestep: 1 step = one time step (SURVEY.md 8d; "
+                         "fixed work: 20 GMRES iterations = 21 apply_M + PC + K ops + evolve; --rtol: converged).  brownian: "
+                         "1 step = one Brownian increment M^{1/2} W")
     ap.add_argument("--timestep-steps", type=int, default=10, help="also time this many time steps of every variant (0 = skip)")
-    ap.add_argument("--nvec", type=int, default=1, help="--mode brownian: independent noise vectors advanced in lockstep "
-                    "(>= 4 uses the fp64-MFMA multi-RHS product; 1 GPU)")
+    ap.add_argument("--other-configs", type=int, default=1, help="N = 1, default workload: also time BASELINE configs[0], [1], [4] (0 = skip)")
     ap.add_argument("--kBT", type=float, default=0.0, help="--mode timestep: > 0 runs the stochastic midpoint (Brownian) step")
     ap.add_argument("--mhalf", default="lanczos_pc", choices=["lanczos_pc", "lanczos", "cholesky"],
                     help="square root used by the Brownian step (lanczos_pc: block-Jacobi preconditioned Lanczos)")
+    ap.add_argument("--lanczos-tol", type=float, default=1e-3, help="error tolerance of the Lanczos square roots")
     ap.add_argument("--sharded-driver", action="store_true", help="use the multi-GPU Brownian driver also at N = 1")
     ap.add_argument("--pc", default="diag", choices=["diag", "block"], help="preconditioner of --mode timestep")
-    ap.add_argument("--solver", default="native", choices=["native", "torch", "graph"],
-                    help="--mode timestep, N = 1: librbl's own GMRES (rbl_gmres_saddle_dev, default), the torch Arnoldi "
-                         "loop, or that loop replayed as one hipGraph")
-    ap.add_argument("--native", action="store_true", help="alias of --solver native")
-    ap.add_argument("--warm-start", action="store_true", help="--mode timestep --rtol ...: native GMRES starts from the previous step's solution")
+    ap.add_argument("--warm-start", action="store_true", help="--mode timestep --rtol ...: GMRES starts from the previous step's solution")
     ap.add_argument("--extrapolate", type=int, default=0, choices=[0, 1, 2], help="--mode timestep --rtol ...: start from the linear (1) "
                     "or quadratic (2) extrapolation of the last solutions (implies --warm-start)")
     ap.add_argument("--block-refresh", type=int, default=1, help="--mode timestep --pc block: rebuild the per-body Cholesky factors only "
                     "every k-th configuration (rbl_set_block_refresh)")
-    ap.add_argument("--graph", action="store_true", help="--mode timestep: replay the fixed-work solve as one hipGraph")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
     ap.add_argument("--tune", type=int, action="append", default=[], help="rbl_set_tuning(0, V) switches for A/B runs (31/32 PC sign, "
-                    "41/42 one-kernel GMRES for small systems), repeatable")
+                    "41/42 one-kernel GMRES for small systems, ...), repeatable")
     ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 
@@ -523,7 +728,8 @@ def main():
     F_local = torch.from_numpy(F_full_host[3 * sm.row0:3 * sm.row1].copy()).to(dev)
     r_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
     U_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # four events per timed step: [gather] e0 [kernel] e1 [all-reduce] e2, preceded by e_start
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
     use_sym = args.variant != 1     # symmetric kernel (each unordered pair once) unless the ordered kernel is forced
     U_part = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
@@ -535,6 +741,8 @@ def main():
         # Symmetric sharding needs all positions on every rank: the O(N_bod) body state is replicated, so each
         # rank evaluates them itself (a ~5 us kernel) instead of gathering them; the force vector arrives
         # sharded (one all-gather) and the partial U is completed by one all-reduce.
+        if k is not None:
+            ev[k][0].record(stream)
         if use_sym:
             ctx.blob_positions(0, nb, r_all.data_ptr())
             r_full = r_all
@@ -543,15 +751,17 @@ def main():
             r_full = sm.set_positions_local(r_local) if world > 1 else r_local
         F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
         if k is not None:
-            ev[k][0].record(stream)
+            ev[k][1].record(stream)
         if use_sym:   # this rank's share of the unordered tile pairs -> partial full-length U -> all-reduce
             ctx.apply_M_sym(F_full.data_ptr(), r_full.data_ptr(), N, rank, world, U_part.data_ptr())
         else:         # ordered pairs, this rank's rows, no reduction
             ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
         if k is not None:
-            ev[k][1].record(stream)
+            ev[k][2].record(stream)
         if use_sym:
             sm.all_reduce_sum(U_part)
+        if k is not None:
+            ev[k][3].record(stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -571,11 +781,12 @@ def main():
     ctx.sync_check()
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    kern_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / args.steps], dtype=torch.float64, device=dev)
+    mine = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / args.steps for i in range(3)]     # gather+positions, kernel, all-reduce
+    per_rank = gather_ranks(mine, dev, world)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item()); kern_ms = float(kern_ms.item())
+    elapsed = float(elapsed.item())
+    kern_ms = float(per_rank[:, 1].max())
 
     if args.dump_check:   # for tests/: a row sample of what was just timed (the oracle comparison happens in the test)
         b0 = sm.row0 + (nrows // 2)
@@ -591,13 +802,26 @@ def main():
             dist.destroy_process_group()
         return
     tstep = None
+    failed = None
     if args.timestep_steps > 0 and phase != "main":
         try:
             tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
-        except Exception as e:                               # the hot-path line must not be lost to the time-step part
+        except Exception as e:                               # the hot-path line must not be lost to the time-step part ...
             if world > 1:
                 raise
+            import traceback
+            traceback.print_exc()
             tstep = {"error": repr(e)}
+            failed = "time-step part failed"                 # ... but a failing step driver makes the exit status non-zero
+    others = None
+    if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
+        try:
+            others = other_configs(dev, stream)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            others = {"error": repr(e)}
+            failed = failed or "other-configs part failed"
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -665,8 +889,18 @@ def main():
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
             "roofline": roof,
         }
+        if world > 1:
+            names = ("positions_and_all_gather_ms", "kernel_ms", "all_reduce_ms")
+            line["per_rank"] = {n_: {"min": float(per_rank[:, i].min()), "max": float(per_rank[:, i].max()),
+                                     "per_rank": [round(float(x), 4) for x in per_rank[:, i]]} for i, n_ in enumerate(names)}
+            line["per_rank"]["note"] = ("GPU milliseconds per step between events on each rank's stream: blob positions + all-gather of the "
+                                        "force shards; this rank's tile pairs (pair kernel + slab reduction); the all-reduce of the partial "
+                                        "U incl. the wait for the slowest rank.  The time-step variants carry librbl's own phase timings "
+                                        "(`phases`) per rank.")
         if tstep is not None:
             line["timestep"] = tstep
+        if others is not None:
+            line["configs"] = others
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]
@@ -676,6 +910,9 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: %s (see the line's error entry)\n" % failed)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

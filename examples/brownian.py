@@ -18,7 +18,7 @@ ctx = DeviceContext(c["a"], c["eta"], True, cfg=c["cfg"], dt=c["dt"], kBT=kBT,
 lib().rbl_set_blk_pc(ctx.h, 1)            # block-diagonal preconditioner
 ctx.set_lanczos(100, 1e-4)                # tolerance of the Lanczos square root
 ctx.set_config(c["X"], c["Q"])
-stepper = BrownianStepper(ctx, nb, nblb, dev, native=True)
+stepper = BrownianStepper(ctx, nb, nblb, dev)
 F = np.tile([0.0, 0.0, 0.2, 0.0, 0.0, 0.0], nb)       # weak pull towards the wall (reference sign convention)
 X0 = ctx.get_config(nb)[0].copy()
 for n in range(10):

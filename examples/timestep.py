@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 ctx = DeviceContext(c["a"], c["eta"], True, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
 lib().rbl_set_blk_pc(ctx.h, 1)
 ctx.set_config(c["X"], c["Q"])
-stepper = DeterministicStepper(ctx, nb, nblb, dev, native=True)   # librbl's own GMRES (rbl_gmres_saddle_dev)
+stepper = DeterministicStepper(ctx, nb, nblb, dev)   # librbl's own GMRES (rbl_gmres_saddle_dev)
 stepper.warm_start = True                                         # start each solve from the previous steps' solutions:
 stepper.extrapolate = 2                                           # 3 x_n - 3 x_{n-1} + x_{n-2} once three exist
 # sign convention of the reference's saddle system (rhs = [slip ; -F], K^T lambda = -F): with this F the

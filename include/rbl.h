@@ -165,7 +165,9 @@ int rbl_RHS_and_Midpoint(rbl_ctx *ctx, const double *Slip, const double *Force, 
                          uint64_t seed, int method, int split_rand, double delta, double *RHS,
                          double *X_half, double *Q_half);
 
-/* Lanczos controls / report (iterations used by the last call, last residual) */
+/* Lanczos controls / report.  max_iter: the basis is kept (max_iter + 1 vectors of 3 N doubles per recurrence).  tol: the recurrence stops when the ERROR ESTIMATE of the increment is below tol (relative):
+ * the last correction d_m = |x_m - x_{m-1}| / |x_m| extrapolated geometrically, d_m rho / (1 - rho), rho = d_m / d_{m-1}.
+ * The report returns the iterations used by the last call and that estimate. */
 int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
 int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);
 
@@ -310,9 +312,30 @@ int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d
  * enqueued on the context's stream and before whatever is enqueued next (e.g. ncclAllReduce / torch.distributed
  * all_reduce on that stream; a host-staged implementation synchronises the stream itself).  Returns 0 on success.
  * All vectors of the Krylov recurrences stay replicated and bitwise identical on every rank, so the ranks take the same
- * convergence decisions.  world == 1 (or fn == NULL) switches back to single-GPU products. */
+ * convergence decisions.  fn == NULL switches back to single-GPU products; a callback with world == 1 keeps the multi-GPU
+ * code path on with one share (every product still ends in a call of `allreduce`): a one-GPU rehearsal of what N ranks run. */
 typedef int (*rbl_allreduce_fn)(void *user, double *d_buf, int64_t count);
 int rbl_set_comm(rbl_ctx *ctx, int rank, int world, rbl_allreduce_fn allreduce, void *user);
+
+/* ---- per-phase timings of the library's own solvers (the reference has one gettimeofday helper,
+ * c_rigid_obj.cpp:22-29, and one printf around M_half_W, :929-932) -----------------------------------------------------
+ * rbl_set_timing(ctx, 1): from now on the phases below are bracketed by hipEvents on the context's stream (a few
+ * microseconds of host time per bracket; off by default).  rbl_get_timings synchronises the stream and returns, per
+ * phase, the GPU time in milliseconds and the number of brackets accumulated since the last rbl_reset_timings (arrays of
+ * RBL_T_COUNT entries; either may be NULL).  RBL_T_TOTAL spans the solver entry points (rbl_gmres_saddle_dev, the
+ * Lanczos square roots, M_RFD); what it holds beyond the other phases is Krylov vector work, K operators, launch gaps and
+ * the host's convergence tests.  On a multi-GPU context (rbl_set_comm) RBL_T_COLLECTIVE is the time the stream spent in
+ * the caller's all-reduce, including the wait for the slowest rank. */
+#define RBL_T_PRODUCT 0     /* mobility products: pair kernels + their slab reduction                         */
+#define RBL_T_PERBODY 1     /* applications of the per-body factors / inverses, preconditioner tail            */
+#define RBL_T_FACTOR 2      /* per-body dense blocks, batched Cholesky, explicit inverses, M^-1 K, (K^T M^-1 K) */
+#define RBL_T_COLLECTIVE 3  /* the all-reduce callback of rbl_set_comm                                          */
+#define RBL_T_DENSE 4       /* dense B M B build, Cholesky, L W (RBL_MHALF_CHOLESKY)                            */
+#define RBL_T_TOTAL 5       /* whole solver calls                                                               */
+#define RBL_T_COUNT 6
+int rbl_set_timing(rbl_ctx *ctx, int on);
+int rbl_reset_timings(rbl_ctx *ctx);
+int rbl_get_timings(rbl_ctx *ctx, double *ms, int64_t *calls);
 
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);
@@ -336,7 +359,9 @@ int rbl_sync_check(rbl_ctx *ctx);
  * body (default; see rbl_block_solve_dev);
  * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an
  * approximate block factor (no factorisation, 29.7 MB instead of 5.9 GB at cfg 3; one or two more GMRES iterations --
- * measured level in time at cfg 3, so not the default).  All per context. */
+ * measured level in time at cfg 3, so not the default);
+ * 81 / 82: Lanczos square roots with the three-term recurrence only (round 1-2; the estimate stagnates near 1e-6) / with
+ * every new vector re-orthogonalised against the whole stored basis (default).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

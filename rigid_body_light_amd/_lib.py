@@ -64,6 +64,9 @@ def lib():
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
+        L.rbl_set_timing.argtypes = [vp, C.c_int]
+        L.rbl_reset_timings.argtypes = [vp]
+        L.rbl_get_timings.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
         _LIB = L
     return _LIB
 
@@ -85,6 +88,7 @@ class DeviceContext:
         self._chk(self.L.rbl_set_parameters(self.h, a, dt, kBT, eta, cfg.ctypes.data, cfg.shape[0]))
         self._chk(self.L.rbl_set_wall_pc(self.h, int(bool(wall))))
         self._chk(self.L.rbl_set_stream(self.h, stream_ptr))
+        self._stream_ptr = int(stream_ptr or 0)
 
     def _chk(self, rc):
         if rc != 0:
@@ -99,9 +103,10 @@ class DeviceContext:
     def set_comm(self, sharded):
         """multi-GPU inside the library's solvers: `sharded` is a dist.ShardedMobility (rank, world, all_reduce_sum);
         every full mobility product of librbl's own GMRES / Lanczos / step drivers becomes this rank's tile pairs + one
-        all-reduce through torch.distributed (RCCL on device buffers; host-staged with gloo).  None switches it off."""
+        all-reduce through torch.distributed (RCCL on device buffers; host-staged with gloo).  None switches it off.  A
+        group of one rank keeps it on only when `sharded` was built with force_collectives (the world-1 RCCL test)."""
         import torch
-        if sharded is None or sharded.world == 1:
+        if sharded is None or not sharded.collectives:
             self._comm_cb = None
             self._chk(self.L.rbl_set_comm(self.h, 0, 1, None, None))
             return
@@ -113,7 +118,13 @@ class DeviceContext:
         def _allreduce(user, ptr, count):
             try:
                 t = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
-                sharded.all_reduce_sum(t)
+                # rbl.h: the all-reduce must be ordered on the CONTEXT's stream (the library enqueues producer and consumer
+                # kernels there); torch issues collectives on its current stream, so make the context's stream current
+                if sharded.device.type == "cuda" and torch.cuda.current_stream(sharded.device).cuda_stream != self._stream_ptr:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(self._stream_ptr, device=sharded.device)):
+                        sharded.all_reduce_sum(t)
+                else:
+                    sharded.all_reduce_sum(t)
                 return 0
             except Exception as e:      # never unwind through the C caller
                 import sys
@@ -125,6 +136,23 @@ class DeviceContext:
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.rbl_set_stream(self.h, stream_ptr))
+        self._stream_ptr = int(stream_ptr or 0)
+
+    TIMING_PHASES = ("product", "per_body", "factor", "collective", "dense", "total")      # RBL_T_* of include/rbl.h
+
+    def set_timing(self, on=True):
+        """hipEvent brackets around the phases of librbl's own solvers (rbl_set_timing)"""
+        self._chk(self.L.rbl_set_timing(self.h, int(bool(on))))
+
+    def reset_timings(self):
+        self._chk(self.L.rbl_reset_timings(self.h))
+
+    def timings(self):
+        """{phase: (milliseconds, brackets)} accumulated since the last reset (synchronises the stream)"""
+        n = len(self.TIMING_PHASES)
+        ms, calls = (C.c_double * n)(), (C.c_int64 * n)()
+        self._chk(self.L.rbl_get_timings(self.h, ms, calls))
+        return {k: (ms[i], calls[i]) for i, k in enumerate(self.TIMING_PHASES)}
 
     def set_tuning(self, jsplit=0, variant=0):
         self._chk(self.L.rbl_set_tuning(self.h, jsplit, variant))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -85,6 +86,72 @@ int rbl_dev_reserve(rbl_ctx *c, RblDevBuf &b, size_t bytes)
     return rbl_fail(c, RBL_ERR_ALLOC, std::string("hipMalloc failed: ") + hipGetErrorString(e));
   }
   b.bytes = bytes;
+  return RBL_OK;
+}
+
+// ---- per-phase timings (include/rbl.h: rbl_set_timing / rbl_get_timings) ----------------------------------------------
+static hipEvent_t timing_event(rbl_ctx *c)
+{
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+RblPhase::RblPhase(rbl_ctx *ctx, int ph) : c(ctx), phase(ph)
+{
+  if (!c || !c->timing_on || !c->dev_ready) return;
+  if (ph == RBL_T_TOTAL) { if (c->timing_total_open) return; }
+  else if (c->timing_open >= 0) return;                 // part of the phase that is already open
+  a = timing_event(c);
+  if (!a || hipEventRecord(a, c->stream) != hipSuccess) { if (a) c->ev_pool.push_back(a); a = nullptr; return; }
+  live = true;
+  if (ph == RBL_T_TOTAL) c->timing_total_open = true; else c->timing_open = ph;
+}
+
+RblPhase::~RblPhase()
+{
+  if (!live) return;
+  if (phase == RBL_T_TOTAL) c->timing_total_open = false; else c->timing_open = -1;
+  hipEvent_t b = timing_event(c);
+  if (b && hipEventRecord(b, c->stream) == hipSuccess) c->ev_spans.push_back({phase, a, b});
+  else { c->ev_pool.push_back(a); if (b) c->ev_pool.push_back(b); }
+}
+
+static int timing_resolve(rbl_ctx *c)
+{
+  if (c->ev_spans.empty()) return RBL_OK;
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  for (const rbl_ctx::TimedSpan &sp : c->ev_spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { c->t_ms[sp.phase] += (double)ms; ++c->t_calls[sp.phase]; }
+    c->ev_pool.push_back(sp.a); c->ev_pool.push_back(sp.b);
+  }
+  c->ev_spans.clear();
+  return RBL_OK;
+}
+
+extern "C" int rbl_set_timing(rbl_ctx *c, int on)
+{
+  if (!c) return RBL_ERR_ARG;
+  if (on) { int rc = rbl_dev_init(c); if (rc) return rc; }
+  c->timing_on = on != 0;
+  return RBL_OK;
+}
+
+extern "C" int rbl_reset_timings(rbl_ctx *c)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = timing_resolve(c); if (rc) return rc;
+  for (int i = 0; i < RBL_T_COUNT; ++i) { c->t_ms[i] = 0.0; c->t_calls[i] = 0; }
+  return RBL_OK;
+}
+
+extern "C" int rbl_get_timings(rbl_ctx *c, double *ms, int64_t *calls)
+{
+  if (!c) return RBL_ERR_ARG;
+  int rc = timing_resolve(c); if (rc) return rc;
+  for (int i = 0; i < RBL_T_COUNT; ++i) { if (ms) ms[i] = c->t_ms[i]; if (calls) calls[i] = c->t_calls[i]; }
   return RBL_OK;
 }
 
@@ -184,7 +251,8 @@ static RblParams ctx_params(const rbl_ctx *c)
 // ---- multi-GPU (rbl_set_comm): this rank's bodies (contiguous split, sizes differ by at most one -- the partition of
 // rigid_body_light_amd/dist.py) and the caller's sum all-reduce.  Per-body work (Cholesky factors, substitutions) is done for
 // the own bodies only, written into a zeroed full-length vector and completed by the all-reduce (an all-gather by sums).
-static bool comm_on(const rbl_ctx *c) { return c->comm_world > 1 && c->comm_fn != nullptr; }
+// (a callback with world == 1 keeps the multi-GPU code path on, with one share: what the world-1 RCCL test drives)
+static bool comm_on(const rbl_ctx *c) { return c->comm_fn != nullptr; }
 
 static void comm_body_range(const rbl_ctx *c, int *b0, int *b1)
 {
@@ -195,6 +263,7 @@ static void comm_body_range(const rbl_ctx *c, int *b0, int *b1)
 
 static int comm_allreduce(rbl_ctx *c, double *d_buf, int64_t count)
 {
+  RblPhase ph(c, RBL_T_COLLECTIVE);
   if (c->comm_fn(c->comm_user, d_buf, count)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
   return RBL_OK;
 }
@@ -211,15 +280,18 @@ static int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const doubl
   if (c->tune_variant == 1) sym = false;
   if (c->tune_variant == 2) sym = full;
   int rc;
-  if (full && c->comm_world > 1 && c->comm_fn) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
+  if (full && comm_on(c)) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, c->sym_tune)))) return rc;
     RblSymTune tune = c->sym_tune;
     if (c->force_relaxed) tune.relaxed = 1;
-    rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
-                           c->n_cu, c->d_err, 1, tune);
-    if (c->comm_fn(c->comm_user, d_out, 3 * nbl)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
-    return RBL_OK;
+    {
+      RblPhase ph(c, RBL_T_PRODUCT);
+      rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
+                             c->n_cu, c->d_err, 1, tune);
+    }
+    return comm_allreduce(c, d_out, 3 * nbl);
   }
+  RblPhase ph(c, RBL_T_PRODUCT);
   if (sym) {
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune)))) return rc;
     RblSymTune tune = c->sym_tune;
@@ -247,20 +319,24 @@ static int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const
   if (c->tune_variant == 3) mfma = true;
   if (c->tune_variant == 1 || c->tune_variant == 2) mfma = false;
   int rc;
-  if (c->comm_world > 1 && c->comm_fn) {   // multi-GPU: pairs of vectors through the sharded two-vector kernel, one all-reduce per pair
+  if (comm_on(c)) {   // multi-GPU: pairs of vectors through the sharded two-vector kernel, one all-reduce per pair
     int k = 0;
     for (; k + 2 <= nrhs; k += 2) {
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, c->sym_tune)))) return rc;
       RblSymTune tune = c->sym_tune;
       if (c->force_relaxed) tune.relaxed = 1;
-      rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
-                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
-      if (c->comm_fn(c->comm_user, d_out + (size_t)k * n3, 2 * n3)) return rbl_fail(c, RBL_ERR_HIP, "all-reduce callback failed");
+      {
+        RblPhase ph(c, RBL_T_PRODUCT);
+        rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
+                               d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
+      }
+      if ((rc = comm_allreduce(c, d_out + (size_t)k * n3, 2 * n3))) return rc;
     }
     for (; k < nrhs; ++k)
       if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
     return RBL_OK;
   }
+  RblPhase ph(c, RBL_T_PRODUCT);
   if (!mfma) {   // 1-3 vectors: pairs of vectors through the two-vector symmetric kernel, a single one alone
     int k = 0;
     const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune) <= c->sym_workspace_budget;
@@ -308,6 +384,8 @@ void rbl_destroy(rbl_ctx *c)
         if (c->chol_aux.ev[i]) (void)hipEventDestroy(c->chol_aux.ev[i]);
       (void)hipStreamDestroy(c->chol_aux.stream);
     }
+    for (const rbl_ctx::TimedSpan &sp : c->ev_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -764,6 +842,7 @@ static bool bf_on(const rbl_ctx *c) { return c->blk_bodyframe && (!c->S.wall || 
 static int bf_build(rbl_ctx *c)
 {
   if (c->bf_valid) return RBL_OK;
+  RblPhase ph(c, RBL_T_FACTOR);
   const RblBodyState &S = c->S;
   const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m;
   int rc = ensure_xq_dev(c); if (rc) return rc;         // d_cfg: the blob positions in the body frame
@@ -801,6 +880,7 @@ static int blk_prepare(rbl_ctx *c, int b0, int b1)
 static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode)
 {
   if (nbo <= 0) return RBL_OK;
+  RblPhase ph(c, RBL_T_PERBODY);
   const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
   const size_t off = (size_t)b0 * (size_t)m;
   if (bf_on(c)) {
@@ -870,6 +950,7 @@ static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out,
 static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
 {
   if (nbo <= 0) return RBL_OK;
+  RblPhase ph(c, RBL_T_PERBODY);
   const int64_t m = 3 * (int64_t)c->S.N_blb;
   const size_t off = (size_t)b0 * (size_t)m;
   if (bf_on(c)) { const int rc = ensure_xq_dev(c); if (rc) return rc; }
@@ -956,9 +1037,16 @@ static int lanczos_coeffs(rbl_ctx *c, const std::vector<double> &alpha, const st
   return RBL_OK;
 }
 
-// The recurrence runs entirely on the device (rbl_launch_lanczos_step keeps alpha, beta there); the host
-// reads them back only to test convergence: every iteration when a product is expensive, every 4th when the
-// iteration is launch-bound (small systems), so the stream is not drained twice per iteration.
+// The recurrence runs entirely on the device (alpha, beta stay there); the host reads them back only to test
+// convergence: every iteration when a product is expensive, every 4th when the iteration is launch-bound (small
+// systems), so the stream is not drained twice per iteration.
+// Round 3: every new vector is re-orthogonalised against the WHOLE basis (classical Gram-Schmidt twice,
+// rbl_launch_lanczos_step_reorth).  The plain three-term recurrence loses orthogonality as soon as a Ritz value has
+// converged; the square-root estimate then stagnates (cfg 2, tolerance 1e-9: 300 iterations, true error 5e-6) while the
+// "relative change" of the coefficient vector keeps shrinking.  The basis is stored for the final combination anyway.
+// Stopping estimate: d_m = |x_m - x_{m-1}| / |x_m| is the size of the LAST correction, not of the error; with the
+// corrections shrinking by rho = d_m / d_{m-1} per iteration the error of x_m is the tail of a geometric series,
+// d_m rho / (1 - rho) -- that is what is compared with the tolerance and reported (rbl_get_lanczos_report).
 static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const double *d_W, double *d_out,
                              int nvec = 1, bool precond = false)
 {
@@ -968,38 +1056,58 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   // nvec = 1 or 2 independent recurrences advanced in lock step: with two (the Brownian step's W1, W2) every
   // iteration is ONE two-vector product whose pair coefficients are shared.
   const int64_t n = 3 * nbl;
+  const bool reorth = c->lanczos_reorth;
   const int maxit = c->lanczos_max_iter;
   const RblParams P = rbl_make_params(c->S.a, c->S.eta);
   int rc;
-  // workspace: V[(maxit+1)][nvec][n] | u[nvec][n], tmp[nvec][n] | per vector: alpha[maxit], beta[maxit], |W|, coef[maxit] | partial sums
+  // workspace: V[(maxit+1)][nvec][n] | u[nvec][n], tmp[nvec][n] | per vector: alpha[maxit], beta[maxit], |W|, coef[maxit] |
+  //            Gram-Schmidt column scratch | partial sums
   const size_t vbytes = sizeof(double) * (size_t)n;
   const size_t nsc = (size_t)3 * maxit + 1;
+  const size_t nh = (size_t)maxit + 2;
+  const size_t npart = reorth ? (size_t)nvec * rbl_gmres_part_doubles() + rbl_lanczos_part_doubles() : rbl_lanczos_part_doubles();
   if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1) * nvec))) return rc;
-  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 2 * nvec + sizeof(double) * (nsc * nvec + rbl_lanczos_part_doubles())))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * 2 * nvec + sizeof(double) * (nsc * nvec + nh * nvec + npart)))) return rc;
   double *V = (double *)c->d_tmp.p;
   double *u = (double *)c->d_tmp2.p, *tmp = u + (size_t)nvec * n, *sc = tmp + (size_t)nvec * n;
-  double *d_part = sc + nsc * nvec;
+  double *d_hcol = sc + nsc * nvec, *d_part = d_hcol + nh * nvec;
+  double *d_part_init = reorth ? d_part + (size_t)nvec * rbl_gmres_part_doubles() : d_part;
   auto d_alpha = [&](int v) { return sc + nsc * v; };
   auto d_beta = [&](int v) { return sc + nsc * v + maxit; };
   auto d_wn = [&](int v) { return sc + nsc * v + 2 * maxit; };
   auto d_coef = [&](int v) { return sc + nsc * v + 2 * maxit + 1; };
   auto Vp = [&](int it, int v) { return V + ((size_t)it * nvec + v) * n; };
-  for (int v = 0; v < nvec; ++v) rbl_launch_lanczos_init(c->stream, n, d_W + (size_t)v * n, d_wn(v), Vp(0, v), d_part);
+  for (int v = 0; v < nvec; ++v) rbl_launch_lanczos_init(c->stream, n, d_W + (size_t)v * n, d_wn(v), Vp(0, v), d_part_init);
   const int check_every = (nbl > 20000) ? 1 : 4;
-  std::vector<double> hs(nsc * nvec), alpha, beta, y_prev;
+  std::vector<double> hs(nsc * nvec), alpha, beta, y_prev, y_pp;
   std::vector<std::vector<double>> y_cur(nvec);
-  std::vector<double> wnorm(nvec, 0.0), resid(nvec, 1.0);
+  std::vector<double> wnorm(nvec, 0.0), resid(nvec, 1.0), d_last(nvec, -1.0);
+  std::vector<int> m_last(nvec, -1);
+  auto change = [](const std::vector<double> &ya, const std::vector<double> &yb) {   // |ya - [yb; 0]| / |ya|
+    double dn = 0.0, yn = 0.0;
+    for (size_t p = 0; p < ya.size(); ++p) {
+      const double yp = p < yb.size() ? yb[p] : 0.0;
+      dn += (ya[p] - yp) * (ya[p] - yp);
+      yn += ya[p] * ya[p];
+    }
+    return yn > 0.0 ? std::sqrt(dn / yn) : 0.0;
+  };
   int m = 0;
   bool done = false;
+  static const bool trace = std::getenv("RBL_LANCZOS_TRACE") != nullptr;      // diagnostic: the estimate's history on stderr
   for (int it = 0; it < maxit && !done; ++it) {
     // inexact Krylov: an estimate wanted to lanczos_tol >= 1e-4 does not notice a product error of ~1e-6
     c->sym_tune.relaxed = (c->gmres_relax && c->lanczos_tol >= 1.0e-4) ? 1 : 0;
     rc = apply_A_dev(c, P, d_r, nbl, Vp(it, 0), u, tmp, nvec, precond);
     c->sym_tune.relaxed = 0;
     if (rc) return rc;
-    // both recurrences of a pair in the same three launches (vectors n apart, their scalars nsc apart)
-    rbl_launch_lanczos_step(c->stream, n, u, Vp(it, 0), it > 0 ? Vp(it - 1, 0) : nullptr, it > 0 ? d_beta(0) + (it - 1) : nullptr,
-                            d_alpha(0) + it, d_beta(0) + it, Vp(it + 1, 0), d_part, nvec, n, (int64_t)nsc);
+    // both recurrences of a pair in the same launches (vectors n apart, their scalars nsc apart)
+    if (reorth)
+      rbl_launch_lanczos_step_reorth(c->stream, n, it + 1, u, V, Vp(it + 1, 0), d_alpha(0) + it, d_beta(0) + it, (int64_t)nsc, d_hcol,
+                                     (int64_t)nh, d_part, nvec);
+    else
+      rbl_launch_lanczos_step(c->stream, n, u, Vp(it, 0), it > 0 ? Vp(it - 1, 0) : nullptr, it > 0 ? d_beta(0) + (it - 1) : nullptr,
+                              d_alpha(0) + it, d_beta(0) + it, Vp(it + 1, 0), d_part, nvec, n, (int64_t)nsc);
     m = it + 1;
     if (m % check_every != 0 && m != maxit) continue;
     RBL_HIP(c, hipMemcpyAsync(hs.data(), sc, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1017,15 +1125,19 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
       for (int k = 0; k < m - 1; ++k)                     // breakdown before the last step: Krylov space exhausted
         if (!(beta[k] > 1e-300)) { mv = k + 1; break; }
       if ((rc = lanczos_coeffs(c, alpha, beta, mv, wnorm[v], y_cur[v]))) return rc;
-      if (mv > 1) {  // relative change of the coefficient vector == change of the estimate (V orthonormal)
+      if (mv > 1) {  // change of the coefficient vector == change of the estimate (V orthonormal), extrapolated to the error
         if ((rc = lanczos_coeffs(c, alpha, beta, mv - 1, wnorm[v], y_prev))) return rc;
-        double dn = 0.0, yn = 0.0;
-        for (int p = 0; p < mv; ++p) {
-          const double yp = p < mv - 1 ? y_prev[p] : 0.0;
-          dn += (y_cur[v][p] - yp) * (y_cur[v][p] - yp);
-          yn += y_cur[v][p] * y_cur[v][p];
+        const double dm = change(y_cur[v], y_prev);
+        double dm1 = (m_last[v] == mv - 1) ? d_last[v] : -1.0;      // the previous correction: kept from the last test ...
+        if (dm1 < 0.0 && mv > 2) {                                   // ... or evaluated now (tests every 4th iteration)
+          if ((rc = lanczos_coeffs(c, alpha, beta, mv - 2, wnorm[v], y_pp))) return rc;
+          dm1 = change(y_prev, y_pp);
         }
-        resid[v] = std::sqrt(dn / yn);
+        double rho = (dm1 > 0.0) ? dm / dm1 : 0.5;
+        if (rho > 0.95) rho = 0.95;                                  // (not contracting yet: at least 19 x the last correction)
+        resid[v] = dm * rho / (1.0 - rho);
+        d_last[v] = dm; m_last[v] = mv;
+        if (trace) std::fprintf(stderr, "rbl lanczos%s: vector %d  m = %d  change %.3e  rho %.3f  error estimate %.3e\n", precond ? " (pc)" : "", v, mv, dm, rho, resid[v]);
       }
       y_cur[v].resize(m, 0.0);                            // a recurrence that broke down early contributes no further vectors
       const bool conv = resid[v] < c->lanczos_tol || mv < m || !(beta[mv - 1] > 1e-300);
@@ -1063,6 +1175,7 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
 {
   const int64_t n = 3 * nbl;
   int rc;
+  RblPhase ph_total(c, RBL_T_TOTAL);
   if (method == RBL_MHALF_LANCZOS || method == RBL_MHALF_LANCZOS_PC) {
     const bool pc = method == RBL_MHALF_LANCZOS_PC;
     if (pc) {   // block-Jacobi factors of the object's own configuration: d_r must be its own blob positions
@@ -1081,6 +1194,7 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
     return RBL_OK;
   }
   if (method != RBL_MHALF_CHOLESKY) return rbl_fail(c, RBL_ERR_ARG, "M_half_W: unknown method");
+  RblPhase ph_dense(c, RBL_T_DENSE);
   const size_t mb = sizeof(double) * (size_t)n * (size_t)n;
   if ((rc = rbl_dev_reserve(c, c->d_mat, mb))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_tmp, rbl_trmv_part_bytes(n)))) return rc;
@@ -1321,7 +1435,8 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
   if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
   if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
-  if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
+  if (variant == 81 || variant == 82) { c->lanczos_reorth = (variant == 82); return RBL_OK; }       // Lanczos: three-term recurrence only / full re-orthogonalisation (default)
+  if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->blk_inv_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
   if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
   if (variant == 51 || variant == 52) { c->gmres_relax = (variant == 52); return RBL_OK; }           // inexact-Krylov relaxed products in GMRES off / on
   if (variant == 53 || variant == 54) { c->force_relaxed = (variant == 54); return RBL_OK; }         // hook: every full product relaxed off / on   // GMRES: reference-sign / restored-sign PC
@@ -1393,6 +1508,7 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
   if (b1 < 0) b1 = S.N_bod;
   if (b0 < 0 || b0 >= b1 || b1 > S.N_bod) return rbl_fail(c, RBL_ERR_ARG, "block factors: need 0 <= body_begin < body_end <= N_bodies");
   if (c->dev_blk_valid && c->blk_b0 <= b0 && b1 <= c->blk_b1) return RBL_OK;
+  RblPhase ph(c, RBL_T_FACTOR);
   const int64_t m = 3 * (int64_t)S.N_blb, msz = m * m;
   const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);      // L_kk^-1 blocks of one body
   int rc;
@@ -1419,6 +1535,7 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
 
 static int pc_block_build(rbl_ctx *c)
 {
+  RblPhase ph(c, RBL_T_FACTOR);
   const RblBodyState &S = c->S;
   const int64_t m = 3 * (int64_t)S.N_blb, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   int b0 = 0, b1 = S.N_bod;                              // multi-GPU: this rank's bodies only (rbl_set_comm)
@@ -1451,14 +1568,14 @@ static int pc_block_build(rbl_ctx *c)
   return RBL_OK;
 }
 
-static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
+static int pc_block_apply_local(rbl_ctx *c, const double *d_in, double *d_out, bool shard)
 {
+  RblPhase ph(c, RBL_T_PERBODY);
   const RblBodyState &S = c->S;
   const int64_t m = 3 * (int64_t)S.N_blb, N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   double *w1 = (double *)c->d_pcw.p, *w2 = w1 + n3, *f6 = w2 + n3 + 36 * (size_t)S.N_bod + 6 * (size_t)S.N_bod;
   const double *lev = (const double *)c->d_lever.p;
   int b0 = 0, b1 = S.N_bod;
-  const bool shard = comm_on(c);                         // own bodies only, completed by one all-reduce of the result
   if (shard) comm_body_range(c, &b0, &b1);
   const int nbo = b1 - b0;
   const size_t off = (size_t)b0 * (size_t)m;
@@ -1481,7 +1598,6 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
         return rbl_fail(c, rc, "body-frame preconditioner launch failed");
       if (ktl) c->ktl_of = d_out;
     }
-    if (shard) return comm_allreduce(c, d_out, n3 + (int64_t)6 * S.N_bod);
     return RBL_OK;
   }
   if (nbo > 0) {
@@ -1498,8 +1614,15 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
     if (ktl) c->ktl_of = d_out;
   }
   (void)f6; (void)off;
-  if (shard) return comm_allreduce(c, d_out, n3 + (int64_t)6 * S.N_bod);
   return RBL_OK;
+}
+
+static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
+{
+  const bool shard = comm_on(c);                         // own bodies only, completed by one all-reduce of the result
+  int rc = pc_block_apply_local(c, d_in, d_out, shard);
+  if (rc || !shard) return rc;
+  return comm_allreduce(c, d_out, (int64_t)3 * c->S.N_bod * c->S.N_blb + (int64_t)6 * c->S.N_bod);
 }
 
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
@@ -1608,11 +1731,12 @@ static int gmres_small(rbl_ctx *c, const double *d_rhs, const double *d_x0, int 
 int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int use_x0,
                          int *iters_out, double *resid_out)
 {
+  RblPhase ph_total(c, RBL_T_TOTAL);
   {
     int rc = need_config(c); if (rc) return rc;
     if ((rc = rbl_dev_init(c))) return rc;
     if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
-    if (c->gmres_small && c->comm_world == 1 && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc)) {
+    if (c->gmres_small && !comm_on(c) && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc)) {
       rc = gmres_small(c, d_rhs, use_x0 ? d_x : nullptr, max_iter, rtol, d_x, iters_out, resid_out);
       if (rc != RBL_ERR_SIZE) return rc;
       c->gmres_small = false;                // this runtime does not grant the LDS the one-kernel solver needs
@@ -1861,6 +1985,7 @@ extern "C" {
 static int m_rfd_core(rbl_ctx *c, const double *d_W, const double *Wh, double delta, double *d_out,
                       double *d_r, double *d_work)
 {
+  RblPhase ph_total(c, RBL_T_TOTAL);
   RblBodyState &S = c->S;
   const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   std::vector<double> uom((size_t)6 * S.N_bod), win((size_t)6 * S.N_bod), Xs, Qs;

@@ -123,11 +123,32 @@ struct rbl_ctx {
   int tune_jsplit = 0;
   int tune_variant = 0;
   RblSymTune sym_tune;
+  // per-phase timings (rbl_set_timing / rbl_get_timings): hipEvent pairs recorded on the context's stream around the phases of
+  // the library's own solvers; resolved (hipEventElapsedTime) when the caller asks
+  bool timing_on = false;
+  int timing_open = -1;                             // the phase (other than RBL_T_TOTAL) whose bracket is open: inner brackets are part of it
+  bool timing_total_open = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct TimedSpan { int phase; hipEvent_t a, b; };
+  std::vector<TimedSpan> ev_spans;
+  double t_ms[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
+  int64_t t_calls[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
   // lanczos
   int lanczos_max_iter = 100;
+  bool lanczos_reorth = true;   // full re-orthogonalisation of the Lanczos basis (rbl_set_tuning 81 / 82: off / on)
   double lanczos_tol = 1e-10;
   int lanczos_iters = 0;
   double lanczos_resid = 0.0;
+};
+
+// RAII bracket of one timed phase (no-op unless rbl_set_timing(ctx, 1)); a bracket opened inside another phase's bracket
+// belongs to the outer one, RBL_T_TOTAL may contain the others
+struct RblPhase {
+  rbl_ctx *c; int phase; hipEvent_t a = nullptr; bool live = false;
+  RblPhase(rbl_ctx *ctx, int ph);
+  ~RblPhase();
+  RblPhase(const RblPhase &) = delete;
+  RblPhase &operator=(const RblPhase &) = delete;
 };
 
 RblParams rbl_make_params(double a, double eta);
@@ -213,6 +234,8 @@ void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, doubl
 void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
                              const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
                              double *part, int nvec = 1, int64_t vec_stride = 0, int64_t scal_stride = 0);
+void rbl_launch_lanczos_step_reorth(hipStream_t st, int64_t n, int k, double *u, const double *V, double *vnext, double *alpha_out,
+                                    double *beta_out, int64_t scal_stride, double *hcol, int64_t hcol_stride, double *part, int nvec);
 void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
                                 double *out, int64_t stride = 0);
 void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,

@@ -1114,14 +1114,19 @@ __global__ __launch_bounds__(256) void k_lz_b(long n, double *__restrict__ u, co
 }
 
 // beta = sqrt(sum(partB));  vnext = u / beta   (zeros on breakdown)
+// (asrc != null: the re-orthogonalised Lanczos step also files its diagonal entry, beta_out[aoff] = asrc[pair * as])
 __global__ __launch_bounds__(256) void k_lz_c(long n, const double *__restrict__ u,
                                               const double *__restrict__ partB, int np,
-                                              double *__restrict__ beta_out, double *__restrict__ vnext, long vs, long ss, long ps)
+                                              double *__restrict__ beta_out, double *__restrict__ vnext, long vs, long ss, long ps,
+                                              const double *__restrict__ asrc, long as, long aoff)
 {
   __shared__ double sh[256];
   u += blockIdx.y * vs; vnext += blockIdx.y * vs; partB += blockIdx.y * ps; beta_out += blockIdx.y * ss;
   const double be = sqrt(lz_sum_parts(partB, np, sh));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *beta_out = be;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *beta_out = be;
+    if (asrc) beta_out[aoff] = asrc[blockIdx.y * as];
+  }
   const double inv = (be > 1e-300) ? 1.0 / be : 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) vnext[i] = inv * u[i];
 }
@@ -1140,11 +1145,14 @@ __global__ __launch_bounds__(256) void k_lz_combine(long n, const double *__rest
 
 // ---- Arnoldi orthogonalisation (GMRES) --------------------------------------------------------
 // h = V[0..k)^T w as per-block partial sums (grid: blocks x vectors); the consumer re-adds them.
+// (vstr: doubles between consecutive basis vectors; blockIdx.z = member of a lock-step pair of recurrences, whose basis /
+// vector / partial sums lie pv / pw / pp doubles further -- the re-orthogonalised two-vector Lanczos)
 __global__ __launch_bounds__(256) void k_mdot_partial(const double *__restrict__ V, long n, const double *__restrict__ w,
-                                                      double *__restrict__ part)
+                                                      double *__restrict__ part, long vstr, long pv, long pw, long pp)
 {
   __shared__ double sh[256];
-  const double *v = V + (size_t)blockIdx.y * (size_t)n;
+  V += (size_t)blockIdx.z * (size_t)pv; w += (size_t)blockIdx.z * (size_t)pw; part += (size_t)blockIdx.z * (size_t)pp;
+  const double *v = V + (size_t)blockIdx.y * (size_t)vstr;
   double a = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a = __builtin_fma(v[i], w[i], a);
   a = lz_block_sum(a, sh);
@@ -1175,12 +1183,14 @@ constexpr int AR_EPT = 4;
 template <bool LAST>
 __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ V, long n, int k, double *__restrict__ w,
                                                      const double *__restrict__ pin, int npin, double *__restrict__ Hcol,
-                                                     double *__restrict__ pout)
+                                                     double *__restrict__ pout, long vstr, long pv, long pw, long pp, long ph)
 {
   __shared__ double h[GM_MAXK];
   __shared__ double sw[16][GM_MAXK];                 // per 16-lane row of the block
   __shared__ double sh[256];
   const int t = threadIdx.x;
+  V += (size_t)blockIdx.y * (size_t)pv; w += (size_t)blockIdx.y * (size_t)pw;      // member of a lock-step pair (see k_mdot_partial)
+  pin += (size_t)blockIdx.y * (size_t)pp; pout += (size_t)blockIdx.y * (size_t)pp; Hcol += (size_t)blockIdx.y * (size_t)ph;
   // h_v = sum of the previous kernel's partials: a 16-lane row per vector (one thread per vector walked npin dependent
   // loads: at 97 partials that prologue WAS the kernel)
   for (int v = t >> 4; v < k; v += 16) {
@@ -1212,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
 #pragma unroll
         for (int e = 0; e < AR_EPT; ++e) {
           const long i = ic + e * stride;
-          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * n + i] : 0.0;
+          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * (size_t)vstr + i] : 0.0;
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1247,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
 #pragma unroll
         for (int e = 0; e < AR_EPT; ++e) {
           const long i = ic + e * stride;
-          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * n + i] : 0.0;
+          m[u][e] = (v0 + u < k && i < n) ? V[(size_t)(v0 + u) * (size_t)vstr + i] : 0.0;
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -1585,7 +1595,8 @@ void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, doubl
   const int g = lz_grid(n);
   hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, const_cast<double *>(d_W), d_W,
                      (const double *)nullptr, (const double *)nullptr, part, 0L, 0L, 0L);
-  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0, 0L, 0L, 0L);
+  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0, 0L, 0L, 0L,
+                     (const double *)nullptr, 0L, 0L);
 }
 
 // one Lanczos step after u = A v:  u -= beta_prev vprev; alpha = v.u; u -= alpha v; beta = |u|; vnext = u/beta
@@ -1601,7 +1612,7 @@ void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double 
   hipLaunchKernelGGL(k_lz_a, dim3(g, nvec), dim3(256), 0, st, (long)n, u, v, vprev, beta_prev, pA, vs, ss, ps);
   hipLaunchKernelGGL(k_lz_b, dim3(g, nvec), dim3(256), 0, st, (long)n, u, v, (const double *)pA, g, alpha_out, pB, vs, ss, ps);
   hipLaunchKernelGGL(k_lz_c, dim3(g, nvec), dim3(256), 0, st, (long)n, (const double *)u, (const double *)pB, g,
-                     beta_out, vnext, vs, ss, ps);
+                     beta_out, vnext, vs, ss, ps, (const double *)nullptr, 0L, 0L);
 }
 
 // out = sum_p coef[p] V_p, consecutive basis vectors `stride` doubles apart (0: contiguous, = n)
@@ -1629,11 +1640,48 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
   int g = (int)std::max<int64_t>(gneed, std::min<int64_t>(256, (n + 255) / 256));    // ... fewer in small systems: more blocks
   if (g > AR_BLOCKS) g = AR_BLOCKS;                                        // beyond 1 048 576 entries the kernels take several passes
   double *p1 = part, *p2 = part + (size_t)GM_MAXK * 128, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
-  hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, p1);
-  hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p1, nb, Hcol, p2);
-  hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn);
+  hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, p1, (long)n, 0L, 0L, 0L);
+  hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p1, nb, Hcol, p2, (long)n, 0L,
+                     0L, 0L, 0L);
+  hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn, (long)n, 0L, 0L,
+                     0L, 0L);
   hipLaunchKernelGGL(k_lz_c, dim3(lz_grid(n)), dim3(256), 0, st, (long)n, (const double *)w, (const double *)pn, g, Hcol + k,
-                     vnext, 0L, 0L, 0L);
+                     vnext, 0L, 0L, 0L, (const double *)nullptr, 0L, 0L);
+}
+
+// One step of the Lanczos recurrence WITH full re-orthogonalisation, for nvec (1 or 2) recurrences in lock step: u_p is made
+// orthogonal (classical Gram-Schmidt twice) to ALL k earlier vectors of its own basis -- for a symmetric operator the
+// Arnoldi process, whose Hessenberg column is the tridiagonal one up to rounding: alpha = h[k-1], beta = |u|.  Basis vector
+// j of recurrence p at V + (j nvec + p) n (the interleaved layout of the two-vector product), u_p at u + p n;
+// alpha_out / beta_out of recurrence p are scal_stride doubles apart; hcol: nvec x hcol_stride (>= k + 1) scratch;
+// part: nvec x rbl_gmres_part_doubles().  The three-term recurrence alone loses orthogonality once a Ritz value has
+// converged, its estimate of M^{1/2} W then stagnates near 1e-6 (round 2's red run); the basis is kept for the final
+// combination anyway, and O(k n) vector work is nothing beside an O(N^2) product.
+void rbl_launch_lanczos_step_reorth(hipStream_t st, int64_t n, int k, double *u, const double *V, double *vnext, double *alpha_out,
+                                    double *beta_out, int64_t scal_stride, double *hcol, int64_t hcol_stride, double *part, int nvec)
+{
+  if (k <= 0 || n <= 0 || nvec < 1) return;
+  int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
+  if (nb < 1) nb = 1;
+  const int64_t gneed = (n + 256 * AR_EPT - 1) / (256 * AR_EPT);
+  int g = (int)std::max<int64_t>(gneed, std::min<int64_t>(256, (n + 255) / 256));
+  if (g > AR_BLOCKS) g = AR_BLOCKS;
+  const long pp = (long)rbl_gmres_part_doubles(), ph = (long)hcol_stride, vstr = (long)nvec * (long)n, pn_ = (long)n;
+  double *p1 = part, *p2 = part + (size_t)GM_MAXK * 128, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
+  // more than GM_MAXK basis vectors: one group of GM_MAXK after the other (classical Gram-Schmidt twice inside a group,
+  // the groups in sequence); the norm partials of the last group's second pass belong to the final vector
+  for (int c0 = 0; c0 < k; c0 += GM_MAXK) {
+    const int kc = k - c0 < GM_MAXK ? k - c0 : GM_MAXK;
+    const double *Vc = V + (size_t)c0 * (size_t)vstr;
+    double *hc = hcol + c0;
+    hipLaunchKernelGGL(k_mdot_partial, dim3(nb, kc, nvec), dim3(256), 0, st, Vc, (long)n, (const double *)u, p1, vstr, pn_, pn_, pp);
+    hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g, nvec), dim3(256), 0, st, Vc, (long)n, kc, u, (const double *)p1, nb, hc, p2, vstr,
+                       pn_, pn_, pp, ph);
+    hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g, nvec), dim3(256), 0, st, Vc, (long)n, kc, u, (const double *)p2, g, hc, pn, vstr,
+                       pn_, pn_, pp, ph);
+  }
+  hipLaunchKernelGGL(k_lz_c, dim3(lz_grid(n), nvec), dim3(256), 0, st, (long)n, (const double *)u, (const double *)pn, g, beta_out,
+                     vnext, pn_, (long)scal_stride, pp, (const double *)(hcol + (k - 1)), ph, (long)(alpha_out - beta_out));
 }
 
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,

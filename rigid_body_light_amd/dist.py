@@ -11,10 +11,8 @@ Two per-rank work splits:
             unordered pair once, ~1.5x less arithmetic), then ONE all-reduce of the 24 N-byte
             partial U.
 
-The per-rank compute is the HIP kernel (DeviceContext.apply_M on the rank's row
-slice).  `row_apply` exists so the CPU gloo test can check the partition /
-exchange logic with the oracle standing in for the kernel; the product never
-sets it.
+The per-rank compute is the HIP kernel (DeviceContext.apply_M / apply_M_sym on the rank's share): the two methods
+`apply_M_rows` and `apply_M_sym_part` are the only places that touch it.
 """
 import torch
 import torch.distributed as dist
@@ -32,7 +30,7 @@ def body_partition(n_bodies, world_size):
 
 
 class ShardedMobility:
-    def __init__(self, n_bodies, blobs_per_body, group=None, device=None, ctx=None, row_apply=None, sym_apply=None):
+    def __init__(self, n_bodies, blobs_per_body, group=None, device=None, ctx=None, force_collectives=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -44,22 +42,24 @@ class ShardedMobility:
         self.max_rows = max(e - b for b, e in self.parts) * blobs_per_body
         self.device = device if device is not None else torch.device("cpu")
         self.ctx = ctx
-        self.row_apply = row_apply
-        self.sym_apply = sym_apply
-        if ctx is None and row_apply is None:
-            raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
         self.r_full = None
+        # force_collectives: issue every collective even in a group of ONE rank (a one-GPU box can then drive the RCCL
+        # code path -- all_gather_into_tensor / all_reduce on device buffers -- that N ranks run; world == 1 otherwise
+        # short-circuits them)
+        self.collectives = bool(dist.is_initialized() and (self.world > 1 or force_collectives))
         # CPU-staged collectives when the process group cannot move device tensors (gloo rehearsal
         # of the multi-rank path on a single GPU); RCCL ("nccl") moves device buffers directly.
         self.stage_cpu = bool(dist.is_initialized() and dist.get_backend(group) == "gloo"
                               and self.device.type == "cuda")
+        self.n_all_gather = self.n_all_reduce = 0      # collectives issued (tests, bench's per_rank block)
 
     # -- exchange -----------------------------------------------------------
     def all_gather_rows(self, local):
         """local: (rows_local*3,) -> (n_blobs*3,) in body order.  Shards are padded to the
         largest shard so a single all_gather_into_tensor moves everything."""
-        if self.world == 1:
+        if not self.collectives:
             return local.clone()
+        self.n_all_gather += 1
         if local.numel() == self.max_rows * 3:      # equal shards (the usual case): no staging copy
             pad = local
         else:
@@ -96,25 +96,28 @@ class ShardedMobility:
         the row tiles (rbl_apply_M_sym_dev: i_first = rank, i_step = world) and produces a PARTIAL full-length U; one
         all-reduce (sum) completes it.  Returns the full U on every rank."""
         F_full = self.all_gather_rows(F_local.contiguous())
-        if self.sym_apply is not None:
-            part = self.sym_apply(F_full, self.r_full, self.rank, self.world)
-        else:
-            part = torch.empty(self.n_blobs * 3, dtype=torch.float64, device=self.device)
-            self.ctx.apply_M_sym(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.rank, self.world,
-                                 part.data_ptr())
-        return self.all_reduce_sum(part)
+        return self.all_reduce_sum(self.apply_M_sym_part(F_full))
+
+    def apply_M_sym_part(self, F_full):
+        """this rank's share of the unordered tile pairs -> partial full-length U (rbl_apply_M_sym_dev)"""
+        if self.ctx is None:
+            raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
+        part = torch.empty(self.n_blobs * 3, dtype=torch.float64, device=self.device)
+        self.ctx.apply_M_sym(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.rank, self.world, part.data_ptr())
+        return part
 
     def agree(self, flag):
         """rank 0's value of a control-flow decision on every rank: data-dependent loop exits (Lanczos convergence)
         must not depend on every rank having bitwise the same numbers, or one rank would leave a collective behind"""
-        if self.world == 1:
+        if not self.collectives:
             return bool(flag)
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=torch.device("cpu") if self.stage_cpu else self.device)
         dist.broadcast(t, src=0, group=self.group)
         return bool(int(t.item()))
 
     def all_reduce_sum(self, part):
-        if self.world > 1:
+        if self.collectives:
+            self.n_all_reduce += 1
             if self.stage_cpu:
                 h = part.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -124,9 +127,10 @@ class ShardedMobility:
         return part
 
     def apply_M_rows(self, F_full):
+        """this rank's rows of U = M F with the ordered-pair kernel (rbl_apply_M_dev)"""
+        if self.ctx is None:
+            raise RuntimeError("ShardedMobility needs a DeviceContext (HIP) to compute with")
         nrows = self.row1 - self.row0
-        if self.row_apply is not None:
-            return self.row_apply(F_full, self.r_full, self.row0, self.row1)
         out = torch.empty(nrows * 3, dtype=torch.float64, device=self.device)
         self.ctx.apply_M(F_full.data_ptr(), self.r_full.data_ptr(), self.n_blobs, self.row0, self.row1,
                          out.data_ptr())

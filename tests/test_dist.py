@@ -30,26 +30,30 @@ def _worker(rank, world, port, n_bodies, wall, ret):
         a, eta = c["a"], 1.0
         cfg = c["cfg"] - c["cfg"].mean(axis=0)
 
-        def row_apply(F_full, r_full, r0, r1):
-            return torch.from_numpy(orc.apply_M_rows(F_full.numpy(), r_full.numpy(), r0, r1, a, eta, wall))
+        class OracleSharded(ShardedMobility):
+            """partition + exchange logic of the product class, the CPU oracle standing in for the two kernel calls"""
 
-        def sym_apply(F_full, r_full, first, step):
-            # semantics of rbl_apply_M_sym_dev: unordered 64-blob tile pairs {I, J>=I}, I % step == first
-            rr, FF = r_full.numpy(), F_full.numpy()
-            B = orc.damp(rr, a) if wall else np.ones(rr.size)
-            M = (B[:, None] * orc.rotne_prager_tensor(rr, a, eta, wall)) * B[None, :]
-            n = rr.size // 3; T = (n + 63) // 64
-            part = np.zeros(3 * n)
-            for I in range(first, T, step):
-                ri = slice(192 * I, min(192 * (I + 1), 3 * n))
-                for J in range(I, T):
-                    cj = slice(192 * J, min(192 * (J + 1), 3 * n))
-                    part[ri] += M[ri, cj] @ FF[cj]
-                    if J > I:
-                        part[cj] += M[cj, ri] @ FF[ri]
-            return torch.from_numpy(part)
+            def apply_M_rows(self, F_full):
+                return torch.from_numpy(orc.apply_M_rows(F_full.numpy(), self.r_full.numpy(), self.row0, self.row1, a, eta, wall))
 
-        sm = ShardedMobility(n_bodies, 12, row_apply=row_apply, sym_apply=sym_apply)
+            def apply_M_sym_part(self, F_full):
+                # semantics of rbl_apply_M_sym_dev: unordered 64-blob tile pairs {I, J>=I}, I % step == first
+                first, step = self.rank, self.world
+                rr, FF = self.r_full.numpy(), F_full.numpy()
+                B = orc.damp(rr, a) if wall else np.ones(rr.size)
+                M = (B[:, None] * orc.rotne_prager_tensor(rr, a, eta, wall)) * B[None, :]
+                n = rr.size // 3; T = (n + 63) // 64
+                part = np.zeros(3 * n)
+                for I in range(first, T, step):
+                    ri = slice(192 * I, min(192 * (I + 1), 3 * n))
+                    for J in range(I, T):
+                        cj = slice(192 * J, min(192 * (J + 1), 3 * n))
+                        part[ri] += M[ri, cj] @ FF[cj]
+                        if J > I:
+                            part[cj] += M[cj, ri] @ FF[ri]
+                return torch.from_numpy(part)
+
+        sm = OracleSharded(n_bodies, 12)
         # each rank computes ONLY its own bodies' blob positions (a8) ...
         r_local = torch.from_numpy(orc.multi_body_pos(c["X"][sm.b0:sm.b1], c["Q"][sm.b0:sm.b1], cfg))
         r_full = sm.set_positions_local(r_local)                      # ... one all-gather per configuration

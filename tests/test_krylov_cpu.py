@@ -1,9 +1,9 @@
-"""CPU tests of the solver DRIVER logic in rigid_body_light_amd/krylov.py with plain torch
-operators standing in for the HIP ones (the driver is external-user code in reference terms)."""
+"""CPU tests of the torch comparator loops (tests/torch_krylov.py: what the GPU tests compare librbl's own GMRES / Lanczos
+with) with plain torch operators standing in for the HIP ones."""
 import numpy as np
 import torch
 
-from rigid_body_light_amd.krylov import gmres_right_pc, lanczos_mhalf, lanczos_mhalf_multi
+from torch_krylov import gmres_right_pc, lanczos_mhalf, lanczos_mhalf_multi
 
 
 def test_gmres_right_preconditioned_solves_spd_and_saddle_like_systems():

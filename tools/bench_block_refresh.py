@@ -16,7 +16,7 @@ for refresh in (1, 2, 4, 8, 16):
         ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3)
         ctx.set_block_refresh(refresh)
         if relaxed: ctx.set_tuning(0, 52)
-        st = BrownianStepper(ctx, nb, nblb, dev, native=True)
+        st = BrownianStepper(ctx, nb, nblb, dev)
         st.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)
         torch.cuda.synchronize(); t0 = time.perf_counter(); its = []; lz = []
         K = 8

@@ -14,7 +14,7 @@ for api in ("python stepper", "rbl_step_brownian"):
     lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3); ctx.set_block_refresh(2)
     if len(sys.argv) > 4: ctx.set_tuning(0, int(sys.argv[4]))
-    st = BrownianStepper(ctx, nb, nblb, dev, native=True)
+    st = BrownianStepper(ctx, nb, nblb, dev)
     one = (lambda k: st.step(Fb, seed=k, method=2, iters=200, rtol=1e-8)) if api == "python stepper" else \
           (lambda k: ctx.step_brownian(Fb, max_iter=200, rtol=1e-8, seed=k, method=2))
     one(0); torch.cuda.synchronize()

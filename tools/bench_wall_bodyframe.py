@@ -18,7 +18,7 @@ for variant in (73, 74):
         ctx.set_block_refresh(2)
         ctx.set_tuning(0, variant)
         if relaxed: ctx.set_tuning(0, 52)
-        st = BrownianStepper(ctx, nb, nblb, dev, native=True)
+        st = BrownianStepper(ctx, nb, nblb, dev)
         st.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)
         torch.cuda.synchronize(); t0 = time.perf_counter(); its = []; lz = []
         K = 6

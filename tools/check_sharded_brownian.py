@@ -13,6 +13,8 @@ from rigid_body_light_amd import make_config                      # noqa: E402
 from rigid_body_light_amd._lib import DeviceContext               # noqa: E402
 from rigid_body_light_amd.dist import ShardedMobility             # noqa: E402
 from rigid_body_light_amd.krylov import BrownianStepper, ShardedBrownianStepper   # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from torch_krylov import TorchBrownianStepper, TorchShardedBrownianStepper        # noqa: E402  (comparators)
 
 
 def main():
@@ -36,12 +38,13 @@ def main():
             from rigid_body_light_amd._lib import lib
             lib().rbl_set_blk_pc(ctx.h, 1)
         if sharded:
-            st = ShardedBrownianStepper(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
-                                        c["dt"], lanczos_tol=ltol, lanczos_max_iter=300, native=native)
+            cls = ShardedBrownianStepper if native else TorchShardedBrownianStepper
+            st = cls(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
+                     c["dt"], lanczos_tol=ltol, lanczos_max_iter=255)
             m, resid = st.step(Fb, W=W, iters=150, rtol=gtol)
         else:
-            ctx.set_lanczos(300, ltol)
-            m, resid = BrownianStepper(ctx, nb, nblb, dev, native=block_pc).step(Fb, W=W, method=2, iters=150, rtol=gtol)   # preconditioned square root, as the sharded driver
+            ctx.set_lanczos(255, ltol)
+            m, resid = (BrownianStepper if block_pc else TorchBrownianStepper)(ctx, nb, nblb, dev).step(Fb, W=W, method=2, iters=150, rtol=gtol)   # preconditioned square root, as the sharded driver
         out.append(ctx.get_config(nb))
     dX = float(np.abs(out[0][0] - out[1][0]).max()); dQ = float(np.abs(out[0][1] - out[1][1]).max())
     moved = float(np.abs(out[0][0] - c["X"]).max())
