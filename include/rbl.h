@@ -355,6 +355,13 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 53 / 54: test hook, every full product through that relaxed kernel off / on;
  * 61 / 62: per-body factors of bodies with 65..170 blobs applied by substitution / through explicit inverses L^-1
  * (default; built with the factors, a sweep becomes one triangular matrix-vector product);
+ * 63 / 64 / 65: explicit inverses of bodies with more than 170 blobs (the reference's own form of the block preconditioner,
+ * Block_diag_invM :461-487, built by the factorisation's MFMA kernels on an augmented matrix: n^3 / 3 more flops per
+ * configuration, applications become batched triangular matrix-vector products over the whole chip) never / always / when
+ * it pays (default: multi-GPU contexts, where a rank's few bodies would each be a latency chain on one CU, and the shared
+ * body-frame factor of free space, which is inverted once);
+ * 83 / 84: keep (also) a single-precision copy of those inverses off (default) / on: the preconditioner and Lanczos runs to
+ * tolerances >= 1e-5 read half the bytes (sums stay fp64; the GMRES solution still satisfies the fp64 system to rtol);
  * 71 / 72: free space only: per-configuration Cholesky factors of every body / one body-frame factor rotated with each
  * body (default; see rbl_block_solve_dev);
  * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an

@@ -375,7 +375,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_blkXf, &c->d_blkAug, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -852,7 +852,16 @@ static int bf_build(rbl_ctx *c)
   rbl_launch_build_M_batched(c->stream, rbl_make_params(S.a, S.eta), false, (const double *)c->d_cfg.p, S.N_blb, 1, Lb, msz, c->d_err);
   if ((rc = rbl_launch_cholesky_batched(c->stream, Lb, m, 1, msz, c->d_err, (double *)c->d_bfLinv.p)))
     return rbl_fail(c, rc, "body-frame cholesky launch failed");
-  c->bf_inv = false;
+  c->bf_inv = false; c->bf_tables = false;
+  if (c->blk_explicit && m > 512 && c->blk_large != 0) {   // large bodies: ONE explicit inverse for all bodies and all time
+    int chunk = 1;
+    if ((rc = rbl_dev_reserve(c, c->d_bfX, rbl_block_inverse_bytes(m, 1)))) return rc;
+    if ((rc = rbl_dev_reserve(c, c->d_blkAug, rbl_block_inverse_large_aug_bytes(m, 1, &chunk)))) return rc;
+    if ((rc = rbl_launch_block_inverse_large(c->stream, Lb, m, 1, msz, (const double *)c->d_bfLinv.p, (double *)c->d_bfX.p, nullptr,
+                                             (double *)c->d_blkAug.p)))
+      return rbl_fail(c, rc, "body-frame inverse (large body) launch failed");
+    c->bf_inv = true;
+  }
   if (c->blk_explicit && m <= 512) {      // (every size the inversion kernel takes: the one-launch preconditioner pays at any of them)
     if ((rc = rbl_dev_reserve(c, c->d_bfX, rbl_block_inverse_bytes(m, 1)))) return rc;
     if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, 1, msz, (const double *)c->d_bfLinv.p, (double *)c->d_bfX.p)))
@@ -863,6 +872,7 @@ static int bf_build(rbl_ctx *c)
     double *Minv = (double *)c->d_bfPC.p;
     rbl_launch_bf_tables(c->stream, (const double *)c->d_bfX.p + (size_t)msz, (const double *)c->d_cfg.p, m, Minv, Minv + (size_t)msz,
                          Minv + (size_t)msz + 6 * (size_t)m, c->d_err);
+    c->bf_tables = true;
   }
   c->bf_valid = true;
   return RBL_OK;
@@ -877,7 +887,7 @@ static int blk_prepare(rbl_ctx *c, int b0, int b1)
   return pc_block_factors(c, b0, b1);
 }
 
-static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode)
+static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode, bool allow_f32 = true)
 {
   if (nbo <= 0) return RBL_OK;
   RblPhase ph(c, RBL_T_PERBODY);
@@ -923,16 +933,19 @@ static int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out,
   if (c->blk_inv_valid) {
     const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
     int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
-    const double *X = (const double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)msz;
+    // the single-precision copy (large bodies, rbl_set_tuning 84) serves whoever tolerates a factor that is exact to 6e-8 only
+    const int f32 = (c->blk_f32_valid && allow_f32) ? 1 : 0;
+    const double *X = f32 ? (const double *)((const float *)c->d_blkXf.p + (size_t)b0 * 2 * (size_t)msz)
+                          : (const double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)msz;
     double *tmp = (double *)c->d_blkTmp.p;
     for (int v0 = 0; v0 < nv; v0 += 3) {              // groups of three vectors share the scratch
       const int g = nv - v0 >= 3 ? 3 : nv - v0;
       const double *pi = in + (size_t)v0 * (size_t)pitch + off;
       double *po = out + (size_t)v0 * (size_t)pitch + off;
-      if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, 0, tmp + off);
-      else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, mode, nullptr);
+      if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, 0, tmp + off, nullptr, f32);
+      else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, po, m, g, pitch, mode, nullptr, nullptr, f32);
       else {                                          // in place: through the scratch
-        rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr);
+        rc = rbl_launch_block_inv_apply(c->stream, X, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr, nullptr, f32);
         for (int v = 0; v < g && !rc; ++v)
           RBL_HIP(c, hipMemcpyAsync(po + (size_t)v * (size_t)pitch, tmp + off + (size_t)v * (size_t)pitch,
                                     sizeof(double) * (size_t)m * (size_t)nbo, hipMemcpyDeviceToDevice, c->stream));
@@ -955,7 +968,7 @@ static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
   const size_t off = (size_t)b0 * (size_t)m;
   if (bf_on(c)) { const int rc = ensure_xq_dev(c); if (rc) return rc; }
   const double *dQ0 = bf_on(c) ? (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0 : nullptr;
-  if (m <= 512)                                         // small bodies: every row independent, rotation fused
+  if (m <= 7936)                                        // every row independent, rotation fused (the vector of a body in 64 KB of LDS)
     return bf_on(c) ? rbl_launch_block_trmv_small(c->stream, (const double *)c->d_bfL.p, m, nbo, 0, in + off, out + off, m, dQ0)
                     : rbl_launch_block_trmv_small(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)(m * m), m, nbo, m * m,
                                                   in + off, out + off, m, nullptr);
@@ -978,10 +991,13 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
   const int64_t n = 3 * nbl;
   if (precond) {
     int rc;
+    // B G (G^-1 M G^-T)^{1/2} W is an exact root for any invertible G applied CONSISTENTLY; the single-precision copy of L^-1
+    // and the fp64 L of the final product agree to 6e-8 only, so it serves the loose tolerances (>= 1e-5) and no others
+    const bool lz32 = c->lanczos_tol >= 1.0e-5;
     if (comm_on(c)) {   // every rank substitutes through ITS bodies' factors only; sums complete the vectors
       int b0, b1; comm_body_range(c, &b0, &b1);
       RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
-      if ((rc = blk_solve(c, b0, b1 - b0, d_x, d_tmp, nvec, n, 2)))
+      if ((rc = blk_solve(c, b0, b1 - b0, d_x, d_tmp, nvec, n, 2, lz32)))
         return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       c->no_damp = true;
@@ -989,12 +1005,12 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       c->no_damp = false;
       if (rc) return rc;
       RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
-      if ((rc = blk_solve(c, b0, b1 - b0, d_y, d_tmp, nvec, n, 1))) return rc;
+      if ((rc = blk_solve(c, b0, b1 - b0, d_y, d_tmp, nvec, n, 1, lz32))) return rc;
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, sizeof(double) * (size_t)nvec * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
       return RBL_OK;
     }
-    if ((rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2)))   // both vectors in one pass over L
+    if ((rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2, lz32)))   // both vectors in one pass over L
       return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
     double *prod = d_y;                                // explicit inverses do not work in place: product into their scratch
     if (c->blk_inv_valid) {
@@ -1005,7 +1021,7 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, prod);
     c->no_damp = false;
     if (rc) return rc;
-    return blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1);
+    return blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1, lz32);
   }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
@@ -1092,7 +1108,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     }
     return yn > 0.0 ? std::sqrt(dn / yn) : 0.0;
   };
-  int m = 0;
+  int m = 0, next_check = check_every;
   bool done = false;
   static const bool trace = std::getenv("RBL_LANCZOS_TRACE") != nullptr;      // diagnostic: the estimate's history on stderr
   for (int it = 0; it < maxit && !done; ++it) {
@@ -1109,7 +1125,9 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
       rbl_launch_lanczos_step(c->stream, n, u, Vp(it, 0), it > 0 ? Vp(it - 1, 0) : nullptr, it > 0 ? d_beta(0) + (it - 1) : nullptr,
                               d_alpha(0) + it, d_beta(0) + it, Vp(it + 1, 0), d_part, nvec, n, (int64_t)nsc);
     m = it + 1;
-    if (m % check_every != 0 && m != maxit) continue;
+    // (the host test is an O(m^3) eigen-solve: tests thin out as the basis grows -- every iteration up to 16, then every m/16-th)
+    if (m < next_check && m != maxit) continue;
+    next_check = m + std::max(check_every, m / 16);
     RBL_HIP(c, hipMemcpyAsync(hs.data(), sc, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
     RBL_HIP(c, hipStreamSynchronize(c->stream));
     bool all_conv = true;
@@ -1435,6 +1453,8 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (variant == 31 || variant == 32) { c->gmres_pc_sign_fix = (variant == 32); return RBL_OK; }
   if (variant == 41 || variant == 42) { c->gmres_small = (variant == 42); return RBL_OK; }           // one-kernel GMRES for small systems off / on
   if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
+  if (variant >= 63 && variant <= 65) { c->blk_large = variant - 63; c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of large bodies never / always / when it pays
+  if (variant == 83 || variant == 84) { c->blk_f32 = (variant == 84); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // single-precision copy of the large inverses off / on
   if (variant == 81 || variant == 82) { c->lanczos_reorth = (variant == 82); return RBL_OK; }       // Lanczos: three-term recurrence only / full re-orthogonalisation (default)
   if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->blk_inv_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
   if (variant == 61 || variant == 62) { c->blk_explicit = (variant == 62); c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of small bodies off / on
@@ -1521,7 +1541,22 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
                                (b1 - q0 < 65535) ? b1 - q0 : 65535, Lb + (size_t)(q0 - b0) * (size_t)msz, msz, c->d_err);
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
-  c->blk_inv_valid = false;
+  c->blk_inv_valid = false; c->blk_f32_valid = false;
+  if (c->blk_explicit && m > 512 && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)))) {
+    // large bodies (shell_N_642 / 2562): explicit inverses through the factorisation's own MFMA kernels -- a rank's few
+    // bodies are then applied by batched triangular matrix-vector products over the whole chip instead of one latency
+    // chain of 3 N_blb / 32 steps per body on one CU each
+    int chunk = 1;
+    if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;
+    if (c->blk_f32 && (rc = rbl_dev_reserve(c, c->d_blkXf, rbl_block_inverse_bytes(m, S.N_bod) / 2))) return rc;
+    if ((rc = rbl_dev_reserve(c, c->d_blkAug, rbl_block_inverse_large_aug_bytes(m, b1 - b0, &chunk)))) return rc;
+    if ((rc = rbl_launch_block_inverse_large(c->stream, Lb, m, b1 - b0, msz, (const double *)c->d_blkLinv.p + (size_t)b0 * lstride,
+                                             (double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)msz,
+                                             c->blk_f32 ? (float *)c->d_blkXf.p + (size_t)b0 * 2 * (size_t)msz : nullptr,
+                                             (double *)c->d_blkAug.p)))
+      return rbl_fail(c, rc, "block inverse (large bodies) launch failed");
+    c->blk_inv_valid = true; c->blk_f32_valid = c->blk_f32;
+  }
   if (c->blk_explicit && rbl_block_inverse_fits(m)) {     // small bodies: explicit L^-1, sweeps become matrix-vector products
     if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;
     if ((rc = rbl_launch_block_inverse(c->stream, Lb, m, b1 - b0, msz, (const double *)c->d_blkLinv.p + (size_t)b0 * lstride,
@@ -1544,7 +1579,7 @@ static int pc_block_build(rbl_ctx *c)
   const size_t off = (size_t)b0 * (size_t)m;
   int rc;
   if (nbo > 0 && (rc = blk_prepare(c, b0, b1))) return rc;
-  if (bf_on(c) && c->bf_inv) return RBL_OK;              // free space, small bodies: everything was built with the body-frame factor
+  if (bf_on(c) && c->bf_tables) return RBL_OK;           // free space, small bodies: everything was built with the body-frame factor
   if ((rc = rbl_dev_reserve(c, c->d_NL, sizeof(double) * 36 * (size_t)S.N_bod))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcw, sizeof(double) * (size_t)(2 * n3 + 6 * 6 * S.N_bod + 2 * 6 * S.N_bod)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_pcMK, sizeof(double) * 6 * (size_t)n3))) return rc;
@@ -1582,7 +1617,7 @@ static int pc_block_apply_local(rbl_ctx *c, const double *d_in, double *d_out, b
   int rc;
   if (shard) RBL_HIP(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)(n3 + 6 * S.N_bod), c->stream));
   c->ktl_of = nullptr;
-  if (bf_on(c) && c->bf_inv) {                           // the whole application in the body frame, one launch
+  if (bf_on(c) && c->bf_tables) {                        // the whole application in the body frame, one launch
     if ((rc = ensure_xq_dev(c))) return rc;
     if (nbo > 0) {
       double *ktl = nullptr;

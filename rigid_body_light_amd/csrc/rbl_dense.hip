@@ -19,6 +19,7 @@ namespace {
 
 constexpr int IB = 32;    // inner step width
 constexpr int NB = 512;   // outer panel width (K of the trailing MFMA update)
+constexpr int NBB_INV = 512;   // panel width of the block inversion of large bodies (rbl_launch_block_inverse_large)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -366,6 +367,9 @@ struct SyrkGrid {
   int tri;           // square update with square super-blocks: only the NSI (NSI + 1) / 2 super-blocks on or below
                      // the diagonal are enumerated (a workgroup of an empty tile still waits for a half-CU slot)
   unsigned nwg;      // = (tri ? NSI (NSI + 1) / 2 : NSI * NSJ) * 64
+  long rshift;       // rows of the updated region start at r0 + rshift (0: the symmetric update of the factorisation) ...
+  int full;          // ... 1: C[i][j] -= sum_k A[i][k] A[j][k] for EVERY (i, j) tile of the region, no lower-triangle test:
+                     //     the row panel and the column panel are different rows of the same columns (block inversion)
 };
 
 static bool syrk_K_ok(int64_t K) { return K >= 4 * KC && K % (2 * KC) == 0; }
@@ -382,6 +386,16 @@ static SyrkGrid syrk_grid(int64_t rows, int64_t cols)
   g.NSJ = (g.TJ + g.SBJ - 1) / g.SBJ;
   g.tri = (rows == cols && g.SBI == g.SBJ) ? 1 : 0;
   g.nwg = (g.tri ? (unsigned)g.NSI * (unsigned)(g.NSI + 1) / 2u : (unsigned)g.NSI * (unsigned)g.NSJ) * 64u;
+  g.rshift = 0; g.full = 0;
+  return g;
+}
+
+// rows [r0 + rshift, ...) x columns [r0, ...): a general C -= A_I A_J^T over a rectangle of tiles
+static SyrkGrid syrk_grid_rect(int64_t rows, int64_t cols, int64_t rshift)
+{
+  SyrkGrid g = syrk_grid(rows, cols);
+  if (g.tri) { g.tri = 0; g.nwg = (unsigned)g.NSI * (unsigned)g.NSJ * 64u; }
+  g.rshift = (long)rshift; g.full = 1;
   return g;
 }
 
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
     SJ = (int)(sb / (unsigned)G.NSI); SI = (int)(sb % (unsigned)G.NSI);
   }
   const int bi = SI * G.SBI + (int)(in / (unsigned)G.SBJ), bj = SJ * G.SBJ + (int)(in % (unsigned)G.SBJ);
-  if (bi >= G.TI || bj >= G.TJ || bi < bj) return;  // outside / strictly-upper block tile (block-uniform)
+  if (bi >= G.TI || bj >= G.TJ || (!G.full && bi < bj)) return;  // outside / strictly-upper block tile (block-uniform)
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // provably uniform: scalar offsets below
 #ifdef RBL_SYRK_PROF
@@ -424,10 +438,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_mfma(double *__restrict__ A, lo
   const unsigned long long tstart = tprev, rstart = __builtin_amdgcn_s_memrealtime();   // shader cycles, 100 MHz ticks
 #endif
   const int wi = wave & 1, wj = wave >> 1;
-  const long bi0 = r0 + (long)bi * 128, bj0 = r0 + (long)bj * 128;
+  const long bi0 = r0 + G.rshift + (long)bi * 128, bj0 = r0 + (long)bj * 128;
   if (bj0 >= c1) return;  // block-uniform
   const long i0 = bi0 + wi * 64, j0 = bj0 + wj * 64;
-  const bool active = (i0 < n) && (j0 < c1) && !(i0 + 63 < j0);  // wave tile holds lower-triangle entries
+  const bool active = (i0 < n) && (j0 < c1) && (G.full || !(i0 + 63 < j0));  // wave tile holds lower-triangle entries
   const int l15 = lane & 15, l4 = lane >> 4;
 
   // loader: thread -> row PAIR 2 (t & 63), column group (t >> 6) * 4 .. +3 of the KC-wide slab: 16-byte loads
@@ -1240,15 +1254,18 @@ constexpr int BIA_R = 63;     // outputs per workgroup: 21 whole blobs (the opti
 // mstride: doubles between the matrices of consecutive bodies (2 n^2; 0 = ONE body-frame matrix shared by all bodies, see
 // the body-frame factors in rbl_api.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
 // blob), rot & 2: the output is rotated back (x_k <- R_b x_k); Q: quaternions of the bodies (4 per body, relative to b = 0).
-template <int NV>
-__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__restrict__ X, long n, long mstride,
+// TM: storage type of the matrix (double; float = the single-precision copy of the explicit inverses of large bodies:
+// half the bytes, converted on load, sums in fp64).  The row blocks with the longest sums are dealt first (revx).
+template <int NV, typename TM>
+__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const TM *__restrict__ X, long n, long mstride,
                                                                 const double *in, double *out, long vec_stride, long rhs_pitch,
                                                                 int upper, const double *__restrict__ Q, int rot)
 {
   extern __shared__ double v[];                      // NV x n vector, then BIA_W x 64 x NV partial sums
   double *red = v + (size_t)NV * n;
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const double *A = X + (size_t)b * (size_t)mstride + (upper ? (size_t)(n * n) : 0);
+  const int bx = upper ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x);      // X v: last rows have the longest sums; X^T v: the first
+  const TM *A = X + (size_t)b * (size_t)mstride + (upper ? (size_t)(n * n) : 0);
   double R[9];
   if (rot) quat_rot_d(Q + 4 * (size_t)b, R);
 #pragma unroll
@@ -1265,7 +1282,7 @@ __global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__
     }
   }
   __syncthreads();
-  const long e0 = (long)blockIdx.x * BIA_R, e = e0 + lane, ec = e < n ? e : n - 1;
+  const long e0 = (long)bx * BIA_R, e = e0 + lane, ec = e < n ? e : n - 1;
   const long eend = (e0 + BIA_R < n) ? e0 + BIA_R : n;
   // X v: columns q <= e (the wave's range ends with its last row);  X^T v: rows q >= e
   const long qlo = upper ? e0 : 0, qhi = upper ? n : eend;
@@ -1274,17 +1291,18 @@ __global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const double *__
   for (int vv = 0; vv < NV; ++vv) acc[vv] = 0.0;
   constexpr int U = 32;                              // loads in flight per lane: the whole sum is latency, not bandwidth
   for (long q0 = qlo + w; q0 < qhi; q0 += BIA_W * U) {
-    double a[U];
-#pragma unroll
+    TM a[U];                                         // unconditional loads (clamped column): a guarded load is a branch and a
+#pragma unroll                                       // memory round trip EACH -- the float instantiation ran 7x slower that way
     for (int u = 0; u < U; ++u) {
       const long q = q0 + BIA_W * u;
-      a[u] = q < qhi ? A[(size_t)q * (size_t)n + ec] : 0.0;
+      if constexpr (std::is_same<TM, double>::value) a[u] = q < qhi ? A[(size_t)q * (size_t)n + ec] : 0.0;   // (compiles to 32 loads back to back)
+      else a[u] = A[(size_t)(q < qhi ? q : qhi - 1) * (size_t)n + ec];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long q = q0 + BIA_W * u;
       const bool ok = q < qhi && (upper ? q >= e : q <= e);
-      const double av = ok ? a[u] : 0.0;
+      const double av = ok ? (double)a[u] : 0.0;
       const long qc = q < qhi ? q : qhi - 1;
 #pragma unroll
       for (int vv = 0; vv < NV; ++vv) acc[vv] = __builtin_fma(av, v[(size_t)vv * n + qc], acc[vv]);
@@ -1366,39 +1384,134 @@ int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int b
   return RBL_OK;
 }
 
+// ---- explicit inverses of LARGE bodies (n > 512: shell_N_642 / 2562, n = 1926 / 7686) -- the reference's own form of the
+// block preconditioner (Block_diag_invM, c_rigid_obj.cpp:461-487: Mob.inverse()) ----------------------------------------
+// Y = L^-T solves Y L^T = I: the SAME recurrence the factorisation runs on the rows below a panel (X = A21 L11^-T).  So the
+// factorisation's own kernels do the inversion on an augmented matrix [L ; I] (2 np x np, np = n rounded up to 32, L padded
+// by the identity): per 512-column panel k_trsm_tall solves the rows [0, pend) of the lower half against the panel's diagonal
+// block, then k_syrk_mfma (rectangular form: SyrkGrid::full) takes that panel out of the columns to its right,
+// Y[0:pend, pend:] -= Y[0:pend, panel] L[pend:, panel]^T -- rows above the panel's last column only (Y is upper triangular:
+// a third of the flops of a dense solve, n^3 / 3).  The lower half then IS X^T column-major = X row-major (layout XU of the
+// small-body inverses); one tiled transpose writes XL.
+template <typename TX>
+__global__ __launch_bounds__(256) void k_aug_fill(const double *__restrict__ L, long n, long strideL, double *__restrict__ Aug, long np)
+{
+  const long col = blockIdx.x;                       // 0 .. np - 1
+  const double *Lb = L + (size_t)blockIdx.y * (size_t)strideL;
+  double *Ab = Aug + (size_t)blockIdx.y * (size_t)(2 * np * np) + (size_t)col * (size_t)(2 * np);
+  for (long i = threadIdx.x; i < 2 * np; i += 256) {
+    double v;
+    if (i < np) v = (i < n && col < n) ? (i >= col ? Lb[(size_t)col * (size_t)n + i] : 0.0) : (i == col ? 1.0 : 0.0);
+    else v = (i - np == col) ? 1.0 : 0.0;
+    Ab[i] = v;
+  }
+}
+
+// lower triangle of X (32 x 32 tiles rb >= cb) from the augmented buffer: XU[r n + c] = XL[c n + r] = X[r][c] = Aug[r][np + c]
+template <typename TX>
+__global__ __launch_bounds__(256) void k_aug_extract(const double *__restrict__ Aug, long n, long np, TX *__restrict__ X)
+{
+  __shared__ double tile[32][33];
+  const long rb = blockIdx.x, cb = blockIdx.y;
+  if (cb > rb) return;
+  const double *Ab = Aug + (size_t)blockIdx.z * (size_t)(2 * np * np);
+  TX *XL = X + (size_t)blockIdx.z * 2 * (size_t)(n * n), *XU = XL + (size_t)(n * n);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const long r = rb * 32 + k, c = cb * 32 + tx;
+    const double v = (r < n && c < n) ? Ab[(size_t)r * (size_t)(2 * np) + np + c] : 0.0;
+    tile[k][tx] = v;
+    if (r < n && c < n && c <= r) XU[(size_t)r * (size_t)n + c] = (TX)v;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const long c = cb * 32 + k, r = rb * 32 + tx;
+    if (r < n && c < n && c <= r) XL[(size_t)c * (size_t)n + r] = (TX)tile[tx][k];
+  }
+}
+
+size_t rbl_block_inverse_large_aug_bytes(int64_t n, int batch, int *chunk_out)
+{
+  const int64_t np = ((n + IB - 1) / IB) * IB;
+  const size_t per = sizeof(double) * 2 * (size_t)(np * np);
+  int chunk = (int)(((size_t)4 << 30) / per);        // ~4 GB of scratch at a time
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  if (chunk > 65535) chunk = 65535;
+  if (chunk_out) *chunk_out = chunk;
+  return per * (size_t)chunk;
+}
+
+// d_X: [XL | XU] per body, 2 n^2 entries of fp64 (d_X) and / or fp32 (d_Xf), either may be NULL; d_aug: scratch of
+// rbl_block_inverse_large_aug_bytes
+int rbl_launch_block_inverse_large(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
+                                   double *d_X, float *d_Xf, double *d_aug)
+{
+  const int64_t np = ((n + IB - 1) / IB) * IB, nsteps = np / IB, ld = 2 * np;
+  const long strideL = (long)(nsteps * IB * IB), strideAug = (long)(ld * np);
+  if ((size_t)NBB_INV * (size_t)ld * 8 >= ((size_t)1 << 31)) return RBL_ERR_SIZE;   // one panel through one buffer descriptor
+  int chunk = 1;
+  (void)rbl_block_inverse_large_aug_bytes(n, batch, &chunk);
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+    const double *Lb = d_L + (size_t)b0 * (size_t)strideA;
+    const double *Li = d_Linv + (size_t)b0 * (size_t)strideL;
+    hipLaunchKernelGGL(k_aug_fill<double>, dim3((unsigned)np, nb), dim3(256), 0, st, Lb, (long)n, (long)strideA, d_aug, (long)np);
+    for (int64_t k = 0; k < np; k += NBB_INV) {
+      const int64_t pw = (np - k < NBB_INV) ? (np - k) : NBB_INV, pend = k + pw;
+      const double *Lk = Li + (size_t)(k / IB) * IB * IB;
+      hipLaunchKernelGGL(k_trsm_tall, dim3((unsigned)((pend + 127) / 128), 1, nb), dim3(256), 0, st, d_aug, (long)ld, (long)(np + pend),
+                         (long)k, (int)(pw / IB), (long)np, Lk, strideAug, strideL);
+      if (pend < np) {
+        if (!syrk_K_ok(pw)) return RBL_ERR_ARG;
+        const SyrkGrid G = syrk_grid_rect(pend, np - pend, np - pend);
+        hipLaunchKernelGGL(k_syrk_mfma, dim3(G.nwg, 1, nb), dim3(256), 0, st, d_aug, (long)ld, (long)pend, (long)np, (long)k, (int)pw,
+                           strideAug, (long)(np + pend), G);
+      }
+    }
+    const dim3 eg((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), nb);
+    if (d_X) hipLaunchKernelGGL(k_aug_extract<double>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np,
+                                d_X + (size_t)b0 * 2 * (size_t)(n * n));
+    if (d_Xf) hipLaunchKernelGGL(k_aug_extract<float>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np,
+                                 d_Xf + (size_t)b0 * 2 * (size_t)(n * n));
+  }
+  return RBL_OK;
+}
+
 // mode 0: x = X^T X v ;  1: x = X v ;  2: x = X^T v  (= (L L^T)^-1 v, L^-1 v, L^-T v).  d_tmp: nv vectors of
 // rhs_pitch doubles (mode 0 only; laid out like d_out).  In place is fine for mode 0, not for 1 / 2.
 // d_Q != NULL: d_X is ONE body-frame inverse shared by all bodies and the factor meant is G_b = R_b L (G G^T = M_b):
 // G^-1 v = X R^T v, G^-T v = R X^T v, (G G^T)^-1 v = R X^T X R^T v  (d_Q: the bodies' quaternions, first body first).
-int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
-                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q)
+// f32: d_X points to the single-precision copy ([XL | XU] of floats).
+template <typename TM>
+static int block_inv_apply_t(hipStream_t st, const TM *d_X, int64_t n, int batch, const double *d_in, double *d_out,
+                             int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q)
 {
-  if (n > BSS_T) return RBL_ERR_SIZE;
-  if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
-  if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
   if (batch > 65535) {                               // bodies ride in gridDim.y: more than that go in several rounds
     for (int b0 = 0; b0 < batch; b0 += 65535) {
       const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
       const size_t vo = (size_t)b0 * (size_t)vec_stride;
-      const int rc = rbl_launch_block_inv_apply(st, d_Q ? d_X : d_X + (size_t)b0 * 2 * (size_t)(n * n), n, nb, d_in + vo, d_out + vo,
-                                                vec_stride, nv, rhs_pitch, mode, d_tmp ? d_tmp + vo : nullptr,
-                                                d_Q ? d_Q + 4 * (size_t)b0 : nullptr);
+      const int rc = block_inv_apply_t<TM>(st, d_Q ? d_X : d_X + (size_t)b0 * 2 * (size_t)(n * n), n, nb, d_in + vo, d_out + vo,
+                                           vec_stride, nv, rhs_pitch, mode, d_tmp ? d_tmp + vo : nullptr,
+                                           d_Q ? d_Q + 4 * (size_t)b0 : nullptr);
       if (rc) return rc;
     }
     return RBL_OK;
   }
   const dim3 grid((unsigned)((n + BIA_R - 1) / BIA_R), batch);
   const long mstride = d_Q ? 0 : 2 * (long)(n * n);
+  int gmax = 3;                                      // vectors sharing one pass over X: what 64 KB of LDS hold
+  while (gmax > 1 && sizeof(double) * ((size_t)gmax * (size_t)n + 64 * BIA_W * (size_t)gmax) > 65536) --gmax;
   auto pass = [&](const double *in, double *out, int upper) {
     const int rot = d_Q ? (upper ? 2 : 1) : 0;
     for (int v0 = 0; v0 < nv;) {
-      const int g = nv - v0 >= 3 ? 3 : nv - v0;
+      const int g = nv - v0 >= gmax ? gmax : nv - v0;
       const size_t lds = sizeof(double) * ((size_t)g * (size_t)n + 64 * BIA_W * (size_t)g);
       const double *pi = in + (size_t)v0 * (size_t)rhs_pitch;
       double *po = out + (size_t)v0 * (size_t)rhs_pitch;
-      if (g == 3) hipLaunchKernelGGL(k_block_inv_apply<3>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
-      else if (g == 2) hipLaunchKernelGGL(k_block_inv_apply<2>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
-      else hipLaunchKernelGGL(k_block_inv_apply<1>, grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+      if (g == 3) hipLaunchKernelGGL((k_block_inv_apply<3, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+      else if (g == 2) hipLaunchKernelGGL((k_block_inv_apply<2, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+      else hipLaunchKernelGGL((k_block_inv_apply<1, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
       v0 += g;
     }
   };
@@ -1407,17 +1520,27 @@ int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int
   return RBL_OK;
 }
 
-// y_b = L_b x_b for small bodies (n <= 512) as a triangular matrix-vector product with every row independent (the kernel of
-// the inverse applications on the factor itself; k_block_trmv walks the columns in one workgroup per body: 50 us at
-// n = 486).  strideA = 0: one shared body-frame factor, then d_Q rotates the result (y_b = R_b L x_b).  Not in place.
+int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
+                               int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q, int f32)
+{
+  if (sizeof(double) * ((size_t)n + 64 * BIA_W) > 65536) return RBL_ERR_SIZE;      // one vector + partial sums in LDS
+  if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
+  if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
+  if (f32) return block_inv_apply_t<float>(st, (const float *)d_X, n, batch, d_in, d_out, vec_stride, nv, rhs_pitch, mode, d_tmp, d_Q);
+  return block_inv_apply_t<double>(st, d_X, n, batch, d_in, d_out, vec_stride, nv, rhs_pitch, mode, d_tmp, d_Q);
+}
+
+// y_b = L_b x_b as a triangular matrix-vector product with every row independent (the kernel of the inverse applications
+// on the factor itself; k_block_trmv walks the columns in one workgroup per body: 50 us at n = 486, and one CU per body
+// whatever the size).  strideA = 0: one shared body-frame factor, then d_Q rotates the result (y_b = R_b L x_b).  Not in place.
 int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                                 double *d_out, int64_t vec_stride, const double *d_Q)
 {
-  if (n > BSS_T || d_in == d_out) return RBL_ERR_ARG;
+  if (sizeof(double) * ((size_t)n + 64 * BIA_W) > 65536 || d_in == d_out) return RBL_ERR_ARG;
   for (int b0 = 0; b0 < batch; b0 += 65535) {
     const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
     const size_t vo = (size_t)b0 * (size_t)vec_stride;
-    hipLaunchKernelGGL(k_block_inv_apply<1>, dim3((unsigned)((n + BIA_R - 1) / BIA_R), nb), dim3(64 * BIA_W),
+    hipLaunchKernelGGL((k_block_inv_apply<1, double>), dim3((unsigned)((n + BIA_R - 1) / BIA_R), nb), dim3(64 * BIA_W),
                        sizeof(double) * ((size_t)n + 64 * BIA_W), st, d_L + (size_t)b0 * (size_t)strideA, (long)n, (long)strideA,
                        d_in + vo, d_out + vo, (long)vec_stride, 0L, 0, d_Q ? d_Q + 4 * (size_t)b0 : nullptr, d_Q ? 2 : 0);
   }

@@ -75,7 +75,12 @@ struct rbl_ctx {
   RblDevBuf d_r, d_F, d_U, d_part, d_W, d_cfg, d_XQ, d_mat, d_tmp, d_tmp2, d_chol;
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
-  RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 of small bodies (two layouts), scratch of their application
+  RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 (two layouts), scratch of their application
+  RblDevBuf d_blkXf, d_blkAug;                      // large bodies: single-precision copy of the inverses; scratch of their inversion
+  int blk_large = 2;                                // explicit inverses of bodies with 3 N_blb > 512: 0 never, 1 always, 2 when it pays
+                                                    // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- rbl_set_tuning 63 / 64 / 65
+  bool blk_f32 = false, blk_f32_valid = false;      // rbl_set_tuning 83 / 84: apply them from a single-precision copy (half the bytes)
+  bool bf_tables = false;                           // d_bfPC holds the body-frame preconditioner tables (small bodies)
   // free space: M_b = (I x R_b) M_body (I x R_b)^T with ONE body-frame matrix for all bodies and all time: its factor
   // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
   RblDevBuf d_bfL, d_bfLinv, d_bfX;
@@ -212,7 +217,11 @@ int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int b
                              double *d_X);
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
                                int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp,
-                               const double *d_Q = nullptr);
+                               const double *d_Q = nullptr, int f32 = 0);
+// explicit inverses of large bodies (3 N_blb > 512) with the factorisation's own MFMA kernels on an augmented matrix
+size_t rbl_block_inverse_large_aug_bytes(int64_t n, int batch, int *chunk_out);
+int rbl_launch_block_inverse_large(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
+                                   double *d_X, float *d_Xf, double *d_aug);
 int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                                 double *d_out, int64_t vec_stride, const double *d_Q);
 void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,

@@ -216,21 +216,38 @@ __global__ __launch_bounds__(TS) void k_tile_bbox(const double *__restrict__ r, 
 __global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbox, int T, int NI,
                                                   unsigned char *__restrict__ farmap)
 {
+  // bit 0: every blob of column tile J is farther than 2a from every row of super-tile S (no pair can overlap);
+  // bit 1: ... and the relaxed (single-precision) sweep of the pair is accurate to ~1e-6 of every separation.  That sweep
+  //        takes coordinates relative to the first blob of tile J: |x_j - o| <= d_J (diagonal of J's box), |x_i - o| <= gap +
+  //        d_I + d_J, so rounding them to fp32 moves a separation by at most eps/2 (gap + d_I + 2 d_J), i.e. by
+  //        eps/2 (1 + (d_I + 2 d_J) / gap) of itself (eps = 1.2e-7): bounded by 1e-6 when d_I + 2 d_J <= 15 gap.  Tiles
+  //        that straddle two far-apart bodies, or suspensions thousands of radii wide, fail the test for the pairs where
+  //        it matters and those are swept in fp64.
   const int J = blockIdx.x * 256 + threadIdx.x, S = blockIdx.y;
   if (J >= T) return;
   double gap2 = 1.0e300;
+  const double *bj = bbox + 6 * (size_t)J;
+  double lo[3] = {1.0e300, 1.0e300, 1.0e300}, hi[3] = {-1.0e300, -1.0e300, -1.0e300};
   for (int a = 0; a < NI; ++a) {
     const int I = NI * S + a;
     if (I >= T) break;
-    const double *bi = bbox + 6 * (size_t)I, *bj = bbox + 6 * (size_t)J;
+    const double *bi = bbox + 6 * (size_t)I;
     double g2 = 0.0;
     for (int d = 0; d < 3; ++d) {
       const double g = fmax(fmax(bj[d] - bi[3 + d], bi[d] - bj[3 + d]), 0.0);
       g2 = __builtin_fma(g, g, g2);
+      lo[d] = fmin(lo[d], bi[d]); hi[d] = fmax(hi[d], bi[3 + d]);
     }
     gap2 = fmin(gap2, g2);
   }
-  farmap[(size_t)S * T + J] = gap2 > 4.0001 ? 1 : 0;
+  double dI2 = 0.0, dJ2 = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    dI2 = __builtin_fma(hi[d] - lo[d], hi[d] - lo[d], dI2);
+    dJ2 = __builtin_fma(bj[3 + d] - bj[d], bj[3 + d] - bj[d], dJ2);
+  }
+  const bool far = gap2 > 4.0001;
+  const bool f32ok = far && (sqrt(dI2) + 2.0 * sqrt(dJ2) <= 15.0 * sqrt(gap2));
+  farmap[(size_t)S * T + J] = far ? (f32ok ? 3 : 1) : 0;
 }
 #ifndef RBL_SYM_UNROLL
 #define RBL_SYM_UNROLL 2
@@ -289,9 +306,17 @@ __device__ __forceinline__ size_t sym_idxJ(const SymLayout &L, int g, int v, lon
   return ((size_t)sym_offJ(L, g) * L.nrhs + (size_t)v * (L.Npad - rj) + (size_t)(b - rj)) * 3;
 }
 
-// PREC = 1 (relaxed product, two rows per lane only): tile pairs the far map proves free of overlaps are swept in packed
-// single precision (rbl_pair_sym_pk), coordinates relative to the workgroup's first row blob; their per-tile sums are
-// added to the double accumulators, so single precision only ever sums 64 x NI terms.  Diagonal / near tiles stay fp64.
+__device__ __forceinline__ double sym_first_lane(double v)      // lane 0's value in every lane (a wavefront-uniform double)
+{
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// PREC = 1 (relaxed product, two rows per lane only): tile pairs the far map proves free of overlaps AND safe for single
+// precision (k_tile_far, bit 1) are swept in packed single precision (rbl_pair_sym_pk), coordinates relative to the first
+// blob of the column tile (round 3; one origin per workgroup let the error grow with the extent of the suspension); their
+// per-tile sums are added to the double accumulators, so single precision only ever sums 64 x NI terms.  Diagonal, near
+// and unsafe tiles stay fp64.
 template <bool WALL, int NI, int SW, int PREC>
 __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict__ r,
                                                         const double *__restrict__ F,
@@ -323,11 +348,7 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);                      // a wave without rows never sweeps, only keeps step
   unsigned flags = 0;
-  double ox = 0.0, oy = 0.0, oz = 0.0;                             // origin of the single-precision coordinates (radius-scaled)
-  if (PREC) {
-    const long b0 = ((long)It00 * TS < N) ? (long)It00 * TS : N - 1;
-    ox = r[3 * b0] * P.inv_a; oy = r[3 * b0 + 1] * P.inv_a; oz = r[3 * b0 + 2] * P.inv_a;
-  }
+  __shared__ double sO[3];                          // relaxed product: origin of the single-precision coordinates = first blob of the j tile
 
   // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
   // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
@@ -354,17 +375,12 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
     load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);
     uix[a] = 0.0; uiy[a] = 0.0; uiz[a] = 0.0;
   }
-  rbl_f2 xi2 = {0, 0}, yi2 = {0, 0}, zi2 = {0, 0}, Fx2 = {0, 0}, Fy2 = {0, 0}, Fz2 = {0, 0};
-  float two_z0 = 0.0f;
+  rbl_f2 Fx2 = {0, 0}, Fy2 = {0, 0}, Fz2 = {0, 0};
   if (PREC) {
     const int a1 = NI - 1;
-    xi2 = (rbl_f2){(float)(xi[0] - ox), (float)(xi[a1] - ox)};
-    yi2 = (rbl_f2){(float)(yi[0] - oy), (float)(yi[a1] - oy)};
-    zi2 = (rbl_f2){(float)(zi[0] - oz), (float)(zi[a1] - oz)};
     Fx2 = (rbl_f2){(float)Fix[0], (float)Fix[a1]};
     Fy2 = (rbl_f2){(float)Fiy[0], (float)Fiy[a1]};
     Fz2 = (rbl_f2){(float)Fiz[0], (float)Fiz[a1]};
-    two_z0 = (float)(2.0 * oz);
   }
 
   for (int J = J0; J < J1; ++J) {
@@ -372,14 +388,18 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
     double xj = 0, yj = 0, zj = 0, Fjx = 0, Fjy = 0, Fjz = 0;
     if (wave == 0) load_blob(j, xj, yj, zj, Fjx, Fjy, Fjz);
     const bool sweeps = J >= It0;                                  // wave-uniform
-    // wave-uniform: every blob of tile J is farther than 2a from every owned row (k_tile_far)
-    const bool far_tile = sweeps && farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    // wave-uniform: every blob of tile J is farther than 2a from every owned row (k_tile_far; bit 1: single precision is safe)
+    const int fmap = (sweeps && farmap) ? __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) : 0;
+    const bool far_tile = fmap != 0;
     __syncthreads();                                               // previous tile consumed, its column sums written
     if (wave == 0) {
       sP0[lane] = (double2_t){xj, yj};
       sP1[lane] = (double2_t){zj, Fjx};
       sP2[lane] = (double2_t){Fjy, Fjz};
       if (PREC) {
+        // coordinates relative to the tile's first blob: what single precision then rounds is a separation-sized number
+        const double ox = sym_first_lane(xj), oy = sym_first_lane(yj), oz = sym_first_lane(zj);
+        if (lane == 0) { sO[0] = ox; sO[1] = oy; sO[2] = oz; }
         sPf[0][lane] = (float)(xj - ox); sPf[PREC ? 1 : 0][lane] = (float)(yj - oy); sPf[PREC ? 2 : 0][lane] = (float)(zj - oz);
         sPf[PREC ? 3 : 0][lane] = (float)Fjx; sPf[PREC ? 4 : 0][lane] = (float)Fjy; sPf[PREC ? 5 : 0][lane] = (float)Fjz;
       }
@@ -388,7 +408,12 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
     __syncthreads();
     if (!sweeps) {
       // the tile lies before this wave's rows: pairs belong to an earlier wave
-    } else if (PREC && far_tile && J >= It0 + NI) {   // relaxed product: packed single precision, both rows of the lane at once
+    } else if (PREC && (fmap & 2) && J >= It0 + NI) {   // relaxed product: packed single precision, both rows of the lane at once
+      const double ox = sO[0], oy = sO[1], oz = sO[2];
+      const int a1 = NI - 1;
+      const rbl_f2 xi2 = {(float)(xi[0] - ox), (float)(xi[a1] - ox)}, yi2 = {(float)(yi[0] - oy), (float)(yi[a1] - oy)},
+                   zi2 = {(float)(zi[0] - oz), (float)(zi[a1] - oz)};
+      const float two_z0 = (float)(2.0 * oz);
       rbl_f2 ax = {0, 0}, ay = {0, 0}, az = {0, 0};
 #pragma unroll 2
       for (int s = 0; s < TS; ++s) {
@@ -528,19 +553,12 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
     load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
     ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = ui0[a];
   }
-  double ox = 0.0, oy = 0.0, oz = 0.0;
-  rbl_f2 xi2 = {0, 0}, yi2 = {0, 0}, zi2 = {0, 0}, F0x = {0, 0}, F0y = {0, 0}, F0z = {0, 0}, F1x = {0, 0}, F1y = {0, 0}, F1z = {0, 0};
-  float two_z0 = 0.0f;
+  __shared__ double sO[3];                          // relaxed product: origin = first blob of the j tile (see k_apply_M_sym)
+  rbl_f2 F0x = {0, 0}, F0y = {0, 0}, F0z = {0, 0}, F1x = {0, 0}, F1y = {0, 0}, F1z = {0, 0};
   if (PREC) {
-    const long b0 = ((long)It00 * TS < N) ? (long)It00 * TS : N - 1;
-    ox = r[3 * b0] * P.inv_a; oy = r[3 * b0 + 1] * P.inv_a; oz = r[3 * b0 + 2] * P.inv_a;
     const int a1 = NI - 1;
-    xi2 = (rbl_f2){(float)(xi[0] - ox), (float)(xi[a1] - ox)};
-    yi2 = (rbl_f2){(float)(yi[0] - oy), (float)(yi[a1] - oy)};
-    zi2 = (rbl_f2){(float)(zi[0] - oz), (float)(zi[a1] - oz)};
     F0x = (rbl_f2){(float)Fi0[0].x, (float)Fi0[a1].x}; F0y = (rbl_f2){(float)Fi0[0].y, (float)Fi0[a1].y}; F0z = (rbl_f2){(float)Fi0[0].z, (float)Fi0[a1].z};
     F1x = (rbl_f2){(float)Fi1[0].x, (float)Fi1[a1].x}; F1y = (rbl_f2){(float)Fi1[0].y, (float)Fi1[a1].y}; F1z = (rbl_f2){(float)Fi1[0].z, (float)Fi1[a1].z};
-    two_z0 = (float)(2.0 * oz);
   }
   for (int J = J0; J < J1; ++J) {
     const long j = (long)J * TS + lane;
@@ -548,8 +566,14 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
     RblV3 Fj0{0, 0, 0}, Fj1{0, 0, 0};
     if (wave == 0) load_blob(j, xj, yj, zj, Fj0, Fj1);
     const bool sweeps = J >= It0;
-    const bool far_tile = sweeps && farmap && __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) != 0;
+    const int fmap = (sweeps && farmap) ? __builtin_amdgcn_readfirstlane((int)farmap[(size_t)I * (size_t)T + J]) : 0;
+    const bool far_tile = fmap != 0;
     __syncthreads();
+    double ox = 0.0, oy = 0.0, oz = 0.0;
+    if (PREC && wave == 0) {
+      ox = sym_first_lane(xj); oy = sym_first_lane(yj); oz = sym_first_lane(zj);
+      if (lane == 0) { sO[0] = ox; sO[1] = oy; sO[2] = oz; }
+    }
     if (wave == 0) {
       sP0[lane] = (double2_t){xj, yj};
       sP1[lane] = (double2_t){zj, Fj0.x};
@@ -581,7 +605,12 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
       __hip_atomic_fetch_add(&sU[wave][1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if (!sweeps) {
-    } else if (PREC && far_tile && J >= It0 + NI) {   // relaxed product: packed single precision, coefficients once for both vectors
+    } else if (PREC && (fmap & 2) && J >= It0 + NI) {   // relaxed product: packed single precision, coefficients once for both vectors
+      const double qx = sO[0], qy = sO[1], qz = sO[2];
+      const int a1 = NI - 1;
+      const rbl_f2 xi2 = {(float)(xi[0] - qx), (float)(xi[a1] - qx)}, yi2 = {(float)(yi[0] - qy), (float)(yi[a1] - qy)},
+                   zi2 = {(float)(zi[0] - qz), (float)(zi[a1] - qz)};
+      const float two_z0 = (float)(2.0 * qz);
       rbl_f2 a0x = {0, 0}, a0y = {0, 0}, a0z = {0, 0}, a1x = {0, 0}, a1y = {0, 0}, a1z = {0, 0};
 #pragma unroll 2
       for (int s = 0; s < TS; ++s) {

@@ -115,3 +115,17 @@ def test_cfg4_size_sharded_brownian_step(monkeypatch, world):
     p = _torchrun(world, ["tools/check_sharded_brownian.py"], timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "world %d" % world in p.stdout and _max_diff(p.stdout, world) < 1e-8
+
+
+def test_world1_nccl_group_runs_the_rccl_code_path():
+    """The `nccl` (= RCCL) branch of dist.py and the raw-device-pointer all-reduce callback of DeviceContext.set_comm have
+    only ever run under gloo with host staging in the rehearsals above.  A process group of ONE rank on the nccl backend
+    drives exactly what N ranks run on one GPU: device-buffer all_gather_into_tensor / all_reduce, and the callback inside
+    rbl_gmres_saddle_dev, the preconditioned Lanczos square root and a whole stochastic step -- equal to the un-sharded
+    results (tools/check_nccl_world1.py; its own process, started before it touches the GPU)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "tools/check_nccl_world1.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "ALL OK" in p.stdout and "side stream" in p.stdout and "FAILED" not in p.stdout
