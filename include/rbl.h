@@ -167,7 +167,8 @@ int rbl_RHS_and_Midpoint(rbl_ctx *ctx, const double *Slip, const double *Force, 
 
 /* Lanczos controls / report.  max_iter: the basis is kept (max_iter + 1 vectors of 3 N doubles per recurrence).  tol: the recurrence stops when the ERROR ESTIMATE of the increment is below tol (relative):
  * the last correction d_m = |x_m - x_{m-1}| / |x_m| extrapolated geometrically, d_m rho / (1 - rho), rho = d_m / d_{m-1}.
- * The report returns the iterations used by the last call and that estimate. */
+ * For RBL_MHALF_LANCZOS_PC the estimate is taken in the Euclidean norm of the increment itself (rbl_set_tuning 85: in its
+ * energy norm).  The report returns the iterations used by the last call and that estimate. */
 int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
 int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);
 
@@ -367,6 +368,9 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an
  * approximate block factor (no factorisation, 29.7 MB instead of 5.9 GB at cfg 3; one or two more GMRES iterations --
  * measured level in time at cfg 3, so not the default);
+ * 85 / 86: preconditioned Lanczos root x = B L z, z = (L^-1 M L^-T)^{1/2} W: stop on the error estimate of z -- the error
+ * of x in the ENERGY norm x^T (B M B)^-1 x, the one that bounds the relative error of the sampled covariance -- / of x itself
+ * in the Euclidean norm (default; L weighs the slowly converging collective modes more: a few more iterations);
  * 81 / 82: Lanczos square roots with the three-term recurrence only (round 1-2; the estimate stagnates near 1e-6) / with
  * every new vector re-orthogonalised against the whole stored basis (default).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);

@@ -115,9 +115,13 @@ class DeviceContext:
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
+        views = {}     # (pointer, count) -> tensor view: librbl all-reduces the same few buffers over and over
+
         def _allreduce(user, ptr, count):
             try:
-                t = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
+                t = views.get((ptr, count))
+                if t is None:
+                    t = views[(ptr, count)] = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
                 # rbl.h: the all-reduce must be ordered on the CONTEXT's stream (the library enqueues producer and consumer
                 # kernels there); torch issues collectives on its current stream, so make the context's stream current
                 if sharded.device.type == "cuda" and torch.cuda.current_stream(sharded.device).cuda_stream != self._stream_ptr:

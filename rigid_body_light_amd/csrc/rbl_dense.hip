@@ -1249,23 +1249,27 @@ __global__ __launch_bounds__(BSS_T) void k_trtri_small(const double *__restrict_
 }
 
 constexpr int BIA_W = 4;      // waves per workgroup of k_block_inv_apply: BIA_R outputs, each wave a quarter of every sum (measured at 50 x 486: 2 waves 27 us, 4 waves 15.8, 8 waves 18.2)
-constexpr int BIA_R = 63;     // outputs per workgroup: 21 whole blobs (the optional output rotation needs whole blobs)
+constexpr int BIA_RQ = 63;    // outputs per workgroup of the rotated forms: 21 whole blobs (the output rotation needs whole blobs)
 
 // mstride: doubles between the matrices of consecutive bodies (2 n^2; 0 = ONE body-frame matrix shared by all bodies, see
 // the body-frame factors in rbl_api.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
 // blob), rot & 2: the output is rotated back (x_k <- R_b x_k); Q: quaternions of the bodies (4 per body, relative to b = 0).
 // TM: storage type of the matrix (double; float = the single-precision copy of the explicit inverses of large bodies:
 // half the bytes, converted on load, sums in fp64).  The row blocks with the longest sums are dealt first (revx).
-template <int NV, typename TM>
-__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const TM *__restrict__ X, long n, long mstride,
+// ROWS: outputs per workgroup -- 63 (whole blobs: the rotated forms) or 64 (with ldx a multiple of 16 every wave load is then
+// four whole 128-byte lines; 63-row segments of an unpadded matrix straddle five: 4.5 instead of 5.3 TB/s at 200 x 1926).
+// ldx: doubles between consecutive columns of a layout (n for the small-body inverses, padded for the large ones).
+template <int NV, typename TM, int ROWS>
+__global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const TM *__restrict__ X, long n, long ldx, long mstride,
                                                                 const double *in, double *out, long vec_stride, long rhs_pitch,
                                                                 int upper, const double *__restrict__ Q, int rot)
 {
+  constexpr int BIA_R = ROWS;
   extern __shared__ double v[];                      // NV x n vector, then BIA_W x 64 x NV partial sums
   double *red = v + (size_t)NV * n;
   const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int bx = upper ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x);      // X v: last rows have the longest sums; X^T v: the first
-  const TM *A = X + (size_t)b * (size_t)mstride + (upper ? (size_t)(n * n) : 0);
+  const TM *A = X + (size_t)b * (size_t)mstride + (upper ? (size_t)(ldx * n) : 0);
   double R[9];
   if (rot) quat_rot_d(Q + 4 * (size_t)b, R);
 #pragma unroll
@@ -1295,8 +1299,8 @@ __global__ __launch_bounds__(64 * BIA_W) void k_block_inv_apply(const TM *__rest
 #pragma unroll                                       // memory round trip EACH -- the float instantiation ran 7x slower that way
     for (int u = 0; u < U; ++u) {
       const long q = q0 + BIA_W * u;
-      if constexpr (std::is_same<TM, double>::value) a[u] = q < qhi ? A[(size_t)q * (size_t)n + ec] : 0.0;   // (compiles to 32 loads back to back)
-      else a[u] = A[(size_t)(q < qhi ? q : qhi - 1) * (size_t)n + ec];
+      if constexpr (std::is_same<TM, double>::value) a[u] = q < qhi ? A[(size_t)q * (size_t)ldx + ec] : 0.0;   // (compiles to 32 loads back to back)
+      else a[u] = A[(size_t)(q < qhi ? q : qhi - 1) * (size_t)ldx + ec];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1366,7 +1370,10 @@ __global__ void k_rotate_bodies(const double *__restrict__ Q, const double *in, 
 // measured (tools/bench_block_solve.py, both sweeps): n = 486 x 50 bodies 124 -> 43 us; n = 126 x 400 and n = 36 x 2000 are
 // chains of 4 and 2 steps only, where the substitution kernel (23 us) beats two matrix-vector launches
 bool rbl_block_inverse_fits(int64_t n) { return n > 192 && n <= BSS_T; }
-size_t rbl_block_inverse_bytes(int64_t n, int batch) { return sizeof(double) * 2 * (size_t)(n * n) * (size_t)batch; }
+// leading dimension of the two layouts of an explicit inverse: n for small bodies (k_trtri_small), a multiple of 32 entries
+// (128 bytes of fp32, 256 of fp64) for large ones so that 64-row segments of a column are whole cache lines
+int64_t rbl_block_inverse_ld(int64_t n) { return n <= BSS_T ? n : ((n + 31) / 32) * 32; }
+size_t rbl_block_inverse_bytes(int64_t n, int batch) { return sizeof(double) * 2 * (size_t)(rbl_block_inverse_ld(n) * n) * (size_t)batch; }
 
 // X_b = L_b^-1 for `batch` factored bodies (d_L, d_Linv as left by rbl_launch_cholesky_batched); d_X: 2 n^2 doubles a body
 int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
@@ -1409,24 +1416,24 @@ __global__ __launch_bounds__(256) void k_aug_fill(const double *__restrict__ L, 
 
 // lower triangle of X (32 x 32 tiles rb >= cb) from the augmented buffer: XU[r n + c] = XL[c n + r] = X[r][c] = Aug[r][np + c]
 template <typename TX>
-__global__ __launch_bounds__(256) void k_aug_extract(const double *__restrict__ Aug, long n, long np, TX *__restrict__ X)
+__global__ __launch_bounds__(256) void k_aug_extract(const double *__restrict__ Aug, long n, long np, long ldx, TX *__restrict__ X)
 {
   __shared__ double tile[32][33];
   const long rb = blockIdx.x, cb = blockIdx.y;
   if (cb > rb) return;
   const double *Ab = Aug + (size_t)blockIdx.z * (size_t)(2 * np * np);
-  TX *XL = X + (size_t)blockIdx.z * 2 * (size_t)(n * n), *XU = XL + (size_t)(n * n);
+  TX *XL = X + (size_t)blockIdx.z * 2 * (size_t)(ldx * n), *XU = XL + (size_t)(ldx * n);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
   for (int k = ty; k < 32; k += 8) {
     const long r = rb * 32 + k, c = cb * 32 + tx;
     const double v = (r < n && c < n) ? Ab[(size_t)r * (size_t)(2 * np) + np + c] : 0.0;
     tile[k][tx] = v;
-    if (r < n && c < n && c <= r) XU[(size_t)r * (size_t)n + c] = (TX)v;
+    if (r < n && c < n && c <= r) XU[(size_t)r * (size_t)ldx + c] = (TX)v;
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const long c = cb * 32 + k, r = rb * 32 + tx;
-    if (r < n && c < n && c <= r) XL[(size_t)c * (size_t)n + r] = (TX)tile[tx][k];
+    if (r < n && c < n && c <= r) XL[(size_t)c * (size_t)ldx + r] = (TX)tile[tx][k];
   }
 }
 
@@ -1470,10 +1477,11 @@ int rbl_launch_block_inverse_large(hipStream_t st, const double *d_L, int64_t n,
       }
     }
     const dim3 eg((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), nb);
-    if (d_X) hipLaunchKernelGGL(k_aug_extract<double>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np,
-                                d_X + (size_t)b0 * 2 * (size_t)(n * n));
-    if (d_Xf) hipLaunchKernelGGL(k_aug_extract<float>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np,
-                                 d_Xf + (size_t)b0 * 2 * (size_t)(n * n));
+    const int64_t ldx = rbl_block_inverse_ld(n);
+    if (d_X) hipLaunchKernelGGL(k_aug_extract<double>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np, (long)ldx,
+                                d_X + (size_t)b0 * 2 * (size_t)(ldx * n));
+    if (d_Xf) hipLaunchKernelGGL(k_aug_extract<float>, eg, dim3(256), 0, st, (const double *)d_aug, (long)n, (long)np, (long)ldx,
+                                 d_Xf + (size_t)b0 * 2 * (size_t)(ldx * n));
   }
   return RBL_OK;
 }
@@ -1487,19 +1495,22 @@ template <typename TM>
 static int block_inv_apply_t(hipStream_t st, const TM *d_X, int64_t n, int batch, const double *d_in, double *d_out,
                              int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q)
 {
+  const int64_t ldx = rbl_block_inverse_ld(n);
   if (batch > 65535) {                               // bodies ride in gridDim.y: more than that go in several rounds
     for (int b0 = 0; b0 < batch; b0 += 65535) {
       const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
       const size_t vo = (size_t)b0 * (size_t)vec_stride;
-      const int rc = block_inv_apply_t<TM>(st, d_Q ? d_X : d_X + (size_t)b0 * 2 * (size_t)(n * n), n, nb, d_in + vo, d_out + vo,
+      const int rc = block_inv_apply_t<TM>(st, d_Q ? d_X : d_X + (size_t)b0 * 2 * (size_t)(ldx * n), n, nb, d_in + vo, d_out + vo,
                                            vec_stride, nv, rhs_pitch, mode, d_tmp ? d_tmp + vo : nullptr,
                                            d_Q ? d_Q + 4 * (size_t)b0 : nullptr);
       if (rc) return rc;
     }
     return RBL_OK;
   }
-  const dim3 grid((unsigned)((n + BIA_R - 1) / BIA_R), batch);
-  const long mstride = d_Q ? 0 : 2 * (long)(n * n);
+  const bool r64 = !d_Q && ldx % 16 == 0 && n > BSS_T;          // aligned 64-row segments (large per-configuration inverses)
+  const int R = r64 ? 64 : BIA_RQ;
+  const dim3 grid((unsigned)((n + R - 1) / R), batch);
+  const long mstride = d_Q ? 0 : 2 * (long)(ldx * n);
   int gmax = 3;                                      // vectors sharing one pass over X: what 64 KB of LDS hold
   while (gmax > 1 && sizeof(double) * ((size_t)gmax * (size_t)n + 64 * BIA_W * (size_t)gmax) > 65536) --gmax;
   auto pass = [&](const double *in, double *out, int upper) {
@@ -1509,9 +1520,11 @@ static int block_inv_apply_t(hipStream_t st, const TM *d_X, int64_t n, int batch
       const size_t lds = sizeof(double) * ((size_t)g * (size_t)n + 64 * BIA_W * (size_t)g);
       const double *pi = in + (size_t)v0 * (size_t)rhs_pitch;
       double *po = out + (size_t)v0 * (size_t)rhs_pitch;
-      if (g == 3) hipLaunchKernelGGL((k_block_inv_apply<3, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
-      else if (g == 2) hipLaunchKernelGGL((k_block_inv_apply<2, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
-      else hipLaunchKernelGGL((k_block_inv_apply<1, TM>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot);
+#define RBL_BIA_LAUNCH(NVV, RR) hipLaunchKernelGGL((k_block_inv_apply<NVV, TM, RR>), grid, dim3(64 * BIA_W), lds, st, d_X, (long)n, (long)ldx, \
+                                                   mstride, pi, po, (long)vec_stride, (long)rhs_pitch, upper, d_Q, rot)
+      if (r64) { if (g == 3) RBL_BIA_LAUNCH(3, 64); else if (g == 2) RBL_BIA_LAUNCH(2, 64); else RBL_BIA_LAUNCH(1, 64); }
+      else { if (g == 3) RBL_BIA_LAUNCH(3, BIA_RQ); else if (g == 2) RBL_BIA_LAUNCH(2, BIA_RQ); else RBL_BIA_LAUNCH(1, BIA_RQ); }
+#undef RBL_BIA_LAUNCH
       v0 += g;
     }
   };
@@ -1540,8 +1553,8 @@ int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, in
   for (int b0 = 0; b0 < batch; b0 += 65535) {
     const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
     const size_t vo = (size_t)b0 * (size_t)vec_stride;
-    hipLaunchKernelGGL((k_block_inv_apply<1, double>), dim3((unsigned)((n + BIA_R - 1) / BIA_R), nb), dim3(64 * BIA_W),
-                       sizeof(double) * ((size_t)n + 64 * BIA_W), st, d_L + (size_t)b0 * (size_t)strideA, (long)n, (long)strideA,
+    hipLaunchKernelGGL((k_block_inv_apply<1, double, BIA_RQ>), dim3((unsigned)((n + BIA_RQ - 1) / BIA_RQ), nb), dim3(64 * BIA_W),
+                       sizeof(double) * ((size_t)n + 64 * BIA_W), st, d_L + (size_t)b0 * (size_t)strideA, (long)n, (long)n, (long)strideA,
                        d_in + vo, d_out + vo, (long)vec_stride, 0L, 0, d_Q ? d_Q + 4 * (size_t)b0 : nullptr, d_Q ? 2 : 0);
   }
   return RBL_OK;

@@ -140,6 +140,7 @@ struct rbl_ctx {
   int64_t t_calls[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
   // lanczos
   int lanczos_max_iter = 100;
+  bool lanczos_out_norm = true;  // preconditioned root: final stopping test in the Euclidean norm of the increment (rbl_set_tuning 85 / 86)
   bool lanczos_reorth = true;   // full re-orthogonalisation of the Lanczos basis (rbl_set_tuning 81 / 82: off / on)
   double lanczos_tol = 1e-10;
   int lanczos_iters = 0;
@@ -213,6 +214,7 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
 // explicit per-body inverses for small bodies (3 N_blb <= 512): substitution sweeps become triangular matrix-vector products
 bool rbl_block_inverse_fits(int64_t n);
 size_t rbl_block_inverse_bytes(int64_t n, int batch);
+int64_t rbl_block_inverse_ld(int64_t n);
 int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
                              double *d_X);
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,

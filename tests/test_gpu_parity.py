@@ -1804,3 +1804,50 @@ def test_contexts_release_their_device_memory():
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 * 2**20, "device memory leaked: %.1f MiB over 30 contexts" % ((free0 - free1) / 2**20)
 
+
+
+def test_phase_timings_through_the_c_abi(shell12):
+    """rbl_set_timing / rbl_get_timings (per-phase timings from the C ABI): hipEvent brackets around the
+    phases of the library's own solvers.  One converged Brownian step at 20 x shell_N_162 with the block preconditioner:
+    the bracket counts are the algorithm's (GMRES iterations + 2 RFD products + Lanczos iterations), the phases are
+    disjoint parts of the solver calls' total, nothing is recorded while the switch is off, and a reset clears the sums."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    from rigid_body_light_amd.krylov import BrownianStepper
+    nb, nblb, wall = 20, 162, True
+    c = make_config(nb, nblb, wall)
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    lib().rbl_set_blk_pc(ctx.h, 1)
+    ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(100, 1e-3)
+    Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
+    st = BrownianStepper(ctx, nb, nblb, dev)
+    st.step(Fb, seed=0, method=2, iters=100, rtol=1e-8)            # timing off: nothing recorded
+    assert all(v == (0.0, 0) for v in ctx.timings().values())
+    ctx.set_timing(True)
+    m, res = st.step(Fb, seed=1, method=2, iters=100, rtol=1e-8)
+    lz = ctx.lanczos_report()[0]
+    t = ctx.timings()
+    assert set(t) == set(ctx.TIMING_PHASES)
+    # GMRES iterations + M_RFD's two + one two-vector product per Lanczos iteration (a system this small tests convergence
+    # every 4th iteration: up to 3 products beyond the iteration that is reported as the first to pass)
+    assert m + 2 + lz <= t["product"][1] <= m + 2 + lz + 3
+    assert t["per_body"][1] >= m + 1 + 2 * lz and t["factor"][1] >= 1
+    assert t["collective"] == (0.0, 0) and t["dense"] == (0.0, 0)  # single GPU, no dense square root
+    assert t["total"][1] == 3                                       # the square roots, M_RFD, the saddle solve
+    parts = t["product"][0] + t["per_body"][0] + t["factor"][0]
+    assert 0.0 < t["product"][0] < parts <= t["total"][0] * 1.001
+    ctx.reset_timings()
+    assert all(v == (0.0, 0) for v in ctx.timings().values())
+    ctx.set_timing(False)
+    st.step(Fb, seed=2, method=2, iters=100, rtol=1e-8)
+    assert all(v == (0.0, 0) for v in ctx.timings().values())
+    # dense square root: its own phase
+    ctx.set_timing(True)
+    r = torch.empty(3 * nb * nblb, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
+    W = torch.randn(3 * nb * nblb, dtype=torch.float64, device=dev); o = torch.empty_like(W)
+    ctx.M_half_W(r.data_ptr(), nb * nblb, W.data_ptr(), "cholesky", o.data_ptr()); ctx.sync_check()
+    t = ctx.timings()
+    assert t["dense"][1] == 1 and t["dense"][0] > 0.0 and t["product"][1] == 0
+    ctx.close()

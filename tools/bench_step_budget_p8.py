@@ -75,8 +75,8 @@ base, rem = divmod(nb, P)
 rows = []
 for rk in range(P):
     b0 = rk * base + min(rk, rem); b1 = b0 + base + (1 if rk < rem else 0)
-    p1 = ev_ms(lambda: ctx.apply_M_sym(x2.data_ptr(), r.data_ptr(), N, rk, P, o2.data_ptr()), 3)
-    p2 = ev_ms(lambda: ctx.apply_M_sym_multi(x2.data_ptr(), r.data_ptr(), N, 2, rk, P, o2.data_ptr()), 3)
+    p1 = ev_ms(lambda: ctx.apply_M_sym(x2.data_ptr(), r.data_ptr(), N, rk, P, o2.data_ptr()), 10)
+    p2 = ev_ms(lambda: ctx.apply_M_sym_multi(x2.data_ptr(), r.data_ptr(), N, 2, rk, P, o2.data_ptr()), 10)
     ctx.set_tuning(0, 64)                                        # invalidates the factors: the next call builds this rank's only
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
