@@ -207,9 +207,9 @@ int rbl_apply_M_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, in
                           int nrhs, double *d_out);
 
 /* Symmetric-kernel shard of apply_M for multi-GPU strong scaling: this call evaluates the
- * unordered blob-tile pairs {I,J}, J >= I, of share i_first out of i_step: one row (super-)tile I out of every
- * i_step consecutive ones, at offset i_first in even groups and i_step - 1 - i_first in odd groups, so that the
- * triangular work is the same for every share (tiles of 64 blobs); it writes the PARTIAL sum of U = [B] M [B] F over all 3*n_blobs entries
+ * unordered blob-tile pairs {I,J}, J >= I, of share i_first out of i_step: one row UNIT out of every i_step consecutive
+ * ones (a unit = the rows one workgroup sweeps: 64 blobs, or 512 for large systems), at offset i_first in even blocks of
+ * units and i_step - 1 - i_first in odd ones, so that the triangular work is the same for every share; it writes the PARTIAL sum of U = [B] M [B] F over all 3*n_blobs entries
  * to d_out; the sum of the i_step partial vectors (an all-reduce) is the full product.
  * i_first = 0, i_step = 1 is the whole product. */
 int rbl_apply_M_sym_dev(rbl_ctx *ctx, const double *d_F, const double *d_r, int64_t n_blobs,

@@ -170,18 +170,31 @@ constexpr int TS = 64;
 
 // Row super-tiles of launch (i_first, i_step) -- rank, world size with several GPUs.  Row I carries T - I tile pairs, so
 // plain striding (I = i_first + e i_step) leaves rank 0 with (i_step - 1) / i_step of a row more than the last rank in
-// EVERY block of i_step rows (8.8 % at 8 ranks, cfg 3).  The e-th owned row is taken from the e-th block of i_step
-// consecutive rows, offset i_first in even blocks and i_step - 1 - i_first in odd ones: two consecutive blocks give
-// every rank the same 2 (T - e i_step) - (i_step - 1) pairs.  Still increasing in e (the column-sum slabs rely on it).
-__device__ __forceinline__ int sym_row_of(int e, int i_first, int i_step)
+// EVERY block of i_step rows (8.8 % at 8 ranks, cfg 3).  Rows are dealt in UNITS of sw consecutive super-tiles (sw = the
+// waves of a workgroup: the rows one workgroup sweeps in lock step; round 3 -- with single super-tiles as units the four
+// waves of a shard's workgroup sat up to 8 i_step tiles apart and idled through each other's regions, so shards ran one
+// wave per workgroup, each staging its own column tiles: 2.9 ms per rank at 8 ranks against 20.5 / 8 = 2.56).  The ge-th
+// owned unit is taken from the ge-th block of i_step consecutive units, offset i_first in even blocks and
+// i_step - 1 - i_first in odd ones: two consecutive blocks give every rank the same work.  Increasing in e (the
+// column-sum slabs rely on it).  sw = 1 or i_step = 1: the plain maps.
+__device__ __forceinline__ int sym_unit_of(int ge, int i_first, int i_step)
 {
-  return e * i_step + ((e & 1) ? i_step - 1 - i_first : i_first);
+  return ge * i_step + ((ge & 1) ? i_step - 1 - i_first : i_first);
 }
-__device__ __forceinline__ bool sym_row_owned(int I, int i_first, int i_step) { return sym_row_of(I / i_step, i_first, i_step) == I; }
-__device__ __forceinline__ int sym_rows_below(int Ilim, int i_first, int i_step)   // owned rows I < Ilim
+__device__ __forceinline__ int sym_row_of(int e, int i_first, int i_step, int sw)
 {
-  const int e = Ilim / i_step;                                        // blocks 0 .. e-1 lie wholly below Ilim
-  return e + (sym_row_of(e, i_first, i_step) < Ilim ? 1 : 0);
+  const int ge = e / sw;
+  return sym_unit_of(ge, i_first, i_step) * sw + (e - ge * sw);
+}
+__device__ __forceinline__ bool sym_unit_owned(int G, int i_first, int i_step) { return sym_unit_of(G / i_step, i_first, i_step) == G; }
+__device__ __forceinline__ bool sym_row_owned(int I, int i_first, int i_step, int sw) { return sym_unit_owned(I / sw, i_first, i_step); }
+__device__ __forceinline__ int sym_rows_below(int Ilim, int i_first, int i_step, int sw)   // owned rows I < Ilim
+{
+  const int Gl = Ilim / sw, rem = Ilim - Gl * sw;                     // units 0 .. Gl-1 lie wholly below Ilim
+  const int eb = Gl / i_step;                                         // blocks 0 .. eb-1 lie wholly below unit Gl
+  int n = (eb + (sym_unit_of(eb, i_first, i_step) < Gl ? 1 : 0)) * sw;
+  if (rem > 0 && sym_unit_owned(Gl, i_first, i_step)) n += rem;
+  return n;
 }
 
 // Bounding box of every 64-blob tile in radius-scaled coordinates: bbox[tile] = {min x,y,z, max x,y,z}.
@@ -265,11 +278,11 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 //   offI(c) = 64 [C c (c+1) / 2 + (NI-1) c],      offJ(g) = g Npad - RJ1 g (g-1) / 2,   RJ(g) = RJ1 g,   RJ1 = 64 NI SW;
 // row shards of a multi-GPU launch own every i_step-th super-tile, their slabs stay rectangular (and are 1/i_step of
 // the single-rank size anyway).  nrhs vectors lie back to back inside a slab.  All in units of blobs (x 3 doubles).
-// SW = 4 for large single-rank systems (two rows per lane), 1 otherwise: with few tiles the lock-step of a multi-wave
-// workgroup and its coarser work units cost more than the slabs save (8 100 blobs: 0.080 ms with SW = 1, 0.108 ms with
-// SW = 4), and the strided rows of a multi-GPU shard (every i_step-th super-tile) put the four waves of a group up to
-// 8 i_step tiles apart (cfg 3 at 8 ranks: 2.7 ms per rank with SW = 1, 4.8 ms with SW = 4; the shards' slabs are
-// 1/i_step of the single-rank ones anyway).
+// SW = 4 for large systems (two rows per lane), 1 otherwise: with few tiles the lock-step of a multi-wave workgroup and
+// its coarser work units cost more than the slabs save (8 100 blobs: 0.080 ms with SW = 1, 0.108 ms with SW = 4).  The
+// rows of a multi-GPU shard are dealt in units of SW consecutive super-tiles (sym_row_of), so a shard's workgroup sweeps
+// four NEIGHBOURING super-tiles exactly like a single-rank one (round 2 dealt single super-tiles: waves up to 8 i_step
+// tiles apart, 4.8 ms per rank at 8 ranks with SW = 4, which is why shards ran SW = 1 at 2.7-2.9 ms then).
 #ifndef RBL_SYM_WAVES
 #define RBL_SYM_WAVES 4
 #endif
@@ -337,14 +350,14 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict
   // workgroups go to the 8 XCDs round-robin in launch order: rotate the row group with the chunk, or a group count that
   // is a multiple of 8 pins every group (and its triangular share of the work) to one XCD for the whole launch
   const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
-  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);   // first tile of the group (wave 0's)
+  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step, SW);   // first tile of the group (wave 0's)
   if (It00 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
   if (J0 < It00) J0 = It00;
   if (J0 >= J1) return;                                            // workgroup-uniform
   const int e = SW * g + wave;
-  const int I = sym_row_of(e, L.i_first, L.i_step);                // this wave's super-tile
+  const int I = sym_row_of(e, L.i_first, L.i_step, SW);                // this wave's super-tile
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);                      // a wave without rows never sweeps, only keeps step
   unsigned flags = 0;
@@ -516,14 +529,14 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
   const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // see k_apply_M_sym
-  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step);
+  const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step, SW);
   if (It00 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
   if (J0 < It00) J0 = It00;
   if (J0 >= J1) return;
   const int e = SW * g + wave;
-  const int I = sym_row_of(e, L.i_first, L.i_step);
+  const int I = sym_row_of(e, L.i_first, L.i_step, SW);
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);
   const long n3 = 3 * N;
@@ -711,11 +724,11 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
   const int J = (int)(j / TS);
   const int NI = L.NI, C = L.C;
   const int Is = J / NI;                                 // super-tile owning row tile J
-  const bool owned = sym_row_owned(Is, L.i_first, L.i_step);   // this launch owned the rows of tile J
+  const bool owned = sym_row_owned(Is, L.i_first, L.i_step, L.SW);   // this launch owned the rows of tile J
   const int c0 = (NI * Is) / C;
   const int nI = owned ? L.nch - c0 : 0;
   const int Ilim = (J + NI - 1) / NI;                    // super-tiles I with NI*I < J
-  const int nE = sym_rows_below(Ilim, L.i_first, L.i_step);   // owned ones among them
+  const int nE = sym_rows_below(Ilim, L.i_first, L.i_step, L.SW);   // owned ones among them
   const int nJ = (nE + L.SW - 1) / L.SW;                 // row groups whose first super-tile precedes J
   double s = 0.0;
   int e = q;
@@ -1405,7 +1418,11 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   int ni = (t >= 128 * i_step) ? 2 : 1;
   if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
-  const int rowsI = (tsup + i_step - 1) / i_step;
+  // workgroups of SW_LARGE waves (= units of SW_LARGE consecutive super-tiles, see sym_row_of) for large systems; a shard
+  // keeps them as long as every rank still gets >= 8 units
+  const int sw = (ni == 2 && tsup >= SW_LARGE * i_step * 8) ? SW_LARGE : 1;
+  const int tunits = (tsup + sw - 1) / sw;
+  const int rowsI = ((tunits + i_step - 1) / i_step) * sw;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
   // wave-units balance the triangular work and hide tile-boundary latency; C = 4..16 is flat at
   // 128 400 blobs (29.8-29.9 ms vs 30.8 at C = 64), C = 2 best at 8 100.  Aim for ~8 rounds of
@@ -1417,7 +1434,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   if (c > 16) c = 16;
   if (tune.chunk > 0) c = tune.chunk;
   L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
-  L.SW = (ni == 2 && i_step == 1) ? SW_LARGE : 1;
+  L.SW = sw;
   L.rowsG = (rowsI + L.SW - 1) / L.SW; L.tri = (i_step == 1) ? 1 : 0; L.nrhs = nrhs; L.i_first = i_first; L.i_step = i_step;
   return L;
 }

@@ -25,7 +25,10 @@ if os.environ.get("CHUNK"):                      # force the chunk length C of t
     ctx.set_tuning(int(os.environ["CHUNK"]), 2)
 for world in WORLDS:
     ts = []; acc = torch.zeros_like(F)
-    for rank in range(world):
+    order = list(range(world))
+    if os.environ.get("REVERSE"):                # rank order of the measurement (is the first one slow because it is first?)
+        order.reverse()
+    for rank in order:
         ctx.apply_M_sym(F.data_ptr(), r.data_ptr(), N, rank, world, U.data_ptr()); ctx.sync_check()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
@@ -36,5 +39,5 @@ for world in WORLDS:
     if world == 1:
         full = acc.clone(); t1 = ts[0]
     err = float((acc - full).norm() / full.norm())
-    print("world %d: per-rank ms min %.3f max %.3f ; t1/(world*max) = %.3f ; sum of shards vs world 1: %.1e"
-          % (world, min(ts), max(ts), t1 / (world * max(ts)), err))
+    print("world %d: per-rank ms min %.3f max %.3f ; t1/(world*max) = %.3f ; sum of shards vs world 1: %.1e ; in rank order %s: %s"
+          % (world, min(ts), max(ts), t1 / (world * max(ts)), err, order, " ".join("%.3f" % t for t in ts)))

@@ -32,7 +32,9 @@ def new_ctx(extra=()):
 
 def ev_ms(fn, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn(); torch.cuda.synchronize()
+    for _ in range(3):                      # (the first launches after a pause run ~10 % slow: clocks)
+        fn()
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
         fn()
