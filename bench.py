@@ -234,9 +234,9 @@ def phase_block(ctx, steps, dev, world):
 
 
 def root_identity_error(ctx, nb, nblb, a, dev):
-    """MEASURED accuracy of the preconditioned Lanczos root G = B L Sp^{1/2} (Sp = L^-1 M L^-T) at the context's current
-    tolerance, outside any timed region: with s = Sp^{1/2} W = L^-1 B^-1 (G W) and v = L^-T W an exact root satisfies
-    G s = B M v (one extra mobility product); returns |G s - B M v| / |B M v|.  The reference's factor is exact
+    """MEASURED accuracy of the preconditioned Lanczos root x = B G Sp^{1/2} W (Sp = G^-1 M G^-T, G the library's factor of
+    this configuration) at the context's current tolerance, outside any timed region: with s = Sp^{1/2} W = G^-1 B^-1 x and
+    v = G^-T W an exact root satisfies root(s) = B M v (one extra mobility product); returns |root(s) - B M v| / |B M v|.  The reference's factor is exact
     (c_rigid_obj.cpp:670-672); an iterative replacement must state its error."""
     N = nb * nblb
     n = 3 * N
@@ -257,8 +257,8 @@ def root_identity_error(ctx, nb, nblb, a, dev):
         return out
 
     x = root(W)
-    s_ = bsolve(x / B, 1)
-    v = bsolve(W, 2)
+    s_ = bsolve(x / B, 5)               # modes 5 / 6: the root's whole factor G (two-level by default), G^-1 and G^-T
+    v = bsolve(W, 6)
     Mv = torch.empty_like(v)
     ctx.set_no_damp(True)
     try:
@@ -487,7 +487,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
     # stochastic midpoint step, converged: BASELINE configs[3] (on N GPUs: `--mode timestep --kBT 1 --gpus N`)
     bro = {}
-    for ltol, relaxed in ((1e-3, False), (1e-6, False), (1e-3, True)):
+    for ltol, relaxed, energy in ((1e-3, False, False), (1e-6, False, False), (1e-3, True, False), (1e-3, False, True)):
         bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
         lib().rbl_set_blk_pc(bctx.h, 1)
         bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(200, ltol)
@@ -496,6 +496,8 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             bctx.set_tuning(0, v)
         if relaxed:                    # inexact Krylov (rbl_set_tuning 52): see the `relaxation` note below
             bctx.set_tuning(0, 52)
+        if energy:                     # stop the root on its energy-norm estimate (rbl_set_tuning 85): see `lanczos_norm` below
+            bctx.set_tuning(0, 85)
         if world > 1:
             from rigid_body_light_amd.dist import ShardedMobility
             bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
@@ -512,11 +514,16 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
                   "relaxed_products": relaxed})
         if world == 1:                 # measured, outside the timed region: one more pair of roots + one product
             d["root_identity_error"] = root_identity_error(bctx, nb, nblb, c["a"], dev)
-        bro["lanczos_%g%s" % (ltol, "_relaxed" if relaxed else "")] = d
+        d["lanczos_stopping_norm"] = "energy" if energy else "euclidean"
+        bro["lanczos_%g%s%s" % (ltol, "_relaxed" if relaxed else "", "_energy_norm" if energy else "")] = d
         del bst, bctx
     bro.update({"kBT": 1.0, "rtol": 1e-8, "initial_guess": "zero (fresh noise every step)",
-                "root_identity_error": "|G s - B M v| / |B M v| with s = L^-1 B^-1 (G W), v = L^-T W for the root G = B L (L^-1 M L^-T)^{1/2} "
-                                       "the step uses, measured after the timed steps at the entry's Lanczos tolerance (zero for an exact root)",
+                "lanczos_norm": "the preconditioned root x = B L z stops on an error estimate of x in its Euclidean norm (default; what "
+                                "root_identity_error measures); the *_energy_norm entry stops on the estimate of z = (L^-1 M L^-T)^{1/2} W, "
+                                "i.e. of x in the energy norm x^T (B M B)^-1 x that bounds the relative error of the sampled covariance -- "
+                                "rounds 1-2 effectively used that one (fewer iterations, larger Euclidean error)",
+                "root_identity_error": "|root(s) - B M v| / |B M v| with s = G^-1 B^-1 root(W), v = G^-T W for the root x = B G (G^-1 M G^-T)^{1/2} W "
+                                       "the step uses (G: two-level factor), measured after the timed steps at the entry's Lanczos tolerance (zero for an exact root)",
                 "relaxation": "the *_relaxed entry is opt-in (rbl_set_tuning 52), everything else is fp64 throughout: an inexact Krylov "
                               "iteration tolerates a relative product error of (tolerance / current residual), so GMRES iterations whose "
                               "residual estimate is below 1e-3 and the Lanczos iterations (tolerance 1e-3) evaluate far tile pairs in packed "

@@ -263,7 +263,11 @@ int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /*
  * rbl_set_parameters, exact for every configuration, not triangular (mode 0 is the same operator either way;
  * rbl_set_tuning(ctx, 0, 71) restores per-configuration Cholesky factors).  rbl_set_no_damp(ctx, 1) makes the matvec entry points
  * apply the plain wall-corrected M (no damping B) until switched off again: together they let a caller compose
- * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product. */
+ * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product.
+ * Modes 5, 6, 7 (all bodies, not in place, single GPU) apply the WHOLE factor G the library's preconditioned Lanczos root
+ * uses on this configuration -- G^-1 x, G^-T x, G x with G = L (I + Q (L_E - I) Q^T), the two-level factor (rbl_set_tuning 88,
+ * default), or G = L: what a test needs to check the root identities  s = G^-1 B^-1 x,  v = G^-T W,  |s|^2 = v^T M v,
+ * root(s) = B M v  whatever the factor. */
 int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode);
 /* the same for the bodies [body_begin, body_end) only (body_end < 0: to the last body): d_in / d_out are still
  * full-length blob vectors, only the entries of those bodies are read and written, and only those bodies are
@@ -368,6 +372,10 @@ int rbl_sync_check(rbl_ctx *ctx);
  * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an
  * approximate block factor (no factorisation, 29.7 MB instead of 5.9 GB at cfg 3; one or two more GMRES iterations --
  * measured level in time at cfg 3, so not the default);
+ * 87 / 88: preconditioned Lanczos root with the block-Jacobi factor L alone / with the two-level factor L (I + Q (L_E - I) Q^T)
+ * (default): a low-rank correction carrying the monopole far field between the bodies (spheres of the bodies' outer radius at
+ * their centres), so that the collective translations converge in the factor instead of the iteration -- about half the
+ * Lanczos iterations; any invertible factor keeps the root exact;
  * 85 / 86: preconditioned Lanczos root x = B L z, z = (L^-1 M L^-T)^{1/2} W: stop on the error estimate of z -- the error
  * of x in the ENERGY norm x^T (B M B)^-1 x, the one that bounds the relative error of the sampled covariance -- / of x itself
  * in the Euclidean norm (default; L weighs the slowly converging collective modes more: a few more iterations);

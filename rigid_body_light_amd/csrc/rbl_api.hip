@@ -375,7 +375,7 @@ void rbl_destroy(rbl_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_blkXf, &c->d_blkAug, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_blkXf, &c->d_blkAug, &c->d_tlQ, &c->d_tlCb, &c->d_tlCs, &c->d_tlA, &c->d_tlLinv, &c->d_tlX, &c->d_tlT, &c->d_tlZ, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -387,6 +387,7 @@ void rbl_destroy(rbl_ctx *c)
     for (const rbl_ctx::TimedSpan &sp : c->ev_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_err2) (void)hipFree(c->d_err2);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_coef) (void)hipHostFree(c->h_coef);
@@ -411,6 +412,13 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
   for (int d = 0; d < 3; ++d) mean[d] /= (double)N_blb;
   for (int k = 0; k < N_blb; ++k)
     for (int d = 0; d < 3; ++d) S.ref_cfg[3 * k + d] -= mean[d];
+  double rmax2 = 0.0;
+  for (int k = 0; k < N_blb; ++k) {
+    const double *p_ = &S.ref_cfg[3 * (size_t)k];
+    rmax2 = std::max(rmax2, p_[0] * p_[0] + p_[1] * p_[1] + p_[2] * p_[2]);
+  }
+  c->body_radius = std::sqrt(rmax2) + a;               // the sphere the two-level factor's far-field model gives a body
+  c->tl_valid = false;
   S.N_blb = N_blb;
   S.params_set = true;
   S.M_scale = 1.0;
@@ -875,6 +883,7 @@ static int bf_build(rbl_ctx *c)
     c->bf_tables = true;
   }
   c->bf_valid = true;
+  c->tl_valid = false;
   return RBL_OK;
 }
 
@@ -984,6 +993,99 @@ static int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
                                out + off, m);
 }
 
+// ---- two-level factor of the preconditioned Lanczos root (round 3) --------------------------------------------------
+// G = B L H with H = I + Q (L_E - I) Q^T: the block-Jacobi factor L times a low-rank correction that carries the monopole
+// far field between the bodies (rbl_body_dev.hip: k_tl_orth for the algebra).  Any invertible G keeps
+// x = G (G^-1 M G^-T)^{1/2} W an exact root; this one moves the collective translations of the bodies -- the modes whose
+// Euclidean-norm error converges last under block-Jacobi -- into the factor: 27 bodies of shell_N_162 above a wall need
+// 3-4 Lanczos iterations to 1e-3 instead of 6-7, 8-10 instead of 14-17 to 1e-6 (tests/experiments/two_level_root.py).
+// Built once per configuration: Z = L^-1 K_t (three vectors through the per-body factors), a 3 N_bod-square sphere tensor,
+// its Cholesky factor and explicit inverse -- all replicated on every rank of a multi-GPU context (Z by own bodies + sum).
+// Not usable (tl_ok = false: plain block-Jacobi) when I + E is not positive definite or the small system does not fit.
+static int tl_build(rbl_ctx *c)
+{
+  if (c->tl_valid) return RBL_OK;
+  c->tl_valid = true; c->tl_ok = false;
+  const RblBodyState &S = c->S;
+  const int Nb = S.N_bod;
+  const int64_t nt = 3 * (int64_t)Nb, n3 = 3 * (int64_t)Nb * S.N_blb;
+  if (!c->tl_on || Nb < 2 || sizeof(double) * ((size_t)nt + 256) > 65536) return RBL_OK;
+  RblPhase ph(c, RBL_T_FACTOR);
+  int rc;
+  if (!c->d_err2) {
+    RBL_HIP(c, hipMalloc((void **)&c->d_err2, sizeof(unsigned)));
+    RBL_HIP(c, hipMemsetAsync(c->d_err2, 0, sizeof(unsigned), c->stream));
+  }
+  if ((rc = rbl_dev_reserve(c, c->d_tlQ, sizeof(double) * 3 * (size_t)n3))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlCb, sizeof(double) * 9 * (size_t)Nb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlCs, sizeof(double) * (size_t)(nt * nt)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlA, sizeof(double) * (size_t)(nt * nt)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlLinv, rbl_cholesky_batched_work_bytes(nt, 1)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlX, rbl_block_inverse_bytes(nt, 1)))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_tlT, sizeof(double) * 2 * 3 * (size_t)nt))) return rc;
+  double *Q = (double *)c->d_tlQ.p;
+  rbl_launch_tl_unit(c->stream, n3, Q);                                  // K_t: one vector per direction holds that column of every body
+  if (comm_on(c)) {
+    int b0, b1; comm_body_range(c, &b0, &b1);
+    if ((rc = rbl_dev_reserve(c, c->d_tlZ, sizeof(double) * 3 * (size_t)n3))) return rc;
+    double *t = (double *)c->d_tlZ.p;
+    RBL_HIP(c, hipMemsetAsync(t, 0, sizeof(double) * 3 * (size_t)n3, c->stream));
+    if ((rc = blk_solve(c, b0, b1 - b0, Q, t, 3, n3, 1, false))) return rc;
+    if ((rc = comm_allreduce(c, t, 3 * n3))) return rc;
+    RBL_HIP(c, hipMemcpyAsync(Q, t, sizeof(double) * 3 * (size_t)n3, hipMemcpyDeviceToDevice, c->stream));
+  } else if ((rc = blk_solve(c, 0, Nb, Q, Q, 3, n3, 1, false))) return rc;   // Z = L^-1 K_t (G^-1 K_t with body-frame factors)
+  rbl_launch_tl_orth(c->stream, Q, n3, S.N_blb, Nb, (double *)c->d_tlCb.p, c->d_err2);
+  // far-field model: the pair tensor of spheres of the bodies' outer radius at the body centres; the wall term only when no
+  // sphere reaches the wall (any SPD model keeps the root exact -- it only has to resemble the true coupling)
+  double zmin = 1.0e300;
+  for (int b = 0; b < Nb; ++b) zmin = std::min(zmin, S.X[3 * (size_t)b + 2]);
+  const bool wall_s = S.wall && zmin > 1.1 * c->body_radius;
+  if ((rc = ensure_xq_dev(c))) return rc;
+  rbl_launch_build_M(c->stream, rbl_make_params(c->body_radius, S.eta), wall_s, false, (const double *)c->d_XQ.p, Nb, (double *)c->d_tlCs.p,
+                     c->d_err2);
+  rbl_launch_tl_E(c->stream, (const double *)c->d_tlCs.p, (const double *)c->d_tlCb.p, Nb, (double *)c->d_tlA.p);
+  if ((rc = rbl_launch_cholesky_batched(c->stream, (double *)c->d_tlA.p, nt, 1, nt * nt, c->d_err2, (double *)c->d_tlLinv.p)))
+    return rbl_fail(c, rc, "two-level factor: cholesky launch failed");
+  if (nt <= 512) rc = rbl_launch_block_inverse(c->stream, (const double *)c->d_tlA.p, nt, 1, nt * nt, (const double *)c->d_tlLinv.p, (double *)c->d_tlX.p);
+  else {
+    int chunk = 1;
+    if ((rc = rbl_dev_reserve(c, c->d_blkAug, rbl_block_inverse_large_aug_bytes(nt, 1, &chunk)))) return rc;
+    rc = rbl_launch_block_inverse_large(c->stream, (const double *)c->d_tlA.p, nt, 1, nt * nt, (const double *)c->d_tlLinv.p, (double *)c->d_tlX.p,
+                                        nullptr, (double *)c->d_blkAug.p);
+  }
+  if (rc) return rbl_fail(c, rc, "two-level factor: inverse launch failed");
+  RBL_HIP(c, hipMemcpyAsync(c->h_err, c->d_err2, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipMemsetAsync(c->d_err2, 0, sizeof(unsigned), c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  c->tl_ok = (*c->h_err == 0);                                           // (not SPD / sphere below the wall: block-Jacobi alone)
+  return RBL_OK;
+}
+
+// w_v <- Op w_v for nvec vectors `pitch` apart;  op 0: H = I + Q (L_E - I) Q^T,  1: H^-1,  2: H^-T
+static int tl_apply(rbl_ctx *c, double *w, int nvec, int64_t pitch, int op)
+{
+  const RblBodyState &S = c->S;
+  const int Nb = S.N_bod;
+  const int64_t nt = 3 * (int64_t)Nb, n3 = 3 * (int64_t)Nb * S.N_blb;
+  const double *Q = (const double *)c->d_tlQ.p;
+  double *t = (double *)c->d_tlT.p, *sv = t + 3 * nt;                     // (up to three vectors at a time)
+  for (int v0 = 0; v0 < nvec; v0 += 3) {
+    const int g = nvec - v0 >= 3 ? 3 : nvec - v0;
+    double *wv = w + (size_t)v0 * (size_t)pitch;
+    rbl_launch_tl_qt(c->stream, Q, n3, S.N_blb, Nb, wv, pitch, g, t, nt);
+    int rc = RBL_OK;
+    for (int v = 0; v < g && !rc; ++v) {
+      const double *tv = t + (size_t)v * nt;
+      double *sp = sv + (size_t)v * nt;
+      if (op == 0) rc = rbl_launch_block_trmv_small(c->stream, (const double *)c->d_tlA.p, nt, 1, 0, tv, sp, 0, nullptr);
+      else rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_tlX.p, nt, 1, tv, sp, nt, 1, nt, op, nullptr);
+    }
+    if (rc) return rbl_fail(c, rc, "two-level factor: application failed");
+    rbl_launch_tl_addq(c->stream, Q, n3, S.N_blb, sv, t, nt, wv, pitch, g);
+  }
+  return RBL_OK;
+}
+
 // y_v = (B M B) x_v for nvec (1 or 2) vectors stored back to back; two vectors share the pair coefficients
 // precond: y_v = L^-1 M L^-T x_v with the per-body Cholesky factors L L^T = M_body (block Jacobi), M undamped
 static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_t nbl,
@@ -995,24 +1097,36 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     // B G (G^-1 M G^-T)^{1/2} W is an exact root for any invertible G applied CONSISTENTLY; the single-precision copy of L^-1
     // and the fp64 L of the final product agree to 6e-8 only, so it serves the loose tolerances (>= 1e-5) and no others
     const bool lz32 = c->lanczos_tol >= 1.0e-5;
+    const bool tl = c->tl_ok;                          // two-level factor: G^-1 = H^-1 L^-1, G^-T = L^-T H^-T
+    const size_t vbytes = sizeof(double) * (size_t)nvec * (size_t)n;
     if (comm_on(c)) {   // every rank substitutes through ITS bodies' factors only; sums complete the vectors
       int b0, b1; comm_body_range(c, &b0, &b1);
-      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
-      if ((rc = blk_solve(c, b0, b1 - b0, d_x, d_tmp, nvec, n, 2, lz32)))
+      const double *src = d_x;
+      if (tl) {                                        // (d_y is free until the product: H^-T x goes there)
+        RBL_HIP(c, hipMemcpyAsync(d_y, d_x, vbytes, hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = tl_apply(c, d_y, nvec, n, 2))) return rc;
+        src = d_y;
+      }
+      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, vbytes, c->stream));
+      if ((rc = blk_solve(c, b0, b1 - b0, src, d_tmp, nvec, n, 2, lz32)))
         return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       c->no_damp = true;
       rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
       c->no_damp = false;
       if (rc) return rc;
-      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, sizeof(double) * (size_t)nvec * (size_t)n, c->stream));
+      RBL_HIP(c, hipMemsetAsync(d_tmp, 0, vbytes, c->stream));
       if ((rc = blk_solve(c, b0, b1 - b0, d_y, d_tmp, nvec, n, 1, lz32))) return rc;
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
-      RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, sizeof(double) * (size_t)nvec * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-      return RBL_OK;
+      RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, vbytes, hipMemcpyDeviceToDevice, c->stream));
+      return tl ? tl_apply(c, d_y, nvec, n, 1) : RBL_OK;
     }
-    if ((rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2, lz32)))   // both vectors in one pass over L
-      return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+    if (tl) {
+      RBL_HIP(c, hipMemcpyAsync(d_tmp, d_x, vbytes, hipMemcpyDeviceToDevice, c->stream));
+      if ((rc = tl_apply(c, d_tmp, nvec, n, 2))) return rc;
+      rc = blk_solve(c, 0, c->S.N_bod, d_tmp, d_tmp, nvec, n, 2, lz32);
+    } else rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2, lz32);   // both vectors in one pass over L
+    if (rc) return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
     double *prod = d_y;                                // explicit inverses do not work in place: product into their scratch
     if (c->blk_inv_valid) {
       if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n))) return rc;
@@ -1022,7 +1136,8 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, prod);
     c->no_damp = false;
     if (rc) return rc;
-    return blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1, lz32);
+    if ((rc = blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1, lz32))) return rc;
+    return tl ? tl_apply(c, d_y, nvec, n, 1) : RBL_OK;
   }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
@@ -1193,6 +1308,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
         rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v) + m, m, zd, (int64_t)nvec * n);
         for (int w = 0; w < 2; ++w) {
           double *zin = w ? zd : zx, *o = w ? od : ox;
+          if (c->tl_ok && (rc = tl_apply(c, zin, 1, n, 0))) return rc;
           if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(o, 0, sizeof(double) * (size_t)n, c->stream));
           if ((rc = blk_trmv(c, b0, b1 - b0, zin, o))) return rc;
           if (comm_on(c) && (rc = comm_allreduce(c, o, n))) return rc;
@@ -1231,6 +1347,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     if (comm_on(c)) comm_body_range(c, &b0, &b1);
     for (int v = 0; v < nvec; ++v) {
       double *o = d_out + (size_t)v * n;
+      if (c->tl_ok && (rc = tl_apply(c, o, 1, n, 0))) return rc;       // x = B L (H y)
       if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)n, c->stream));
       if ((rc = blk_trmv(c, b0, b1 - b0, o, tmp))) return rc;
       if (comm_on(c) && (rc = comm_allreduce(c, tmp, n))) return rc;
@@ -1257,7 +1374,8 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
       int b0 = 0, b1 = -1;
       if (comm_on(c)) comm_body_range(c, &b0, &b1);
       if (b1 != b0 && (rc = blk_prepare(c, b0, b1))) return rc;
-    }
+      if ((rc = tl_build(c))) return rc;
+    } else c->tl_ok = false;
     int v = 0;   // pairs of vectors in lock step (shared pair coefficients), a single one alone
     for (; v + 2 <= nvec; v += 2)
       if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 2, pc))) return rc;
@@ -1388,10 +1506,31 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
 {
   if (!c) return RBL_ERR_ARG;
   int rc = sync_bodies(c); if (rc) return rc;
-  if (mode < 0 || mode > 3 || !d_in || !d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x");
+  if (mode < 0 || mode > 7 || mode == 4 || !d_in || !d_out)
+    return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 0 (L L^T)^-1, 1 L^-1, 2 L^-T, 3 L x; 5 G^-1, 6 G^-T, 7 G x (factor of the preconditioned root)");
   if (body_end < 0) body_end = c->S.N_bod;
   if ((rc = blk_prepare(c, body_begin, body_end))) return rc;
   const int nb = body_end - body_begin;
+  if (mode >= 5) {        // the whole factor of the preconditioned Lanczos root, G = L H (two-level) or L: all bodies, not in place
+    if (body_begin != 0 || body_end != c->S.N_bod || d_in == d_out)
+      return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: modes 5-7 take all bodies and do not work in place");
+    if (comm_on(c)) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: modes 5-7 are single-GPU test hooks");
+    if ((rc = tl_build(c))) return rc;
+    const int64_t n3 = (int64_t)3 * c->S.N_bod * c->S.N_blb;
+    if (mode == 5) {                                   // G^-1 = H^-1 L^-1
+      if ((rc = blk_solve(c, 0, nb, d_in, d_out, 1, 0, 1, false))) return rc;
+      return c->tl_ok ? tl_apply(c, d_out, 1, n3, 1) : RBL_OK;
+    }
+    if ((rc = rbl_dev_reserve(c, c->d_tlZ, sizeof(double) * 3 * (size_t)n3))) return rc;
+    double *t = (double *)c->d_tlZ.p;
+    RBL_HIP(c, hipMemcpyAsync(t, d_in, sizeof(double) * (size_t)n3, hipMemcpyDeviceToDevice, c->stream));
+    if (mode == 6) {                                   // G^-T = L^-T H^-T
+      if (c->tl_ok && (rc = tl_apply(c, t, 1, n3, 2))) return rc;
+      return blk_solve(c, 0, nb, t, d_out, 1, 0, 2, false);
+    }
+    if (c->tl_ok && (rc = tl_apply(c, t, 1, n3, 0))) return rc;       // G x = L (H x)
+    return blk_trmv(c, 0, nb, t, d_out);
+  }
   if (mode == 3 && d_in == d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 3 does not work in place");
   rc = mode == 3 ? blk_trmv(c, body_begin, nb, d_in, d_out) : blk_solve(c, body_begin, nb, d_in, d_out, 1, 0, mode);
   if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
@@ -1509,6 +1648,7 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
   if (variant >= 63 && variant <= 65) { c->blk_large = variant - 63; c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of large bodies never / always / when it pays
   if (variant == 83 || variant == 84) { c->blk_f32 = (variant == 84); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // single-precision copy of the large inverses off / on
+  if (variant == 87 || variant == 88) { c->tl_on = (variant == 88); c->tl_valid = false; return RBL_OK; }   // preconditioned root: block-Jacobi factor alone / two-level factor (default)
   if (variant == 85 || variant == 86) { c->lanczos_out_norm = (variant == 86); return RBL_OK; }       // preconditioned root: stop on the energy-norm / increment-norm (default) estimate
   if (variant == 81 || variant == 82) { c->lanczos_reorth = (variant == 82); return RBL_OK; }       // Lanczos: three-term recurrence only / full re-orthogonalisation (default)
   if (variant == 71 || variant == 72) { c->blk_bodyframe = (variant == 72); c->bf_valid = false; c->dev_pc_valid = false; c->dev_blk_valid = false; c->blk_inv_valid = false; return RBL_OK; }   // body-frame factors in free space off / on
@@ -1539,6 +1679,7 @@ static int sync_bodies(rbl_ctx *c)
                        (double *)c->d_pos.p);
   c->dev_bodies_valid = true;
   c->dev_pc_valid = false;
+  c->tl_valid = false;
   // the per-body Cholesky factors follow every configuration change unless the caller asked to keep them for a few
   // (rbl_set_block_refresh): as a preconditioner, or as the L of B L (L^-1 M L^-T)^{1/2} W, any nearby factor serves
   if (c->dev_blk_valid && ++c->blk_age >= c->blk_refresh) c->dev_blk_valid = false;   // blk_age: changes since the build
@@ -1620,6 +1761,7 @@ static int pc_block_factors(rbl_ctx *c, int b0, int b1)
     c->blk_inv_valid = true;
   }
   c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1; c->blk_age = 0;
+  c->tl_valid = false;
   return RBL_OK;
 }
 

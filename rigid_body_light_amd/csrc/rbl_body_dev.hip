@@ -554,6 +554,111 @@ __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__
   }
 }
 
+// ---- two-level factor of the preconditioned Lanczos root (round 3; rbl_api.hip: tl_build) ----------------------------
+// The block-Jacobi factor L leaves the body-body far field to the Krylov iteration; in the Euclidean norm of the increment
+// what converges last are the collective translations of the bodies.  Monopole model of the far field:
+//     M~ = D + K_t C K_t^T = L (I + Q E Q^T) L^T,    Z_b = L_b^-1 K_t,b  (3 columns per body),  R_b = Z_b^T Z_b = C_b C_b^T,
+//     Q_b = Z_b C_b^-T  (orthonormal),   E = blockdiag(C_b^T) C blockdiag(C_b),   C[b,b'] = pair tensor of spheres of the
+//     bodies' radius at the body centres (b != b').
+// k_tl_orth : per body, R_b, its 3 x 3 Cholesky factor C_b (kept) and Q_b = Z_b C_b^-T in place (Z: [3][n3], column d of
+//             every body in vector d -- the bodies do not couple, one vector holds one column of all of them)
+// k_tl_E    : A = I + E from the dense sphere tensor (3 N_bod square, column-major), diagonal blocks dropped
+// k_tl_qt   : t[3 b + c] = Q_c,b . w_b      (nvec vectors)
+// k_tl_addq : w_b += sum_c Q_c,b (s[3 b + c] - t[3 b + c])   -- (Op - I) t with s = Op t
+__global__ __launch_bounds__(BT) void k_tl_orth(double *__restrict__ Z, long n3, int N_blb, double *__restrict__ Cb, unsigned *err)
+{
+  __shared__ double s[6][BT];
+  __shared__ double Ci[9];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const long o = 3L * b * N_blb, m = 3L * N_blb;
+  double *z0 = Z + o, *z1 = Z + n3 + o, *z2 = Z + 2 * n3 + o;
+  double f[6] = {0, 0, 0, 0, 0, 0};   // R00 R10 R11 R20 R21 R22
+  for (long k = t; k < m; k += BT) {
+    const double a = z0[k], bb = z1[k], c = z2[k];
+    f[0] += a * a; f[1] += bb * a; f[2] += bb * bb; f[3] += c * a; f[4] += c * bb; f[5] += c * c;
+  }
+  block_reduce<6>(f, s, t);
+  if (t == 0) {
+    // lower Cholesky of R (row-major 3 x 3 in Cb) and the inverse of its transpose's action: Q = Z C^-T
+    const double c00 = sqrt(f[0]);
+    const double c10 = f[1] / c00, c11 = sqrt(f[2] - c10 * c10);
+    const double c20 = f[3] / c00, c21 = (f[4] - c20 * c10) / c11, c22 = sqrt(f[5] - c20 * c20 - c21 * c21);
+    if (!(f[0] > 0.0) || !(c11 > 0.0) || !(c22 > 0.0)) atomicOr(err, (unsigned)RBL_FLAG_NOT_SPD);
+    double *C = Cb + 9 * (size_t)b;
+    C[0] = c00; C[1] = 0; C[2] = 0; C[3] = c10; C[4] = c11; C[5] = 0; C[6] = c20; C[7] = c21; C[8] = c22;
+    // X = C^-1 (lower): Q = Z X^T, i.e. q_j = sum_{i <= j} X[j][i] z_i
+    const double x00 = 1.0 / c00, x11 = 1.0 / c11, x22 = 1.0 / c22;
+    const double x10 = -c10 * x00 * x11, x21 = -c21 * x11 * x22, x20 = -(c20 * x00 + c21 * x10) * x22;
+    Ci[0] = x00; Ci[1] = 0; Ci[2] = 0; Ci[3] = x10; Ci[4] = x11; Ci[5] = 0; Ci[6] = x20; Ci[7] = x21; Ci[8] = x22;
+  }
+  __syncthreads();
+  for (long k = t; k < m; k += BT) {
+    const double a = z0[k], bb = z1[k], c = z2[k];
+    z0[k] = Ci[0] * a;
+    z1[k] = Ci[3] * a + Ci[4] * bb;
+    z2[k] = Ci[6] * a + Ci[7] * bb + Ci[8] * c;
+  }
+}
+
+__global__ void k_tl_E(const double *__restrict__ Cs /* sphere tensor, n x n */, const double *__restrict__ Cb, int N_bod,
+                       double *__restrict__ A)
+{
+  const int bj = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;   // block (bi, bj) of A
+  if (bj >= N_bod) return;
+  const long n = 3L * N_bod;
+  double Eb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (bi != bj) {
+    const double *Ci = Cb + 9 * (size_t)bi, *Cj = Cb + 9 * (size_t)bj;
+    double T[9], U[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) T[3 * r + c] = Cs[(size_t)(3 * bj + c) * n + 3 * bi + r];
+    for (int r = 0; r < 3; ++r)                       // U = T C_j
+      for (int c = 0; c < 3; ++c) U[3 * r + c] = T[3 * r] * Cj[c] + T[3 * r + 1] * Cj[3 + c] + T[3 * r + 2] * Cj[6 + c];
+    for (int r = 0; r < 3; ++r)                       // E_b = C_i^T U
+      for (int c = 0; c < 3; ++c) Eb[3 * r + c] = Ci[r] * U[c] + Ci[3 + r] * U[3 + c] + Ci[6 + r] * U[6 + c];
+  } else {
+    Eb[0] = Eb[4] = Eb[8] = 1.0;
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) A[(size_t)(3 * bj + c) * n + 3 * bi + r] = Eb[3 * r + c];
+}
+
+__global__ __launch_bounds__(BT) void k_tl_qt(const double *__restrict__ Q, long n3, int N_blb, const double *__restrict__ w,
+                                              long wpitch, double *__restrict__ tt, long tpitch)
+{
+  __shared__ double s[3][BT];
+  const int b = blockIdx.x, v = blockIdx.y, t = threadIdx.x;
+  const long o = 3L * b * N_blb, m = 3L * N_blb;
+  const double *wv = w + (size_t)v * wpitch + o;
+  double f[3] = {0, 0, 0};
+  for (long k = t; k < m; k += BT) {
+    const double x = wv[k];
+    f[0] += Q[o + k] * x; f[1] += Q[n3 + o + k] * x; f[2] += Q[2 * n3 + o + k] * x;
+  }
+  block_reduce<3>(f, s, t);
+  if (t < 3) tt[(size_t)v * tpitch + 3 * b + t] = f[t];
+}
+
+__global__ void k_tl_addq(const double *__restrict__ Q, long n3, int N_blb, const double *__restrict__ sv,
+                          const double *__restrict__ tt, long tpitch, double *__restrict__ w, long wpitch)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (k >= n3) return;
+  const long b = k / (3L * N_blb);
+  const double *s = sv + (size_t)v * tpitch + 3 * b, *t = tt + (size_t)v * tpitch + 3 * b;
+  w[(size_t)v * wpitch + k] += Q[k] * (s[0] - t[0]) + Q[n3 + k] * (s[1] - t[1]) + Q[2 * n3 + k] * (s[2] - t[2]);
+}
+
+// K_t: unit translation of every body in direction d -> vector d of out ([3][n3])
+__global__ void k_tl_unit(long n3, double *__restrict__ out)
+{
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n3) return;
+  const int d = (int)(k % 3);
+  out[k] = d == 0 ? 1.0 : 0.0; out[n3 + k] = d == 1 ? 1.0 : 0.0; out[2 * n3 + k] = d == 2 ? 1.0 : 0.0;
+}
+
 __global__ void k_unit_U(int N_bod, int c, double *__restrict__ U)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,4 +771,29 @@ void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const doubl
   if (N_bod <= 0) return;
   hipLaunchKernelGGL(k_pc_diag_apply, dim3(N_bod), dim3(BT), 0, st, d_lever, d_invM2, d_NL, N_blb,
                      (long)3 * N_blb * N_bod, d_in, d_out, fsign);
+}
+
+// ---- two-level factor of the preconditioned Lanczos root (see k_tl_orth) -------------------------------------------------
+void rbl_launch_tl_unit(hipStream_t st, int64_t n3, double *d_out)
+{
+  hipLaunchKernelGGL(k_tl_unit, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, (long)n3, d_out);
+}
+void rbl_launch_tl_orth(hipStream_t st, double *d_Z, int64_t n3, int N_blb, int N_bod, double *d_Cb, unsigned *d_err)
+{
+  hipLaunchKernelGGL(k_tl_orth, dim3(N_bod), dim3(BT), 0, st, d_Z, (long)n3, N_blb, d_Cb, d_err);
+}
+void rbl_launch_tl_E(hipStream_t st, const double *d_Cs, const double *d_Cb, int N_bod, double *d_A)
+{
+  hipLaunchKernelGGL(k_tl_E, dim3((unsigned)((N_bod + 63) / 64), (unsigned)N_bod), dim3(64), 0, st, d_Cs, d_Cb, N_bod, d_A);
+}
+void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_w, int64_t wpitch, int nvec,
+                      double *d_t, int64_t tpitch)
+{
+  hipLaunchKernelGGL(k_tl_qt, dim3(N_bod, nvec), dim3(BT), 0, st, d_Q, (long)n3, N_blb, d_w, (long)wpitch, d_t, (long)tpitch);
+}
+void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
+                        double *d_w, int64_t wpitch, int nvec)
+{
+  hipLaunchKernelGGL(k_tl_addq, dim3((unsigned)((n3 + 255) / 256), nvec), dim3(256), 0, st, d_Q, (long)n3, N_blb, d_s, d_t, (long)tpitch,
+                     d_w, (long)wpitch);
 }

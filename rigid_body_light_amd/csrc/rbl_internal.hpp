@@ -81,6 +81,11 @@ struct rbl_ctx {
                                                     // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- rbl_set_tuning 63 / 64 / 65
   bool blk_f32 = false, blk_f32_valid = false;      // rbl_set_tuning 83 / 84: apply them from a single-precision copy (half the bytes)
   bool bf_tables = false;                           // d_bfPC holds the body-frame preconditioner tables (small bodies)
+  // two-level factor of the preconditioned Lanczos root (rbl_api.hip: tl_build): G = L (I + Q (L_E - I) Q^T)
+  RblDevBuf d_tlQ, d_tlCb, d_tlCs, d_tlA, d_tlLinv, d_tlX, d_tlT, d_tlZ;
+  bool tl_on = true, tl_valid = false, tl_ok = false;   // rbl_set_tuning 87 / 88; built for the current configuration; usable (SPD)
+  unsigned *d_err2 = nullptr;                       // error word of the two-level build: a failure there is not an error, only "not usable"
+  double body_radius = 0.0;                         // max |c_k| + a: the sphere the far-field model gives a body
   // free space: M_b = (I x R_b) M_body (I x R_b)^T with ONE body-frame matrix for all bodies and all time: its factor
   // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
   RblDevBuf d_bfL, d_bfLinv, d_bfX;
@@ -286,5 +291,13 @@ int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
                             double *d_out, double *d_ktl, double *d_y1);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
+// two-level factor of the preconditioned Lanczos root (rbl_body_dev.hip: k_tl_*)
+void rbl_launch_tl_unit(hipStream_t st, int64_t n3, double *d_out);
+void rbl_launch_tl_orth(hipStream_t st, double *d_Z, int64_t n3, int N_blb, int N_bod, double *d_Cb, unsigned *d_err);
+void rbl_launch_tl_E(hipStream_t st, const double *d_Cs, const double *d_Cb, int N_bod, double *d_A);
+void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_w, int64_t wpitch, int nvec,
+                      double *d_t, int64_t tpitch);
+void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
+                        double *d_w, int64_t wpitch, int nvec);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

@@ -501,8 +501,8 @@ def test_cfg2_full_size_lanczos_square_roots():
     matrix-free square roots against the dense matrix of the SAME configuration (k_build_M, bit-identical to the oracle's
     assembly).  Any exact root G of A = B M B gives |G^T-free identities| we can test with one vector:
       plain Lanczos (symmetric root S):   y = S W:  y.y = W.A W  and  S y = A W;
-      preconditioned (G = B L Sp^{1/2}, Sp = L^-1 M L^-T):  s = L^-1 B^-1 (G W) = Sp^{1/2} W:  s.s = v.M v with
-      v = L^-T W, and G s = B M v."""
+      preconditioned (x = B G Sp^{1/2} W, Sp = G^-1 M G^-T, G = L or the two-level factor L (I + Q (L_E - I) Q^T)):
+      s = G^-1 B^-1 x = Sp^{1/2} W:  s.s = v.M v with v = G^-T W, and root(s) = B M v.  Both factors are run."""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext
@@ -546,19 +546,31 @@ def test_cfg2_full_size_lanczos_square_roots():
     # iterations): held at 1e-3, 1e-6 and 1e-9.  The plain root of this matrix converges algebraically (the corrections
     # shrink by ~5 % per iteration: M has eigenvalues close to the branch point of the square root; 100 iterations for 1e-3,
     # ~250 for 1e-4, ~1000 for 1e-6), so it is held at 1e-3 and 1e-4; its honest estimate is what makes that visible.
+    its_bj = {}
+    ctx.set_tuning(0, 87)                                         # block-Jacobi factor alone: iteration counts for comparison
+    for tol in (1e-3, 1e-6):
+        ctx.set_lanczos(600, tol)
+        x = root(W, "lanczos_pc")
+        its_bj[tol] = ctx.lanczos_report()[0]
+        s_ = bsolve(x / B, 5); v = bsolve(W, 6); Mv = Mu @ v
+        assert float(torch.linalg.norm(root(s_, "lanczos_pc") - B * Mv) / torch.linalg.norm(B * Mv)) < 10.0 * tol
+        assert torch.equal(bsolve(W, 6), bsolve(W, 2))            # without the two-level part the whole factor is L
+    ctx.set_tuning(0, 88)
     for tol in (1e-3, 1e-4, 1e-6, 1e-9):
         acc = 10.0 * tol
         ctx.set_lanczos(600, tol)
         x = root(W, "lanczos_pc")
         its_pc, est_pc = ctx.lanczos_report()
-        s_ = bsolve(x / B, 1)                                     # Sp^{1/2} W
-        v = bsolve(W, 2)                                          # L^-T W
+        s_ = bsolve(x / B, 5)                                     # Sp^{1/2} W = G^-1 B^-1 x  (G: the root's whole factor, two-level by default)
+        v = bsolve(W, 6)                                          # G^-T W
         Mv = Mu @ v
         e_norm_pc = abs(float(s_ @ s_) - float(v @ Mv)) / float(v @ Mv)
         e_sq_pc = float(torch.linalg.norm(root(s_, "lanczos_pc") - B * Mv) / torch.linalg.norm(B * Mv))
         print("tol %g: preconditioned root %d iterations, estimate %.2e, measured %.2e (norm identity %.1e)" % (tol, its_pc, est_pc, e_sq_pc, e_norm_pc))
         assert e_norm_pc < acc and e_sq_pc < acc, (tol, its_pc, e_norm_pc, e_sq_pc)
         assert est_pc < tol and its_pc < 100                      # converged by its own estimate, not stopped by the cap
+        if tol in its_bj:      # the two-level factor's point: fewer iterations than block-Jacobi where the collective modes limit
+            assert its_pc <= its_bj[tol] and (tol < 1e-3 or its_pc < its_bj[tol]), (tol, its_pc, its_bj[tol])   # (tests every 4th iteration here)
         report[tol] = (its_pc, est_pc, e_sq_pc)
         if tol < 1e-4:
             continue
@@ -576,7 +588,7 @@ def test_cfg2_full_size_lanczos_square_roots():
     e = torch.zeros(n, dtype=torch.float64, device=dev); e[3 * nblb * b:3 * nblb * (b + 1)] = W[3 * nblb * b:3 * nblb * (b + 1)]
     sol = bsolve(e, 0)[3 * nblb * b:3 * nblb * (b + 1)]
     assert float(torch.linalg.norm(blk @ sol - e[3 * nblb * b:3 * nblb * (b + 1)]) / torch.linalg.norm(W[3 * nblb * b:3 * nblb * (b + 1)])) < 1e-10
-    print("cfg2 full size, (iterations, estimate, measured |G s - B M v| / |B M v|) preconditioned [| plain]:", report)
+    print("cfg2 full size, (iterations, estimate, measured |G s - B M v| / |B M v|) preconditioned [| plain]:", report, "; block-Jacobi factor alone:", its_bj)
     ctx.close()
 
 
@@ -925,6 +937,7 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
     for sharded in (False, "torch loop", "native loop"):
         ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
+        ctx.set_tuning(0, 87)      # block-Jacobi factor of the preconditioned root: what the torch comparator composes (different factors give different, equally exact roots)
         if sharded:
             cls = ShardedBrownianStepper if sharded == "native loop" else TorchShardedBrownianStepper
             st = cls(ctx, ShardedMobility(nb, 12, device=dev, ctx=ctx), nb, 12, dev, a, wall, kBT, dt,
@@ -1532,9 +1545,10 @@ def test_one_kernel_gmres_equals_general_solver(wall, nb, nblb):
 
 @pytest.mark.parametrize("wall", [False, True])
 def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
-    """method 'lanczos_pc': x = B L S^{1/2} W with S = L^-1 M L^-T (L L^T = per-body mobility: the Cholesky factor of the
-    wall-corrected block, or in free space the body-frame Cholesky factor rotated with the body) -- against the same
-    expression assembled from the oracle's dense matrix; and its covariance factor is exact: (B L S^1/2)(...)^T = B M B."""
+    """method 'lanczos_pc': x = B G S^{1/2} W with S = G^-1 M G^-T, G = L (block-Jacobi: L L^T = per-body mobility -- the
+    Cholesky factor of the wall-corrected block, or in free space the body-frame Cholesky factor rotated with the body) or the
+    two-level factor L (I + Q (L_E - I) Q^T) (default) -- against the same expression assembled from the oracle's dense matrix
+    for BOTH factors; and the covariance factor is exact: (B G S^1/2)(...)^T = B M B."""
     from oracle import oracle as onp
     nb = 5
     X, Q = random_positions(nb, wall=wall, seed=160)
@@ -1565,14 +1579,42 @@ def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
             Rb = Rotation.from_quat([Qn[b, 1], Qn[b, 2], Qn[b, 3], Qn[b, 0]]).as_matrix()
             L[sl, sl] = np.kron(np.eye(12), Rb) @ Lbody
             assert np.linalg.norm(L[sl, sl] @ L[sl, sl].T - M[sl, sl]) < 1e-12 * np.linalg.norm(M[sl, sl])   # a factor of M_b
-    Li = np.linalg.inv(L)
-    S = Li @ M @ Li.T
-    lam, Z = np.linalg.eigh(0.5 * (S + S.T))
-    Sh = (Z * np.sqrt(lam)) @ Z.T
-    ref = B * (L @ (Sh @ W))
-    assert rel(x, ref) < 1e-9
-    G = (B[:, None] * L) @ Sh                                         # the square root this method realises
-    assert np.linalg.norm(G @ G.T - (B[:, None] * M) * B[None, :]) < 1e-10 * np.linalg.norm(M)
+    def check(x_, Lf):                          # x = B Lf S^{1/2} W with S = Lf^-1 M Lf^-T, for the factor Lf
+        Li = np.linalg.inv(Lf)
+        S = Li @ M @ Li.T
+        lam, Z = np.linalg.eigh(0.5 * (S + S.T))
+        Sh = (Z * np.sqrt(lam)) @ Z.T
+        assert rel(x_, B * (Lf @ (Sh @ W))) < 1e-9
+        G = (B[:, None] * Lf) @ Sh                                    # the square root this method realises
+        assert np.linalg.norm(G @ G.T - (B[:, None] * M) * B[None, :]) < 1e-10 * np.linalg.norm(M)
+
+    # default: the TWO-LEVEL factor L (I + Q (L_E - I) Q^T) (csrc/rbl_api.hip tl_build), restated in numpy: Z = L^-1 K_t,
+    # R_b = Z_b^T Z_b = C_b C_b^T, Q_b = Z_b C_b^-T, E = blockdiag(C_b^T) C blockdiag(C_b) with C the pair tensor of spheres
+    # of the bodies' outer radius at the body centres (off-diagonal blocks; the wall term when no sphere reaches the wall)
+    c0 = np.asarray(shell12, dtype=np.float64) - np.asarray(shell12, dtype=np.float64).mean(axis=0)
+    Rs = np.linalg.norm(c0, axis=1).max() + 1.0
+    Kt = np.zeros((n3, 3 * nb))
+    for b in range(nb):
+        for d in range(3):
+            Kt[36 * b + d:36 * (b + 1):3, 3 * b + d] = 1.0
+    Zt = np.linalg.solve(L, Kt)
+    Cb = np.zeros((3 * nb, 3 * nb)); Qm = np.zeros_like(Zt)
+    for b in range(nb):
+        sl, s3 = slice(36 * b, 36 * (b + 1)), slice(3 * b, 3 * b + 3)
+        Cb[s3, s3] = np.linalg.cholesky(Zt[sl, s3].T @ Zt[sl, s3])
+        Qm[sl, s3] = Zt[sl, s3] @ np.linalg.inv(Cb[s3, s3]).T
+    Xc = np.asarray(X, dtype=np.float64)
+    Cs = orc.rotne_prager_tensor(Xc.reshape(-1), Rs, 1.0, bool(wall and Xc[:, 2].min() > 1.1 * Rs))
+    for b in range(nb):
+        Cs[3 * b:3 * b + 3, 3 * b:3 * b + 3] = 0.0
+    try:
+        LE = np.linalg.cholesky(np.eye(3 * nb) + Cb.T @ Cs @ Cb)
+        check(x, L @ (np.eye(n3) + Qm @ (LE - np.eye(3 * nb)) @ Qm.T))
+    except np.linalg.LinAlgError:               # model not positive definite: the library falls back to block-Jacobi, too
+        check(x, L)
+    cb.cb.set_tuning(0, 87)                     # block-Jacobi factor alone
+    check(cb.M_half_W(W, method="lanczos_pc"), L)
+    cb.cb.set_tuning(0, 88)
     it, res = cb.cb.lanczos_report()
     cb.cb.set_lanczos(100, 1e-3)
     cb.M_half_W(W, method="lanczos_pc"); it_pc = cb.cb.lanczos_report()[0]
@@ -1850,4 +1892,68 @@ def test_phase_timings_through_the_c_abi(shell12):
     ctx.M_half_W(r.data_ptr(), nb * nblb, W.data_ptr(), "cholesky", o.data_ptr()); ctx.sync_check()
     t = ctx.timings()
     assert t["dense"][1] == 1 and t["dense"][0] > 0.0 and t["product"][1] == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("nb,nblb", [(6, 42), (30, 162), (200, 12)])
+def test_two_level_factor_of_the_preconditioned_root(orc, wall, nb, nblb):
+    """The factor G = L (I + Q (L_E - I) Q^T) of the preconditioned Lanczos root (rbl_block_solve_dev modes 5, 6, 7): G^-1 G = I,
+    G^-T is the transpose of G^-1 (adjoint identity), and G G^T = D + K_t C K_t^T differs from the block-diagonal D = L L^T by a
+    correction of rank 3 N_bod supported on the bodies' translations -- checked as (G G^T - L L^T) orthogonal to every vector
+    that has zero net force on every body.  Sizes: the small system's explicit inverse through k_trtri_small (3 N_bod = 18, 90)
+    and through the augmented-matrix inversion (600).  Then the root itself: the identity root(s) = B M v to 10 x tolerance."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb; n = 3 * N
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    rng = np.random.default_rng(nb)
+    x = torch.from_numpy(rng.standard_normal(n)).to(dev); y = torch.from_numpy(rng.standard_normal(n)).to(dev)
+
+    def op(vec, mode):
+        out = torch.empty_like(vec)
+        ctx.block_solve(vec.contiguous().data_ptr(), out.data_ptr(), mode); ctx.sync_check()
+        return out
+
+    assert not torch.equal(op(x, 5), op(x, 1))                                       # the two-level part is there
+    assert rel(op(op(x, 7), 5).cpu().numpy(), x.cpu().numpy()) < 1e-11              # G^-1 G = I
+    assert rel(op(op(x, 5), 7).cpu().numpy(), x.cpu().numpy()) < 1e-11              # G G^-1 = I
+    assert abs(float(y @ op(x, 5)) - float(op(y, 6) @ x)) < 1e-11 * float(x.norm() * op(y, 6).norm())   # <y, G^-1 x> = <G^-T y, x>
+    # G G^T - L L^T = L Q (...) Q^T L^T lives on the translations K_t: invisible to force-free vectors
+    z = x.view(nb, nblb, 3) - x.view(nb, nblb, 3).mean(dim=1, keepdim=True)         # zero net force on every body
+    z = z.reshape(-1).contiguous()
+    w_tl = op(op(z, 5), 6)                                                           # (G G^T)^-1 z = G^-T G^-1 z
+    w_bj = op(z, 0)                                                                  # (L L^T)^-1 z
+    d = (w_tl - w_bj).view(nb, nblb, 3)
+    # (G G^T)^-1 - (L L^T)^-1 = L^-T Q (...) Q^T L^-1: its range is L^-T Q = M_b^-1 K_t -- so M_b d_b is a rigid translation
+    r = torch.empty(n, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr()); ctx.sync_check()
+    rh = r.cpu().numpy()
+    for b in (0, nb - 1):
+        sl = slice(3 * nblb * b, 3 * nblb * (b + 1))
+        Mb = orc.rotne_prager_tensor(rh[sl], c["a"], c["eta"], wall)
+        t = (Mb @ d[b].reshape(-1).cpu().numpy()).reshape(nblb, 3)
+        assert np.abs(t - t.mean(axis=0)).max() < 1e-9 * max(np.abs(t).max(), 1e-300) + 1e-12 * np.abs(w_bj.cpu().numpy()).max() * np.abs(Mb).max()
+    # the root with this factor: identity to 10 x tolerance, fewer iterations than with block-Jacobi alone
+    z_ = r.view(-1, 3)[:, 2]
+    B = torch.where(z_ >= c["a"], torch.ones_like(z_), z_ / c["a"]).repeat_interleave(3)
+    W = torch.from_numpy(rng.standard_normal(n)).to(dev)
+
+    def root(vec):
+        out = torch.empty_like(vec)
+        ctx.M_half_W(r.data_ptr(), N, vec.contiguous().data_ptr(), "lanczos_pc", out.data_ptr()); ctx.sync_check()
+        return out
+
+    for tol in (1e-3, 1e-7):
+        ctx.set_lanczos(200, tol)
+        xx = root(W); its = ctx.lanczos_report()[0]
+        s_ = op(xx / B, 5); v = op(W, 6)
+        Mv = torch.empty_like(v)
+        ctx.set_no_damp(True); ctx.apply_M(v.data_ptr(), r.data_ptr(), N, 0, N, Mv.data_ptr()); ctx.set_no_damp(False); ctx.sync_check()
+        e = float(torch.linalg.norm(root(s_) - B * Mv) / torch.linalg.norm(B * Mv))
+        ctx.set_tuning(0, 87); root(W); its_bj = ctx.lanczos_report()[0]; ctx.set_tuning(0, 88)
+        assert e < 10.0 * tol and its <= its_bj, (tol, e, its, its_bj)
     ctx.close()
