@@ -1217,8 +1217,8 @@ def test_wall_system_with_the_free_space_body_frame_factor(orc):
             z = r.view(-1, 3)[:, 2]
             B = torch.where(z >= c["a"], torch.ones_like(z), z / c["a"]).repeat_interleave(3)
             s_ = torch.empty_like(W); v_ = torch.empty_like(W)
-            ctx.block_solve((xr / B).contiguous().data_ptr(), s_.data_ptr(), 1)        # G^-1 B^-1 x = S^{1/2} W
-            ctx.block_solve(W.data_ptr(), v_.data_ptr(), 2); ctx.sync_check()         # G^-T W
+            ctx.block_solve((xr / B).contiguous().data_ptr(), s_.data_ptr(), 5)        # G^-1 B^-1 x = S^{1/2} W  (whole factor: body-frame blocks x two-level part)
+            ctx.block_solve(W.data_ptr(), v_.data_ptr(), 6); ctx.sync_check()         # G^-T W
             lhs, rhs = float(s_ @ s_), float(v_ @ (M @ v_))
             assert abs(lhs - rhs) < 1e-8 * rhs
         ctx.close()
@@ -1697,6 +1697,7 @@ def test_block_refresh_keeps_factors(orc, shell12):
     ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_block_refresh(2)
     ctx.set_lanczos(n3, 1e-13)
+    ctx.set_tuning(0, 87)          # the numpy restatement below is the block-Jacobi factor's root (the two-level one has its own tests)
     v = torch.from_numpy(np.random.default_rng(202).standard_normal(n3)).to(dev)
     def solve():
         o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check(); return o.cpu().numpy()

@@ -87,6 +87,11 @@ for rk in range(P):
     pb = [ev_ms(lambda md=md: ctx.block_solve(v.data_ptr(), o.data_ptr(), md, b0, b1), 10) for md in (0, 1, 2, 3)]
     fb = e0.elapsed_time(e1) - pb[0]
     rows.append((rk, b1 - b0, p1, p2, fb, pb))
+# the two-level factor of the Lanczos root is rebuilt per configuration on EVERY rank (replicated, apart from Z = L^-1 K_t)
+def tl_rebuild():
+    ctx.set_tuning(0, 88)                                        # invalidates the two-level factor only
+    ctx.block_solve(v.data_ptr(), o.data_ptr(), 5)
+t_tl = ev_ms(tl_rebuild, 5) - ev_ms(lambda: ctx.block_solve(v.data_ptr(), o.data_ptr(), 5), 5)
 ctx.close()
 print("| rank | bodies | 1-vector product share | 2-vector product share | factor + inverse build | (L L^T)^-1 v | L^-1 v | L^-T v | L v |")
 print("|---|---|---|---|---|---|---|---|---|")
@@ -105,6 +110,7 @@ n_pc = mg + 1 + 2                        # preconditioner applications (iteratio
 items = [("two-vector products (Lanczos)", n_pair, p2), ("one-vector products (GMRES + M_RFD)", n_single, p1),
          ("(L L^T)^-1 applications (preconditioner, M^-1 K)", n_pc, pb[0]), ("L^-T and L^-1 applications (Lanczos)", 2 * L, 0.5 * (pb[1] + pb[2])),
          ("L v (the two increments)", 2, pb[3]), ("factor + inverse build (every 2nd configuration of two per step)", 1, fb),
+         ("two-level factor of the root: sphere tensor, 3 N_bod-square Cholesky + inverse (replicated)", 1, t_tl),
          ("replicated: vector work, K operators, host", 1, replicated)]
 print("| piece | count per step | slowest rank, ms each | ms per step |")
 print("|---|---|---|---|")
