@@ -1375,7 +1375,7 @@ static int mhalf_dev_multi(rbl_ctx *c, const double *d_r, int64_t nbl, const dou
       if (comm_on(c)) comm_body_range(c, &b0, &b1);
       if (b1 != b0 && (rc = blk_prepare(c, b0, b1))) return rc;
       if ((rc = tl_build(c))) return rc;
-    } else c->tl_ok = false;
+    }
     int v = 0;   // pairs of vectors in lock step (shared pair coefficients), a single one alone
     for (; v + 2 <= nvec; v += 2)
       if ((rc = mhalf_lanczos_dev(c, d_r, nbl, d_W + (size_t)v * n, d_out + (size_t)v * n, 2, pc))) return rc;
