@@ -330,8 +330,12 @@ __device__ __forceinline__ double sym_first_lane(double v)      // lane 0's valu
 // blob of the column tile (round 3; one origin per workgroup let the error grow with the extent of the suspension); their
 // per-tile sums are added to the double accumulators, so single precision only ever sums 64 x NI terms.  Diagonal, near
 // and unsafe tiles stay fp64.
+// (the four-wave wall instance is held to 168 VGPRs -- three waves per SIMD instead of two at the 186 the compiler takes
+// unasked: no spill, 2 % faster at cfg 3 on one box, A/B gpurun_out/r03k/ab_wpe3.txt; HIP's second launch bound is the
+// minimum number of waves per SIMD.  The other instances are left alone: the relaxed one would spill, the small ones
+// already fit four.)
 template <bool WALL, int NI, int SW, int PREC>
-__global__ __launch_bounds__(TS *SW) void k_apply_M_sym(const double *__restrict__ r,
+__global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 3 : 1) void k_apply_M_sym(const double *__restrict__ r,
                                                         const double *__restrict__ F,
                                                         double *__restrict__ slabI,
                                                         double *__restrict__ slabJ, long N, SymLayout L, RblParams P,
