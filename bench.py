@@ -657,6 +657,83 @@ def other_configs(dev, stream):
     return out
 
 
+class LineGuard:
+    """N > 1 inside ONE torchrun job (the way the driver starts the scaling runs): the headline line is complete before the
+    time-step part begins, and must not be lost to it.  Rank 0 keeps the finished line here; a watchdog thread prints it --
+    with the reason in `timestep.error` -- and ends the process with status 4 if another rank reports a failure (a flag
+    file: a rank stuck in a collective cannot be reached any other way) or the time-step part overruns its limit.  A failing
+    rank raises its flag, waits for rank 0 to print, then fails (torchrun then stops the remaining ranks)."""
+
+    def __init__(self, world, rank, limit_s):
+        import tempfile
+        import threading
+        self.world, self.rank, self.limit_s = world, rank, limit_s
+        self.flag = os.path.join(tempfile.gettempdir(), "rbl_bench_%s_%s.failed" % (os.environ.get("MASTER_PORT", "0"),
+                                                                                    os.environ.get("TORCHELASTIC_RUN_ID", "0")))
+        self.line = None
+        self.lock = threading.Lock()
+        self.done = threading.Event()
+        self.thread = None
+        if rank == 0:                        # a stale flag of an earlier job; the barriers of the timed region come after this
+            try:
+                os.unlink(self.flag)
+            except OSError:
+                pass
+
+    def arm(self, line):
+        import threading
+        if self.world == 1 or self.rank != 0:
+            return
+        self.line = line
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def _watch(self):
+        t_end = time.monotonic() + self.limit_s
+        while not self.done.wait(0.5):
+            why = None
+            if os.path.exists(self.flag):
+                try:
+                    why = open(self.flag).read().strip() or "a rank failed"
+                except OSError:
+                    why = "a rank failed"
+            elif time.monotonic() > t_end:
+                why = "the time-step part did not finish within %d s" % self.limit_s
+            if why:
+                self.bail(why)
+
+    def bail(self, why):
+        """print the headline line with the reason and end this process (never returns)"""
+        with self.lock:
+            if self.line is not None:
+                self.line["timestep"] = {"error": why}
+                print(json.dumps(self.line), flush=True)
+                self.line = None
+            sys.stderr.write("bench.py: time-step part failed: %s\n" % why)
+            sys.stderr.flush()
+            os._exit(4)
+
+    def rank_failed(self, exc):
+        """called on the rank where the time-step part raised"""
+        import traceback
+        traceback.print_exc()
+        why = "rank %d: %r" % (self.rank, exc)
+        if self.rank == 0:
+            self.bail(why)
+        try:
+            with open(self.flag, "w") as f:
+                f.write(why)
+        except OSError:
+            pass
+        time.sleep(5.0)                      # rank 0's watchdog prints the line; then fail for real
+        raise exc
+
+    def disarm(self):
+        self.done.set()
+        with self.lock:
+            self.line = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -734,6 +811,7 @@ def main():
         ctx.set_tuning(0, v)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
     nrows = sm.row1 - sm.row0
+    guard = LineGuard(world, rank, limit_s=1500)
 
     F_full_host = np.random.default_rng(2).standard_normal(3 * N)
     F_local = torch.from_numpy(F_full_host[3 * sm.row0:3 * sm.row1].copy()).to(dev)
@@ -812,28 +890,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    tstep = None
-    failed = None
-    if args.timestep_steps > 0 and phase != "main":
-        try:
-            tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
-        except Exception as e:                               # the hot-path line must not be lost to the time-step part ...
-            if world > 1:
-                raise
-            import traceback
-            traceback.print_exc()
-            tstep = {"error": repr(e)}
-            failed = "time-step part failed"                 # ... but a failing step driver makes the exit status non-zero
-    others = None
-    if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
-        try:
-            others = other_configs(dev, stream)
-        except Exception as e:
-            import traceback
-            traceback.print_exc()
-            others = {"error": repr(e)}
-            failed = failed or "other-configs part failed"
-
+    line = None
     if rank == 0:
         sec_per_step = elapsed / args.steps
         # ordered-pair equivalents one launch (this rank) covers: its rows x all columns, or its
@@ -908,6 +965,33 @@ def main():
                                         "force shards; this rank's tile pairs (pair kernel + slab reduction); the all-reduce of the partial "
                                         "U incl. the wait for the slowest rank.  The time-step variants carry librbl's own phase timings "
                                         "(`phases`) per rank.")
+    tstep = None
+    failed = None
+    if args.timestep_steps > 0 and phase != "main":
+        guard.arm(dict(line) if line is not None else None)
+        try:
+            if os.environ.get("RBL_BENCH_INJECT_FAILURE") == str(rank):     # tests/test_multirank_gpu.py: the guard itself
+                raise RuntimeError("injected failure (test hook)")
+            tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
+        except Exception as e:                               # the hot-path line must not be lost to the time-step part ...
+            if world > 1:
+                guard.rank_failed(e)                         # rank 0 prints the line with the reason; status 4
+            import traceback
+            traceback.print_exc()
+            tstep = {"error": repr(e)}
+            failed = "time-step part failed"                 # ... but a failing step driver makes the exit status non-zero
+        guard.disarm()
+    others = None
+    if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
+        try:
+            others = other_configs(dev, stream)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            others = {"error": repr(e)}
+            failed = failed or "other-configs part failed"
+
+    if rank == 0:
         if tstep is not None:
             line["timestep"] = tstep
         if others is not None:

@@ -76,6 +76,22 @@ def test_bench_self_launches_two_ranks(timestep_steps):
         assert t["brownian_converged"]["lanczos_0.001"]["gmres_residual_max"] < 1e-8
 
 
+@pytest.mark.parametrize("failing_rank", ["0", "1"])
+def test_headline_line_survives_a_failing_time_step_part(monkeypatch, failing_rank):
+    """the driver's scaling runs start bench.py under ONE torchrun job: if the time-step part fails on any rank after the hot
+    path was timed, rank 0 still prints the one line (with the reason in `timestep.error`) and the job's status is non-zero"""
+    import json
+    monkeypatch.setenv("RBL_BENCH_INJECT_FAILURE", failing_rank)
+    p = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3", "--warmup", "1",
+                      "--cpu-budget", "0", "--timestep-steps", "1"])
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and 0.0 < d["roofline"]["frac"] <= 1.0
+    assert "rank %s" % failing_rank in d["timestep"]["error"] and "injected failure" in d["timestep"]["error"]
+
+
 def _max_diff(stdout, world):
     line = [l for l in stdout.splitlines() if l.startswith("world %d:" % world)][-1]
     return float(line.split("=")[1].split(",")[0])
