@@ -380,7 +380,10 @@ int rbl_sync_check(rbl_ctx *ctx);
  * of x in the ENERGY norm x^T (B M B)^-1 x, the one that bounds the relative error of the sampled covariance -- / of x itself
  * in the Euclidean norm (default; L weighs the slowly converging collective modes more: a few more iterations);
  * 81 / 82: Lanczos square roots with the three-term recurrence only (round 1-2; the estimate stagnates near 1e-6) / with
- * every new vector re-orthogonalised against the whole stored basis (default).  All per context. */
+ * every new vector re-orthogonalised against the whole stored basis (default);
+ * 91 / 92: rbl_gmres_saddle_dev on launch-bound systems (<= 20 000 blobs): convergence test (a copy of the Hessenberg
+ * columns + a stream drain) every 4th iteration / first two iterations before the previous solve's count, then where the
+ * residual's rate puts it (default); either way the solve ends at the first iteration that passes.  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

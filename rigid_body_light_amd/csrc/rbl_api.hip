@@ -1061,8 +1061,8 @@ static int tl_build(rbl_ctx *c)
   return RBL_OK;
 }
 
-// w_v <- Op w_v for nvec vectors `pitch` apart;  op 0: H = I + Q (L_E - I) Q^T,  1: H^-1,  2: H^-T
-static int tl_apply(rbl_ctx *c, double *w, int nvec, int64_t pitch, int op)
+// wo_v = Op w_v for nvec vectors `pitch` apart (wo == w allowed);  op 0: H = I + Q (L_E - I) Q^T,  1: H^-1,  2: H^-T
+static int tl_apply(rbl_ctx *c, const double *w, double *wo, int nvec, int64_t pitch, int op)
 {
   const RblBodyState &S = c->S;
   const int Nb = S.N_bod;
@@ -1071,17 +1071,15 @@ static int tl_apply(rbl_ctx *c, double *w, int nvec, int64_t pitch, int op)
   double *t = (double *)c->d_tlT.p, *sv = t + 3 * nt;                     // (up to three vectors at a time)
   for (int v0 = 0; v0 < nvec; v0 += 3) {
     const int g = nvec - v0 >= 3 ? 3 : nvec - v0;
-    double *wv = w + (size_t)v0 * (size_t)pitch;
+    const double *wv = w + (size_t)v0 * (size_t)pitch;
     rbl_launch_tl_qt(c->stream, Q, n3, S.N_blb, Nb, wv, pitch, g, t, nt);
     int rc = RBL_OK;
-    for (int v = 0; v < g && !rc; ++v) {
-      const double *tv = t + (size_t)v * nt;
-      double *sp = sv + (size_t)v * nt;
-      if (op == 0) rc = rbl_launch_block_trmv_small(c->stream, (const double *)c->d_tlA.p, nt, 1, 0, tv, sp, 0, nullptr);
-      else rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_tlX.p, nt, 1, tv, sp, nt, 1, nt, op, nullptr);
-    }
+    if (op != 0) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_tlX.p, nt, 1, t, sv, nt, g, nt, op, nullptr);   // all g vectors in one pass
+    else
+      for (int v = 0; v < g && !rc; ++v)
+        rc = rbl_launch_block_trmv_small(c->stream, (const double *)c->d_tlA.p, nt, 1, 0, t + (size_t)v * nt, sv + (size_t)v * nt, 0, nullptr);
     if (rc) return rbl_fail(c, rc, "two-level factor: application failed");
-    rbl_launch_tl_addq(c->stream, Q, n3, S.N_blb, sv, t, nt, wv, pitch, g);
+    rbl_launch_tl_addq(c->stream, Q, n3, S.N_blb, sv, t, nt, wv, wo + (size_t)v0 * (size_t)pitch, pitch, g);
   }
   return RBL_OK;
 }
@@ -1103,8 +1101,7 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       int b0, b1; comm_body_range(c, &b0, &b1);
       const double *src = d_x;
       if (tl) {                                        // (d_y is free until the product: H^-T x goes there)
-        RBL_HIP(c, hipMemcpyAsync(d_y, d_x, vbytes, hipMemcpyDeviceToDevice, c->stream));
-        if ((rc = tl_apply(c, d_y, nvec, n, 2))) return rc;
+        if ((rc = tl_apply(c, d_x, d_y, nvec, n, 2))) return rc;
         src = d_y;
       }
       RBL_HIP(c, hipMemsetAsync(d_tmp, 0, vbytes, c->stream));
@@ -1119,16 +1116,15 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       if ((rc = blk_solve(c, b0, b1 - b0, d_y, d_tmp, nvec, n, 1, lz32))) return rc;
       if ((rc = comm_allreduce(c, d_tmp, (int64_t)nvec * n))) return rc;
       RBL_HIP(c, hipMemcpyAsync(d_y, d_tmp, vbytes, hipMemcpyDeviceToDevice, c->stream));
-      return tl ? tl_apply(c, d_y, nvec, n, 1) : RBL_OK;
+      return tl ? tl_apply(c, d_y, d_y, nvec, n, 1) : RBL_OK;
     }
-    if (tl) {
-      RBL_HIP(c, hipMemcpyAsync(d_tmp, d_x, vbytes, hipMemcpyDeviceToDevice, c->stream));
-      if ((rc = tl_apply(c, d_tmp, nvec, n, 2))) return rc;
-      rc = blk_solve(c, 0, c->S.N_bod, d_tmp, d_tmp, nvec, n, 2, lz32);
+    if (tl) {                                          // H^-T x staged in d_y (free until the product), then out of place through L^-T
+      if ((rc = tl_apply(c, d_x, d_y, nvec, n, 2))) return rc;
+      rc = blk_solve(c, 0, c->S.N_bod, d_y, d_tmp, nvec, n, 2, lz32);
     } else rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2, lz32);   // both vectors in one pass over L
     if (rc) return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
     double *prod = d_y;                                // explicit inverses do not work in place: product into their scratch
-    if (c->blk_inv_valid) {
+    if (c->blk_inv_valid || (bf_on(c) && c->bf_inv)) {
       if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n))) return rc;
       prod = (double *)c->d_blkTmp.p;
     }
@@ -1137,7 +1133,7 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
     c->no_damp = false;
     if (rc) return rc;
     if ((rc = blk_solve(c, 0, c->S.N_bod, prod, d_y, nvec, n, 1, lz32))) return rc;
-    return tl ? tl_apply(c, d_y, nvec, n, 1) : RBL_OK;
+    return tl ? tl_apply(c, d_y, d_y, nvec, n, 1) : RBL_OK;
   }
   if (c->S.wall) return apply_M_multi_enqueue(c, true, d_x, d_r, nbl, nvec, d_y);   // kernel applies B M B itself
   for (int v = 0; v < nvec; ++v)                                                     // free-space M, damping around it
@@ -1308,7 +1304,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
         rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v) + m, m, zd, (int64_t)nvec * n);
         for (int w = 0; w < 2; ++w) {
           double *zin = w ? zd : zx, *o = w ? od : ox;
-          if (c->tl_ok && (rc = tl_apply(c, zin, 1, n, 0))) return rc;
+          if (c->tl_ok && (rc = tl_apply(c, zin, zin, 1, n, 0))) return rc;
           if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(o, 0, sizeof(double) * (size_t)n, c->stream));
           if ((rc = blk_trmv(c, b0, b1 - b0, zin, o))) return rc;
           if (comm_on(c) && (rc = comm_allreduce(c, o, n))) return rc;
@@ -1347,7 +1343,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     if (comm_on(c)) comm_body_range(c, &b0, &b1);
     for (int v = 0; v < nvec; ++v) {
       double *o = d_out + (size_t)v * n;
-      if (c->tl_ok && (rc = tl_apply(c, o, 1, n, 0))) return rc;       // x = B L (H y)
+      if (c->tl_ok && (rc = tl_apply(c, o, o, 1, n, 0))) return rc;       // x = B L (H y)
       if (comm_on(c)) RBL_HIP(c, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)n, c->stream));
       if ((rc = blk_trmv(c, b0, b1 - b0, o, tmp))) return rc;
       if (comm_on(c) && (rc = comm_allreduce(c, tmp, n))) return rc;
@@ -1519,16 +1515,16 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
     const int64_t n3 = (int64_t)3 * c->S.N_bod * c->S.N_blb;
     if (mode == 5) {                                   // G^-1 = H^-1 L^-1
       if ((rc = blk_solve(c, 0, nb, d_in, d_out, 1, 0, 1, false))) return rc;
-      return c->tl_ok ? tl_apply(c, d_out, 1, n3, 1) : RBL_OK;
+      return c->tl_ok ? tl_apply(c, d_out, d_out, 1, n3, 1) : RBL_OK;
     }
     if ((rc = rbl_dev_reserve(c, c->d_tlZ, sizeof(double) * 3 * (size_t)n3))) return rc;
     double *t = (double *)c->d_tlZ.p;
     RBL_HIP(c, hipMemcpyAsync(t, d_in, sizeof(double) * (size_t)n3, hipMemcpyDeviceToDevice, c->stream));
     if (mode == 6) {                                   // G^-T = L^-T H^-T
-      if (c->tl_ok && (rc = tl_apply(c, t, 1, n3, 2))) return rc;
+      if (c->tl_ok && (rc = tl_apply(c, t, t, 1, n3, 2))) return rc;
       return blk_solve(c, 0, nb, t, d_out, 1, 0, 2, false);
     }
-    if (c->tl_ok && (rc = tl_apply(c, t, 1, n3, 0))) return rc;       // G x = L (H x)
+    if (c->tl_ok && (rc = tl_apply(c, t, t, 1, n3, 0))) return rc;       // G x = L (H x)
     return blk_trmv(c, 0, nb, t, d_out);
   }
   if (mode == 3 && d_in == d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 3 does not work in place");
@@ -1648,6 +1644,7 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
   if (variant >= 63 && variant <= 65) { c->blk_large = variant - 63; c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of large bodies never / always / when it pays
   if (variant == 83 || variant == 84) { c->blk_f32 = (variant == 84); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // single-precision copy of the large inverses off / on
+  if (variant == 91 || variant == 92) { c->gmres_predict = (variant == 92); c->gmres_last_used = 0; return RBL_OK; }   // launch-bound GMRES: convergence test every 4th iteration / where the previous solve and the residual's rate put it (default)
   if (variant == 87 || variant == 88) { c->tl_on = (variant == 88); c->tl_valid = false; return RBL_OK; }   // preconditioned root: block-Jacobi factor alone / two-level factor (default)
   if (variant == 85 || variant == 86) { c->lanczos_out_norm = (variant == 86); return RBL_OK; }       // preconditioned root: stop on the energy-norm / increment-norm (default) estimate
   if (variant == 81 || variant == 82) { c->lanczos_reorth = (variant == 82); return RBL_OK; }       // Lanczos: three-term recurrence only / full re-orthogonalisation (default)
@@ -2036,8 +2033,13 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   RBL_HIP(c, hipMemsetAsync(H, 0, sizeof(double) * (size_t)ldh * m, c->stream));
   rbl_launch_lanczos_init(c->stream, nsys, d_rhs, d_beta, V, part2);                    // V_0 = b/|b|, beta = |b|
   std::vector<double> Hh((size_t)ldh * m + 1), y;
-  // convergence test: every iteration when an iteration is expensive, every 4th when it is launch-bound
+  // convergence test: every iteration when an iteration is expensive.  When it is launch-bound a test (copy + stream
+  // drain) costs as much as half an iteration: the first one waits until two iterations before the count the previous
+  // solve needed (time steps repeat), later ones follow the residual's rate, at most four iterations apart; a test
+  // looks at every iteration since the one before, so the solve still ends at the first iteration that passes.
   const int check_every = ((int64_t)S.N_bod * S.N_blb > 20000) ? 1 : 4;
+  int next_check = check_every, last_checked = 0;
+  if (check_every > 1 && c->gmres_predict && c->gmres_last_used > 0) next_check = c->gmres_last_used >= 8 ? c->gmres_last_used - 2 : c->gmres_last_used;
   int used = 0;
   double resid = 1.0;
   // least squares min |beta e1 - H_k y| by Givens rotations on a host copy; returns the residual estimate
@@ -2084,16 +2086,29 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches
     rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
     used = j + 1;
-    if (rtol > 0.0 && (used % check_every == 0 || used == m)) {
+    if (rtol > 0.0 && (used >= next_check || used == m)) {
       RBL_HIP(c, hipMemcpyAsync(Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used), hipMemcpyDeviceToHost, c->stream));
       RBL_HIP(c, hipStreamSynchronize(c->stream));
-      // the test may only have become true somewhere in the last 4 iterations: take the first k that passes
-      int k0 = used - (check_every - 1) < 1 ? 1 : used - (check_every - 1), hit = 0;
-      for (int k = k0; k <= used; ++k) {
+      // the test may have become true anywhere since the last look: take the first k that passes
+      int hit = 0;
+      double r_before = resid;
+      for (int k = last_checked + 1; k <= used; ++k) {
+        r_before = resid;
         resid = solve_ls(k, y);
         if (resid < rtol) { hit = k; break; }
       }
       if (hit) { used = hit; break; }
+      last_checked = used;
+      int ahead = 1;
+      if (check_every > 1 && !c->gmres_predict) ahead = check_every - (used % check_every);
+      else if (check_every > 1) {                        // iterations the residual still needs at its current rate
+        ahead = check_every;
+        if (resid > 0.0 && r_before > resid) {
+          const double rem = std::log(rtol / resid) / std::log(resid / r_before);
+          ahead = rem < 1.0 ? 1 : (rem > (double)check_every ? check_every : (int)rem);
+        }
+      }
+      next_check = used + ahead;
     }
   }
   if (!(rtol > 0.0) || y.size() != (size_t)used) {
@@ -2108,6 +2123,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   if ((rc = rbl_apply_PC_dev(c, z, d_x))) return rc;                                   // x = P^-1 z
   if (iters_out) *iters_out = used;
   if (resid_out) *resid_out = resid;
+  if (rtol > 0.0) c->gmres_last_used = used;
   return finish_and_check(c);
 }
 

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__
 //             every body in vector d -- the bodies do not couple, one vector holds one column of all of them)
 // k_tl_E    : A = I + E from the dense sphere tensor (3 N_bod square, column-major), diagonal blocks dropped
 // k_tl_qt   : t[3 b + c] = Q_c,b . w_b      (nvec vectors)
-// k_tl_addq : w_b += sum_c Q_c,b (s[3 b + c] - t[3 b + c])   -- (Op - I) t with s = Op t
+// k_tl_addq : wo_b = w_b + sum_c Q_c,b (s[3 b + c] - t[3 b + c])   -- (Op - I) t with s = Op t; wo == w allowed
 __global__ __launch_bounds__(BT) void k_tl_orth(double *__restrict__ Z, long n3, int N_blb, double *__restrict__ Cb, unsigned *err)
 {
   __shared__ double s[6][BT];
@@ -640,14 +640,14 @@ __global__ __launch_bounds__(BT) void k_tl_qt(const double *__restrict__ Q, long
 }
 
 __global__ void k_tl_addq(const double *__restrict__ Q, long n3, int N_blb, const double *__restrict__ sv,
-                          const double *__restrict__ tt, long tpitch, double *__restrict__ w, long wpitch)
+                          const double *__restrict__ tt, long tpitch, const double *w, double *wo, long wpitch)
 {
   const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
   if (k >= n3) return;
   const long b = k / (3L * N_blb);
   const double *s = sv + (size_t)v * tpitch + 3 * b, *t = tt + (size_t)v * tpitch + 3 * b;
-  w[(size_t)v * wpitch + k] += Q[k] * (s[0] - t[0]) + Q[n3 + k] * (s[1] - t[1]) + Q[2 * n3 + k] * (s[2] - t[2]);
+  wo[(size_t)v * wpitch + k] = w[(size_t)v * wpitch + k] + Q[k] * (s[0] - t[0]) + Q[n3 + k] * (s[1] - t[1]) + Q[2 * n3 + k] * (s[2] - t[2]);
 }
 
 // K_t: unit translation of every body in direction d -> vector d of out ([3][n3])
@@ -792,8 +792,8 @@ void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, 
   hipLaunchKernelGGL(k_tl_qt, dim3(N_bod, nvec), dim3(BT), 0, st, d_Q, (long)n3, N_blb, d_w, (long)wpitch, d_t, (long)tpitch);
 }
 void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
-                        double *d_w, int64_t wpitch, int nvec)
+                        const double *d_w, double *d_wo, int64_t wpitch, int nvec)
 {
   hipLaunchKernelGGL(k_tl_addq, dim3((unsigned)((n3 + 255) / 256), nvec), dim3(256), 0, st, d_Q, (long)n3, N_blb, d_s, d_t, (long)tpitch,
-                     d_w, (long)wpitch);
+                     d_w, d_wo, (long)wpitch);
 }

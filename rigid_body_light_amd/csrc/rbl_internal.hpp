@@ -56,6 +56,8 @@ struct RblDevBuf {
 struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
   int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
+  int ni1 = 0;             // > 0: rows per lane of the one-vector kernel (0 = heuristic; experiments)
+  int sw = 0;              // > 0: waves per workgroup (0 = heuristic; experiments)
   int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
 
@@ -143,6 +145,8 @@ struct rbl_ctx {
   std::vector<TimedSpan> ev_spans;
   double t_ms[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
   int64_t t_calls[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
+  bool gmres_predict = true;    // rbl_set_tuning 91 / 92
+  int gmres_last_used = 0;      // iterations of the previous converged solve: where the next one looks first (launch-bound systems)
   // lanczos
   int lanczos_max_iter = 100;
   bool lanczos_out_norm = true;  // preconditioned root: final stopping test in the Euclidean norm of the increment (rbl_set_tuning 85 / 86)
@@ -298,6 +302,6 @@ void rbl_launch_tl_E(hipStream_t st, const double *d_Cs, const double *d_Cb, int
 void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_w, int64_t wpitch, int nvec,
                       double *d_t, int64_t tpitch);
 void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
-                        double *d_w, int64_t wpitch, int nvec);
+                        const double *d_w, double *d_wo, int64_t wpitch, int nvec);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);

@@ -23,6 +23,10 @@
 #include <type_traits>
 #include <cmath>
 
+#ifdef RBL_WAVE_TRACE
+extern __device__ unsigned long long *g_wave_trace;   // tools/wave_trace.hip
+#endif
+
 namespace {
 
 constexpr int TB = 256;  // threads per block = j-tile length
@@ -325,6 +329,21 @@ __device__ __forceinline__ double sym_first_lane(double v)      // lane 0's valu
   return __hiloint2double(hi, lo);
 }
 
+// Wave timeline of the symmetric kernel for tools/wave_trace.hip (never in the product build): every workgroup leaves
+// {start, end} of its first wave on the 100 MHz constant clock, its HW_ID and XCC_ID in g_wave_trace[4 * workgroup].
+#ifdef RBL_WAVE_TRACE
+#define RBL_WT_BEGIN const unsigned long long wt_begin = wall_clock64();
+#define RBL_WT_END                                                                                                        \
+  if (::g_wave_trace && threadIdx.x == 0) {                                                                                 \
+    unsigned long long *wt = ::g_wave_trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);                           \
+    wt[0] = wt_begin; wt[1] = wall_clock64();                                                                             \
+    wt[2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); wt[3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20); \
+  }
+#else
+#define RBL_WT_BEGIN
+#define RBL_WT_END
+#endif
+
 // PREC = 1 (relaxed product, two rows per lane only): tile pairs the far map proves free of overlaps AND safe for single
 // precision (k_tile_far, bit 1) are swept in packed single precision (rbl_pair_sym_pk), coordinates relative to the first
 // blob of the column tile (round 3; one origin per workgroup let the error grow with the extent of the suspension); their
@@ -354,6 +373,7 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
   // workgroups go to the 8 XCDs round-robin in launch order: rotate the row group with the chunk, or a group count that
   // is a multiple of 8 pins every group (and its triangular share of the work) to one XCD for the whole launch
   const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+  RBL_WT_BEGIN
   const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step, SW);   // first tile of the group (wave 0's)
   if (It00 >= T) return;
   int J0 = c * C;
@@ -513,6 +533,7 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
     }
   }
   if (flags) atomicOr(err, flags);
+  RBL_WT_END
 }
 
 // ---------------------------------------------------------------------------
@@ -1421,10 +1442,12 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // VALU-issue bound either way) but half the column-sum slab to write and re-read
   int ni = (t >= 128 * i_step) ? 2 : 1;
   if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
+  if (nrhs == 1 && tune.ni1 > 0) ni = tune.ni1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   // workgroups of SW_LARGE waves (= units of SW_LARGE consecutive super-tiles, see sym_row_of) for large systems; a shard
   // keeps them as long as every rank still gets >= 8 units
-  const int sw = (ni == 2 && tsup >= SW_LARGE * i_step * 8) ? SW_LARGE : 1;
+  int sw = (ni == 2 && tsup >= SW_LARGE * i_step * 8) ? SW_LARGE : 1;
+  if (tune.sw > 0) sw = tune.sw;
   const int tunits = (tsup + sw - 1) / sw;
   const int rowsI = ((tunits + i_step - 1) / i_step) * sw;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
@@ -1508,6 +1531,11 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   } else if (L.NI == 2) {
     if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
     else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+#ifdef RBL_WAVE_TRACE
+  } else if (L.SW == 2) {                  // experiment (tools/wave_trace.hip): one row per lane, two waves per workgroup
+    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+#endif
   } else {
     if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
     else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);

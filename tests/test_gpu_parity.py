@@ -1267,6 +1267,40 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub2, Ua2) < 1e-8
 
 
+def test_gmres_convergence_tests_follow_the_previous_solve():
+    """launch-bound systems: the first convergence test of a solve waits until two iterations before the previous solve's
+    count, later ones follow the residual's rate (rbl_api.hip: gmres_saddle_core_) -- WHEN the tests happen must not change
+    the answer: repeated solves return the count and the solution of the first (which had no history), an easier system
+    after a harder one still stops at its own first passing iteration, and a harder one after an easy one runs on"""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    from rigid_body_light_amd.krylov import DeterministicStepper
+    nb, nblb = 12, 42
+    c = make_config(nb, nblb, True)
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(c["a"], c["eta"], True, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    lib().rbl_set_blk_pc(ctx.h, 1)
+    ctx.set_config(c["X"], c["Q"])
+    st = DeterministicStepper(ctx, nb, nblb, dev)
+    Fb = np.random.default_rng(5).standard_normal(6 * nb)
+    runs = [st.solve(Fb, iters=80, rtol=1e-10) for _ in range(3)]
+    m0 = runs[0][2]
+    assert m0 >= 8 and runs[0][3] < 1e-10
+    for lam, U, m, resid in runs[1:]:
+        assert m == m0 and resid == runs[0][3]
+        assert torch.equal(U, runs[0][1]) and torch.equal(lam, runs[0][0])
+    lam_e, U_e, m_e, r_e = st.solve(Fb, iters=80, rtol=1e-3)             # easy after hard: first look would be at m0 - 2
+    assert m_e < m0 - 2 and r_e < 1e-3
+    ctx2 = DeviceContext(c["a"], c["eta"], True, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    lib().rbl_set_blk_pc(ctx2.h, 1)
+    ctx2.set_config(c["X"], c["Q"])
+    lam_f, U_f, m_f, r_f = DeterministicStepper(ctx2, nb, nblb, dev).solve(Fb, iters=80, rtol=1e-3)   # the same, without history
+    assert m_f == m_e and torch.equal(U_f, U_e)
+    lam_h, U_h, m_h, r_h = st.solve(Fb, iters=80, rtol=1e-10)            # hard after easy
+    assert m_h == m0 and torch.equal(U_h, runs[0][1])
+
+
 @pytest.mark.parametrize("wall", [False, True])
 def test_symmetric_kernel_equals_ordered_kernel_over_sizes(wall):
     """Cross-kernel sweep over blob counts around every layout switch of the symmetric kernel (tiles of 64, one / two rows
