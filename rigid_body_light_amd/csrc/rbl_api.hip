@@ -229,6 +229,24 @@ static int copy_d2h(rbl_ctx *c, void *dst, const void *src, size_t bytes)
   return RBL_OK;
 }
 
+// Small device -> host read that the host needs NOW (Krylov coefficients, norms): through a pinned buffer of the context and
+// a stream drain -- 11.6 us on MI355X; with a pageable target the runtime stages the copy itself and the same read costs
+// 21 us (tools/launch_costs.hip).
+constexpr size_t RBL_PIN_BYTES = (size_t)1 << 20;
+static int read_back(rbl_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+  if (bytes <= RBL_PIN_BYTES) {
+    if (!c->h_pin) RBL_HIP(c, hipHostMalloc(&c->h_pin, RBL_PIN_BYTES, hipHostMallocDefault));
+    RBL_HIP(c, hipMemcpyAsync(c->h_pin, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(dst, c->h_pin, bytes);
+    return RBL_OK;
+  }
+  RBL_HIP(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  return RBL_OK;
+}
+
 // read + clear the latched device flags (stream must be idle for h_err to be valid)
 static int finish_and_check(rbl_ctx *c)
 {
@@ -390,6 +408,7 @@ void rbl_destroy(rbl_ctx *c)
     if (c->d_err2) (void)hipFree(c->d_err2);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_coef) (void)hipHostFree(c->h_coef);
   }
   delete c;
@@ -1243,8 +1262,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     // (the host test is an O(m^3) eigen-solve: tests thin out as the basis grows -- every iteration up to 16, then every m/16-th)
     if (m < next_check && m != maxit) continue;
     next_check = m + std::max(check_every, m / 16);
-    RBL_HIP(c, hipMemcpyAsync(hs.data(), sc, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, c->stream));
-    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = read_back(c, hs.data(), sc, sizeof(double) * hs.size()))) return rc;
     bool all_conv = true;
     for (int v = 0; v < nvec; ++v) {
       const double *h = hs.data() + nsc * v;
@@ -1312,11 +1330,9 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
         }
         double h2[2] = {0.0, 0.0}, hx[2] = {0.0, 0.0};
         rbl_launch_dot2(c->stream, od, od, nullptr, n, d_dot);
-        RBL_HIP(c, hipMemcpyAsync(h2, d_dot, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-        RBL_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = read_back(c, h2, d_dot, sizeof(double) * 2))) return rc;
         rbl_launch_dot2(c->stream, ox, ox, nullptr, n, d_dot);
-        RBL_HIP(c, hipMemcpyAsync(hx, d_dot, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-        RBL_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = read_back(c, hx, d_dot, sizeof(double) * 2))) return rc;
         const double dout = hx[0] > 0.0 ? std::sqrt(h2[0] / hx[0]) : 0.0;
         // rho of the coefficient sequence (same contraction, other norm); resid[v] = d_m rho / (1 - rho) in the energy norm
         const double ratio = d_last[v] > 0.0 ? resid[v] / d_last[v] : 1.0;
@@ -1983,11 +1999,9 @@ int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double r
   rbl_launch_axpby(c->stream, nsys, 1.0, d_rhs, -1.0, r0, r0);                          // r0 = b - A x0
   double nn[2] = {0.0, 0.0};
   rbl_launch_dot2(c->stream, d_rhs, d_rhs, nullptr, nsys, dn);                          // |b|^2
-  RBL_HIP(c, hipMemcpyAsync(&nn[0], dn, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = read_back(c, &nn[0], dn, sizeof(double)))) return rc;
   rbl_launch_dot2(c->stream, r0, r0, nullptr, nsys, dn);                                // |r0|^2
-  RBL_HIP(c, hipMemcpyAsync(&nn[1], dn, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  RBL_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = read_back(c, &nn[1], dn, sizeof(double)))) return rc;
   const double nb2 = nn[0], nr2 = nn[1];
   const double scale = (nb2 > 0.0 && nr2 > 0.0) ? std::sqrt(nb2 / nr2) : 1.0;          // |b| / |r0|
   if (nr2 == 0.0) { if (iters_out) *iters_out = 0; if (resid_out) *resid_out = 0.0; return RBL_OK; }   // x0 already solves it
@@ -2087,8 +2101,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
     used = j + 1;
     if (rtol > 0.0 && (used >= next_check || used == m)) {
-      RBL_HIP(c, hipMemcpyAsync(Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used), hipMemcpyDeviceToHost, c->stream));
-      RBL_HIP(c, hipStreamSynchronize(c->stream));
+      if ((rc = read_back(c, Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used)))) return rc;
       // the test may have become true anywhere since the last look: take the first k that passes
       int hit = 0;
       double r_before = resid;
@@ -2112,8 +2125,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     }
   }
   if (!(rtol > 0.0) || y.size() != (size_t)used) {
-    RBL_HIP(c, hipMemcpyAsync(Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used), hipMemcpyDeviceToHost, c->stream));
-    RBL_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = read_back(c, Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used)))) return rc;
     resid = solve_ls(used, y);
   }
   for (int k = 0; k < used; ++k)

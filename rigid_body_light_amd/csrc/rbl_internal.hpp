@@ -110,6 +110,7 @@ struct rbl_ctx {
   unsigned *d_err = nullptr;
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
+  void *h_pin = nullptr;      // pinned, 1 MB: target of the small device-to-host reads of the solver loops (read_back)
   std::vector<double> h_xq;   // [X | Q] packed for one upload
   bool dev_cfg_valid = false; // d_cfg holds the current reference configuration
   double *h_coef = nullptr;   // pinned, 2 x 512 doubles: Krylov coefficients go up without draining the stream (the next write is a solve later)
