@@ -811,7 +811,7 @@ def main():
         ctx.set_tuning(0, v)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
     nrows = sm.row1 - sm.row0
-    guard = LineGuard(world, rank, limit_s=1500)
+    guard = LineGuard(world, rank, limit_s=500)      # below the 600 s after which the RCCL watchdog aborts a stuck rank
 
     F_full_host = np.random.default_rng(2).standard_normal(3 * N)
     F_local = torch.from_numpy(F_full_host[3 * sm.row0:3 * sm.row1].copy()).to(dev)
