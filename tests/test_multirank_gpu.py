@@ -118,19 +118,43 @@ def test_three_rank_uneven_split_brownian_step(monkeypatch, block_pc):
 
 
 @pytest.mark.parametrize("world", [1, 2])
-def test_cfg4_size_sharded_brownian_step(monkeypatch, world):
+def test_cfg4_size_sharded_brownian_step(monkeypatch, world, orc, tmp_path):
     """BASELINE configs[3] at full size (200 x shell_N_642, wall-corrected + Brownian), ONE stochastic midpoint step:
     the multi-GPU driver (ShardedBrownianStepper: tile-pair-sharded products, block-Jacobi preconditioned Lanczos with
     per-rank body factors, block-PC GMRES) at world size 1 and as a 2-rank gloo rehearsal on one GPU, against the
-    single-process BrownianStepper with the same injected noise."""
+    single-process BrownianStepper with the same injected noise -- and against the CPU ORACLE: the saddle system the
+    sharded solve was given, evaluated by the oracle on every blob row of two whole bodies (one from each rank's share)
+    and on their force / torque rows, is satisfied by the solution the sharded solve returned."""
+    import numpy as np
+    from rigid_body_light_amd import make_config
+    dump = str(tmp_path / "cfg4_solve.npz")
     monkeypatch.setenv("RBL_CHECK_BODIES", "200")
     monkeypatch.setenv("RBL_CHECK_BLOBS", "642")
     monkeypatch.setenv("RBL_CHECK_BLOCK_PC", "1")
     monkeypatch.setenv("RBL_CHECK_LANCZOS_TOL", "1e-10")
     monkeypatch.setenv("RBL_CHECK_GMRES_TOL", "1e-10")
+    monkeypatch.setenv("RBL_CHECK_DUMP", dump)
     p = _torchrun(world, ["tools/check_sharded_brownian.py"], timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "world %d" % world in p.stdout and _max_diff(p.stdout, world) < 1e-8
+    nb, nblb = 200, 642
+    c = make_config(nb, nblb, True)
+    z = np.load(dump)
+    n3 = 3 * nb * nblb
+    lam, U, rhs = z["x"][:n3], z["x"][n3:].reshape(nb, 6), z["rhs"]
+    r = orc.multi_body_pos(z["X"], z["Q"], c["cfg"] - c["cfg"].mean(axis=0))
+    bnorm = np.linalg.norm(rhs)
+    for b in (37, 163):                                   # [M lambda - K U ; K^T lambda] = rhs   (src/Rigid.py:73-80)
+        rows = slice(3 * nblb * b, 3 * nblb * (b + 1))
+        Ml = orc.apply_M_rows(lam, r, nblb * b, nblb * (b + 1), c["a"], c["eta"], True, nthreads=8)
+        lever = r[rows].reshape(nblb, 3) - z["X"][b]
+        KU = U[b, :3] + np.cross(U[b, 3:], lever)
+        res_blob = Ml - KU.reshape(-1) - rhs[rows]
+        lb = lam[rows].reshape(nblb, 3)
+        ktl = np.concatenate([lb.sum(axis=0), np.cross(lever, lb).sum(axis=0)])
+        res_body = ktl - rhs[n3 + 6 * b:n3 + 6 * b + 6]
+        # a body's rows carry 1/200 of the residual on average: GMRES stopped at 1e-10 |rhs| for the whole vector
+        assert np.linalg.norm(res_blob) < 2e-9 * bnorm and np.linalg.norm(res_body) < 2e-9 * bnorm
 
 
 def test_world1_nccl_group_runs_the_rccl_code_path():

@@ -43,6 +43,16 @@ def main():
             cls = ShardedBrownianStepper if native else TorchShardedBrownianStepper
             st = cls(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
                      c["dt"], lanczos_tol=ltol, lanczos_max_iter=255)
+            dump = os.environ.get("RBL_CHECK_DUMP", "")
+            if dump and rank == 0:        # for the test's ORACLE check of the sharded solve: system, solution and the predictor configuration it lives at
+                solve = st.saddle_solve
+
+                def capture(rhs, iters, rtol, solve=solve, ctx=ctx):
+                    x, m_, r_ = solve(rhs, iters, rtol)
+                    Xh, Qh = ctx.get_config(nb)
+                    np.savez(dump, rhs=rhs.cpu().numpy(), x=x.cpu().numpy(), X=Xh, Q=Qh)
+                    return x, m_, r_
+                st.saddle_solve = capture
             m, resid = st.step(Fb, W=W, iters=150, rtol=gtol)
         else:
             ctx.set_lanczos(255, ltol)
