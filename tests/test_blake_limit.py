@@ -76,11 +76,12 @@ def test_oracle_wall_mobility_tends_to_blake_tensor():
 
 
 @pytest.mark.gpu
-def test_hip_wall_product_tends_to_blake_tensor():
+def test_hip_wall_product_tends_to_blake_tensor(shell12):
     """the same limit through the C ABI: U_i = M_ij F_j of the HIP product for two blobs at different heights"""
     from rigid_body_light_amd import RigidBody
     eta, a = 0.8, 1e-3
-    rb = RigidBody(np.zeros((1, 3)), np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0, 0.0]]), a, eta, 0.01, wall_PC=True)
+    # (the object needs a rigid body to exist -- any will do: apply_M takes the blob set it is given)
+    rb = RigidBody(shell12, np.array([[0.0, 0.0, 3.0]]), np.array([[1.0, 0.0, 0.0, 0.0]]), a, eta, 0.01, wall_PC=True)
     worst = 0.0
     for x, y in _pairs(25, 2):
         r = np.concatenate([x, y])
