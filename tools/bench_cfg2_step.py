@@ -37,3 +37,12 @@ for rnd in range(3):
             m, r = bst.step(Fb, seed=seed0 + 1 + k, method=2, iters=200, rtol=1e-8); its.append(m)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         print("round %d tuning %d: %.3f ms per step, GMRES iterations %s" % (rnd, t, dt * 1e3, its), flush=True)
+    # the same steps through the one-call C entry point (rbl_step_brownian): no Python between the pieces of a step
+    ctx.set_config(c["X"], c["Q"])
+    its = []
+    ctx.step_brownian(Fb, 200, 1e-8, seed=100 * rnd, method=2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        m, r = ctx.step_brownian(Fb, 200, 1e-8, seed=100 * rnd + 1 + k, method=2); its.append(m)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    print("round %d one-call entry (tuning %d): %.3f ms per step, GMRES iterations %s" % (rnd, tb, dt * 1e3, its), flush=True)
