@@ -383,7 +383,10 @@ int rbl_sync_check(rbl_ctx *ctx);
  * every new vector re-orthogonalised against the whole stored basis (default);
  * 91 / 92: rbl_gmres_saddle_dev on launch-bound systems (<= 20 000 blobs): convergence test (a copy of the Hessenberg
  * columns + a stream drain) every 4th iteration / first two iterations before the previous solve's count, then where the
- * residual's rate puts it (default); either way the solve ends at the first iteration that passes.  All per context. */
+ * residual's rate puts it (default); either way the solve ends at the first iteration that passes;
+ * 93 / 94: symmetric pair kernels of large systems (four-wave workgroups): one work unit per workgroup, dealt to the XCDs in
+ * launch order / a fixed set of resident workgroups drawing units from a counter (default: an XCD that runs faster takes
+ * more units; the slabs are addressed by unit, so results are bitwise the same either way).  All per context. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

@@ -1660,6 +1660,7 @@ int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
   if (variant == 73 || variant == 74) { c->bf_wall_approx = (variant == 74); c->dev_pc_valid = false; c->dev_blk_valid = false; return RBL_OK; }   // wall case: free-space body-frame factor as an APPROXIMATE block factor off / on
   if (variant >= 63 && variant <= 65) { c->blk_large = variant - 63; c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // explicit inverses of large bodies never / always / when it pays
   if (variant == 83 || variant == 84) { c->blk_f32 = (variant == 84); c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; return RBL_OK; }   // single-precision copy of the large inverses off / on
+  if (variant == 93 || variant == 94) { c->sym_tune.queue = (variant == 93) ? -1 : 0; return RBL_OK; }   // large systems: one unit per workgroup in launch order / work queue (default)
   if (variant == 91 || variant == 92) { c->gmres_predict = (variant == 92); c->gmres_last_used = 0; return RBL_OK; }   // launch-bound GMRES: convergence test every 4th iteration / where the previous solve and the residual's rate put it (default)
   if (variant == 87 || variant == 88) { c->tl_on = (variant == 88); c->tl_valid = false; return RBL_OK; }   // preconditioned root: block-Jacobi factor alone / two-level factor (default)
   if (variant == 85 || variant == 86) { c->lanczos_out_norm = (variant == 86); return RBL_OK; }       // preconditioned root: stop on the energy-norm / increment-norm (default) estimate

@@ -58,6 +58,7 @@ struct RblSymTune {        // per-context tuning of the symmetric matvec kernels
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
   int ni1 = 0;             // > 0: rows per lane of the one-vector kernel (0 = heuristic; experiments)
   int sw = 0;              // > 0: waves per workgroup (0 = heuristic; experiments)
+  int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (rbl_set_tuning 93); 0: work queue there (94)
   int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
 

@@ -231,8 +231,9 @@ __global__ __launch_bounds__(TS) void k_tile_bbox(const double *__restrict__ r, 
 // farmap[S][J] = 1 when every blob of tile J is farther than 2a from every blob of row super-tile S
 // (NI consecutive tiles): one byte per (super-tile, tile), read as a wave-uniform value by the matvec kernel.
 __global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbox, int T, int NI,
-                                                  unsigned char *__restrict__ farmap)
+                                                  unsigned char *__restrict__ farmap, unsigned *queue)
 {
+  if (queue && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue = 0u;   // work queue of the pair kernel that follows
   // bit 0: every blob of column tile J is farther than 2a from every row of super-tile S (no pair can overlap);
   // bit 1: ... and the relaxed (single-precision) sweep of the pair is accurate to ~1e-6 of every separation.  That sweep
   //        takes coordinates relative to the first blob of tile J: |x_j - o| <= d_J (diagonal of J's box), |x_i - o| <= gap +
@@ -333,15 +334,15 @@ __device__ __forceinline__ double sym_first_lane(double v)      // lane 0's valu
 // {start, end} of its first wave on the 100 MHz constant clock, its HW_ID and XCC_ID in g_wave_trace[4 * workgroup].
 #ifdef RBL_WAVE_TRACE
 #define RBL_WT_BEGIN const unsigned long long wt_begin = wall_clock64();
-#define RBL_WT_END                                                                                                        \
-  if (::g_wave_trace && threadIdx.x == 0) {                                                                                 \
-    unsigned long long *wt = ::g_wave_trace + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);                           \
+#define RBL_WT_END(unit)                                                                                                  \
+  if (::g_wave_trace && threadIdx.x == 0) {                                                                               \
+    unsigned long long *wt = ::g_wave_trace + 4 * (size_t)(unit);                                                        \
     wt[0] = wt_begin; wt[1] = wall_clock64();                                                                             \
     wt[2] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); wt[3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20); \
   }
 #else
 #define RBL_WT_BEGIN
-#define RBL_WT_END
+#define RBL_WT_END(unit)
 #endif
 
 // PREC = 1 (relaxed product, two rows per lane only): tile pairs the far map proves free of overlaps AND safe for single
@@ -358,7 +359,8 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
                                                         const double *__restrict__ F,
                                                         double *__restrict__ slabI,
                                                         double *__restrict__ slabJ, long N, SymLayout L, RblParams P,
-                                                        unsigned *err, const unsigned char *__restrict__ farmap)
+                                                        unsigned *err, const unsigned char *__restrict__ farmap,
+                                                        unsigned *queue)
 {
   // A lane owns NI rows (row "super-tile" I = tiles NI*I .. NI*I+NI-1): the j data read from
   // LDS and the ds_add of M_ji F_i are shared by NI pair evaluations.  The SW waves of the workgroup own SW
@@ -370,9 +372,14 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
-  // workgroups go to the 8 XCDs round-robin in launch order: rotate the row group with the chunk, or a group count that
-  // is a multiple of 8 pins every group (and its triangular share of the work) to one XCD for the whole launch
-  const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+  unsigned flags = 0;
+  __shared__ double sO[3];                          // relaxed product: origin of the single-precision coordinates = first blob of the j tile
+  // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
+  // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  // one work unit: row group g x chunk c (everything below runs once per unit; `return` ends the unit)
+  auto sweep_unit = [&](const int c, const int g, const unsigned unit) {
   RBL_WT_BEGIN
   const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step, SW);   // first tile of the group (wave 0's)
   if (It00 >= T) return;
@@ -384,13 +391,6 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
   const int I = sym_row_of(e, L.i_first, L.i_step, SW);                // this wave's super-tile
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);                      // a wave without rows never sweeps, only keeps step
-  unsigned flags = 0;
-  __shared__ double sO[3];                          // relaxed product: origin of the single-precision coordinates = first blob of the j tile
-
-  // All pair arithmetic of this kernel runs in coordinates divided by the blob radius (the mobility entries
-  // are functions of r/a only): Pu is the a = 1 parameter set, positions are scaled once when loaded.
-  const RblParams Pu = unit_params(P);
-  const RblWallK WK = rbl_wall_k_resident();
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -532,8 +532,30 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
       }
     }
   }
+  RBL_WT_END(unit)
+  };
+  if (!queue) {
+    // one unit per workgroup.  Workgroups go to the 8 XCDs round-robin in launch order: rotate the row group with the chunk,
+    // or a group count that is a multiple of 8 pins every group (and its triangular share of the work) to one XCD
+    sweep_unit((int)blockIdx.y, (int)((blockIdx.x + blockIdx.y) % gridDim.x), blockIdx.y * gridDim.x + blockIdx.x);
+  } else {
+    // WORK QUEUE (large systems): a fixed set of resident workgroups draws units from one counter until it runs dry, so an
+    // XCD that runs faster -- they differ by up to 5 % under fp64 load, and launch-order dispatch deals every XCD the same
+    // number of workgroups -- simply takes more units, and nobody idles for longer than one unit at the end.  The slabs are
+    // addressed by unit, not by workgroup: results do not depend on who swept what.  Long chunks first.
+    __shared__ unsigned s_unit;
+    const unsigned n_units = (unsigned)L.rowsG * (unsigned)L.nch;
+    for (;;) {
+      __syncthreads();                                   // the previous unit's LDS is dead
+      if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u);
+      __syncthreads();
+      const unsigned u = s_unit;
+      if (u >= n_units) break;
+      const int by = (int)(u / (unsigned)L.rowsG), bx = (int)(u - (unsigned)by * (unsigned)L.rowsG);
+      sweep_unit(L.nch - 1 - by, (bx + by) % L.rowsG, u);
+    }
+  }
   if (flags) atomicOr(err, flags);
-  RBL_WT_END
 }
 
 // ---------------------------------------------------------------------------
@@ -544,7 +566,7 @@ template <bool WALL, int NI, int SW, int PREC>
 __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
                                                          double *__restrict__ slabI, double *__restrict__ slabJ, long N,
                                                          SymLayout L, RblParams P, unsigned *err,
-                                                         const unsigned char *__restrict__ farmap)
+                                                         const unsigned char *__restrict__ farmap, unsigned *queue)
 {
   static_assert(PREC == 0 || NI == 2, "the packed single-precision sweep carries the two rows of a lane");
   __shared__ double2_t sP0[TS], sP1[TS], sP2[TS], sP3[TS], sP4[TS];  // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
@@ -553,7 +575,12 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int T = L.T, C = L.C;
-  const int c = blockIdx.y, g = (int)((blockIdx.x + blockIdx.y) % gridDim.x);   // see k_apply_M_sym
+  const long n3 = 3 * N;
+  unsigned flags = 0;
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  __shared__ double sO[3];                          // relaxed product: origin = first blob of the j tile (see k_apply_M_sym)
+  auto sweep_unit = [&](const int c, const int g) {     // one work unit (see k_apply_M_sym)
   const int It00 = NI * sym_row_of(SW * g, L.i_first, L.i_step, SW);
   if (It00 >= T) return;
   int J0 = c * C;
@@ -564,10 +591,6 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
   const int I = sym_row_of(e, L.i_first, L.i_step, SW);
   const bool wlive = e < L.rowsI && NI * I < T;
   const int It0 = wlive ? NI * I : (1 << 30);
-  const long n3 = 3 * N;
-  unsigned flags = 0;
-  const RblParams Pu = unit_params(P);
-  const RblWallK WK = rbl_wall_k_resident();
   auto load_blob = [&](long idx, double &x, double &y, double &z, RblV3 &f0, RblV3 &f1) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -591,7 +614,6 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
     load_blob(wlive ? (long)(It0 + a) * TS + lane : N + 1 + a, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
     ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = ui0[a];
   }
-  __shared__ double sO[3];                          // relaxed product: origin = first blob of the j tile (see k_apply_M_sym)
   rbl_f2 F0x = {0, 0}, F0y = {0, 0}, F0z = {0, 0}, F1x = {0, 0}, F1y = {0, 0}, F1z = {0, 0};
   if (PREC) {
     const int a1 = NI - 1;
@@ -718,6 +740,22 @@ __global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restric
         double *p1 = slabI + sym_idxI(L, c, 1, (long)(It0 + a) * TS + lane);
         p1[0] = ui1[a].x; p1[1] = ui1[a].y; p1[2] = ui1[a].z;
       }
+    }
+  }
+  };
+  if (!queue) {
+    sweep_unit((int)blockIdx.y, (int)((blockIdx.x + blockIdx.y) % gridDim.x));
+  } else {                                              // work queue, as in k_apply_M_sym
+    __shared__ unsigned s_unit;
+    const unsigned n_units = (unsigned)L.rowsG * (unsigned)L.nch;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_unit = atomicAdd(queue, 1u);
+      __syncthreads();
+      const unsigned u = s_unit;
+      if (u >= n_units) break;
+      const int by = (int)(u / (unsigned)L.rowsG), bx = (int)(u - (unsigned)by * (unsigned)L.rowsG);
+      sweep_unit(L.nch - 1 - by, (bx + by) % L.rowsG);
     }
   }
   if (flags) atomicOr(err, flags);
@@ -1479,39 +1517,48 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
   if (C_out) *C_out = L.C;
   // slabs + tile bounding boxes + far map (one byte per (row super-tile, tile))
   return ((sym_slabI_blobs(L) + sym_slabJ_blobs(L)) * 3 * nrhs + (size_t)L.T * 6) * sizeof(double) +
-         (size_t)((L.T + L.NI - 1) / L.NI) * (size_t)L.T + 64;
+         (size_t)((L.T + L.NI - 1) / L.NI) * (size_t)L.T + 64 + 128;      // (+ the work-queue counter, 64-byte aligned, behind the far map)
 }
 
 template <bool WALL, int NI, int SW>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
-                       double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed)
+                       double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed,
+                       int n_cu, bool use_queue)
 {
   const int T = L.T, nrhs = L.nrhs;
   dim3 grid((unsigned)L.rowsG, (unsigned)L.nch), block(TS * SW);
   const int64_t n = 3 * n_blobs;
   dim3 g2((unsigned)((n + 63) / 64), (unsigned)nrhs), b2(64 * RG);
   unsigned char *farmap = nullptr;
+  unsigned *queue = nullptr;
   if (NI == 2) {   // large systems only: two more tiny launches, then most tile pairs skip the overlap test
     double *bbox = slabJ + sym_slabJ_blobs(L) * 3 * nrhs;
     farmap = (unsigned char *)(bbox + (size_t)T * 6);
     const int nsup = (T + NI - 1) / NI;
+    // work queue (multi-wave workgroups = large systems): its counter sits behind the far map and is zeroed by k_tile_far
+    if (use_queue && SW > 1) {
+      queue = (unsigned *)(((uintptr_t)(farmap + (size_t)nsup * (size_t)T) + 63) & ~(uintptr_t)63);
+      // more workgroups than can be resident do no harm (late ones find the queue empty); fewer would leave CUs idle
+      const unsigned want = (unsigned)(n_cu > 0 ? n_cu : 256) * 4u, have = (unsigned)L.rowsG * (unsigned)L.nch;
+      grid = dim3(want < have ? want : have, 1);
+    }
     hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)T), dim3(TS), 0, st, d_r, (long)n_blobs, P.inv_a, bbox);
     hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
-                       (const double *)bbox, T, NI, farmap);
+                       (const double *)bbox, T, NI, farmap, queue);
   }
   constexpr int PR = (NI == 2) ? 1 : 0;      // the relaxed form exists for two rows per lane
   if (nrhs == 2 && relaxed && NI == 2)
     hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW, PR>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
-                       d_err, (const unsigned char *)farmap);
+                       d_err, (const unsigned char *)farmap, queue);
   else if (nrhs == 2)
     hipLaunchKernelGGL((k_apply_M_sym2<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
-                       d_err, (const unsigned char *)farmap);
+                       d_err, (const unsigned char *)farmap, queue);
   else if (relaxed && NI == 2)
     hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, PR>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
-                       d_err, (const unsigned char *)farmap);
+                       d_err, (const unsigned char *)farmap, queue);
   else
     hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
-                       d_err, (const unsigned char *)farmap);
+                       d_err, (const unsigned char *)farmap, queue);
   hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
 }
 
@@ -1526,19 +1573,19 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
   const bool relaxed = tune.relaxed != 0;
   if (L.NI == 2 && L.SW == SW_LARGE) {
-    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
-    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
+    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
   } else if (L.NI == 2) {
-    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
-    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed);
+    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
+    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
 #ifdef RBL_WAVE_TRACE
   } else if (L.SW == 2) {                  // experiment (tools/wave_trace.hip): one row per lane, two waves per workgroup
-    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
-    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
+    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
 #endif
   } else {
-    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
-    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false);
+    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
+    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
   }
 }
 

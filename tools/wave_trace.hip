@@ -2,7 +2,7 @@
 // workgroup's wave started and ended (100 MHz constant clock) and on which XCD / SE / CU / SIMD it ran.  Compiles the
 // product's own kernel source with -DRBL_WAVE_TRACE (the hooks are empty in the library build).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DRBL_WAVE_TRACE -Irigid_body_light_amd/csrc tools/wave_trace.hip -o tools/wave_trace
-//   tools/wave_trace [n_blobs [wall [rows_per_lane [chunk [waves_per_workgroup]]]]] > gpurun_out/wave_trace.csv       (summary on stderr)
+//   tools/wave_trace [n_blobs [wall [rows_per_lane [chunk [waves_per_workgroup [queue: -1 off]]]]]] > gpurun_out/wave_trace.csv       (summary on stderr)
 #include <hip/hip_runtime.h>
 __device__ unsigned long long *g_wave_trace = nullptr;
 #include "rbl_kernels.hip"
@@ -28,6 +28,7 @@ int main(int argc, char **argv)
   if (argc > 3) tune.ni1 = atoi(argv[3]);
   if (argc > 4) tune.chunk = atoi(argv[4]);
   if (argc > 5) tune.sw = atoi(argv[5]);
+  if (argc > 6) tune.queue = atoi(argv[6]);
   const size_t wb = rbl_apply_M_sym_bytes(N, ncu, 1, 1, tune);
   double *dr, *dF, *dU, *dW; unsigned *derr;
   hipMalloc((void **)&dr, 24 * N); hipMalloc((void **)&dF, 24 * N); hipMalloc((void **)&dU, 24 * N); hipMalloc((void **)&dW, wb);
