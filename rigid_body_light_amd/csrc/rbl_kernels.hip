@@ -562,8 +562,13 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 // The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
 // coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back.
 // ---------------------------------------------------------------------------
+#ifndef RBL_SYM2_MIN_WAVES
+#define RBL_SYM2_MIN_WAVES 1      // waves per SIMD the two-vector wall instance is held to.  Measured with 3 (tools/build_variant.sh s2w3
+                                  // -DRBL_SYM2_MIN_WAVES=3: 168 VGPRs + 232 B of scratch instead of 235 VGPRs): Brownian step 608.6-609.1 ms
+                                  // against 608.9-609.3 -- no change, left at the compiler's choice
+#endif
 template <bool WALL, int NI, int SW, int PREC>
-__global__ __launch_bounds__(TS *SW) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
+__global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? RBL_SYM2_MIN_WAVES : 1) void k_apply_M_sym2(const double *__restrict__ r, const double *__restrict__ F,
                                                          double *__restrict__ slabI, double *__restrict__ slabJ, long N,
                                                          SymLayout L, RblParams P, unsigned *err,
                                                          const unsigned char *__restrict__ farmap, unsigned *queue)
