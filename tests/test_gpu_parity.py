@@ -1267,6 +1267,54 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
     assert rel(Ub2, Ua2) < 1e-8
 
 
+@pytest.mark.parametrize("general_solver", [False, True])
+def test_restart_from_get_config_reproduces_the_trajectory_bitwise(shell12, general_solver):
+    """checkpoint / resume: the reference's only state export is getConfig / setConfig (c_rigid_obj.cpp:201-255; SURVEY.md
+    section 5).  Here that IS the whole state of a Brownian trajectory: the noise is a function of the caller's seed, every
+    sum on the device has a fixed order.  Four stochastic midpoint steps in one context == two steps, get_config, a NEW
+    context started from it, two more steps with the same seeds -- bit for bit when re-normalising the saved quaternions is
+    a no-op, to rounding otherwise."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    if general_solver:                                     # 336 blobs: the multi-kernel GMRES / Lanczos loops
+        from rigid_body_light_amd import make_config
+        nb = 8
+        cc = make_config(nb, 42, True)
+        X, Q, cfg, rad = cc["X"], cc["Q"], cc["cfg"], cc["a"]
+    else:                                                  # 60 blobs: the whole solve in one kernel (rbl_small.hip)
+        nb = 5
+        X, Q = random_positions(nb, wall=True, seed=77)
+        X[:, 2] += 2.0
+        cfg, rad = shell12, 1.0
+    F = np.tile([0.0, 0.0, 0.1, 0.0, 0.0, 0.0], nb)
+
+    def fresh(Xc, Qc):
+        ctx = DeviceContext(rad, 1.0, True, cfg=cfg, dt=0.01, kBT=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_lanczos(100, 1e-8)
+        ctx.set_config(Xc, Qc)
+        return ctx
+
+    a = fresh(X, Q)
+    for n in range(4):
+        a.step_brownian(F, 60, 1e-10, seed=100 + n, method=2)
+    Xa, Qa = a.get_config(nb)
+    b = fresh(X, Q)
+    for n in range(2):
+        b.step_brownian(F, 60, 1e-10, seed=100 + n, method=2)
+    Xm, Qm = b.get_config(nb)
+    c2 = fresh(Xm.copy(), Qm.copy())
+    for n in range(2, 4):
+        c2.step_brownian(F, 60, 1e-10, seed=100 + n, method=2)
+    Xc, Qc = c2.get_config(nb)
+    assert np.abs(Xa - X).max() > 1e-3                     # it moved
+    # setConfig normalises the quaternions it is given (:216); on saved unit quaternions that division can move a last bit,
+    # and the two trajectories then differ by rounding -- nothing else distinguishes them
+    assert np.abs(Xa - Xc).max() < 1e-12 and np.abs(Qa - Qc).max() < 1e-12
+    if np.array_equal(Qm / np.linalg.norm(Qm, axis=1, keepdims=True), Qm):
+        assert np.array_equal(Xa, Xc) and np.array_equal(Qa, Qc)
+
+
 def test_gmres_convergence_tests_follow_the_previous_solve():
     """launch-bound systems: the first convergence test of a solve waits until two iterations before the previous solve's
     count, later ones follow the residual's rate (rbl_api.hip: gmres_saddle_core_) -- WHEN the tests happen must not change
