@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """CPU check of the device pair arithmetic (host build of rbl_pair.hpp, see pair_host.cpp) against the reference
 fixtures in tests/golden/: prints the worst error of the fast ordered form and of the symmetric form (M_ij and its
-transpose M_ji) relative to max(|block|, free-space scale).  Development aid for algebra changes in rbl_pair.hpp."""
+transpose M_ji) relative to max(|block|, free-space scale).  Development aid for algebra changes in rbl_pair.hpp (lives under
+tests/ because it uses the oracle as its checker).   python tests/host_pair/check.py"""
 import ctypes as C
 import json
 import os
@@ -13,8 +14,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SO = "/tmp/libpair_host.so"
 subprocess.check_call(["g++", "-O2", "-ffp-contract=fast", "-mfma", "-std=c++17", "-shared", "-fPIC",
-                       "-I" + os.path.join(ROOT, "tools", "host_pair"), "-o", SO,
-                       os.path.join(ROOT, "tools", "host_pair", "pair_host.cpp")])
+                       "-I" + os.path.join(ROOT, "tests", "host_pair"), "-o", SO,
+                       os.path.join(ROOT, "tests", "host_pair", "pair_host.cpp")])
 L = C.CDLL(SO)
 dp = C.POINTER(C.c_double)
 L.fast_block.argtypes = [dp, dp, C.c_int, C.c_int, C.c_double, C.c_int, dp]

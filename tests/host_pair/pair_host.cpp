@@ -1,5 +1,5 @@
 // Host build of the device pair arithmetic (rbl_pair.hpp) for CPU-side algebra checks -- see hip/hip_runtime.h here.
-//   g++ -O2 -ffp-contract=fast -mfma -shared -fPIC -Itools/host_pair -o /tmp/libpair_host.so tools/host_pair/pair_host.cpp
+//   g++ -O2 -ffp-contract=fast -mfma -shared -fPIC -Itests/host_pair -o /tmp/libpair_host.so tests/host_pair/pair_host.cpp
 #include "../../rigid_body_light_amd/csrc/rbl_pair.hpp"
 
 static RblParams make_params(double a)
