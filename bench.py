@@ -477,11 +477,11 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         d.update({"rtol": 1e-8, "preconditioner": "block-diagonal, per-body factors rebuilt every 4th step",
                   "initial_guess": "quadratic extrapolation of the last three solutions (constant body force)"})
         out["converged"] = d
-        # the same with the opt-in relaxation (rbl_set_tuning 52): the residual b - A x0 of the extrapolated guess is fp64,
+        # the same with the opt-in relaxation (RBL_OPT_RELAXED_KRYLOV = 1): the residual b - A x0 of the extrapolated guess is fp64,
         # the 1-2 products of the correction solve run on the packed-single-precision far field (inexact Krylov)
-        ctx.set_tuning(0, 52)
+        ctx.set_option("relaxed_krylov", 1)
         d = timed(lambda k: stp.step(Fb, 200, 1e-8))
-        ctx.set_tuning(0, 51)
+        ctx.set_option("relaxed_krylov", 0)
         d.update({"rtol": 1e-8, "relaxed_products": True})
         out["converged_relaxed"] = d
         lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
@@ -494,10 +494,10 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
         for v in args.tune:
             bctx.set_tuning(0, v)
-        if relaxed:                    # inexact Krylov (rbl_set_tuning 52): see the `relaxation` note below
-            bctx.set_tuning(0, 52)
-        if energy:                     # stop the root on its energy-norm estimate (rbl_set_tuning 85): see `lanczos_norm` below
-            bctx.set_tuning(0, 85)
+        if relaxed:                    # inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1): see the `relaxation` note below
+            bctx.set_option("relaxed_krylov", 1)
+        if energy:                     # stop the root on its energy-norm estimate (RBL_OPT_LANCZOS_EUCLID_NORM = 0): see `lanczos_norm` below
+            bctx.set_option("lanczos_euclid_norm", 0)
         if world > 1:
             from rigid_body_light_amd.dist import ShardedMobility
             bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
@@ -524,7 +524,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
                                 "rounds 1-2 effectively used that one (fewer iterations, larger Euclidean error)",
                 "root_identity_error": "|root(s) - B M v| / |B M v| with s = G^-1 B^-1 root(W), v = G^-T W for the root x = B G (G^-1 M G^-T)^{1/2} W "
                                        "the step uses (G: two-level factor), measured after the timed steps at the entry's Lanczos tolerance (zero for an exact root)",
-                "relaxation": "the *_relaxed entry is opt-in (rbl_set_tuning 52), everything else is fp64 throughout: an inexact Krylov "
+                "relaxation": "the *_relaxed entry is opt-in (RBL_OPT_RELAXED_KRYLOV = 1), everything else is fp64 throughout: an inexact Krylov "
                               "iteration tolerates a relative product error of (tolerance / current residual), so GMRES iterations whose "
                               "residual estimate is below 1e-3 and the Lanczos iterations (tolerance 1e-3) evaluate far tile pairs in packed "
                               "single precision (product error ~1e-6, 1.8x faster); the solution still satisfies the fp64 system to 1e-8 "

@@ -41,6 +41,7 @@ extern "C" {
 #define RBL_ERR_ALLOC 9
 #define RBL_ERR_NONFINITE 10  /* result contains inf/nan                                  */
 #define RBL_ERR_ARG 11
+#define RBL_ERR_COMM 12       /* a collective failed (RCCL error, librccl not loadable, callback returned non-zero) */
 
 typedef struct rbl_ctx rbl_ctx;
 
@@ -145,6 +146,29 @@ int rbl_M_RFD(rbl_ctx *ctx, const double *W, uint64_t seed, double delta, double
 /* KTinv_RFD(), c_rigid_obj.cpp:743-767: K^T (1/delta)[Kinv(q+)^T - Kinv(q-)^T] W, W[6Nb] -> out[6Nb] */
 int rbl_KTinv_RFD(rbl_ctx *ctx, const double *W, double delta, double *out);
 
+/* M_RFD_cfgs(U, delta), c_rigid_obj.cpp:798-818: blob positions of the two configurations displaced by +-(delta/2) U
+ * (U[6Nb], displacement units) -> r_plus[3N], r_minus[3N] (computed on the GPU; nothing is committed).  The reference
+ * also draws a noise vector there that it never uses (:801). */
+int rbl_M_RFD_cfgs(rbl_ctx *ctx, const double *U, double delta, double *r_plus, double *r_minus);
+
+/* M_RFD_from_U(U, W), c_rigid_obj.cpp:820-842: (1/delta) [M(q + delta/2 U) - M(q - delta/2 U)] W with the caller's
+ * displacement U[6Nb] and vector W[3N] -> out[3N].  The reference hard-codes delta = 1e-3 here (:822). */
+int rbl_M_RFD_from_U(rbl_ctx *ctx, const double *U, const double *W, double delta, double *out);
+
+/* KT_RFD_from_U(U, W), c_rigid_obj.cpp:844-863: (1/delta) [K(q + delta/2 U)^T - K(q - delta/2 U)^T] W, W[3N] -> out[6Nb]
+ * (delta = 1e-3 in the reference, :846). */
+int rbl_KT_RFD_from_U(rbl_ctx *ctx, const double *U, const double *W, double delta, double *out);
+
+/* evolve_X_Q_RFD(U), c_rigid_obj.cpp:880-893: commit the configuration displaced by U[6Nb] (displacement units: NOT
+ * multiplied by dt), rebuild K, and KEEP the preconditioner of the configuration it was built for (:892 sets
+ * PC_mat_Set = true: an RFD displacement is of size delta, the factors of q serve q + delta U). */
+int rbl_evolve_X_Q_RFD(rbl_ctx *ctx, const double *U);
+
+/* The saddle operator a caller's Krylov solver applies, src/Rigid.py:73-80:  x = [lambda (3N) ; U (6Nb)]  ->
+ * [M lambda - K U ; K^T lambda] on the object's own configuration, host vectors, ONE upload and ONE download (the
+ * wrapper composes it from multi_body_pos + apply_M + K_x_U + KT_x_Lam: four round trips). */
+int rbl_apply_saddle(rbl_ctx *ctx, const double *x, double *out);
+
 /* update_X_Q(U), c_rigid_obj.cpp:798-863: the configuration displaced by U[6Nb] (translation and rotation
  * vector per body, displacement units) -> X_out[3Nb], Q_out[4Nb] (scalar-first); nothing is committed. */
 int rbl_update_X_Q(rbl_ctx *ctx, const double *U, double *X_out, double *Q_out);
@@ -167,8 +191,8 @@ int rbl_RHS_and_Midpoint(rbl_ctx *ctx, const double *Slip, const double *Force, 
 
 /* Lanczos controls / report.  max_iter: the basis is kept (max_iter + 1 vectors of 3 N doubles per recurrence).  tol: the recurrence stops when the ERROR ESTIMATE of the increment is below tol (relative):
  * the last correction d_m = |x_m - x_{m-1}| / |x_m| extrapolated geometrically, d_m rho / (1 - rho), rho = d_m / d_{m-1}.
- * For RBL_MHALF_LANCZOS_PC the estimate is taken in the Euclidean norm of the increment itself (rbl_set_tuning 85: in its
- * energy norm).  The report returns the iterations used by the last call and that estimate. */
+ * For RBL_MHALF_LANCZOS_PC the estimate is taken in the Euclidean norm of the increment itself (RBL_OPT_LANCZOS_EUCLID_NORM = 0:
+ * in its energy norm).  The report returns the iterations used by the last call and that estimate. */
 int rbl_set_lanczos(rbl_ctx *ctx, int max_iter, double tol);
 int rbl_get_lanczos_report(const rbl_ctx *ctx, int *iters, double *resid);
 
@@ -228,6 +252,10 @@ int rbl_apply_M_sym_info(rbl_ctx *ctx, int64_t n_blobs, int i_step, int nrhs, in
  * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */
 int rbl_blob_positions_dev(rbl_ctx *ctx, int body_begin, int body_end, double *d_out);
 
+/* multi_body_pos() into a device vector d_out[3 N] according to the context's communicator: all bodies on this rank (single
+ * GPU, tile-pair split), or -- RBL_OPT_COMM_SPLIT = 1 -- this rank's bodies followed by ONE all-gather over the ranks. */
+int rbl_multi_body_pos_dev(rbl_ctx *ctx, double *d_out);
+
 /* dense build on the device: d_out column-major n3 x n3 (ld = n3) */
 int rbl_rotne_prager_tensor_dev(rbl_ctx *ctx, const double *d_r, int64_t n_blobs,
                                 int scale_damp, double *d_out);
@@ -261,11 +289,11 @@ int rbl_apply_saddle_dev(rbl_ctx *ctx, const double *d_x, double *d_out);     /*
  * factor of the body's block, rebuilt per configuration.  In free space every body's block is ONE body-frame matrix seen
  * through the body's rotation, M_b = (I x R_b) M_body (I x R_b)^T, so the factor is L = (I x R_b) chol(M_body): built once per
  * rbl_set_parameters, exact for every configuration, not triangular (mode 0 is the same operator either way;
- * rbl_set_tuning(ctx, 0, 71) restores per-configuration Cholesky factors).  rbl_set_no_damp(ctx, 1) makes the matvec entry points
+ * RBL_OPT_BODYFRAME_FACTOR = 0 restores per-configuration Cholesky factors).  rbl_set_no_damp(ctx, 1) makes the matvec entry points
  * apply the plain wall-corrected M (no damping B) until switched off again: together they let a caller compose
  * the preconditioned square root  B L (L^-1 M L^-T)^{1/2} W  around its own (e.g. sharded) product.
  * Modes 5, 6, 7 (all bodies, not in place, single GPU) apply the WHOLE factor G the library's preconditioned Lanczos root
- * uses on this configuration -- G^-1 x, G^-T x, G x with G = L (I + Q (L_E - I) Q^T), the two-level factor (rbl_set_tuning 88,
+ * uses on this configuration -- G^-1 x, G^-T x, G x with G = L (I + Q (L_E - I) Q^T), the two-level factor (RBL_OPT_LANCZOS_TWO_LEVEL,
  * default), or G = L: what a test needs to check the root identities  s = G^-1 B^-1 x,  v = G^-T W,  |s|^2 = v^T M v,
  * root(s) = B M v  whatever the factor. */
 int rbl_block_solve_dev(rbl_ctx *ctx, const double *d_in, double *d_out, int mode);
@@ -310,17 +338,47 @@ int rbl_RHS_and_Midpoint_dev(rbl_ctx *ctx, const double *d_Slip, const double *d
 
 /* ---- multi-GPU inside the library's own solvers --------------------------------------------------------------
  * One process per GPU, every rank holds the same (replicated) body state and calls the same entry points with the
- * same arguments.  After rbl_set_comm every FULL mobility product the library evaluates for itself -- the iterations
- * of rbl_gmres_saddle_dev, of the Lanczos square roots, M_RFD, rbl_apply_saddle_dev, the whole-step entry points --
- * is this rank's share of the unordered blob-tile pairs (as rbl_apply_M_sym_dev(rank, world)) followed by ONE call of
- * `allreduce`, which must leave the sum over all ranks in d_buf[0..count) on every rank, ordered after the work already
- * enqueued on the context's stream and before whatever is enqueued next (e.g. ncclAllReduce / torch.distributed
- * all_reduce on that stream; a host-staged implementation synchronises the stream itself).  Returns 0 on success.
- * All vectors of the Krylov recurrences stay replicated and bitwise identical on every rank, so the ranks take the same
- * convergence decisions.  fn == NULL switches back to single-GPU products; a callback with world == 1 keeps the multi-GPU
- * code path on with one share (every product still ends in a call of `allreduce`): a one-GPU rehearsal of what N ranks run. */
+ * same arguments.  Once a context has a communicator, every FULL mobility product the library evaluates for itself --
+ * the iterations of rbl_gmres_saddle_dev, of the Lanczos square roots, M_RFD, rbl_apply_saddle_dev, the whole-step
+ * entry points, and rbl_apply_M_dev over the full row range -- is this rank's share of the work followed by one
+ * collective (RBL_OPT_COMM_SPLIT):
+ *   0 (default)  unordered blob-tile pairs, dealt as rbl_apply_M_sym_dev(rank, world) deals them; the partial
+ *                full-length U is completed by ONE sum all-reduce (24 N bytes);
+ *   1            rows by body index (SURVEY.md 8e / north_star): each rank computes the geometry of ITS bodies, the blob
+ *                positions are all-gathered once per configuration, a product is the ordered-pair kernel on the rank's own
+ *                rows followed by ONE all-gather of U.
+ * Per-body work (block factors, their applications) is done by the body's owner -- bodies are split contiguously by
+ * index, sizes differing by at most one -- and completed by an in-place all-gather of the owners' segments.  All vectors
+ * of the Krylov recurrences stay replicated and bitwise identical on every rank, so the ranks take the same convergence
+ * decisions.
+ *
+ * (a) RCCL inside the library -- what a C / C++ host (the reference is one, c_rigid_obj.cpp:997-1027) uses: rank 0 calls
+ *     rbl_comm_unique_id and hands the RBL_COMM_ID_BYTES bytes to the other ranks by whatever means the host has (MPI_Bcast,
+ *     a file, torch.distributed); every rank then calls rbl_comm_init_rccl (collective: ncclCommInitRank on the context's
+ *     device).  The collectives are ncclAllReduce / ncclAllGather / grouped ncclBroadcast enqueued on the context's stream;
+ *     no host code runs between two products of a solve.  librccl is opened at run time (dlopen "librccl.so.1"): the copy
+ *     already in the process (PyTorch's) or ROCm's.  world == 1 is allowed and keeps the multi-GPU code path on with one
+ *     share: a one-GPU rehearsal of what N ranks run.
+ * (b) the caller's callbacks (rbl_set_comm / rbl_set_comm_ops) -- rehearsals over other transports (gloo with host staging).
+ *     `allreduce` must leave the sum over all ranks in d_buf[0..count) on every rank; `allgatherv` (optional) must leave
+ *     rank r's segment d_buf[offsets[r] .. offsets[r] + counts[r]) on every rank, in place; both ordered after the work
+ *     already enqueued on the context's stream and before whatever is enqueued next.  Without `allgatherv` the library
+ *     zero-pads and sums instead.  allreduce == NULL switches back to single-GPU products.
+ * rbl_comm_finalize destroys the communicator (rbl_destroy does it too). */
 typedef int (*rbl_allreduce_fn)(void *user, double *d_buf, int64_t count);
+typedef int (*rbl_allgatherv_fn)(void *user, double *d_buf, const int64_t *offsets, const int64_t *counts);
 int rbl_set_comm(rbl_ctx *ctx, int rank, int world, rbl_allreduce_fn allreduce, void *user);
+int rbl_set_comm_ops(rbl_ctx *ctx, int rank, int world, rbl_allreduce_fn allreduce, rbl_allgatherv_fn allgatherv, void *user);
+#define RBL_COMM_ID_BYTES 128
+int rbl_comm_unique_id(void *id_out /* RBL_COMM_ID_BYTES */);
+int rbl_comm_init_rccl(rbl_ctx *ctx, const void *unique_id, int rank, int world);
+int rbl_comm_finalize(rbl_ctx *ctx);
+/* kind: 0 single GPU, 1 callbacks, 2 RCCL inside the library */
+int rbl_comm_info(const rbl_ctx *ctx, int *rank, int *world, int *kind);
+/* the context's collectives themselves on a device buffer (tests, benchmarks): sum all-reduce; in-place all-gather of the
+ * per-rank segments d_buf[offsets[r] .. + counts[r]) */
+int rbl_comm_allreduce_dev(rbl_ctx *ctx, double *d_buf, int64_t count);
+int rbl_comm_allgatherv_dev(rbl_ctx *ctx, double *d_buf, const int64_t *offsets, const int64_t *counts);
 
 /* ---- per-phase timings of the library's own solvers (the reference has one gettimeofday helper,
  * c_rigid_obj.cpp:22-29, and one printf around M_half_W, :929-932) -----------------------------------------------------
@@ -345,48 +403,62 @@ int rbl_get_timings(rbl_ctx *ctx, double *ms, int64_t *calls);
 /* stream-synchronise, read and clear the latched device error word */
 int rbl_sync_check(rbl_ctx *ctx);
 
-/* tuning / test hook.  jsplit: j-split of the ordered kernel (0 = heuristic).  variant: 0 = heuristic
- * (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 = force the ordered kernel,
- * 2 = force the symmetric kernel (with jsplit > 0: its column-chunk length), 3 = force the MFMA multi-RHS kernel;
- * 21 / 22 (experiment switch): one / two rows per lane in the two-vector symmetric kernel;
- * 31 / 32: rbl_gmres_saddle_dev applies apply_PC with the reference's sign of the force block (:601: the preconditioned
- * operator then has eigenvalues near -1 AND +1) / with that sign restored (default; one cluster, fewer iterations, same
- * solution);
- * 41 / 42: rbl_gmres_saddle_dev never / when it fits (default) runs the whole solve of a small system (<= 256 blobs,
- * diagonal PC, <= 255 iterations) as ONE kernel launch on one CU;
- * 51 / 52: inexact-Krylov relaxation off (default) / on: once rbl_gmres_saddle_dev's residual estimate is below
- * rtol x 1e5, its mobility products evaluate far tile pairs in packed single precision (relative product error ~1e-6,
- * ~1.8x faster); the solution still satisfies the fp64 system to rtol (tests check the true residual);
- * 53 / 54: test hook, every full product through that relaxed kernel off / on;
- * 61 / 62: per-body factors of bodies with 65..170 blobs applied by substitution / through explicit inverses L^-1
- * (default; built with the factors, a sweep becomes one triangular matrix-vector product);
- * 63 / 64 / 65: explicit inverses of bodies with more than 170 blobs (the reference's own form of the block preconditioner,
- * Block_diag_invM :461-487, built by the factorisation's MFMA kernels on an augmented matrix: n^3 / 3 more flops per
- * configuration, applications become batched triangular matrix-vector products over the whole chip) never / always / when
- * it pays (default: multi-GPU contexts, where a rank's few bodies would each be a latency chain on one CU, and the shared
- * body-frame factor of free space, which is inverted once);
- * 83 / 84: keep (also) a single-precision copy of those inverses off (default) / on: the preconditioner and Lanczos runs to
- * tolerances >= 1e-5 read half the bytes (sums stay fp64; the GMRES solution still satisfies the fp64 system to rtol);
- * 71 / 72: free space only: per-configuration Cholesky factors of every body / one body-frame factor rotated with each
- * body (default; see rbl_block_solve_dev);
- * 73 / 74: with the wall term: exact per-configuration block factors (default) / the FREE-SPACE body-frame factor as an
- * approximate block factor (no factorisation, 29.7 MB instead of 5.9 GB at cfg 3; one or two more GMRES iterations --
- * measured level in time at cfg 3, so not the default);
- * 87 / 88: preconditioned Lanczos root with the block-Jacobi factor L alone / with the two-level factor L (I + Q (L_E - I) Q^T)
- * (default): a low-rank correction carrying the monopole far field between the bodies (spheres of the bodies' outer radius at
- * their centres), so that the collective translations converge in the factor instead of the iteration -- about half the
- * Lanczos iterations; any invertible factor keeps the root exact;
- * 85 / 86: preconditioned Lanczos root x = B L z, z = (L^-1 M L^-T)^{1/2} W: stop on the error estimate of z -- the error
- * of x in the ENERGY norm x^T (B M B)^-1 x, the one that bounds the relative error of the sampled covariance -- / of x itself
- * in the Euclidean norm (default; L weighs the slowly converging collective modes more: a few more iterations);
- * 81 / 82: Lanczos square roots with the three-term recurrence only (round 1-2; the estimate stagnates near 1e-6) / with
- * every new vector re-orthogonalised against the whole stored basis (default);
- * 91 / 92: rbl_gmres_saddle_dev on launch-bound systems (<= 20 000 blobs): convergence test (a copy of the Hessenberg
- * columns + a stream drain) every 4th iteration / first two iterations before the previous solve's count, then where the
- * residual's rate puts it (default); either way the solve ends at the first iteration that passes;
- * 93 / 94: symmetric pair kernels of large systems (four-wave workgroups): one work unit per workgroup, dealt to the XCDs in
- * launch order / a fixed set of resident workgroups drawing units from a counter (default: an XCD that runs faster takes
- * more units; the slabs are addressed by unit, so results are bitwise the same either way).  All per context. */
+/* ---- named per-context options ---------------------------------------------------------------------------------
+ * rbl_set_option(ctx, RBL_OPT_*, value) / rbl_get_option: an unknown key or a value outside the option's range returns
+ * RBL_ERR_ARG and changes nothing.  rbl_option_info gives name, range and default of a key (tests enumerate
+ * 1 .. RBL_OPT_COUNT - 1), rbl_option_key the key of a name (0: unknown).  All per context; defaults in brackets. */
+enum {
+  RBL_OPT_MATVEC_KERNEL = 1,       /* [0] 0 heuristic (symmetric kernel for full products, MFMA kernel for >= 4 vectors), 1 ordered-rows
+                                      kernel, 2 symmetric kernel, 3 MFMA multi-RHS kernel also for few vectors                        */
+  RBL_OPT_ORDERED_JSPLIT = 2,      /* [0] j-split of the ordered kernel (0 = heuristic)                                               */
+  RBL_OPT_SYM_CHUNK = 3,           /* [0] column tiles per work unit of the symmetric kernels (0 = heuristic)                         */
+  RBL_OPT_SYM_ROWS_PER_LANE = 4,   /* [0] rows per lane of the one-vector symmetric kernel: 0 heuristic, 1, 2 (experiments)            */
+  RBL_OPT_SYM2_ROWS_PER_LANE = 5,  /* [0] the same for the two-vector kernel                                                          */
+  RBL_OPT_SYM_WAVES = 6,           /* [0] waves per workgroup of the symmetric kernels (0 = heuristic; experiments)                   */
+  RBL_OPT_SYM_WORK_QUEUE = 7,      /* [1] large systems (four-wave workgroups): 1 a fixed set of resident workgroups draws work units
+                                      from a counter (an XCD that runs faster takes more), 0 one unit per workgroup in launch order;
+                                      the slabs are addressed by unit, so results are bitwise the same either way                   */
+  RBL_OPT_GMRES_PC_SIGN_FIX = 8,   /* [1] rbl_gmres_saddle_dev applies apply_PC with the sign of its force block restored (one
+                                      eigenvalue cluster at +1; fewer iterations, same solution); 0: the reference's sign (:601)    */
+  RBL_OPT_GMRES_ONE_KERNEL = 9,    /* [1] small systems (<= 256 blobs, diagonal PC, <= 255 iterations): whole solve in ONE launch    */
+  RBL_OPT_GMRES_PREDICT_CHECKS = 10, /* [1] launch-bound systems (<= 20 000 blobs): convergence tests placed by the previous solve's
+                                      count and the residual's rate; 0: every 4th iteration                                         */
+  RBL_OPT_GMRES_OVERLAP_CHECK = 11, /* [1] large systems: the host reads the Hessenberg column of iteration j while the GPU already
+                                      applies the preconditioner of iteration j + 1 (no idle stream at the test); 0: drain, then go on */
+  RBL_OPT_RELAXED_KRYLOV = 12,     /* [0] inexact Krylov: once GMRES's residual estimate is below rtol x 1e5 (and in Lanczos runs to
+                                      tolerances >= 1e-4) far tile pairs are evaluated in packed single precision (relative product
+                                      error <= 3e-6, ~1.8x faster); the solution still satisfies the fp64 system to rtol             */
+  RBL_OPT_RELAXED_ALWAYS = 13,     /* [0] test hook: every full product through that relaxed kernel                                   */
+  RBL_OPT_BLOCK_EXPLICIT_SMALL = 14, /* [1] per-body factors of bodies with <= 170 blobs applied through explicit inverses L^-1       */
+  RBL_OPT_BLOCK_EXPLICIT_LARGE = 15, /* [2] explicit inverses of larger bodies (the reference's own form of Block_diag_invM,
+                                      :461-487): 0 never, 1 always, 2 when it pays (multi-GPU contexts; the shared body-frame factor) */
+  RBL_OPT_BLOCK_INVERSE_F32 = 16,  /* [0] keep (also) a single-precision copy of the large inverses: the preconditioner and Lanczos
+                                      runs to tolerances >= 1e-5 read half the bytes (sums stay fp64)                               */
+  RBL_OPT_BODYFRAME_FACTOR = 17,   /* [1] free space: ONE body-frame factor rotated with each body; 0: per-configuration factors     */
+  RBL_OPT_BODYFRAME_WALL_APPROX = 18, /* [0] with the wall term: the free-space body-frame factor as an APPROXIMATE block factor      */
+  RBL_OPT_BLOCK_REFRESH = 19,      /* [1] keep the per-body factors for this many configuration changes (rbl_set_block_refresh)      */
+  RBL_OPT_LANCZOS_TWO_LEVEL = 20,  /* [1] preconditioned root: two-level factor L (I + Q (L_E - I) Q^T); 0: block-Jacobi factor L    */
+  RBL_OPT_LANCZOS_EUCLID_NORM = 21, /* [1] preconditioned root stops on the error estimate of x itself (Euclidean norm);
+                                      0: of z = (L^-1 M L^-T)^{1/2} W, i.e. of x in the energy norm x^T (B M B)^-1 x                 */
+  RBL_OPT_LANCZOS_REORTH = 22,     /* [1] every new Lanczos vector re-orthogonalised against the whole basis; 0: three-term recurrence */
+  RBL_OPT_NO_DAMP = 23,            /* [0] transient: the matvec entry points apply the plain wall-corrected M, no damping B          */
+  RBL_OPT_COMM_SPLIT = 24,         /* [0] multi-GPU contexts: 0 unordered tile pairs + all-reduce(U), 1 rows by body index +
+                                      all-gather(positions, U) -- see "multi-GPU" above                                             */
+  RBL_OPT_FUSED_KRYLOV = 25,       /* [1] launch-bound systems: the small kernels of a GMRES / Lanczos iteration fused (slab sums +
+                                      saddle tail + Gram-Schmidt passes in cooperative kernels); 0: one kernel per operation        */
+  RBL_OPT_COUNT = 26
+};
+int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
+int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);
+int rbl_option_info(int option, const char **name, int64_t *min_value, int64_t *max_value, int64_t *default_value);
+int rbl_option_key(const char *name);
+
+/* DEPRECATED (rounds 1-3; kept for one more round): the switchboard of magic integers, now a shim over rbl_set_option.
+ * variant 0..3 = RBL_OPT_MATVEC_KERNEL (jsplit: RBL_OPT_ORDERED_JSPLIT, or RBL_OPT_SYM_CHUNK with variant 2);
+ * off / on pairs: 21/22 SYM2_ROWS_PER_LANE 1/2, 31/32 GMRES_PC_SIGN_FIX, 41/42 GMRES_ONE_KERNEL, 51/52 RELAXED_KRYLOV,
+ * 53/54 RELAXED_ALWAYS, 61/62 BLOCK_EXPLICIT_SMALL, 63/64/65 BLOCK_EXPLICIT_LARGE 0/1/2, 71/72 BODYFRAME_FACTOR,
+ * 73/74 BODYFRAME_WALL_APPROX, 81/82 LANCZOS_REORTH, 83/84 BLOCK_INVERSE_F32, 85/86 LANCZOS_EUCLID_NORM,
+ * 87/88 LANCZOS_TWO_LEVEL, 91/92 GMRES_PREDICT_CHECKS, 93/94 SYM_WORK_QUEUE; anything else: RBL_ERR_ARG. */
 int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus

@@ -63,6 +63,19 @@ def lib():
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rbl_set_comm_ops.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+        L.rbl_comm_unique_id.argtypes = [vp]
+        L.rbl_comm_init_rccl.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.rbl_comm_finalize.argtypes = [vp]
+        L.rbl_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rbl_comm_allreduce_dev.argtypes = [vp, vp, i64]
+        L.rbl_comm_allgatherv_dev.argtypes = [vp, vp, C.POINTER(i64), C.POINTER(i64)]
+        L.rbl_set_option.argtypes = [vp, C.c_int, i64]
+        L.rbl_get_option.argtypes = [vp, C.c_int, C.POINTER(i64)]
+        L.rbl_option_info.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.rbl_option_key.argtypes = [C.c_char_p]
+        L.rbl_apply_saddle.argtypes = [vp, vp, vp]
+        L.rbl_multi_body_pos_dev.argtypes = [vp, vp]
         L.rbl_RHS_and_Midpoint_dev.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, dbl, vp, vp, vp]
         L.rbl_set_timing.argtypes = [vp, C.c_int]
         L.rbl_reset_timings.argtypes = [vp]
@@ -100,43 +113,106 @@ class DeviceContext:
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1)
         self._chk(self.L.rbl_set_config(self.h, X.ctypes.data, Q.ctypes.data, X.size // 3))
 
-    def set_comm(self, sharded):
-        """multi-GPU inside the library's solvers: `sharded` is a dist.ShardedMobility (rank, world, all_reduce_sum);
-        every full mobility product of librbl's own GMRES / Lanczos / step drivers becomes this rank's tile pairs + one
-        all-reduce through torch.distributed (RCCL on device buffers; host-staged with gloo).  None switches it off.  A
-        group of one rank keeps it on only when `sharded` was built with force_collectives (the world-1 RCCL test)."""
+    def set_comm(self, sharded, native=None):
+        """multi-GPU inside the library's solvers: `sharded` is a dist.ShardedMobility (rank, world, process group).  Every
+        full mobility product of librbl's own GMRES / Lanczos / step drivers becomes this rank's share + one collective.
+        native (default: whenever the process group moves device buffers, i.e. backend nccl): RCCL INSIDE librbl --
+        rank 0's rbl_comm_unique_id is broadcast through the process group once, then rbl_comm_init_rccl; no Python runs
+        between two products of a solve.  Otherwise (gloo rehearsals, several ranks sharing one GPU) the collectives are
+        callbacks into torch.distributed, host-staged.  None switches it off.  A group of one rank keeps it on only when
+        `sharded` was built with force_collectives (the world-1 RCCL test)."""
         import torch
+        import torch.distributed as dist
         if sharded is None or not sharded.collectives:
-            self._comm_cb = None
+            self._comm_cb = self._comm_cb2 = None
             self._chk(self.L.rbl_set_comm(self.h, 0, 1, None, None))
+            return
+        if native is None:
+            native = not sharded.stage_cpu and sharded.device.type == "cuda"
+        if native:
+            ident = [None]
+            if sharded.rank == 0:
+                buf = C.create_string_buffer(128)
+                if self.L.rbl_comm_unique_id(buf) != 0:
+                    raise RblError("rbl_comm_unique_id failed (librccl not loadable?)")
+                ident[0] = buf.raw
+            dist.broadcast_object_list(ident, src=dist.get_global_rank(sharded.group, 0) if sharded.group is not None else 0,
+                                       group=sharded.group)
+            self._comm_cb = self._comm_cb2 = None
+            self._chk(self.L.rbl_comm_init_rccl(self.h, ident[0], sharded.rank, sharded.world))
             return
 
         class _View:   # a raw device pointer as a torch tensor (no copy)
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
-        views = {}     # (pointer, count) -> tensor view: librbl all-reduces the same few buffers over and over
+        views = {}     # (pointer, count) -> tensor view: librbl works on the same few buffers over and over
+
+        def _view(ptr, count):
+            t = views.get((ptr, count))
+            if t is None:
+                t = views[(ptr, count)] = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
+            return t
+
+        def _on_ctx_stream(fn):
+            # rbl.h: a collective must be ordered on the CONTEXT's stream (the library enqueues producer and consumer
+            # kernels there); torch issues collectives on its current stream, so make the context's stream current
+            if sharded.device.type == "cuda" and torch.cuda.current_stream(sharded.device).cuda_stream != self._stream_ptr:
+                with torch.cuda.stream(torch.cuda.ExternalStream(self._stream_ptr, device=sharded.device)):
+                    fn()
+            else:
+                fn()
 
         def _allreduce(user, ptr, count):
             try:
-                t = views.get((ptr, count))
-                if t is None:
-                    t = views[(ptr, count)] = torch.as_tensor(_View(ptr, int(count)), device=sharded.device)
-                # rbl.h: the all-reduce must be ordered on the CONTEXT's stream (the library enqueues producer and consumer
-                # kernels there); torch issues collectives on its current stream, so make the context's stream current
-                if sharded.device.type == "cuda" and torch.cuda.current_stream(sharded.device).cuda_stream != self._stream_ptr:
-                    with torch.cuda.stream(torch.cuda.ExternalStream(self._stream_ptr, device=sharded.device)):
-                        sharded.all_reduce_sum(t)
-                else:
-                    sharded.all_reduce_sum(t)
+                _on_ctx_stream(lambda: sharded.all_reduce_sum(_view(ptr, count)))
                 return 0
             except Exception as e:      # never unwind through the C caller
                 import sys
                 print("rbl all-reduce callback failed: %r" % (e,), file=sys.stderr)
                 return 1
 
+        def _allgatherv(user, ptr, offs, cnts):
+            try:
+                W = sharded.world
+                o = [int(offs[r]) for r in range(W)]
+                n = [int(cnts[r]) for r in range(W)]
+                _on_ctx_stream(lambda: sharded.all_gather_segments(lambda a, k: _view(ptr + 8 * a, k), o, n))
+                return 0
+            except Exception as e:
+                import sys
+                print("rbl all-gather callback failed: %r" % (e,), file=sys.stderr)
+                return 1
+
         self._comm_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)(_allreduce)
-        self._chk(self.L.rbl_set_comm(self.h, sharded.rank, sharded.world, C.cast(self._comm_cb, C.c_void_p), None))
+        self._comm_cb2 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64))(_allgatherv)
+        self._chk(self.L.rbl_set_comm_ops(self.h, sharded.rank, sharded.world, C.cast(self._comm_cb, C.c_void_p),
+                                          C.cast(self._comm_cb2, C.c_void_p), None))
+
+    def comm_info(self):
+        """(rank, world, kind) of the context's communicator; kind 0 none, 1 callbacks, 2 RCCL inside librbl"""
+        r, w, k = C.c_int(0), C.c_int(1), C.c_int(0)
+        self._chk(self.L.rbl_comm_info(self.h, C.byref(r), C.byref(w), C.byref(k)))
+        return r.value, w.value, k.value
+
+    def comm_finalize(self):
+        self._chk(self.L.rbl_comm_finalize(self.h))
+        self._comm_cb = self._comm_cb2 = None
+
+    # -- named options (include/rbl.h RBL_OPT_*) -----------------------------------------
+    def _opt_key(self, name):
+        key = name if isinstance(name, int) else self.L.rbl_option_key(str(name).encode())
+        if not key:
+            raise RblError("unknown option %r" % (name,))
+        return key
+
+    def set_option(self, name, value):
+        self._chk(self.L.rbl_set_option(self.h, self._opt_key(name), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._chk(self.L.rbl_get_option(self.h, self._opt_key(name), C.byref(v)))
+        return v.value
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.rbl_set_stream(self.h, stream_ptr))
@@ -159,6 +235,7 @@ class DeviceContext:
         return {k: (ms[i], calls[i]) for i, k in enumerate(self.TIMING_PHASES)}
 
     def set_tuning(self, jsplit=0, variant=0):
+        """deprecated switchboard of rounds 1-3 (a shim over set_option inside librbl)"""
         self._chk(self.L.rbl_set_tuning(self.h, jsplit, variant))
 
     def apply_M(self, dF, dr, n_blobs, row_begin, row_end, dout):
@@ -286,6 +363,10 @@ class DeviceContext:
 
     def blob_positions(self, body_begin, body_end, dout):
         self._chk(self.L.rbl_blob_positions_dev(self.h, body_begin, body_end, dout))
+
+    def multi_body_pos(self, dout):
+        """all blob positions into a device vector; on a row-split multi-GPU context: own bodies + one all-gather"""
+        self._chk(self.L.rbl_multi_body_pos_dev(self.h, dout))
 
     def build_M(self, dr, n_blobs, scale_damp, dout):
         self._chk(self.L.rbl_rotne_prager_tensor_dev(self.h, dr, n_blobs, int(scale_damp), dout))

@@ -1,6 +1,6 @@
 """In-tree build of the native parts (no network, no cmake needed):
 
-  librbl.so            hipcc --offload-arch=gfx950   csrc/rbl_{kernels,dense,api}.hip + rbl_host.cpp
+  librbl.so            hipcc --offload-arch=gfx950   csrc/rbl_*.hip + rbl_host.cpp
   c_rigid.<abi>.so     g++ + pybind11               csrc/c_rigid.cpp  (links librbl.so, rpath $ORIGIN)
 
 Both land next to this file so they travel with the tree (gpurun snapshot) and are the
@@ -18,8 +18,9 @@ OBJ = os.path.join(HERE, "build")
 ARCH = os.environ.get("RBL_OFFLOAD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_body_dev.hip", "rbl_small.hip", "rbl_api.hip", "rbl_host.cpp"]
-HEADERS = ["rbl_internal.hpp", "rbl_pair.hpp", "rbl_pair_pk.hpp", os.path.join("..", "..", "include", "rbl.h")]
+HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_body_dev.hip", "rbl_small.hip", "rbl_core.hip", "rbl_options.hip", "rbl_comm.hip",
+               "rbl_products.hip", "rbl_bodies.hip", "rbl_roots.hip", "rbl_solvers.hip", "rbl_steps.hip", "rbl_host.cpp"]
+HEADERS = ["rbl_internal.hpp", "rbl_api_internal.hpp", "rbl_pair.hpp", "rbl_pair_pk.hpp", os.path.join("..", "..", "include", "rbl.h")]
 
 
 def lib_path():
@@ -80,6 +81,12 @@ def build(force=False, verbose_resources=False):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
               "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
               ext_src, "-o", ext_path(), "-L" + HERE, "-lrbl", "-Wl,-rpath,$ORIGIN"])
+    # the C++-only multi-GPU host (examples/host_rccl_step.cpp): librbl's C ABI and nothing else
+    host_src = os.path.join(HERE, "..", "examples", "host_rccl_step.cpp")
+    host_bin = os.path.join(HERE, "..", "examples", "host_rccl_step")
+    if os.path.exists(host_src) and (force or _newer(host_bin, [host_src, lib_path(), hdrs[-1]])):
+        _run([HIPCC, "-O2", "-std=c++17", host_src, "-I" + os.path.join(HERE, "..", "include"), "-L" + HERE, "-lrbl",
+              "-Wl,-rpath,$ORIGIN/../rigid_body_light_amd", "-o", host_bin])
     return lib_path(), ext_path()
 
 

@@ -341,7 +341,62 @@ struct CManyBodies {
     return out;
   }
 
-  void set_tuning(int jsplit, int variant) { check(rbl_set_tuning(ctx, jsplit, variant)); }
+  // [M lambda - K U ; K^T lambda], src/Rigid.py:73-80 in ONE boundary crossing
+  darr apply_saddle(darr x)
+  {
+    const py::ssize_t n = n3() + 6 * (py::ssize_t)n_bod();
+    if (x.size() != n) throw std::runtime_error("apply_saddle: input must have length 3*N_blobs + 6*N_bod");
+    darr out(n);
+    check(rbl_apply_saddle(ctx, x.data(), out.mutable_data()));
+    return out;
+  }
+
+  py::tuple M_RFD_cfgs(darr U, double delta)                        // :798 (unbound in the reference)
+  {
+    if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("M_RFD_cfgs: U must have length 6*N_bod");
+    darr rp(n3()), rm(n3());
+    check(rbl_M_RFD_cfgs(ctx, U.data(), delta, rp.mutable_data(), rm.mutable_data()));
+    return py::make_tuple(rp, rm);
+  }
+
+  darr M_RFD_from_U(darr U, darr W, double delta)                   // :820 (unbound in the reference)
+  {
+    if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("M_RFD_from_U: U must have length 6*N_bod");
+    if (W.size() != n3()) throw std::runtime_error("M_RFD_from_U: W must have length 3*N_blobs");
+    darr out(n3());
+    check(rbl_M_RFD_from_U(ctx, U.data(), W.data(), delta, out.mutable_data()));
+    return out;
+  }
+
+  darr KT_RFD_from_U(darr U, darr W, double delta)                  // :844 (unbound in the reference)
+  {
+    if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("KT_RFD_from_U: U must have length 6*N_bod");
+    if (W.size() != n3()) throw std::runtime_error("KT_RFD_from_U: W must have length 3*N_blobs");
+    darr out(6 * (py::ssize_t)n_bod());
+    check(rbl_KT_RFD_from_U(ctx, U.data(), W.data(), delta, out.mutable_data()));
+    return out;
+  }
+
+  void evolve_X_Q_RFD(darr U)                                       // :880 (unbound in the reference)
+  {
+    if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("evolve_X_Q_RFD: U must have length 6*N_bod");
+    check(rbl_evolve_X_Q_RFD(ctx, U.data()));
+  }
+
+  void set_option(const std::string &name, int64_t value)
+  {
+    const int key = rbl_option_key(name.c_str());
+    if (!key) throw std::runtime_error("set_option: unknown option '" + name + "'");
+    check(rbl_set_option(ctx, key, value));
+  }
+  int64_t get_option(const std::string &name) const
+  {
+    const int key = rbl_option_key(name.c_str());
+    int64_t v = 0;
+    if (!key || rbl_get_option(ctx, key, &v)) throw std::runtime_error("get_option: unknown option '" + name + "'");
+    return v;
+  }
+  void set_tuning(int jsplit, int variant) { check(rbl_set_tuning(ctx, jsplit, variant)); }   // deprecated shim
   uintptr_t handle() const { return (uintptr_t)ctx; }
 };
 
@@ -388,6 +443,13 @@ PYBIND11_MODULE(c_rigid, m)
       .def("rotne_prager_tensor", &CManyBodies::rotne_prager_tensor, py::arg("r_vecs"), py::arg("scale_damp") = false)
       .def("cholesky_lower", &CManyBodies::cholesky_lower, py::arg("M"))
       .def("pair_blocks", &CManyBodies::pair_blocks)
+      .def("apply_saddle", &CManyBodies::apply_saddle, py::arg("x"))
+      .def("M_RFD_cfgs", &CManyBodies::M_RFD_cfgs, py::arg("U"), py::arg("delta") = 1.0e-4)
+      .def("M_RFD_from_U", &CManyBodies::M_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)
+      .def("KT_RFD_from_U", &CManyBodies::KT_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)
+      .def("evolve_X_Q_RFD", &CManyBodies::evolve_X_Q_RFD, py::arg("U"))
+      .def("set_option", &CManyBodies::set_option, py::arg("name"), py::arg("value"))
+      .def("get_option", &CManyBodies::get_option, py::arg("name"))
       .def("set_tuning", &CManyBodies::set_tuning, py::arg("jsplit") = 0, py::arg("variant") = 0)
       .def("handle", &CManyBodies::handle, "address of the underlying rbl_ctx (for the ctypes device API)")
       .def_property_readonly_static("precision", [](py::object) { return std::string(rbl_precision()); },

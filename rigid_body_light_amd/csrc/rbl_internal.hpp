@@ -9,6 +9,8 @@
 #include "../../include/rbl.h"
 #include "rbl_pair.hpp"
 
+#pragma GCC visibility push(hidden)   // nothing declared here is part of librbl.so's ABI (that is include/rbl.h alone)
+
 // ----------------------------------------------------------------------------
 // Host-side rigid-body state: the O(N_bod) bookkeeping of CManyBodies
 // (reference c_rigid_obj.cpp:144-168 members).  Plain C++, no Eigen.
@@ -105,6 +107,7 @@ struct rbl_ctx {
   int step_hist_n = 0, step_hist_head = 0;          // entries held, slot of the newest one
   int64_t step_x_size = 0;
   bool dev_bodies_valid = false, dev_pc_valid = false, dev_xq_valid = false;
+  bool pc_keep_once = false;    // rbl_evolve_X_Q_RFD: the next configuration re-synchronisation keeps the device preconditioner
   bool dev_blk_valid = false;   // per-body Cholesky factors (d_blkL, d_blkLinv) match the current configuration ...
   int blk_b0 = 0, blk_b1 = 0;   // ... for the bodies [blk_b0, blk_b1) (a multi-GPU driver factors only its own bodies)
   int blk_refresh = 1, blk_age = 0;   // rbl_set_block_refresh: keep the factors for blk_refresh configuration changes
@@ -129,8 +132,13 @@ struct rbl_ctx {
   // multi-GPU (rbl_set_comm): this context is rank comm_rank of comm_world; every full mobility product inside the
   // library becomes this rank's share of the unordered tile pairs followed by comm_fn (sum all-reduce over the ranks)
   int comm_rank = 0, comm_world = 1;
+  int comm_kind = 0;                                // 0 single GPU, 1 the caller's callbacks (rbl_set_comm / rbl_set_comm_ops), 2 RCCL inside the library (rbl_comm_init_rccl)
   rbl_allreduce_fn comm_fn = nullptr;
-  void *comm_user = nullptr;      // systems that fit one CU: the whole solve in ONE kernel launch (rbl_small.hip)
+  rbl_allgatherv_fn comm_gather_fn = nullptr;       // optional: in-place all-gather of per-rank segments (NULL: zero-padded sum all-reduce)
+  void *comm_user = nullptr;
+  void *comm_nccl = nullptr;                        // ncclComm_t of the native communicator
+  int comm_split = 0;                               // RBL_OPT_COMM_SPLIT: 0 unordered tile pairs + all-reduce(U), 1 rows by body index + all-gather (north_star)
+  std::vector<int64_t> comm_offs, comm_cnts;        // scratch of the all-gather calls
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
@@ -147,7 +155,10 @@ struct rbl_ctx {
   std::vector<TimedSpan> ev_spans;
   double t_ms[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
   int64_t t_calls[RBL_T_COUNT] = {0, 0, 0, 0, 0, 0};
-  bool gmres_predict = true;    // rbl_set_tuning 91 / 92
+  bool gmres_predict = true;    // RBL_OPT_GMRES_PREDICT_CHECKS
+  bool gmres_overlap = true;    // RBL_OPT_GMRES_OVERLAP_CHECK: next iteration's preconditioner enqueued before the host reads the Hessenberg column
+  bool fused_krylov = true;     // RBL_OPT_FUSED_KRYLOV
+  hipEvent_t ev_check = nullptr;   // recorded behind the asynchronous copy of the Hessenberg columns (overlapped convergence test)
   int gmres_last_used = 0;      // iterations of the previous converged solve: where the next one looks first (launch-bound systems)
   // lanczos
   int lanczos_max_iter = 100;
@@ -307,3 +318,5 @@ void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb
                         const double *d_w, double *d_wo, int64_t wpitch, int nvec);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);
+
+#pragma GCC visibility pop

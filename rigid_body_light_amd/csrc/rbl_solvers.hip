@@ -1,0 +1,236 @@
+// rbl_solvers.hip -- right-preconditioned GMRES on the saddle operator.
+// Part of the implementation of the C ABI in include/rbl.h (split from the former rbl_api.hip along its sections);
+// shared internals are declared in rbl_api_internal.hpp.  Nothing here falls back to a CPU path.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "rbl_api_internal.hpp"
+
+// ---- GMRES on the saddle operator --------------------------------------------
+// Right-preconditioned GMRES(max_iter), no restart:  A = apply_saddle (src/Rigid.py:73-80), P^-1 = apply_PC
+// (c_rigid_obj.cpp:589-616), Arnoldi with classical Gram-Schmidt applied twice.  Everything stays on the
+// device and the stream is not drained inside the loop: the Hessenberg matrix lives in HBM and is read back
+// once at the end (fixed work, rtol <= 0) or, for the convergence test, every iteration (large systems) /
+// every 4th (small, launch-bound ones).
+
+static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                             double *resid_out);
+
+// Small systems (<= 256 blobs, diagonal PC): geometry, preconditioner build and the whole Arnoldi / Givens loop in ONE
+// kernel launch on one CU (rbl_small.hip) -- launch-bound otherwise (cfg 1: ~6 launches per iteration).
+static int gmres_small(rbl_ctx *c, const double *d_rhs, const double *d_x0, int max_iter, double rtol, double *d_x,
+                       int *iters_out, double *resid_out)
+{
+  int rc = ensure_xq_dev(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const size_t wd = rbl_gmres_small_work_doubles(S.N_blb, S.N_bod, max_iter);
+  if ((rc = rbl_dev_reserve(c, c->d_gm, sizeof(double) * (wd + 2)))) return rc;
+  double *work = (double *)c->d_gm.p, *scal = work + wd;
+  const double *dX = (const double *)c->d_XQ.p, *dQ = dX + 3 * (size_t)S.N_bod;
+  rc = rbl_launch_gmres_small(c->stream, rbl_make_params(S.a, S.eta), S.wall, dX, dQ, (const double *)c->d_cfg.p, S.N_blb,
+                              S.N_bod, d_rhs, d_x0, d_x, max_iter, rtol, c->gmres_pc_sign_fix ? 1.0 : c->pc_fsign, work, scal,
+                              c->d_err);
+  if (rc == RBL_ERR_SIZE) return rc;       // the caller falls back to the general solver
+  if (rc) return rbl_fail(c, rc, "gmres (one-kernel solver): launch failed");
+  double hs[2] = {0.0, 0.0};
+  RBL_HIP(c, hipMemcpyAsync(hs, scal, sizeof(hs), hipMemcpyDeviceToHost, c->stream));
+  if ((rc = finish_and_check(c))) return rc;
+  int it = 0;
+  std::memcpy(&it, &hs[0], sizeof(int));
+  if (iters_out) *iters_out = it;
+  if (resid_out) *resid_out = hs[1];
+  return RBL_OK;
+}
+
+// use_x0 != 0: d_x holds an initial guess (e.g. the previous time step's solution): the solver iterates on the
+// residual b - A x0 (one extra product) and the tolerance stays relative to |b|.
+int rbl_gmres_saddle_dev(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int use_x0,
+                         int *iters_out, double *resid_out)
+{
+  RblPhase ph_total(c, RBL_T_TOTAL);
+  {
+    int rc = need_config(c); if (rc) return rc;
+    if ((rc = rbl_dev_init(c))) return rc;
+    if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+    if (c->gmres_small && !comm_on(c) && rbl_gmres_small_fits(c->S.N_blb, c->S.N_bod, max_iter, c->S.block_pc)) {
+      rc = gmres_small(c, d_rhs, use_x0 ? d_x : nullptr, max_iter, rtol, d_x, iters_out, resid_out);
+      if (rc != RBL_ERR_SIZE) return rc;
+      c->gmres_small = false;                // this runtime does not grant the LDS the one-kernel solver needs
+    }
+  }
+  if (!use_x0) return gmres_saddle_core(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (!d_rhs || !d_x) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+  const int64_t nsys = (int64_t)3 * c->S.N_bod * c->S.N_blb + (int64_t)6 * c->S.N_bod;
+  const size_t vb = sizeof(double) * (size_t)nsys;
+  if ((rc = rbl_dev_reserve(c, c->d_bd2, 3 * vb + sizeof(double) * (2 + 2 * 512)))) return rc;   // + dot2 scratch
+  double *r0 = (double *)c->d_bd2.p, *dx = r0 + nsys, *x0 = dx + nsys, *dn = x0 + nsys;
+  RBL_HIP(c, hipMemcpyAsync(x0, d_x, vb, hipMemcpyDeviceToDevice, c->stream));
+  if ((rc = rbl_apply_saddle_dev(c, x0, r0))) return rc;
+  rbl_launch_axpby(c->stream, nsys, 1.0, d_rhs, -1.0, r0, r0);                          // r0 = b - A x0
+  double nn[2] = {0.0, 0.0};
+  rbl_launch_dot2(c->stream, d_rhs, d_rhs, nullptr, nsys, dn);                          // |b|^2
+  if ((rc = read_back(c, &nn[0], dn, sizeof(double)))) return rc;
+  rbl_launch_dot2(c->stream, r0, r0, nullptr, nsys, dn);                                // |r0|^2
+  if ((rc = read_back(c, &nn[1], dn, sizeof(double)))) return rc;
+  const double nb2 = nn[0], nr2 = nn[1];
+  const double scale = (nb2 > 0.0 && nr2 > 0.0) ? std::sqrt(nb2 / nr2) : 1.0;          // |b| / |r0|
+  if (nr2 == 0.0) { if (iters_out) *iters_out = 0; if (resid_out) *resid_out = 0.0; return RBL_OK; }   // x0 already solves it
+  double resid = 0.0;
+  if ((rc = gmres_saddle_core(c, r0, max_iter, rtol > 0.0 ? rtol * scale : rtol, dx, iters_out, &resid))) return rc;
+  rbl_launch_axpby(c->stream, nsys, 1.0, x0, 1.0, dx, d_x);                             // x = x0 + dx
+  if (resid_out) *resid_out = resid / scale;
+  return finish_and_check(c);
+}
+
+static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                              double *resid_out);
+
+// any invertible right preconditioner leaves the solution unchanged: inside the solve the force block of apply_PC
+// takes the sign that makes A P^-1 ~ I (see rbl_ctx::pc_fsign); the bound apply_PC keeps the reference's convention
+static int gmres_saddle_core(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                             double *resid_out)
+{
+  const double keep = c->pc_fsign;
+  if (c->gmres_pc_sign_fix) c->pc_fsign = 1.0;
+  const int rc = gmres_saddle_core_(c, d_rhs, max_iter, rtol, d_x, iters_out, resid_out);
+  c->pc_fsign = keep;
+  return rc;
+}
+
+static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                              double *resid_out)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  if (!d_rhs || !d_x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres: bad arguments");
+  if (max_iter + 1 > rbl_gmres_max_vectors()) return rbl_fail(c, RBL_ERR_ARG, "gmres: at most 255 iterations (no restart)");
+  const RblBodyState &S = c->S;
+  const int64_t nsys = (int64_t)3 * S.N_bod * S.N_blb + (int64_t)6 * S.N_bod;
+  const int m = max_iter, ldh = m + 1;
+  const size_t vb = sizeof(double) * (size_t)nsys;
+  // workspace: V[(m+1)][nsys] | w | z | H[(m+1) x m] column-major | beta | y[m] | partial sums
+  const size_t need = vb * (size_t)(m + 3) + sizeof(double) * ((size_t)ldh * m + 1 + m + rbl_gmres_part_doubles() +
+                                                               rbl_lanczos_part_doubles());
+  if ((rc = rbl_dev_reserve(c, c->d_gm, need))) return rc;
+  // (beta sits in FRONT of H: a convergence test reads back 1 + ldh * used doubles, not the whole ldh x m array)
+  double *V = (double *)c->d_gm.p, *w = V + (size_t)(m + 1) * nsys, *z = w + nsys, *d_beta = z + nsys, *H = d_beta + 1,
+         *d_y = H + (size_t)ldh * m, *part = d_y + m, *part2 = part + rbl_gmres_part_doubles();
+  RBL_HIP(c, hipMemsetAsync(H, 0, sizeof(double) * (size_t)ldh * m, c->stream));
+  rbl_launch_lanczos_init(c->stream, nsys, d_rhs, d_beta, V, part2);                    // V_0 = b/|b|, beta = |b|
+  std::vector<double> Hh((size_t)ldh * m + 1), y;
+  // convergence test: every iteration when an iteration is expensive.  When it is launch-bound a test (copy + stream
+  // drain) costs as much as half an iteration: the first one waits until two iterations before the count the previous
+  // solve needed (time steps repeat), later ones follow the residual's rate, at most four iterations apart; a test
+  // looks at every iteration since the one before, so the solve still ends at the first iteration that passes.
+  const int check_every = ((int64_t)S.N_bod * S.N_blb > 20000) ? 1 : 4;
+  int next_check = check_every, last_checked = 0;
+  if (check_every > 1 && c->gmres_predict && c->gmres_last_used > 0) next_check = c->gmres_last_used >= 8 ? c->gmres_last_used - 2 : c->gmres_last_used;
+  int used = 0;
+  double resid = 1.0;
+  // least squares min |beta e1 - H_k y| by Givens rotations on a host copy; returns the residual estimate
+  auto solve_ls = [&](int k, std::vector<double> &yout) -> double {
+    std::vector<double> R(Hh.begin() + 1, Hh.begin() + 1 + (size_t)ldh * k), g((size_t)k + 1, 0.0);
+    const double beta = Hh[0];
+    g[0] = beta;
+    std::vector<double> cs((size_t)k), sn((size_t)k);
+    for (int j = 0; j < k; ++j) {
+      double *col = R.data() + (size_t)j * ldh;
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * col[i] + sn[i] * col[i + 1];
+        col[i + 1] = -sn[i] * col[i] + cs[i] * col[i + 1];
+        col[i] = t;
+      }
+      const double den = std::hypot(col[j], col[j + 1]);
+      cs[j] = den > 0.0 ? col[j] / den : 1.0;
+      sn[j] = den > 0.0 ? col[j + 1] / den : 0.0;
+      col[j] = den; col[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+    }
+    yout.assign((size_t)k, 0.0);
+    for (int i = k - 1; i >= 0; --i) {
+      double v = g[i];
+      for (int j = i + 1; j < k; ++j) v -= R[(size_t)j * ldh + i] * yout[j];
+      const double d = R[(size_t)i * ldh + i];
+      yout[i] = d != 0.0 ? v / d : 0.0;
+    }
+    return beta > 0.0 ? std::fabs(g[k]) / beta : 0.0;
+  };
+  // Overlapped convergence test (large systems, RBL_OPT_GMRES_OVERLAP_CHECK): the Hessenberg columns of iteration j go to the
+  // host by an asynchronous copy; the preconditioner of iteration j + 1 is enqueued BEFORE the host waits for that copy, so
+  // the stream never runs dry at a test -- on N GPUs no rank drains per iteration.  A solve that ends at j has applied one
+  // preconditioner too many (0.2 ms at cfg 3 against a 20 ms product; enqueuing the whole next iteration would waste a product).
+  const size_t pin_need = sizeof(double) * (1 + (size_t)ldh * m);
+  const bool overlap_ok = c->gmres_overlap && check_every == 1 && pin_need <= ((size_t)1 << 20);
+  if (overlap_ok && !c->ev_check) RBL_HIP(c, hipEventCreateWithFlags(&c->ev_check, hipEventDisableTiming));
+  if (overlap_ok && !c->h_pin) RBL_HIP(c, hipHostMalloc(&c->h_pin, (size_t)1 << 20, hipHostMallocDefault));
+  bool z_ready = false;                                // z = P^-1 V_j is already enqueued (by the previous iteration's test)
+  for (int j = 0; j < m; ++j) {
+    const double *vj = V + (size_t)j * nsys;
+    if (!z_ready) {
+      c->ktl_arm = true;                               // the PC's K^T Lambda by-product feeds the product that follows
+      if ((rc = rbl_apply_PC_dev(c, vj, z))) { c->ktl_arm = false; return rc; }
+    }
+    z_ready = false;
+    // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
+    // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
+    c->sym_tune.relaxed = (c->gmres_relax && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
+    rc = rbl_apply_saddle_dev(c, z, w);
+    c->sym_tune.relaxed = 0;
+    c->ktl_arm = false; c->ktl_of = nullptr;
+    if (rc) return rc;
+    double *Hcol = H + (size_t)j * ldh;
+    // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches
+    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
+    used = j + 1;
+    if (rtol > 0.0 && (used >= next_check || used == m)) {
+      const size_t hb = sizeof(double) * (1 + (size_t)ldh * used);
+      if (overlap_ok && used < m) {
+        RBL_HIP(c, hipMemcpyAsync(c->h_pin, d_beta, hb, hipMemcpyDeviceToHost, c->stream));
+        RBL_HIP(c, hipEventRecord(c->ev_check, c->stream));
+        c->ktl_arm = true;                             // iteration j + 1's preconditioner, ahead of the host's wait
+        if ((rc = rbl_apply_PC_dev(c, V + (size_t)(j + 1) * nsys, z))) { c->ktl_arm = false; return rc; }
+        z_ready = true;
+        RBL_HIP(c, hipEventSynchronize(c->ev_check));
+        std::memcpy(Hh.data(), c->h_pin, hb);
+      } else if ((rc = read_back(c, Hh.data(), d_beta, hb))) return rc;
+      // the test may have become true anywhere since the last look: take the first k that passes
+      int hit = 0;
+      double r_before = resid;
+      for (int k = last_checked + 1; k <= used; ++k) {
+        r_before = resid;
+        resid = solve_ls(k, y);
+        if (resid < rtol) { hit = k; break; }
+      }
+      if (hit) { used = hit; c->ktl_arm = false; c->ktl_of = nullptr; break; }
+      last_checked = used;
+      int ahead = 1;
+      if (check_every > 1 && !c->gmres_predict) ahead = check_every - (used % check_every);
+      else if (check_every > 1) {                        // iterations the residual still needs at its current rate
+        ahead = check_every;
+        if (resid > 0.0 && r_before > resid) {
+          const double rem = std::log(rtol / resid) / std::log(resid / r_before);
+          ahead = rem < 1.0 ? 1 : (rem > (double)check_every ? check_every : (int)rem);
+        }
+      }
+      next_check = used + ahead;
+    }
+  }
+  if (!(rtol > 0.0) || y.size() != (size_t)used) {
+    if ((rc = read_back(c, Hh.data(), d_beta, sizeof(double) * (1 + (size_t)ldh * used)))) return rc;
+    resid = solve_ls(used, y);
+  }
+  for (int k = 0; k < used; ++k)
+    if (!std::isfinite(y[k])) return rbl_fail(c, RBL_ERR_NONFINITE, "gmres: non-finite Hessenberg solve");
+  if ((rc = upload_coef(c, d_y, y.data(), used, 0))) return rc;
+  rbl_launch_lanczos_combine(c->stream, nsys, V, d_y, used, z);                        // z = V y
+  if ((rc = rbl_apply_PC_dev(c, z, d_x))) return rc;                                   // x = P^-1 z
+  if (iters_out) *iters_out = used;
+  if (resid_out) *resid_out = resid;
+  if (rtol > 0.0) c->gmres_last_used = used;
+  return finish_and_check(c);
+}

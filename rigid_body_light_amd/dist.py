@@ -126,6 +126,26 @@ class ShardedMobility:
                 dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         return part
 
+    def all_gather_segments(self, view, offs, cnts):
+        """in-place all-gather of per-rank segments of ONE device vector: rank r owns [offs[r], offs[r] + cnts[r]);
+        view(a, k) returns the tensor over elements [a, a + k).  (librbl's all-gather callback in the rehearsals; the
+        native communicator does this with ncclAllGather / grouped ncclBroadcast itself.)"""
+        if not self.collectives:
+            return
+        self.n_all_gather += 1
+        for r in range(self.world):
+            if cnts[r] <= 0:
+                continue
+            seg = view(offs[r], cnts[r])
+            src = dist.get_global_rank(self.group, r) if self.group is not None else r
+            if self.stage_cpu:
+                h = seg.cpu()
+                dist.broadcast(h, src=src, group=self.group)
+                if r != self.rank:
+                    seg.copy_(h)
+            else:
+                dist.broadcast(seg, src=src, group=self.group)
+
     def apply_M_rows(self, F_full):
         """this rank's rows of U = M F with the ordered-pair kernel (rbl_apply_M_dev)"""
         if self.ctx is None:

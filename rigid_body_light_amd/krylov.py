@@ -9,7 +9,7 @@ this project calls one time step:
 Every loop runs inside librbl (rbl_gmres_saddle_dev, the Lanczos square roots, rbl_RHS_and_Midpoint_dev); the classes
 below only hold the device vectors (torch tensors as plain buffers) and the O(N_bod) host bookkeeping between the
 calls.  On N GPUs the same loops run with the context switched to multi-GPU products (DeviceContext.set_comm ->
-rbl_set_comm).  The torch Arnoldi / Lanczos loops the tests compare these with live in tests/torch_krylov.py.
+rbl_comm_init_rccl: RCCL inside librbl; rbl_set_comm_ops callbacks in the gloo rehearsals).  The torch Arnoldi / Lanczos loops the tests compare these with live in tests/torch_krylov.py.
 """
 import numpy as np
 import torch
@@ -64,10 +64,11 @@ class ShardedDeterministicStepper(DeterministicStepper):
     host looks at the Hessenberg matrix once per convergence test.  Everything else -- K ops, preconditioner, Krylov
     vectors -- is O(N), replicated and bitwise identical on every rank."""
 
-    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device):
+    def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device, set_comm=True):
         super().__init__(ctx, n_bodies, blobs_per_body, device)
         self.sm = sharded
-        ctx.set_comm(sharded)
+        if set_comm:                  # (False: the caller has given the context its communicator already)
+            ctx.set_comm(sharded)
 
 
 class BrownianStepper(DeterministicStepper):
@@ -121,10 +122,11 @@ class ShardedBrownianStepper(BrownianStepper):
     and bitwise identical on every rank (the noise comes from a seeded device generator)."""
 
     def __init__(self, ctx, sharded, n_bodies, blobs_per_body, device, a, wall, kBT, dt,
-                 lanczos_tol=1e-3, lanczos_max_iter=100, precondition=True):
+                 lanczos_tol=1e-3, lanczos_max_iter=100, precondition=True, set_comm=True):
         super().__init__(ctx, n_bodies, blobs_per_body, device)
         self.sm = sharded
-        ctx.set_comm(sharded)
+        if set_comm:                  # (False: the caller has given the context its communicator already)
+            ctx.set_comm(sharded)
         self.a, self.wall, self.kBT, self.dt = a, wall, kBT, dt
         self.ltol, self.lmax = lanczos_tol, lanczos_max_iter
         self.precondition = precondition      # block-Jacobi preconditioned square root (librbl's RBL_MHALF_LANCZOS_PC)

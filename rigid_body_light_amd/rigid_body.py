@@ -8,7 +8,8 @@ of per-method checks; shapes follow the shape X was given in (2-D in -> (-1, 3) 
 reference src/Rigid.py:54,60,66).
 
 Beyond the reference surface (its C++ has these, its Python does not): `M_half_W`, `M_RFD`,
-`KTinv_RFD`, `apply_M_multi`, `dense_mobility`.
+`KTinv_RFD`, `M_RFD_cfgs`, `M_RFD_from_U`, `KT_RFD_from_U`, `evolve_rigid_bodies_RFD`, `apply_M_multi`,
+`dense_mobility`.
 """
 import numpy as np
 
@@ -107,11 +108,8 @@ class RigidBody:
 
     def apply_saddle(self, x):
         """[M lambda - K U ; K^T lambda]  (reference src/Rigid.py:73-80)."""
-        x = self._require(x, "system")
-        n = self._expected_size("blob")
-        lam, U = x[:n], x[n:]
-        slip = self.apply_M(lam, self.get_blob_positions()) - self.K_dot(U).reshape(-1)
-        return np.concatenate((slip, self.KT_dot(lam).reshape(-1)))
+        return self.cb.apply_saddle(self._require(x, "system"))    # one boundary crossing (rbl_apply_saddle); the reference
+                                                                    # composes it from four calls through its extension
 
     def apply_PC(self, b):
         return self.cb.apply_PC(self._require(b, "system"))
@@ -129,6 +127,23 @@ class RigidBody:
     def KTinv_RFD(self, W, delta=1.0e-4):
         """reference c_rigid_obj.cpp:743-767 (C++ only); W has length 6*N_bodies."""
         return self.cb.KTinv_RFD(self._require(W, "body"), delta)
+
+    def M_RFD_cfgs(self, U, delta=1.0e-4):
+        """blob positions of the configurations displaced by +-(delta/2) U (reference :798-818, C++ only) -> (r_plus, r_minus)."""
+        return self.cb.M_RFD_cfgs(self._require(U, "body"), delta)
+
+    def M_RFD_from_U(self, U, W, delta=1.0e-3):
+        """(1/delta)[M(q + delta/2 U) - M(q - delta/2 U)] W for the caller's displacement U (reference :820-842, C++ only)."""
+        return self.cb.M_RFD_from_U(self._require(U, "body"), self._require(W, "blob"), delta)
+
+    def KT_RFD_from_U(self, U, W, delta=1.0e-3):
+        """(1/delta)[K(q + delta/2 U)^T - K(q - delta/2 U)^T] W (reference :844-863, C++ only); W has length 3*N_blobs."""
+        return self.cb.KT_RFD_from_U(self._require(U, "body"), self._require(W, "blob"), delta)
+
+    def evolve_rigid_bodies_RFD(self, U):
+        """commit the configuration displaced by U (displacement units, no dt) and keep the preconditioner
+        (reference evolve_X_Q_RFD :880-893, C++ only)."""
+        self.cb.evolve_X_Q_RFD(self._require(U, "body"))
 
     def update_X_Q(self, U):
         """configuration displaced by U (translation + rotation vector per body), NOT committed

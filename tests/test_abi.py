@@ -45,6 +45,94 @@ def test_context_lifecycle_and_loud_failure_without_device():
     lib.rbl_destroy(h)
 
 
+def option_keys():
+    """RBL_OPT_* enumerators of include/rbl.h -> {name: value}"""
+    text = open(os.path.join(ROOT, "include", "rbl.h")).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(RBL_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+
+
+def test_every_option_is_named_bounded_and_round_trips():
+    """include/rbl.h's named options (the replacement of the rbl_set_tuning switchboard): every key 1 .. RBL_OPT_COUNT - 1 has a
+    table row (name, range, default), starts at its default, round-trips its extreme values, rejects values outside its range
+    and unknown keys with RBL_ERR_ARG leaving the option unchanged; the deprecated shim sets the same state."""
+    i64 = ctypes.c_int64
+    lib = ctypes.CDLL(os.path.join(ROOT, "rigid_body_light_amd", "librbl.so"))
+    lib.rbl_create.restype = ctypes.c_void_p
+    lib.rbl_destroy.argtypes = [ctypes.c_void_p]
+    lib.rbl_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, i64]
+    lib.rbl_get_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(i64)]
+    lib.rbl_option_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)] + [ctypes.POINTER(i64)] * 3
+    lib.rbl_option_key.argtypes = [ctypes.c_char_p]
+    lib.rbl_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    keys = option_keys()
+    count = keys.pop("RBL_OPT_COUNT")
+    assert sorted(keys.values()) == list(range(1, count)), "RBL_OPT_* keys must be 1 .. RBL_OPT_COUNT - 1 without gaps"
+    h = lib.rbl_create()
+
+    def get(k):
+        v = i64(-12345)
+        assert lib.rbl_get_option(h, k, ctypes.byref(v)) == 0
+        return v.value
+
+    names = set()
+    for enum_name, k in sorted(keys.items(), key=lambda kv: kv[1]):
+        nm, lo, hi, df = ctypes.c_char_p(), i64(), i64(), i64()
+        assert lib.rbl_option_info(k, ctypes.byref(nm), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(df)) == 0, enum_name
+        name = nm.value.decode()
+        assert name and name not in names and "RBL_OPT_" + name.upper() == enum_name
+        names.add(name)
+        assert lib.rbl_option_key(name.encode()) == k
+        assert lo.value <= df.value <= hi.value
+        assert get(k) == df.value, name                                  # a fresh context holds the defaults
+        for v in (lo.value, hi.value, df.value):
+            assert lib.rbl_set_option(h, k, v) == 0 and get(k) == v, (name, v)
+        for bad in (lo.value - 1, hi.value + 1):
+            assert lib.rbl_set_option(h, k, bad) == 11 and get(k) == df.value, (name, bad)   # RBL_ERR_ARG, unchanged
+    for bad_key in (0, count, -3, 1000):
+        v = i64(7)
+        assert lib.rbl_set_option(h, bad_key, 1) == 11
+        assert lib.rbl_get_option(h, bad_key, ctypes.byref(v)) == 11 and v.value == 7
+        assert lib.rbl_option_info(bad_key, None, None, None, None) == 11
+    assert lib.rbl_option_key(b"no_such_option") == 0
+    # the rounds 1-3 switchboard is a shim over the same table
+    shim = {31: ("gmres_pc_sign_fix", 0), 42: ("gmres_one_kernel", 1), 52: ("relaxed_krylov", 1), 54: ("relaxed_always", 1),
+            61: ("block_explicit_small", 0), 63: ("block_explicit_large", 0), 64: ("block_explicit_large", 1), 65: ("block_explicit_large", 2),
+            71: ("bodyframe_factor", 0), 74: ("bodyframe_wall_approx", 1), 81: ("lanczos_reorth", 0), 84: ("block_inverse_f32", 1),
+            85: ("lanczos_euclid_norm", 0), 87: ("lanczos_two_level", 0), 91: ("gmres_predict_checks", 0), 93: ("sym_work_queue", 0),
+            22: ("sym2_rows_per_lane", 2)}
+    for code, (name, val) in shim.items():
+        assert lib.rbl_set_tuning(h, 0, code) == 0 and get(lib.rbl_option_key(name.encode())) == val, code
+    assert lib.rbl_set_tuning(h, 5, 2) == 0 and get(lib.rbl_option_key(b"matvec_kernel")) == 2 and get(lib.rbl_option_key(b"sym_chunk")) == 5
+    assert lib.rbl_set_tuning(h, 0, 0) == 0 and get(lib.rbl_option_key(b"matvec_kernel")) == 0 and get(lib.rbl_option_key(b"sym_chunk")) == 0
+    assert lib.rbl_set_tuning(h, 0, 77) == 11                             # unknown switch: an error now, not a silent kernel choice
+    lib.rbl_destroy(h)
+
+
+def test_communicator_entry_points_without_a_device():
+    """rbl_comm_*: argument checks and the no-communicator state work without a GPU; the collectives themselves are GPU tests."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "rigid_body_light_amd", "librbl.so"))
+    lib.rbl_create.restype = ctypes.c_void_p
+    lib.rbl_destroy.argtypes = [ctypes.c_void_p]
+    lib.rbl_comm_info.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.rbl_comm_init_rccl.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.rbl_set_comm_ops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.rbl_comm_finalize.argtypes = [ctypes.c_void_p]
+    h = lib.rbl_create()
+    r, w, k = ctypes.c_int(9), ctypes.c_int(9), ctypes.c_int(9)
+    assert lib.rbl_comm_info(h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)) == 0 and (r.value, w.value, k.value) == (0, 1, 0)
+    ident = (ctypes.c_char * 128)()
+    assert lib.rbl_comm_init_rccl(h, ident, 2, 2) == 11          # rank out of range
+    assert lib.rbl_comm_init_rccl(h, None, 0, 1) == 11
+    assert lib.rbl_set_comm_ops(h, 3, 2, None, None, None) == 11
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+    cb = CB(lambda user, buf, n: 0)
+    assert lib.rbl_set_comm_ops(h, 1, 2, ctypes.cast(cb, ctypes.c_void_p), None, None) == 0
+    assert lib.rbl_comm_info(h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)) == 0 and (r.value, w.value, k.value) == (1, 2, 1)
+    assert lib.rbl_comm_finalize(h) == 0
+    assert lib.rbl_comm_info(h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)) == 0 and (r.value, w.value, k.value) == (0, 1, 0)
+    lib.rbl_destroy(h)
+
+
 def test_isa_counts_match_the_kernel_sources():
     """bench.py prices its roofline with per-pair instruction counts taken from the assembly of the SAME kernel sources the
     library is built from (tools/isa_stats.py, run by rigid_body_light_amd/build.py): the file exists, belongs to the

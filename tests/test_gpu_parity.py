@@ -186,7 +186,7 @@ def test_apply_M_multi_mfma_vs_oracle(orc, wall, nrhs):
     assert U.shape == (nrhs, r.size)
     for k in range(nrhs):
         assert rel(U[k], orc.apply_M(F[k], r, c["a"], c["eta"], wall, mode="matfree")) < 1e-12
-    rb.cb.set_tuning(0, 3)                 # force the MFMA kernel even for few vectors
+    rb.cb.set_option("matvec_kernel", 3)                 # force the MFMA kernel even for few vectors
     U3 = rb.apply_M_multi(F, r)
     assert rel(U3, U) < 1e-13
 
@@ -547,7 +547,7 @@ def test_cfg2_full_size_lanczos_square_roots():
     # shrink by ~5 % per iteration: M has eigenvalues close to the branch point of the square root; 100 iterations for 1e-3,
     # ~250 for 1e-4, ~1000 for 1e-6), so it is held at 1e-3 and 1e-4; its honest estimate is what makes that visible.
     its_bj = {}
-    ctx.set_tuning(0, 87)                                         # block-Jacobi factor alone: iteration counts for comparison
+    ctx.set_option("lanczos_two_level", 0)                                         # block-Jacobi factor alone: iteration counts for comparison
     for tol in (1e-3, 1e-6):
         ctx.set_lanczos(600, tol)
         x = root(W, "lanczos_pc")
@@ -555,7 +555,7 @@ def test_cfg2_full_size_lanczos_square_roots():
         s_ = bsolve(x / B, 5); v = bsolve(W, 6); Mv = Mu @ v
         assert float(torch.linalg.norm(root(s_, "lanczos_pc") - B * Mv) / torch.linalg.norm(B * Mv)) < 10.0 * tol
         assert torch.equal(bsolve(W, 6), bsolve(W, 2))            # without the two-level part the whole factor is L
-    ctx.set_tuning(0, 88)
+    ctx.set_option("lanczos_two_level", 1)
     for tol in (1e-3, 1e-4, 1e-6, 1e-9):
         acc = 10.0 * tol
         ctx.set_lanczos(600, tol)
@@ -937,7 +937,7 @@ def test_sharded_brownian_step_equals_library_step(shell12, wall, precondition):
     for sharded in (False, "torch loop", "native loop"):
         ctx = DeviceContext(a, eta, wall, cfg=shell12, dt=dt, kBT=kBT, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
-        ctx.set_tuning(0, 87)      # block-Jacobi factor of the preconditioned root: what the torch comparator composes (different factors give different, equally exact roots)
+        ctx.set_option("lanczos_two_level", 0)      # block-Jacobi factor of the preconditioned root: what the torch comparator composes (different factors give different, equally exact roots)
         if sharded:
             cls = ShardedBrownianStepper if sharded == "native loop" else TorchShardedBrownianStepper
             st = cls(ctx, ShardedMobility(nb, 12, device=dev, ctx=ctx), nb, 12, dev, a, wall, kBT, dt,
@@ -1005,7 +1005,7 @@ def test_block_solve_body_ranges(orc, shell12, wall):
 @pytest.mark.parametrize("nblb", [42, 65, 75, 86, 162, 170])
 def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     """Bodies of order 192 < 3 N_blb <= 512 apply (L L^T)^-1, L^-1, L^-T through explicit inverses X = L^-1 (k_trtri_small
-    + k_block_inv_apply) instead of substitution chains: every mode against the substitution kernels (rbl_set_tuning 61)
+    + k_block_inv_apply) instead of substitution chains: every mode against the substitution kernels (RBL_OPT_BLOCK_EXPLICIT_SMALL = 0)
     and against dense numpy factors, on full and ragged 32-blocks and 64-row tiles (n = 195, 225, 258, 486, 510; 126 is
     below the switch and takes the substitution path both times), body ranges and in place."""
     import torch
@@ -1025,7 +1025,7 @@ def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     for variant in (61, 62):
         ctx = DeviceContext(1.0, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
-        ctx.set_tuning(0, 71)                    # per-configuration Cholesky factors (the body-frame form has its own test)
+        ctx.set_option("bodyframe_factor", 0)                    # per-configuration Cholesky factors (the body-frame form has its own test)
         ctx.set_tuning(0, variant)
         for mode in (0, 1, 2):
             o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
@@ -1056,7 +1056,7 @@ def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
 @pytest.mark.parametrize("nblb", [642, 2562])
 def test_large_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     """Bodies of more than 170 blobs (shell_N_642 / 2562: n = 1926 / 7686, ragged last 32-block): the explicit inverses
-    X = L^-1 built by the factorisation's own MFMA kernels on the augmented matrix [L ; I] (rbl_set_tuning 64) against the
+    X = L^-1 built by the factorisation's own MFMA kernels on the augmented matrix [L ; I] (RBL_OPT_BLOCK_EXPLICIT_LARGE = 1) against the
     substitution kernels (63) and against dense numpy factors of the oracle's per-body mobility -- every mode, body
     ranges, in place; L x through the row-parallel kernel; and the single-precision copy (84) to its own accuracy."""
     import torch
@@ -1075,10 +1075,10 @@ def test_large_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     for variant in (63, 64, 84):
         ctx = DeviceContext(a, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
-        ctx.set_tuning(0, 71)                    # per-configuration Cholesky factors (free space would share ONE body-frame factor)
+        ctx.set_option("bodyframe_factor", 0)                    # per-configuration Cholesky factors (free space would share ONE body-frame factor)
         ctx.set_tuning(0, 64 if variant == 84 else variant)
         if variant == 84:
-            ctx.set_tuning(0, 84)
+            ctx.set_option("block_inverse_f32", 1)
         for mode in (0, 1, 2, 3):
             o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
             res[(variant, mode)] = o
@@ -1113,7 +1113,7 @@ def test_free_space_body_frame_factors(orc, nblb):
     oracle:  mode 0 = M_b^-1 v;  mode 1 (G^-1) after mode 3 (G x) = identity;  mode 2 (G^-T): G^-1 M_b G^-T = identity;
     mode 3: G G^T v = M_b v with G^T v = M_b (G^-T ... ) -- checked as mode3(mode1(M_b v)) = M_b v and
     mode1(M_b mode2(v)) = v.  Sizes: substitution (n = 36, 126, 600) and explicit-inverse (258, 486) forms, body ranges, in
-    place; and mode 0 equals the per-configuration Cholesky path (rbl_set_tuning 71) to rounding."""
+    place; and mode 0 equals the per-configuration Cholesky path (RBL_OPT_BODYFRAME_FACTOR = 0) to rounding."""
     import torch
     from rigid_body_light_amd._lib import DeviceContext
     nb = 5
@@ -1183,7 +1183,7 @@ def test_free_space_body_frame_factors(orc, nblb):
 
 
 def test_wall_system_with_the_free_space_body_frame_factor(orc):
-    """rbl_set_tuning 74 (opt-in): with the wall term the blocks differ from body to body, but the free-space body-frame
+    """RBL_OPT_BODYFRAME_WALL_APPROX = 1 (opt-in): with the wall term the blocks differ from body to body, but the free-space body-frame
     factor is still an invertible block factor, so both of its uses stay exact: the block-preconditioned GMRES reaches the
     same solution (a few more iterations), and B G (G^-1 M G^-T)^{1/2} W is a square root of B M B -- checked through the
     factor-independent identity G^-1 B^-1 x = S^{1/2} W  =>  |S^{1/2} W|^2 = (G^-T W) . M (G^-T W)."""
@@ -1247,7 +1247,7 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
         ctx.set_config(X, Q)
         st = (DeterministicStepper if native else TorchDeterministicStepper)(ctx, nb, 12, dev)
         if native:
-            ctx.set_tuning(0, 31)      # the reference's sign of apply_PC's force block, as the torch driver applies it
+            ctx.set_option("gmres_pc_sign_fix", 0)      # the reference's sign of apply_PC's force block, as the torch driver applies it
         lam, U, m, resid = st.solve(Fb, iters=12)                       # fixed work
         lam2, U2, m2, resid2 = st.solve(Fb, iters=120, rtol=1e-11)      # converged
         sols[native] = (U.cpu().numpy(), resid, U2.cpu().numpy(), m2, resid2)
@@ -1258,7 +1258,7 @@ def test_native_gmres_equals_torch_gmres(shell12, block):
             assert float(torch.linalg.norm(out - b) / torch.linalg.norm(b)) < 1e-9
             # default of the library's solver: the preconditioner's force block with its sign restored (A P^-1 ~ I instead
             # of eigenvalues at -1 and +1) -- same solution, no more iterations
-            ctx.set_tuning(0, 32)
+            ctx.set_option("gmres_pc_sign_fix", 1)
             lam3, U3, m3, resid3 = st.solve(Fb, iters=120, rtol=1e-11)
             assert resid3 < 1e-11 and m3 <= m2 + 3 and rel(U3.cpu().numpy(), U2.cpu().numpy()) < 1e-8
     (Ua, ra, Ua2, ma, ra2), (Ub, rb, Ub2, mb, rb2) = sols[False], sols[True]
@@ -1371,7 +1371,7 @@ def test_symmetric_kernel_equals_ordered_kernel_over_sizes(wall):
         r = torch.from_numpy(pos.reshape(-1)).to(dev)
         x = torch.from_numpy(rng.standard_normal(3 * N)).to(dev)
         ref = torch.empty_like(x); out = torch.empty_like(x)
-        ctx.set_tuning(0, 1)                                           # ordered rows
+        ctx.set_option("matvec_kernel", 1)                                           # ordered rows
         ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
         for chunk in ((0,) if N < 8000 else (0, 1, 3, 7)):
             ctx.set_tuning(chunk, 2)                                   # symmetric, heuristic or forced chunk length
@@ -1417,10 +1417,10 @@ def test_apply_M_four_wave_path_ragged_vs_oracle(orc, wall):
     for b0 in (0, 100, 4100, 8192 - 30, N - 70):                # incl. rows of the last row group and the ragged tile
         Uo = orc.apply_M_rows(xh, rh, b0, b0 + 70, c["a"], c["eta"], wall, nthreads=8)
         assert rel(oh[3 * b0:3 * b0 + 210], Uo) < 1e-12, b0
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     rlx = torch.empty_like(x)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, rlx.data_ptr())
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     assert float(torch.linalg.norm(rlx - out) / torch.linalg.norm(out)) < 3e-6
     ctx.close()
@@ -1428,7 +1428,7 @@ def test_apply_M_four_wave_path_ragged_vs_oracle(orc, wall):
 
 @pytest.mark.parametrize("nb,nblb,wall", [(60, 162, True), (60, 162, False), (200, 642, True)])
 def test_relaxed_product_accuracy(nb, nblb, wall):
-    """The RELAXED product (rbl_set_tuning 54 forces it; far tile pairs in packed single precision, coordinates relative
+    """The RELAXED product (RBL_OPT_RELAXED_ALWAYS = 1 forces it; far tile pairs in packed single precision, coordinates relative
     to the column tile's first blob, per-tile sums added in double) against the fp64 product: ~1e-6 relative -- what an inexact Krylov
     iteration may use once its residual is small.  Never the default."""
     import torch
@@ -1446,9 +1446,9 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     x = torch.from_numpy(np.random.default_rng(12).standard_normal(3 * N)).to(dev)
     ref = torch.empty_like(x); rel_ = torch.empty_like(x)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, rel_.data_ptr())
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     again = torch.empty_like(x)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, again.data_ptr())
     ctx.sync_check()
@@ -1457,22 +1457,22 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     rows = (rel_ - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
     assert 0.0 < err < 3e-6 and float(rows.max()) < 3e-5, (err, float(rows.max()))
     # multi-GPU shards (one wave per workgroup, every i_step-th row super-tile) have it too: three relaxed shards add up
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     acc = torch.zeros_like(x)
     for first in range(3):
         pshard = torch.empty_like(x)
         ctx.apply_M_sym(x.data_ptr(), r.data_ptr(), N, first, 3, pshard.data_ptr())
         acc += pshard
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 3e-6
     # the two-vector kernel (lock-step Lanczos) has the same relaxed form
     X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
     R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
     ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, R2.data_ptr())
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, S2.data_ptr())
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     assert float(torch.linalg.norm(R2[0] - ref) / torch.linalg.norm(ref)) < 1e-13
     for k in range(2):
@@ -1487,7 +1487,7 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     pair whose boxes are too extended for their gap is swept in fp64 (k_tile_far, bit 1): the product error stays ~1e-6
     however wide the suspension is.  (One origin per workgroup -- round 2 -- put rows of other bodies arbitrarily far from
     it: here, 30 close pairs of bodies 7 600 radii apart, near neighbours 3-4 radii from rows 2e5 radii from that origin.)
-    Then the inexact-Krylov GMRES (rbl_set_tuning 52) on the same configuration: TRUE fp64 residual below the tolerance."""
+    Then the inexact-Krylov GMRES (RBL_OPT_RELAXED_KRYLOV = 1) on the same configuration: TRUE fp64 residual below the tolerance."""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext, lib
@@ -1507,9 +1507,9 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     x = torch.from_numpy(np.random.default_rng(12).standard_normal(3 * N)).to(dev)
     ref = torch.empty_like(x); rlx = torch.empty_like(x)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, rlx.data_ptr())
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     err = float(torch.linalg.norm(rlx - ref) / torch.linalg.norm(ref))
     rows = (rlx - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
@@ -1517,9 +1517,9 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
     R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
     ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, R2.data_ptr())
-    ctx.set_tuning(0, 54)
+    ctx.set_option("relaxed_always", 1)
     ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, S2.data_ptr())
-    ctx.set_tuning(0, 53)
+    ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     for k in range(2):
         assert float(torch.linalg.norm(S2[k] - R2[k]) / torch.linalg.norm(R2[k])) < 6e-6
@@ -1530,9 +1530,9 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     b[3 * N:] = torch.from_numpy(np.tile([0.1, 0.0, -1.0, 0.0, 0.2, 0.0], nb)).to(dev)
     b[:3 * N] = 0.01 * x
     sol = torch.empty_like(b)
-    ctx.set_tuning(0, 52)
+    ctx.set_option("relaxed_krylov", 1)
     m, res = ctx.gmres_saddle(b.data_ptr(), 200, 1e-8, sol.data_ptr())
-    ctx.set_tuning(0, 51)
+    ctx.set_option("relaxed_krylov", 0)
     out = torch.empty_like(b)
     ctx.apply_saddle(sol.data_ptr(), out.data_ptr()); ctx.sync_check()
     true_res = float(torch.linalg.norm(out - b) / torch.linalg.norm(b))
@@ -1542,7 +1542,7 @@ def test_relaxed_product_in_a_wide_suspension(wall):
 
 @pytest.mark.parametrize("nb,nblb", [(60, 162), (200, 642)])
 def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
-    """Inexact Krylov (rbl_set_tuning 52): GMRES with the block-diagonal PC to 1e-8 on a wall system (9 720 blobs and
+    """Inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1): GMRES with the block-diagonal PC to 1e-8 on a wall system (9 720 blobs and
     cfg 3's 128 400), products relaxed once the residual estimate is below 1e-3.  The solution must satisfy the fp64 saddle
     system to the same tolerance (TRUE residual, evaluated with the fp64 operator) and agree with the all-fp64 solve.
     (Iterative refinement around all-relaxed inner solves was tried: 2 fp64 + 18 relaxed products instead of 6 + 11 --
@@ -1564,7 +1564,7 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
         ctx.set_tuning(0, variant)
         x = torch.empty_like(b)
         m, res = ctx.gmres_saddle(b.data_ptr(), 100, 1e-8, x.data_ptr())
-        ctx.set_tuning(0, 51)
+        ctx.set_option("relaxed_krylov", 0)
         out = torch.empty_like(b)
         ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
         true_res = float(torch.linalg.norm(out - b) / torch.linalg.norm(b))
@@ -1576,7 +1576,7 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
         b2 = b + 1e-5 * torch.from_numpy(rng.standard_normal(nsys)).to(dev) * torch.linalg.norm(b) / np.sqrt(nsys)
         ctx.set_tuning(0, variant)
         m2, res2 = ctx.gmres_saddle(b2.data_ptr(), 100, 1e-8, x.data_ptr(), use_x0=True)
-        ctx.set_tuning(0, 51)
+        ctx.set_option("relaxed_krylov", 0)
         ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
         true2 = float(torch.linalg.norm(out - b2) / torch.linalg.norm(b2))
         assert res2 < 1e-8 and true2 < 2e-8 and m2 < m, (variant, m2, res2, true2)
@@ -1694,9 +1694,9 @@ def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
         check(x, L @ (np.eye(n3) + Qm @ (LE - np.eye(3 * nb)) @ Qm.T))
     except np.linalg.LinAlgError:               # model not positive definite: the library falls back to block-Jacobi, too
         check(x, L)
-    cb.cb.set_tuning(0, 87)                     # block-Jacobi factor alone
+    cb.cb.set_option("lanczos_two_level", 0)                     # block-Jacobi factor alone
     check(cb.M_half_W(W, method="lanczos_pc"), L)
-    cb.cb.set_tuning(0, 88)
+    cb.cb.set_option("lanczos_two_level", 1)
     it, res = cb.cb.lanczos_report()
     cb.cb.set_lanczos(100, 1e-3)
     cb.M_half_W(W, method="lanczos_pc"); it_pc = cb.cb.lanczos_report()[0]
@@ -1779,7 +1779,7 @@ def test_block_refresh_keeps_factors(orc, shell12):
     ctx = DeviceContext(1.0, 1.0, True, cfg=shell12, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_block_refresh(2)
     ctx.set_lanczos(n3, 1e-13)
-    ctx.set_tuning(0, 87)          # the numpy restatement below is the block-Jacobi factor's root (the two-level one has its own tests)
+    ctx.set_option("lanczos_two_level", 0)          # the numpy restatement below is the block-Jacobi factor's root (the two-level one has its own tests)
     v = torch.from_numpy(np.random.default_rng(202).standard_normal(n3)).to(dev)
     def solve():
         o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check(); return o.cpu().numpy()
@@ -2037,6 +2037,6 @@ def test_two_level_factor_of_the_preconditioned_root(orc, wall, nb, nblb):
         Mv = torch.empty_like(v)
         ctx.set_no_damp(True); ctx.apply_M(v.data_ptr(), r.data_ptr(), N, 0, N, Mv.data_ptr()); ctx.set_no_damp(False); ctx.sync_check()
         e = float(torch.linalg.norm(root(s_) - B * Mv) / torch.linalg.norm(B * Mv))
-        ctx.set_tuning(0, 87); root(W); its_bj = ctx.lanczos_report()[0]; ctx.set_tuning(0, 88)
+        ctx.set_option("lanczos_two_level", 0); root(W); its_bj = ctx.lanczos_report()[0]; ctx.set_option("lanczos_two_level", 1)
         assert e < 10.0 * tol and its <= its_bj, (tol, e, its, its_bj)
     ctx.close()

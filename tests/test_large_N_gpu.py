@@ -149,7 +149,7 @@ def test_more_bodies_than_a_grid_dimension(orc, wall):
     ctx.apply_PC(z.data_ptr(), p1.data_ptr()); ctx.sync_check()
     assert bool(torch.isfinite(p1).all())
     if not wall:
-        ctx.set_tuning(0, 71)
+        ctx.set_option("bodyframe_factor", 0)
         p2 = torch.empty_like(z)
         ctx.apply_PC(z.data_ptr(), p2.data_ptr()); ctx.sync_check()
         assert float(torch.linalg.norm(p1 - p2) / torch.linalg.norm(p2)) < 1e-10

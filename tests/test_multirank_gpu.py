@@ -158,14 +158,32 @@ def test_cfg4_size_sharded_brownian_step(monkeypatch, world, orc, tmp_path):
 
 
 def test_world1_nccl_group_runs_the_rccl_code_path():
-    """The `nccl` (= RCCL) branch of dist.py and the raw-device-pointer all-reduce callback of DeviceContext.set_comm have
-    only ever run under gloo with host staging in the rehearsals above.  A process group of ONE rank on the nccl backend
-    drives exactly what N ranks run on one GPU: device-buffer all_gather_into_tensor / all_reduce, and the callback inside
-    rbl_gmres_saddle_dev, the preconditioned Lanczos square root and a whole stochastic step -- equal to the un-sharded
-    results (tools/check_nccl_world1.py; its own process, started before it touches the GPU)."""
+    """RCCL INSIDE librbl (rbl_comm_init_rccl: ncclAllReduce / ncclAllGather on the context's stream) and the callback form
+    (rbl_set_comm_ops over torch.distributed `nccl` on device buffers) have only ever run under gloo with host staging in
+    the rehearsals above.  A communicator of ONE rank drives exactly what N ranks run on one GPU -- rbl_gmres_saddle_dev with
+    the body-sharded block preconditioner, the preconditioned Lanczos square root and a whole stochastic step, with both
+    work splits (tile pairs + all-reduce; rows by body index + all-gather of positions and U), on torch's current stream and
+    on a side stream -- equal to the un-sharded results (tools/check_nccl_world1.py; its own process)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "tools/check_nccl_world1.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "ALL OK" in p.stdout and "side stream" in p.stdout and "FAILED" not in p.stdout
+    assert "RCCL in librbl, split 0" in p.stdout and "RCCL in librbl, split 1" in p.stdout and "callbacks, split 1" in p.stdout
+
+
+def test_cpp_only_host_drives_rccl_inside_librbl(tmp_path):
+    """examples/host_rccl_step.cpp: a C++ host with no Python and no PyTorch in the process (what the reference itself is,
+    c_rigid_obj.cpp:997-1027) creates the unique id, initialises RCCL inside librbl and runs Brownian steps through the C ABI;
+    the steps of its communicator context must reproduce the same steps on a plain single-GPU context (one rank here: a
+    one-GPU box; the same binary takes N ranks, one process per GPU)."""
+    exe = os.path.join(ROOT, "examples", "host_rccl_step")
+    assert os.path.exists(exe), "examples/host_rccl_step is not built: run rigid_body_light_amd/build.py"
+    csv = os.path.join(ROOT, "rigid_body_light_amd", "structures", "shell_N_162.csv")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for split in ("0", "1"):
+        p = subprocess.run([exe, "0", "1", str(tmp_path / ("id%s" % split)), csv, "8", "3", split], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        assert "HOST OK" in p.stdout and "communicator kind 2" in p.stdout and p.stdout.count("GMRES iterations") == 3

@@ -1,4 +1,4 @@
-"""Per-body factor application for LARGE bodies (shell_N_642 / 2562): substitution chains (rbl_set_tuning 63) vs explicit
+"""Per-body factor application for LARGE bodies (shell_N_642 / 2562): substitution chains (RBL_OPT_BLOCK_EXPLICIT_LARGE = 0) vs explicit
 inverses (64) vs their single-precision copy (84), for all bodies and for one rank's share at P = 8, with the achieved
 HBM rate (bytes = the triangle(s) of the factor / inverse one application reads) and the cost of the build.
 usage: bench_block_inverse_large.py [bodies blobs [wall]]"""
@@ -17,7 +17,7 @@ print("%d x shell_N_%d, %s: n = %d, factor %.2f GB (fp64, lower triangles %.2f G
 for variants, name, bpe in (((63,), "substitution (63)", 8.0), ((64,), "explicit inverse fp64 (64)", 8.0), ((64, 84), "explicit inverse fp32 copy (64+84)", 4.0)):
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
-    ctx.set_tuning(0, 71)
+    ctx.set_option("bodyframe_factor", 0)
     for t in variants:
         ctx.set_tuning(0, t)
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check()

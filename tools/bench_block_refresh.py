@@ -15,7 +15,7 @@ for refresh in (1, 2, 4, 8, 16):
         lib().rbl_set_blk_pc(ctx.h, 1)
         ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3)
         ctx.set_block_refresh(refresh)
-        if relaxed: ctx.set_tuning(0, 52)
+        if relaxed: ctx.set_option("relaxed_krylov", 1)
         st = BrownianStepper(ctx, nb, nblb, dev)
         st.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)
         torch.cuda.synchronize(); t0 = time.perf_counter(); its = []; lz = []

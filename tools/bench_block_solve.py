@@ -31,7 +31,7 @@ for variant, name in ((61, "substitution"), (62, "explicit inverse")):
     ctx.close()
 # per-configuration factors (what a wall-corrected system needs) for comparison
 ctx = DeviceContext(c["a"], c["eta"], False, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
-ctx.set_config(c["X"], c["Q"]); ctx.set_tuning(0, 71)
+ctx.set_config(c["X"], c["Q"]); ctx.set_option("bodyframe_factor", 0)
 ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); torch.cuda.synchronize()
 line = "per-configuration Cholesky (tuning 71):"
 for mode in (0, 1, 2):

@@ -79,7 +79,7 @@ for rk in range(P):
     b0 = rk * base + min(rk, rem); b1 = b0 + base + (1 if rk < rem else 0)
     p1 = ev_ms(lambda: ctx.apply_M_sym(x2.data_ptr(), r.data_ptr(), N, rk, P, o2.data_ptr()), 10)
     p2 = ev_ms(lambda: ctx.apply_M_sym_multi(x2.data_ptr(), r.data_ptr(), N, 2, rk, P, o2.data_ptr()), 10)
-    ctx.set_tuning(0, 64)                                        # invalidates the factors: the next call builds this rank's only
+    ctx.set_option("block_explicit_large", 1)                                        # invalidates the factors: the next call builds this rank's only
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 0, b0, b1)
@@ -89,7 +89,7 @@ for rk in range(P):
     rows.append((rk, b1 - b0, p1, p2, fb, pb))
 # the two-level factor of the Lanczos root is rebuilt per configuration on EVERY rank (replicated, apart from Z = L^-1 K_t)
 def tl_rebuild():
-    ctx.set_tuning(0, 88)                                        # invalidates the two-level factor only
+    ctx.set_option("lanczos_two_level", 1)                                        # invalidates the two-level factor only
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 5)
 t_tl = ev_ms(tl_rebuild, 5) - ev_ms(lambda: ctx.block_solve(v.data_ptr(), o.data_ptr(), 5), 5)
 ctx.close()

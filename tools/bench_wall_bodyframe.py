@@ -1,5 +1,5 @@
 """Wall-corrected system: exact per-configuration block factors vs the free-space body-frame factor used as an approximate
-block factor (rbl_set_tuning 74): Brownian step time and iteration counts at cfg 3."""
+block factor (RBL_OPT_BODYFRAME_WALL_APPROX = 1): Brownian step time and iteration counts at cfg 3."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from rigid_body_light_amd import make_config
@@ -17,7 +17,7 @@ for variant in (73, 74):
         ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3)
         ctx.set_block_refresh(2)
         ctx.set_tuning(0, variant)
-        if relaxed: ctx.set_tuning(0, 52)
+        if relaxed: ctx.set_option("relaxed_krylov", 1)
         st = BrownianStepper(ctx, nb, nblb, dev)
         st.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)
         torch.cuda.synchronize(); t0 = time.perf_counter(); its = []; lz = []

@@ -35,7 +35,7 @@ def main():
                             stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(c["X"], c["Q"])
         if not native:
-            ctx.set_tuning(0, 87)      # the torch comparator composes the root with the block-Jacobi factor; librbl's default is two-level
+            ctx.set_option("lanczos_two_level", 0)      # the torch comparator composes the root with the block-Jacobi factor; librbl's default is two-level
         if block_pc:
             from rigid_body_light_amd._lib import lib
             lib().rbl_set_blk_pc(ctx.h, 1)

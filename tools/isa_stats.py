@@ -112,6 +112,32 @@ def main():
         per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]   # a transcendental counted as ONE flop
         res["%s<%s,%d>" % (kern, "true" if wall else "false", ni)] = {
             "block": best[0], "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
+    # the ordered-rows kernel k_apply_M<WALL> (row-sharded multi-GPU split): its sweep is a run of one-pair head blocks (distance,
+    # rsq, three ds_read_b128 broadcasts of the staged j blob) followed by ONE body block that finishes those pairs together
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*?9k_apply_MILb([01])EE\S*):", l)
+        if not m:
+            continue
+        wall = m.group(2) == "1"
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        instances["k_apply_M<%s>" % ("true" if wall else "false")] = isa_hash(lines, i, end)
+        blks = [(name, classify(ops)) for name, ops in blocks_of(lines, i, end)]
+        for b, (name, c) in enumerate(blks):
+            if not (c["rsq"] == 1 and c["lds"] == 3 and not c["div"]):
+                continue
+            nhead = 0
+            while b + nhead < len(blks) and blks[b + nhead][1]["rsq"] == 1 and blks[b + nhead][1]["lds"] == 3:
+                nhead += 1
+            if b + nhead >= len(blks):
+                break
+            body = blks[b + nhead][1]
+            if body["lds"] or body["div"] or body["f64"] < 8 * nhead:
+                break
+            per = {k: c[k] + body[k] / float(nhead) for k in ("fma", "mul", "add", "trans", "f64", "valu", "valu_other", "lds", "salu")}
+            per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]
+            res["k_apply_M<%s>" % ("true" if wall else "false")] = {"block": "%s x%d + %s" % (name, nhead, blks[b + nhead][0]),
+                                                                     "ordered_pairs_per_trip": nhead, "per_ordered_pair": per}
+            break
     import hashlib
     import os
     h = hashlib.sha256()
@@ -122,6 +148,11 @@ def main():
                "kernel_source_sha256": h.hexdigest(), "kernels": res, "instance_isa_sha256": instances},
               open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
+        if "per_ordered_pair" in v:
+            p = v["per_ordered_pair"]
+            print("%-28s %s: %.1f VALU (%.1f f64: %.1f fma %.1f mul %.1f add %.1f trans) %.1f LDS -> %.0f flop / ORDERED pair"
+                  % (k, v["block"], p["valu"], p["f64"], p["fma"], p["mul"], p["add"], p["trans"], p["lds"], p["flop"]))
+            continue
         p = v["per_unordered_pair"]
         if "pk_fma" in p:
             print("%-28s %s: %.1f VALU (%.1f pk_fma %.1f pk_mul %.1f pk_add %.1f rsq_f32) %.1f LDS / unordered pair"
