@@ -150,7 +150,8 @@ def isa_counts(kernel):
         d = json.load(open(path))
         if d.get("kernel_source_sha256") != kernel_source_hash():
             return None
-        return d["kernels"][kernel]["per_unordered_pair"]
+        k = d["kernels"][kernel]
+        return k.get("per_unordered_pair") or k["per_ordered_pair"]     # (the ordered-rows kernel is counted per ORDERED pair)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -159,7 +160,7 @@ def pmc_traffic(kernel, config, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only while the built
     library holds the same kernel code as the profiled one: the file records the sha256 of the profiled instance's
     instruction text, tools/isa_stats.py computes the same for every build (librbl.isa.json)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_bench_%s_pmc.json" % (rnd, config))
         try:
             d = json.load(open(path))
@@ -206,6 +207,13 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
                                 "would need %.2f TB)" % (rows, N, N, t1 - t0, 8.0 * (3 * N) ** 2 / 1e12),
                       "seconds_per_step": t_full}
     return out
+
+
+def apply_opts(ctx, args):
+    """--opt name=value switches onto a context (named options of include/rbl.h)"""
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name.strip(), int(val))
 
 
 def gather_ranks(values, dev, world):
@@ -289,8 +297,7 @@ def timestep_mode(args, dev, world=1, rank=0):
         from rigid_body_light_amd._lib import lib
         lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"])
-    for v in args.tune:
-        ctx.set_tuning(0, v)
+    apply_opts(ctx, args)
     iters = 20 if args.rtol <= 0 else 200
     rtol = args.rtol if args.rtol > 0 else None
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
@@ -458,7 +465,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         return d
 
     out = {}
-    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
+    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev, set_comm=False) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
     stp.step(Fb, 20)
     d = timed(lambda k: stp.step(Fb, 20), tctx=ctx)
     d.update({"apply_M_per_timestep": 21, "definition": "deterministic fixed-work step (SURVEY.md 8d): 20 GMRES iterations on the saddle "
@@ -487,13 +494,15 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         lib().rbl_set_blk_pc(ctx.h, 0); ctx.set_block_refresh(1)
     # stochastic midpoint step, converged: BASELINE configs[3] (on N GPUs: `--mode timestep --kBT 1 --gpus N`)
     bro = {}
-    for ltol, relaxed, energy in ((1e-3, False, False), (1e-6, False, False), (1e-3, True, False), (1e-3, False, True)):
+    variants = [(1e-3, False, False, 0), (1e-6, False, False, 0), (1e-3, True, False, 0), (1e-3, False, True, 0)]
+    if world > 1:
+        variants.append((1e-3, False, False, 1))       # the same step with the row split (all-gather of positions and U)
+    for ltol, relaxed, energy, split in variants:
         bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
         lib().rbl_set_blk_pc(bctx.h, 1)
         bctx.set_config(c["X"], c["Q"]); bctx.set_lanczos(200, ltol)
         bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
-        for v in args.tune:
-            bctx.set_tuning(0, v)
+        apply_opts(bctx, args)
         if relaxed:                    # inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1): see the `relaxation` note below
             bctx.set_option("relaxed_krylov", 1)
         if energy:                     # stop the root on its energy-norm estimate (RBL_OPT_LANCZOS_EUCLID_NORM = 0): see `lanczos_norm` below
@@ -502,6 +511,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             from rigid_body_light_amd.dist import ShardedMobility
             bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
                                          lanczos_tol=ltol, lanczos_max_iter=200)
+            bctx.set_option("comm_split", split)
             one = lambda k: bst.step(Fb, seed=k, iters=200, rtol=1e-8)
             lz = lambda: list(bst.lanczos_iterations)
         else:
@@ -515,8 +525,11 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         if world == 1:                 # measured, outside the timed region: one more pair of roots + one product
             d["root_identity_error"] = root_identity_error(bctx, nb, nblb, c["a"], dev)
         d["lanczos_stopping_norm"] = "energy" if energy else "euclidean"
-        bro["lanczos_%g%s%s" % (ltol, "_relaxed" if relaxed else "", "_energy_norm" if energy else "")] = d
-        del bst, bctx
+        d["comm_split"] = ["tile pairs + all-reduce", "rows by body index + all-gather"][split] if world > 1 else None
+        bro["lanczos_%g%s%s%s" % (ltol, "_relaxed" if relaxed else "", "_energy_norm" if energy else "", "_rows" if split else "")] = d
+        del bst
+        bctx.close()
+        del bctx
     bro.update({"kBT": 1.0, "rtol": 1e-8, "initial_guess": "zero (fresh noise every step)",
                 "lanczos_norm": "the preconditioned root x = B L z stops on an error estimate of x in its Euclidean norm (default; what "
                                 "root_identity_error measures); the *_energy_norm entry stops on the estimate of z = (L^-1 M L^-T)^{1/2} W, "
@@ -657,6 +670,101 @@ def other_configs(dev, stream):
     return out
 
 
+def headline_timesteps(tstep):
+    """BASELINE.json's metric is `timesteps/sec + M.F GFLOP/s`: the first half at the top level of the line (SURVEY.md 8d defines the
+    steps; every entry is measured over --timestep-steps consecutive steps in `timestep`, residuals and iteration counts there)."""
+    out = {"deterministic_fixed_work": tstep["deterministic_fixed"]["timesteps_per_sec"],
+           "deterministic_fixed_work_residual": tstep["deterministic_fixed"]["gmres_residual_max"]}
+    if "converged" in tstep:
+        out["deterministic_converged"] = tstep["converged"]["timesteps_per_sec"]
+    b = tstep.get("brownian_converged", {}).get("lanczos_0.001")
+    if b:
+        out["brownian_converged"] = b["timesteps_per_sec"]
+        out["brownian_converged_apply_M_per_step"] = brownian_products(b)
+    out["definition"] = ("SURVEY.md 8(d): deterministic_fixed_work = 20 GMRES iterations (21 apply_M, diagonal PC; NOT converged, see the residual); "
+                         "deterministic_converged = block PC, GMRES to 1e-8 from the extrapolated previous solutions (constant body force); "
+                         "brownian_converged = stochastic midpoint step, fresh noise every step, GMRES to 1e-8 from zero, square roots by "
+                         "preconditioned Lanczos to 1e-3 -- the physically meaningful step of configs[3]")
+    return out
+
+
+def brownian_products(b):
+    """full mobility products of one converged Brownian step: GMRES iterations (+ 1 when the last preconditioner needs none: no) +
+    2 RFD products + the Lanczos pair iterations (one two-vector product each, counted as 2)"""
+    its = b["gmres_iterations"]
+    lz = b["lanczos_iterations_last_step"]
+    return float(sum(its)) / len(its) + 2.0 + 2.0 * float(lz[0])
+
+
+def cpu_timestep_baseline(tstep, cb):
+    """what the same steps would take on the host: the CPU oracle's measured seconds per apply_M (cpu_baseline) x the MEASURED number of
+    products of each step (O(N) work -- K operators, preconditioner applications -- left out: a lower bound on the CPU time)"""
+    out = {"kind": "port", "note": "oracle-timed apply_M x the measured product count of the GPU step (O(N) work not counted)"}
+    for label, leg in (("1core", cb["1core"]), ("allcores", cb["allcores"])):
+        sec = leg["seconds_per_step"]
+        d = {"cores": leg["cores"], "deterministic_fixed_work": 1.0 / (21.0 * sec)}
+        if "converged" in tstep:
+            its = tstep["converged"]["gmres_iterations"]
+            d["deterministic_converged"] = 1.0 / ((float(sum(its)) / len(its) + 1.0) * sec)       # + the residual of the initial guess
+        b = tstep.get("brownian_converged", {}).get("lanczos_0.001")
+        if b:
+            d["brownian_converged"] = 1.0 / (brownian_products(b) * sec)
+        d["unit"] = "timesteps/s"
+        out[label] = d
+    return out
+
+
+def dropin_block(dev):
+    """The reference's real usage model (src/Rigid.py:69-80): an EXTERNAL Krylov solver -- scipy.sparse.linalg.gmres -- over
+    RigidBody.apply_saddle / apply_PC through the drop-in wrapper, host vectors in and out (PCIe inclusive), next to the library's own
+    device-resident solver on the same system."""
+    import scipy.sparse.linalg as spla
+    from rigid_body_light_amd import RigidBody, make_config
+    out = {}
+    for name, block in (("cfg1", False), ("cfg2", True), ("cfg3", True)):
+        nb, nblb, wall = CONFIGS[name]
+        c = make_config(nb, nblb, wall)
+        rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall, block_PC=block)
+        n3, nsys = 3 * nb * nblb, 3 * nb * nblb + 6 * nb
+        x = np.random.default_rng(11).standard_normal(nsys)
+        rb.apply_saddle(x); rb.apply_PC(x)                     # builds the preconditioner, sizes the workspaces
+        reps = 200 if name == "cfg1" else 20 if name == "cfg2" else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rb.apply_saddle(x)
+        t_sad = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rb.apply_PC(x)
+        t_pc = (time.perf_counter() - t0) / reps
+        rhs = np.concatenate([np.zeros(n3), -np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)])
+        count = [0]
+
+        def op(y):                                               # right preconditioning: (A P^-1) y = b, x = P^-1 y
+            count[0] += 1
+            return rb.apply_saddle(rb.apply_PC(y))
+
+        A = spla.LinearOperator((nsys, nsys), matvec=op, dtype=np.float64)
+        t0 = time.perf_counter()
+        y, info = spla.gmres(A, rhs, rtol=1e-8, atol=0.0, restart=100, maxiter=2)
+        xs = rb.apply_PC(y)
+        t_solve = time.perf_counter() - t0
+        res = float(np.linalg.norm(rb.apply_saddle(xs) - rhs) / np.linalg.norm(rhs))
+        # the library's own solver on the same system (device-resident vectors, rbl_step_deterministic without the update)
+        t0 = time.perf_counter()
+        m_lib, r_lib = rb.cb.solve_saddle(rhs, 200, 1e-8)[1:]
+        t_lib = time.perf_counter() - t0
+        out[name] = {"workload": "%d x shell_N_%d, %s, %s PC" % (nb, nblb, "wall-corrected" if wall else "free-space", "block" if block else "diagonal"),
+                     "apply_saddle_ms": t_sad * 1e3, "apply_PC_ms": t_pc * 1e3,
+                     "scipy_gmres": {"ms": t_solve * 1e3, "operator_calls": count[0], "info": int(info), "true_residual": res},
+                     "rbl_gmres_saddle": {"ms": t_lib * 1e3, "iterations": int(m_lib), "residual_estimate": float(r_lib)}}
+    out["note"] = ("host-pointer API through `import Rigid`-compatible RigidBody: every call uploads its argument and downloads its result "
+                   "(apply_saddle = ONE boundary crossing, rbl_apply_saddle; the reference composes it from four).  scipy_gmres = "
+                   "scipy.sparse.linalg.gmres on A P^-1 (right preconditioning with apply_PC as the reference defines it), rtol 1e-8; "
+                   "rbl_gmres_saddle = the library's device-resident solver on the same right-hand side, host vectors in and out")
+    return out
+
+
 class LineGuard:
     """N > 1 inside ONE torchrun job (the way the driver starts the scaling runs): the headline line is complete before the
     time-step part begins, and must not be lost to it.  Rank 0 keeps the finished line here; a watchdog thread prints it --
@@ -764,8 +872,8 @@ def main():
                     "every k-th configuration (rbl_set_block_refresh)")
     ap.add_argument("--rtol", type=float, default=0.0, help="--mode timestep: converge GMRES to this relative residual "
                     "instead of the fixed 20 iterations")
-    ap.add_argument("--tune", type=int, action="append", default=[], help="rbl_set_tuning(0, V) switches for A/B runs (31/32 PC sign, "
-                    "41/42 one-kernel GMRES for small systems, ...), repeatable")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="rbl_set_option switches for A/B runs "
+                    "(include/rbl.h RBL_OPT_*: gmres_pc_sign_fix=0, sym_work_queue=0, comm_split=1, ...), repeatable")
     ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 
@@ -806,51 +914,12 @@ def main():
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=stream.cuda_stream)
     ctx.set_config(c["X"], c["Q"])
     if args.jsplit or args.variant:
-        ctx.set_tuning(args.jsplit, args.variant)
-    for v in args.tune:
-        ctx.set_tuning(0, v)
+        ctx.set_tuning(args.jsplit, args.variant)        # (kernel choice + its split: the one call the old switchboard keeps)
+    apply_opts(ctx, args)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
     nrows = sm.row1 - sm.row0
     guard = LineGuard(world, rank, limit_s=500)      # below the 600 s after which the RCCL watchdog aborts a stuck rank
-
-    F_full_host = np.random.default_rng(2).standard_normal(3 * N)
-    F_local = torch.from_numpy(F_full_host[3 * sm.row0:3 * sm.row1].copy()).to(dev)
-    r_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
-    U_local = torch.empty(3 * nrows, dtype=torch.float64, device=dev)
-    # four events per timed step: [gather] e0 [kernel] e1 [all-reduce] e2, preceded by e_start
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-
-    use_sym = args.variant != 1     # symmetric kernel (each unordered pair once) unless the ordered kernel is forced
-    U_part = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
-
-    r_all = torch.empty(3 * N, dtype=torch.float64, device=dev) if use_sym else None
-
-    def step(k=None):
-        # a8: blob positions from (X,Q); one exchange; then this rank's share of U = B M B F.
-        # Symmetric sharding needs all positions on every rank: the O(N_bod) body state is replicated, so each
-        # rank evaluates them itself (a ~5 us kernel) instead of gathering them; the force vector arrives
-        # sharded (one all-gather) and the partial U is completed by one all-reduce.
-        if k is not None:
-            ev[k][0].record(stream)
-        if use_sym:
-            ctx.blob_positions(0, nb, r_all.data_ptr())
-            r_full = r_all
-        else:
-            ctx.blob_positions(sm.b0, sm.b1, r_local.data_ptr())
-            r_full = sm.set_positions_local(r_local) if world > 1 else r_local
-        F_full = sm.all_gather_rows(F_local) if world > 1 else F_local
-        if k is not None:
-            ev[k][1].record(stream)
-        if use_sym:   # this rank's share of the unordered tile pairs -> partial full-length U -> all-reduce
-            ctx.apply_M_sym(F_full.data_ptr(), r_full.data_ptr(), N, rank, world, U_part.data_ptr())
-        else:         # ordered pairs, this rank's rows, no reduction
-            ctx.apply_M(F_full.data_ptr(), r_full.data_ptr(), N, sm.row0, sm.row1, U_local.data_ptr())
-        if k is not None:
-            ev[k][2].record(stream)
-        if use_sym:
-            sm.all_reduce_sum(U_part)
-        if k is not None:
-            ev[k][3].record(stream)
+    kname_w = "true" if wall else "false"
 
     def barrier():
         torch.cuda.synchronize()
@@ -858,29 +927,149 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.sync_check()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    t1 = time.perf_counter()
-    ctx.sync_check()
+    F_full_host = np.random.default_rng(2).standard_normal(3 * N)
+    use_sym = args.variant != 1     # symmetric kernel (each unordered pair once) unless the ordered kernel is forced
+    U_full = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    r_all = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    F_full = torch.from_numpy(F_full_host).to(dev)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    mine = [sum(e[i].elapsed_time(e[i + 1]) for e in ev) / args.steps for i in range(3)]     # gather+positions, kernel, all-reduce
-    per_rank = gather_ranks(mine, dev, world)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    kern_ms = float(per_rank[:, 1].max())
+    def roofline_of(kname, pairs_per_launch, ordered, kern_ms, traffic_cfg=None):
+        """price one launch: EXECUTED flops of the kernel's sweep (assembly of this build) x the pairs it covers.  achieved <= peak
+        by construction; the reference-arithmetic price (204 / 59 flop per ORDERED pair) is kept beside it."""
+        ref_tflops = FLOPS_PER_PAIR[wall] * (pairs_per_launch if ordered else 2.0 * pairs_per_launch) / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "fp64-valu", "kernel": kname, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "kernel_ms": kern_ms,
+                "reference_equivalent_tflops": ref_tflops,
+                "reference_equivalent": "%.0f flop/ordered pair (SURVEY.md 8d, reference arithmetic) x %.4g ordered pairs/launch"
+                                        % (FLOPS_PER_PAIR[wall], pairs_per_launch if ordered else 2.0 * pairs_per_launch)}
+        isa = isa_counts(kname)
+        if isa is None:
+            roof.update({"achieved": None, "frac": None, "traffic": None,
+                         "note": "librbl.isa.json missing or not from the current kernel sources: run rigid_body_light_amd/build.py"})
+            return roof
+        achieved = isa["flop"] * pairs_per_launch / (kern_ms * 1e-3) / 1e12
+        issue = isa["valu"] * pairs_per_launch / 64.0 * 4.0 / (N_SIMD * PEAK_CLOCK_GHZ * 1e9) / (kern_ms * 1e-3)
+        traffic, tsrc = pmc_traffic(kname, traffic_cfg, world) if traffic_cfg else (None, None)
+        roof.update({"achieved": achieved, "frac": achieved / PEAK_FP64_TFLOPS, "valu_issue_frac": issue, "traffic": traffic,
+                     "algorithmic": "%.0f executed flop (%.0f fma x2 + %.0f mul + %.0f add + %.0f rsq) and %.1f VALU instructions per "
+                                    "%s pair in the sweep of this build (librbl.isa.json) x %.4g such pairs/launch"
+                                    % (isa["flop"], isa["fma"], isa["mul"], isa["add"], isa["trans"], isa["valu"],
+                                       "ORDERED" if ordered else "UNORDERED", pairs_per_launch),
+                     "note": "fp64 VALU-issue bound (fp64 VALU and fp64 MFMA share one pipe on gfx950, so peak = the fp64 vector = "
+                             "matrix peak at 2.4 GHz).  frac = executed flops / peak; valu_issue_frac = VALU instructions x 4 cycles / "
+                             "(1024 SIMDs x 2.4 GHz x kernel time): the share of the chip's issue slots at the spec clock the kernel "
+                             "fills (the rest: the clock the chip sustains under fp64 load, ~2.1 GHz, and the quarter-rate v_rsq_f64)."})
+        if tsrc is not None:
+            roof["traffic_source"] = tsrc.get("source")
+        return roof
+
+    partitionings = None
+    if world == 1:
+        # ---- one GPU: blob positions -> U = B M B F, the kernel bracketed by events on its own stream ------------------------
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+        def step(k=None):
+            if k is not None:
+                ev[k][0].record(stream)
+            ctx.blob_positions(0, nb, r_all.data_ptr())                               # a8: blob positions from (X, Q)
+            if k is not None:
+                ev[k][1].record(stream)
+            ctx.apply_M(F_full.data_ptr(), r_all.data_ptr(), N, 0, N, U_full.data_ptr())   # heuristic: the symmetric kernel
+            if k is not None:
+                ev[k][2].record(stream)
+
+        for _ in range(args.warmup):
+            step()
+        ctx.sync_check()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        barrier()
+        t1 = time.perf_counter()
+        ctx.sync_check()
+        elapsed = t1 - t0
+        kern_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+        # the same K steps twice more: box-to-box and run-to-run spread of this kernel (20.3 - 22.1 ms in round 3) is larger than
+        # most kernel changes, so the line carries min / median of three passes; `value` stays the contract's first pass
+        passes = [elapsed / args.steps * 1e3]
+        for _ in range(2):
+            barrier(); ta = time.perf_counter()
+            for k in range(args.steps):
+                step()
+            barrier(); passes.append((time.perf_counter() - ta) / args.steps * 1e3)
+        ctx.sync_check()
+        repeats = {"ms_per_step": [round(x, 4) for x in passes], "min": min(passes), "median": sorted(passes)[1],
+                   "note": "three passes of --steps steps each; `value` / `ms_per_step` are the first (the contract's timed region)"}
+        if use_sym:
+            ni, chunk, wbytes = ctx.apply_M_sym_info(N, 1, 1)
+            kname = "k_apply_M_sym<%s,%d>" % (kname_w, ni)
+            roof = roofline_of(kname, 0.5 * float(N) * float(N), False, kern_ms, args.config)
+            roof["launch"] = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
+        else:
+            roof = roofline_of("k_apply_M<%s>" % kname_w, float(N) * float(N), True, kern_ms)
+        parallelism = "one GPU"
+        U_check = U_full
+    else:
+        # ---- N GPUs: the library's own sharded product (what every Krylov iteration of its solvers runs), both work splits --
+        # RCCL inside librbl when the process group is nccl; callbacks into torch.distributed (host-staged) in a gloo rehearsal
+        ctx.set_comm(sm)
+        rank_, world_, kind = ctx.comm_info()
+        assert world_ == world and rank_ == rank
+        partitionings = {}
+        ctx.set_timing(True)
+        for pname, split in (("tile_pairs", 0), ("rows", 1)):
+            ctx.set_option("comm_split", split)
+
+            def step():
+                ctx.multi_body_pos(r_all.data_ptr())      # tile pairs: every rank all bodies; rows: own bodies + all-gather
+                ctx.apply_M(F_full.data_ptr(), r_all.data_ptr(), N, 0, N, U_full.data_ptr())   # this rank's share + ONE collective
+
+            for _ in range(args.warmup):
+                step()
+            ctx.sync_check()
+            barrier()
+            ctx.reset_timings()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            ctx.sync_check()
+            tm = ctx.timings()
+            el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            el = float(el.item())
+            pr = gather_ranks([tm["product"][0] / args.steps, tm["collective"][0] / args.steps, tm["collective"][1] / args.steps], dev, world)
+            k_ms = float(pr[:, 0].max())
+            if split == 0:
+                ni, chunk, wbytes = ctx.apply_M_sym_info(N, world, 1)
+                rf = roofline_of("k_apply_M_sym<%s,%d>" % (kname_w, ni), 0.5 * float(N) * float(N) / world, False, k_ms)
+                rf["launch"] = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
+                what = ("unordered tile pairs dealt over the ranks (positions replicated: a 5 us kernel per rank instead of a collective), "
+                        "partial U completed by ONE sum all-reduce of 24 N bytes")
+            else:
+                rf = roofline_of("k_apply_M<%s>" % kname_w, float(nrows) * float(N), True, k_ms)
+                what = ("rows by body index (north_star / SURVEY.md 8e): each rank computes ITS bodies' blob positions, ONE all-gather shares "
+                        "them, ordered-pair kernel on the rank's rows, ONE all-gather of U (24 N bytes)")
+            partitionings[pname] = {
+                "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+                "mf_gflops": 18.0 * float(N) ** 2 / (el / args.steps) / 1e9, "what": what, "roofline": rf,
+                "per_rank": {"kernel_ms": {"min": float(pr[:, 0].min()), "max": float(pr[:, 0].max()), "per_rank": [round(float(x), 4) for x in pr[:, 0]]},
+                             "collective_ms": {"min": float(pr[:, 1].min()), "max": float(pr[:, 1].max()), "per_rank": [round(float(x), 4) for x in pr[:, 1]]},
+                             "collectives_per_step": float(pr[0, 2])}}
+            if split == 0:
+                elapsed, kern_ms, roof = el, k_ms, rf
+                U_check = U_full.clone()
+        ctx.set_option("comm_split", 0)
+        ctx.set_timing(False)
+        repeats = None
+        parallelism = ("tile-pair-sharded x%d, positions replicated, all-reduce(U) [value]; also rows-by-body x%d, all-gather(positions) + "
+                       "all-gather(U) [partitionings.rows]; collectives: %s" % (world, world, "RCCL inside librbl (rbl_comm_init_rccl)" if kind == 2 else
+                                                                               "callbacks into torch.distributed (%s rehearsal)" % args.backend))
 
     if args.dump_check:   # for tests/: a row sample of what was just timed (the oracle comparison happens in the test)
         b0 = sm.row0 + (nrows // 2)
-        got = (U_part[3 * b0:3 * b0 + 24] if use_sym else U_local[3 * (b0 - sm.row0):3 * (b0 - sm.row0) + 24]).cpu().numpy()
-        np.savez("%s.rank%d.npz" % (args.dump_check, rank), row0=b0, values=got, world=world, rank=rank)
+        np.savez("%s.rank%d.npz" % (args.dump_check, rank), row0=b0, values=U_check[3 * b0:3 * b0 + 24].cpu().numpy(), world=world, rank=rank)
 
     phase = os.environ.get("RBL_BENCH_PHASE", "all")       # set by self_launch: main | timestep | all
     if phase == "timestep":                                  # second job of a self-launched N-rank run: only the time steps
@@ -893,51 +1082,11 @@ def main():
     line = None
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        # ordered-pair equivalents one launch (this rank) covers: its rows x all columns, or its
-        # 1/world share of the unordered tile pairs (each standing for two ordered pairs)
-        pairs_per_launch = float(N) * float(N) / world if use_sym else float(nrows) * float(N)
-        ref_tflops = FLOPS_PER_PAIR[wall] * pairs_per_launch / (kern_ms * 1e-3) / 1e12
-        kname = "k_apply_M<%s>" % ("true" if wall else "false")
-        isa = None
-        sym_info = None
-        if use_sym:
-            ni, chunk, wbytes = ctx.apply_M_sym_info(N, world, 1)
-            kname = "k_apply_M_sym<%s,%d>" % ("true" if wall else "false", ni)
-            isa = isa_counts(kname)
-            sym_info = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
-        # EXECUTED work: what the kernel's far-tile sweep issues per unordered pair (assembly of this build) x the
-        # unordered pairs of one launch.  achieved <= peak by construction; the reference-arithmetic price
-        # (204 / 59 flop per ORDERED pair) is kept beside it as reference_equivalent_tflops.
-        roof = {"bound": "fp64-valu", "kernel": kname, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "kernel_ms": kern_ms,
-                "reference_equivalent_tflops": ref_tflops,
-                "reference_equivalent": "%.0f flop/ordered pair (SURVEY.md 8d, reference arithmetic) x %.4g ordered pairs/launch"
-                                        % (FLOPS_PER_PAIR[wall], pairs_per_launch)}
-        if isa is not None:
-            upairs = 0.5 * pairs_per_launch
-            achieved = isa["flop"] * upairs / (kern_ms * 1e-3) / 1e12
-            issue = isa["valu"] * upairs / 64.0 * 4.0 / (N_SIMD * PEAK_CLOCK_GHZ * 1e9) / (kern_ms * 1e-3)
-            traffic, tsrc = pmc_traffic(kname, args.config, world)
-            roof.update({"achieved": achieved, "frac": achieved / PEAK_FP64_TFLOPS,
-                         "valu_issue_frac": issue,
-                         "traffic": traffic,
-                         "algorithmic": "%.0f executed flop (%.0f fma x2 + %.0f mul + %.0f add + %.0f rsq) and %.1f VALU instructions per "
-                                        "UNORDERED pair in the far-tile sweep of this build (librbl.isa.json) x %.4g unordered pairs/launch"
-                                        % (isa["flop"], isa["fma"], isa["mul"], isa["add"], isa["trans"], isa["valu"], upairs),
-                         "note": "fp64 VALU-issue bound (fp64 VALU and fp64 MFMA share one pipe on gfx950, so peak = the fp64 vector = "
-                                 "matrix peak at 2.4 GHz).  frac = executed flops / peak; valu_issue_frac = VALU instructions x 4 cycles / "
-                                 "(1024 SIMDs x 2.4 GHz x kernel time): the share of the chip's issue slots at the spec clock the kernel "
-                                 "fills (the rest: the clock the chip sustains under fp64 load, ~2.1 GHz, and the quarter-rate v_rsq_f64)."})
-            if tsrc is not None:
-                roof["traffic_source"] = tsrc.get("source")
-        else:
-            roof.update({"achieved": None, "frac": None, "traffic": None,
-                         "note": "librbl.isa.json missing or not from the current kernel sources: run rigid_body_light_amd/build.py"})
-        if sym_info:
-            roof["launch"] = sym_info
         line = {
             "metric": "timesteps/sec + M.F GFLOP/s (BASELINE.json metric): value = M.F passes/sec, 1 step = one matrix-free "
-                      "apply_M pass of the hot path (blob positions -> [all-gather] -> U = B M B F); M.F GFLOP/s in `mf_gflops`, "
-                      "timesteps/sec in `timestep`; %d x shell_N_%d, %s, fp64" % (nb, nblb, "wall-corrected" if wall else "free-space"),
+                      "apply_M pass of the hot path (blob positions -> U = B M B F, the product every Krylov iteration of a time step "
+                      "runs); M.F GFLOP/s in `mf_gflops`, whole time steps in `timesteps_per_sec`; %d x shell_N_%d, %s, fp64"
+                      % (nb, nblb, "wall-corrected" if wall else "free-space"),
             "value": 1.0 / sec_per_step,
             "unit": "steps/s",
             "n_gpus": world,
@@ -951,20 +1100,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: 200 bodies x shell_N_642 blobs, wall-corrected mobility"
                                    if args.config == "cfg3" else args.config,
-                       "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
-                       "parallelism": ("tile-pair-sharded x%d, positions replicated, all-gather(F) + all-reduce(U)" if use_sym else
-                                       "body-row-sharded x%d, all-gather(pos,F)") % world},
+                       "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall, "parallelism": parallelism},
             "mf_gflops": 18.0 * float(N) ** 2 / sec_per_step / 1e9,
             "roofline": roof,
         }
-        if world > 1:
-            names = ("positions_and_all_gather_ms", "kernel_ms", "all_reduce_ms")
-            line["per_rank"] = {n_: {"min": float(per_rank[:, i].min()), "max": float(per_rank[:, i].max()),
-                                     "per_rank": [round(float(x), 4) for x in per_rank[:, i]]} for i, n_ in enumerate(names)}
-            line["per_rank"]["note"] = ("GPU milliseconds per step between events on each rank's stream: blob positions + all-gather of the "
-                                        "force shards; this rank's tile pairs (pair kernel + slab reduction); the all-reduce of the partial "
-                                        "U incl. the wait for the slowest rank.  The time-step variants carry librbl's own phase timings "
-                                        "(`phases`) per rank.")
+        if repeats is not None:
+            line["repeats"] = repeats
+        if partitionings is not None:
+            line["partitionings"] = partitionings
+            line["per_rank"] = dict(partitionings["tile_pairs"]["per_rank"],
+                                    note="GPU milliseconds per step and rank between hipEvents on the context's stream (rbl_get_timings): "
+                                         "kernel = this rank's share (pair kernel + slab reduction); collective = the all-reduce / all-gather incl. "
+                                         "the wait for the slowest rank.  Both work splits in `partitionings`; the time-step variants carry the "
+                                         "library's phase timings (`phases`) per rank.")
     tstep = None
     failed = None
     if args.timestep_steps > 0 and phase != "main":
@@ -982,6 +1130,7 @@ def main():
             failed = "time-step part failed"                 # ... but a failing step driver makes the exit status non-zero
         guard.disarm()
     others = None
+    dropin = None
     if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
         try:
             others = other_configs(dev, stream)
@@ -990,20 +1139,34 @@ def main():
             traceback.print_exc()
             others = {"error": repr(e)}
             failed = failed or "other-configs part failed"
+        try:
+            dropin = dropin_block(dev)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            dropin = {"error": repr(e)}
+            failed = failed or "drop-in part failed"
 
     if rank == 0:
         if tstep is not None:
             line["timestep"] = tstep
+            if "error" not in tstep:
+                line["timesteps_per_sec"] = headline_timesteps(tstep)
         if others is not None:
             line["configs"] = others
+        if dropin is not None:
+            line["dropin"] = dropin
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]
             line["cpu_baseline_allcores"] = cb["allcores"]
             line["speedup_vs_cpu_1core"] = line["value"] / cb["1core"]["value"]
             line["speedup_vs_cpu_allcores"] = line["value"] / cb["allcores"]["value"]
+            if tstep is not None and "error" not in tstep:
+                line["cpu_baseline_timestep"] = cpu_timestep_baseline(tstep, cb)
         print(json.dumps(line), flush=True)
     if world > 1:
+        ctx.close()                                          # (destroys the library's communicator before the process group goes)
         dist.destroy_process_group()
     if failed:
         sys.stderr.write("bench.py: %s (see the line's error entry)\n" % failed)

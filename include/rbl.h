@@ -316,6 +316,9 @@ int rbl_set_block_refresh(rbl_ctx *ctx, int every);
 int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double rtol, double *d_x,
                          int use_x0 /* d_x holds an initial guess, e.g. the previous step's solution */,
                          int *iters, double *resid);
+/* the same solve for host vectors (one upload of rhs [and x0], one download of x): what a caller of the wrapper's apply_saddle /
+ * apply_PC would otherwise loop over from outside (src/Rigid.py:69-80) */
+int rbl_gmres_saddle(rbl_ctx *ctx, const double *rhs, int max_iter, double rtol, double *x, int use_x0, int *iters, double *resid);
 /* Whole time steps in one call, on the object's own configuration (the reference has no driver; these are what
  * rigid_body_light_amd/krylov.py's steppers do, for hosts without a Python loop).
  *   rbl_step_deterministic: solve [M -K; K^T 0][lambda; U] = [slip; -F_body] (rbl_gmres_saddle_dev; slip NULL = 0;
@@ -446,7 +449,10 @@ enum {
                                       all-gather(positions, U) -- see "multi-GPU" above                                             */
   RBL_OPT_FUSED_KRYLOV = 25,       /* [1] launch-bound systems: the small kernels of a GMRES / Lanczos iteration fused (slab sums +
                                       saddle tail + Gram-Schmidt passes in cooperative kernels); 0: one kernel per operation        */
-  RBL_OPT_COUNT = 26
+  RBL_OPT_RELAXED_GAP_RATIO = 26,  /* [0] relaxed product: a far tile pair is swept in single precision when the extents of its boxes,
+                                      d_I + 2 d_J, are at most this many times their gap (0 = the library's default); smaller = fewer
+                                      pairs relaxed, smaller product error (6e-8 (1 + ratio) of a separation)                        */
+  RBL_OPT_COUNT = 27
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

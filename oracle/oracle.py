@@ -315,6 +315,28 @@ def M_RFD(orc, W, X, Qn, ref_cfg, a, eta, wall, delta):
     return (Mp - Mm) / delta
 
 
+def M_RFD_cfgs(orc, U, X, Qn, ref_cfg, delta):
+    """c_rigid_obj.cpp:798-818: blob positions at q +- (delta/2) U."""
+    cfg = np.asarray(ref_cfg).reshape(-1, 3)
+    Xp, Qp = update_X_Q(X, Qn, 0.5 * delta * np.asarray(U))
+    Xm, Qm = update_X_Q(X, Qn, -0.5 * delta * np.asarray(U))
+    return orc.multi_body_pos(Xp, Qp, cfg), orc.multi_body_pos(Xm, Qm, cfg)
+
+
+def M_RFD_from_U(orc, U, W, X, Qn, ref_cfg, a, eta, wall, delta=1.0e-3):
+    """c_rigid_obj.cpp:820-842 (delta = 1e-3 hard-coded there, :822)."""
+    rp, rm = M_RFD_cfgs(orc, U, X, Qn, ref_cfg, delta)
+    return (orc.apply_M(W, rp, a, eta, wall) - orc.apply_M(W, rm, a, eta, wall)) / delta
+
+
+def KT_RFD_from_U(U, W, X, Qn, ref_cfg, delta=1.0e-3):
+    """c_rigid_obj.cpp:844-863."""
+    cfg = np.asarray(ref_cfg).reshape(-1, 3)
+    Xp, Qp = update_X_Q(X, Qn, 0.5 * delta * np.asarray(U))
+    Xm, Qm = update_X_Q(X, Qn, -0.5 * delta * np.asarray(U))
+    return (K_matrix(Xp, Qp, cfg).T @ W - K_matrix(Xm, Qm, cfg).T @ W) / delta
+
+
 def KTinv_RFD(W, X, Qn, ref_cfg, delta):
     """c_rigid_obj.cpp:743-767."""
     cfg = np.asarray(ref_cfg).reshape(-1, 3)

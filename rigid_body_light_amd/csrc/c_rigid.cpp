@@ -351,6 +351,25 @@ struct CManyBodies {
     return out;
   }
 
+  // right-preconditioned GMRES on the saddle operator inside the library (host vectors) -> (x, iterations, residual estimate)
+  py::tuple solve_saddle(darr rhs, int max_iter, double rtol, py::object x0)
+  {
+    const py::ssize_t n = n3() + 6 * (py::ssize_t)n_bod();
+    if (rhs.size() != n) throw std::runtime_error("solve_saddle: rhs must have length 3*N_blobs + 6*N_bod");
+    darr x(n);
+    int use_x0 = 0;
+    if (!x0.is_none()) {
+      darr g = x0.cast<darr>();
+      if (g.size() != n) throw std::runtime_error("solve_saddle: x0 must have length 3*N_blobs + 6*N_bod");
+      std::memcpy(x.mutable_data(), g.data(), sizeof(double) * (size_t)n);
+      use_x0 = 1;
+    }
+    int it = 0;
+    double res = 0.0;
+    check(rbl_gmres_saddle(ctx, rhs.data(), max_iter, rtol, x.mutable_data(), use_x0, &it, &res));
+    return py::make_tuple(x, it, res);
+  }
+
   py::tuple M_RFD_cfgs(darr U, double delta)                        // :798 (unbound in the reference)
   {
     if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("M_RFD_cfgs: U must have length 6*N_bod");
@@ -444,6 +463,8 @@ PYBIND11_MODULE(c_rigid, m)
       .def("cholesky_lower", &CManyBodies::cholesky_lower, py::arg("M"))
       .def("pair_blocks", &CManyBodies::pair_blocks)
       .def("apply_saddle", &CManyBodies::apply_saddle, py::arg("x"))
+      .def("solve_saddle", &CManyBodies::solve_saddle, py::arg("rhs"), py::arg("max_iter") = 100, py::arg("rtol") = 1.0e-8,
+           py::arg("x0") = py::none())
       .def("M_RFD_cfgs", &CManyBodies::M_RFD_cfgs, py::arg("U"), py::arg("delta") = 1.0e-4)
       .def("M_RFD_from_U", &CManyBodies::M_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)
       .def("KT_RFD_from_U", &CManyBodies::KT_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)

@@ -231,14 +231,15 @@ __global__ __launch_bounds__(TS) void k_tile_bbox(const double *__restrict__ r, 
 // farmap[S][J] = 1 when every blob of tile J is farther than 2a from every blob of row super-tile S
 // (NI consecutive tiles): one byte per (super-tile, tile), read as a wave-uniform value by the matvec kernel.
 __global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbox, int T, int NI,
-                                                  unsigned char *__restrict__ farmap, unsigned *queue)
+                                                  unsigned char *__restrict__ farmap, unsigned *queue, double gap_ratio)
 {
   if (queue && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue = 0u;   // work queue of the pair kernel that follows
   // bit 0: every blob of column tile J is farther than 2a from every row of super-tile S (no pair can overlap);
   // bit 1: ... and the relaxed (single-precision) sweep of the pair is accurate to ~1e-6 of every separation.  That sweep
   //        takes coordinates relative to the first blob of tile J: |x_j - o| <= d_J (diagonal of J's box), |x_i - o| <= gap +
   //        d_I + d_J, so rounding them to fp32 moves a separation by at most eps/2 (gap + d_I + 2 d_J), i.e. by
-  //        eps/2 (1 + (d_I + 2 d_J) / gap) of itself (eps = 1.2e-7): bounded by 1e-6 when d_I + 2 d_J <= 15 gap.  Tiles
+  //        eps/2 (1 + (d_I + 2 d_J) / gap) of itself (eps = 1.2e-7): bounded by 6e-8 (1 + gap_ratio) when d_I + 2 d_J <= gap_ratio gap
+  //        (RBL_OPT_RELAXED_GAP_RATIO; the pair entries amplify a separation error ~3x: 1/r and 1/r^3 terms).  Tiles
   //        that straddle two far-apart bodies, or suspensions thousands of radii wide, fail the test for the pairs where
   //        it matters and those are swept in fp64.
   const int J = blockIdx.x * 256 + threadIdx.x, S = blockIdx.y;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void k_tile_far(const double *__restrict__ bbo
     dJ2 = __builtin_fma(bj[3 + d] - bj[d], bj[3 + d] - bj[d], dJ2);
   }
   const bool far = gap2 > 4.0001;
-  const bool f32ok = far && (sqrt(dI2) + 2.0 * sqrt(dJ2) <= 15.0 * sqrt(gap2));
+  const bool f32ok = far && (sqrt(dI2) + 2.0 * sqrt(dJ2) <= gap_ratio * sqrt(gap2));
   farmap[(size_t)S * T + J] = far ? (f32ok ? 3 : 1) : 0;
 }
 #ifndef RBL_SYM_UNROLL
@@ -1528,7 +1529,7 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
 template <bool WALL, int NI, int SW>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
                        double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed,
-                       int n_cu, bool use_queue)
+                       int n_cu, bool use_queue, double gap_ratio)
 {
   const int T = L.T, nrhs = L.nrhs;
   dim3 grid((unsigned)L.rowsG, (unsigned)L.nch), block(TS * SW);
@@ -1549,7 +1550,7 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
     }
     hipLaunchKernelGGL(k_tile_bbox, dim3((unsigned)T), dim3(TS), 0, st, d_r, (long)n_blobs, P.inv_a, bbox);
     hipLaunchKernelGGL(k_tile_far, dim3((unsigned)((T + 255) / 256), (unsigned)nsup), dim3(256), 0, st,
-                       (const double *)bbox, T, NI, farmap, queue);
+                       (const double *)bbox, T, NI, farmap, queue, gap_ratio);
   }
   constexpr int PR = (NI == 2) ? 1 : 0;      // the relaxed form exists for two rows per lane
   if (nrhs == 2 && relaxed && NI == 2)
@@ -1577,20 +1578,21 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   double *slabI = d_work;
   double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
   const bool relaxed = tune.relaxed != 0;
+  const double gr = tune.gap_ratio > 0 ? (double)tune.gap_ratio : 15.0;
   if (L.NI == 2 && L.SW == SW_LARGE) {
-    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
-    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
+    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
+    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
   } else if (L.NI == 2) {
-    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
-    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0);
+    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
+    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
 #ifdef RBL_WAVE_TRACE
   } else if (L.SW == 2) {                  // experiment (tools/wave_trace.hip): one row per lane, two waves per workgroup
-    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
-    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
+    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
+    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
 #endif
   } else {
-    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
-    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0);
+    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
+    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
   }
 }
 

@@ -46,6 +46,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->gmres_relax = v != 0; }},
     {RBL_OPT_RELAXED_ALWAYS, "relaxed_always", 0, 1, 0, [](const rbl_ctx *c) -> int64_t { return c->force_relaxed; },
      [](rbl_ctx *c, int64_t v) { c->force_relaxed = v != 0; }},
+    {RBL_OPT_RELAXED_GAP_RATIO, "relaxed_gap_ratio", 0, 64, 0, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.gap_ratio; },
+     [](rbl_ctx *c, int64_t v) { c->sym_tune.gap_ratio = (int)v; }},
     {RBL_OPT_BLOCK_EXPLICIT_SMALL, "block_explicit_small", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->blk_explicit; },
      [](rbl_ctx *c, int64_t v) { c->blk_explicit = v != 0; drop_factors(c); }},
     {RBL_OPT_BLOCK_EXPLICIT_LARGE, "block_explicit_large", 0, 2, 2, [](const rbl_ctx *c) -> int64_t { return c->blk_large; },

@@ -234,3 +234,20 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   if (rtol > 0.0) c->gmres_last_used = used;
   return finish_and_check(c);
 }
+
+// host-vector form: one upload, the device-resident solve, one download
+int rbl_gmres_saddle(rbl_ctx *c, const double *rhs, int max_iter, double rtol, double *x, int use_x0, int *iters, double *resid)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!rhs || !x || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres_saddle: bad arguments");
+  const size_t nsys = (size_t)3 * c->S.N_bod * c->S.N_blb + (size_t)6 * c->S.N_bod;
+  if ((rc = rbl_dev_reserve(c, c->d_step, sizeof(double) * 2 * nsys))) return rc;
+  double *d_x = (double *)c->d_step.p, *d_rhs = d_x + nsys;
+  c->step_hist_n = 0; c->step_x_size = 0;                 // (d_step is shared with the time-step entry points' history)
+  if ((rc = copy_h2d(c, d_rhs, rhs, sizeof(double) * nsys))) return rc;
+  if (use_x0 && (rc = copy_h2d(c, d_x, x, sizeof(double) * nsys))) return rc;
+  if ((rc = rbl_gmres_saddle_dev(c, d_rhs, max_iter, rtol, d_x, use_x0, iters, resid))) return rc;
+  if ((rc = copy_d2h(c, x, d_x, sizeof(double) * nsys))) return rc;
+  return finish_and_check(c);
+}

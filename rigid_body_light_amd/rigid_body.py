@@ -7,7 +7,7 @@ pybind11 class `c_rigid.CManyBodies`.  Size rules are kept in one table (`_expec
 of per-method checks; shapes follow the shape X was given in (2-D in -> (-1, 3) out, flat in -> flat out,
 reference src/Rigid.py:54,60,66).
 
-Beyond the reference surface (its C++ has these, its Python does not): `M_half_W`, `M_RFD`,
+Beyond the reference surface (its C++ has these, its Python does not): `solve_saddle`, `M_half_W`, `M_RFD`,
 `KTinv_RFD`, `M_RFD_cfgs`, `M_RFD_from_U`, `KT_RFD_from_U`, `evolve_rigid_bodies_RFD`, `apply_M_multi`,
 `dense_mobility`.
 """
@@ -113,6 +113,13 @@ class RigidBody:
 
     def apply_PC(self, b):
         return self.cb.apply_PC(self._require(b, "system"))
+
+    def solve_saddle(self, rhs, max_iter=100, rtol=1.0e-8, x0=None):
+        """Solve [M -K; K^T 0] x = rhs by the library's own right-preconditioned GMRES (apply_PC as preconditioner), all
+        iterations on the GPU: what a user of the reference loops over apply_saddle / apply_PC for from outside
+        (src/Rigid.py:69-80).  -> (x, iterations, residual estimate)"""
+        return self.cb.solve_saddle(self._require(rhs, "system"), int(max_iter), float(rtol),
+                                    None if x0 is None else self._require(x0, "system"))
 
     # ------------------------------------------------------------------ beyond the reference's Python surface
     def M_half_W(self, W=None, seed=0, method="cholesky"):

@@ -1,0 +1,97 @@
+"""Round 4: the host-pointer entry points a user of the reference's wrapper meets -- apply_saddle in one boundary crossing, the
+reference's real usage model (an external SciPy Krylov solver over apply_saddle / apply_PC, src/Rigid.py:69-80), the library's own
+solver for host vectors, and the C++-only members of the RFD family (c_rigid_obj.cpp:798-863, 880-893) against their numpy
+restatements in oracle/oracle.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _body(nb, nblb, wall, block=False, dt=0.01):
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(nb, nblb, wall)
+    return c, RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], dt, wall_PC=wall, block_PC=block)
+
+
+@pytest.mark.parametrize("nb,nblb,wall", [(10, 12, False), (10, 12, True), (5, 162, True)])
+def test_apply_saddle_one_crossing_equals_the_reference_composition(orc, nb, nblb, wall):
+    """rbl_apply_saddle == the four-call composition of src/Rigid.py:73-80 == the oracle's dense saddle product"""
+    from oracle import oracle as O
+    c, rb = _body(nb, nblb, wall)
+    n3 = 3 * nb * nblb
+    x = np.random.default_rng(4).standard_normal(n3 + 6 * nb)
+    got = rb.apply_saddle(x)
+    lam, U = x[:n3], x[n3:]
+    comp = np.concatenate((rb.apply_M(lam, rb.get_blob_positions()) - rb.K_dot(U).reshape(-1), rb.KT_dot(lam).reshape(-1)))
+    assert np.linalg.norm(got - comp) <= 1e-13 * np.linalg.norm(comp)
+    cfg = c["cfg"] - c["cfg"].mean(axis=0)
+    r = orc.multi_body_pos(c["X"], c["Q"], cfg)
+    K = O.K_matrix(c["X"], c["Q"], cfg)
+    ref = np.concatenate((orc.apply_M(lam, r, c["a"], c["eta"], wall, mode="dense") - K @ U, K.T @ lam))
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+    with pytest.raises(RuntimeError):
+        rb.apply_saddle(x[:-1])
+
+
+@pytest.mark.parametrize("nb,nblb,wall,block", [(10, 12, False, False), (8, 162, True, True)])
+def test_scipy_gmres_over_the_dropin_operators_equals_the_native_solver(nb, nblb, wall, block):
+    """the reference's usage model: scipy.sparse.linalg.gmres over RigidBody.apply_saddle with apply_PC as (right)
+    preconditioner; its solution and the library's own device-resident GMRES (solve_saddle) agree to the tolerance, and
+    both satisfy the system"""
+    import scipy.sparse.linalg as spla
+    c, rb = _body(nb, nblb, wall, block)
+    n3, nsys = 3 * nb * nblb, 3 * nb * nblb + 6 * nb
+    rhs = np.concatenate([0.1 * np.random.default_rng(9).standard_normal(n3), -np.tile([0.0, 0.0, -1.0, 0.3, 0.0, 0.0], nb)])
+    A = spla.LinearOperator((nsys, nsys), matvec=lambda y: rb.apply_saddle(rb.apply_PC(y)), dtype=np.float64)
+    y, info = spla.gmres(A, rhs, rtol=1e-10, atol=0.0, restart=200, maxiter=1)
+    assert info == 0
+    xs = rb.apply_PC(y)
+    xn, its, res = rb.solve_saddle(rhs, max_iter=200, rtol=1e-10)
+    bn = np.linalg.norm(rhs)
+    assert 0 < its < 200 and res < 1e-10
+    assert np.linalg.norm(rb.apply_saddle(xs) - rhs) < 1e-9 * bn and np.linalg.norm(rb.apply_saddle(xn) - rhs) < 1e-9 * bn
+    assert np.linalg.norm(xs - xn) < 1e-7 * np.linalg.norm(xn)
+    # warm start from the solution: nothing left to do
+    xw, itw, resw = rb.solve_saddle(rhs, max_iter=200, rtol=1e-8, x0=xn)
+    assert itw <= 1 and np.linalg.norm(xw - xn) < 1e-7 * np.linalg.norm(xn)
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_rfd_family_vs_numpy_restatements(orc, wall):
+    """M_RFD_cfgs (:798), M_RFD_from_U (:820), KT_RFD_from_U (:844), evolve_X_Q_RFD (:880) -- C++-only in the reference"""
+    from oracle import oracle as O
+    nb, nblb = 6, 12
+    c, rb = _body(nb, nblb, wall, block=True)
+    cfg = c["cfg"] - c["cfg"].mean(axis=0)
+    rng = np.random.default_rng(21)
+    U = rng.standard_normal(6 * nb)
+    W = rng.standard_normal(3 * nb * nblb)
+    rp, rm = rb.M_RFD_cfgs(U, 1e-2)
+    op, om = O.M_RFD_cfgs(orc, U, c["X"], c["Q"], cfg, 1e-2)
+    assert np.abs(rp - op).max() < 1e-13 and np.abs(rm - om).max() < 1e-13 and np.abs(rp - rm).max() > 1e-4
+    got = rb.M_RFD_from_U(U, W)                                   # delta = 1e-3 as the reference hard-codes (:822)
+    ref = O.M_RFD_from_U(orc, U, W, c["X"], c["Q"], cfg, c["a"], c["eta"], wall)
+    assert np.linalg.norm(got - ref) < 1e-8 * np.linalg.norm(ref)  # a difference quotient: 1e-16 / 1e-3 of the products
+    got = rb.KT_RFD_from_U(U, W)
+    ref = O.KT_RFD_from_U(U, W, c["X"], c["Q"], cfg)
+    assert np.linalg.norm(got - ref) < 1e-9 * np.linalg.norm(ref)
+    X0, Q0 = rb.get_config()
+    assert np.array_equal(X0.reshape(-1), np.asarray(c["X"]).reshape(-1))       # none of the above commits anything
+    # evolve_X_Q_RFD: commits q displaced by U (no dt), K follows, the preconditioner is kept
+    x = rng.standard_normal(3 * nb * nblb + 6 * nb)
+    pc_before = rb.apply_PC(x)
+    d = 1e-4 * U
+    rb.evolve_rigid_bodies_RFD(d)
+    Xn, Qn = rb.get_config()
+    Xo, Qo = O.update_X_Q(c["X"], c["Q"], d)
+    assert np.abs(Xn.reshape(-1, 3) - Xo).max() < 1e-14 and np.abs(Qn.reshape(-1, 4) - Qo).max() < 1e-14
+    assert np.abs(rb.get_blob_positions().reshape(-1) - orc.multi_body_pos(Xo, Qo, cfg)).max() < 1e-13
+    pc_after = rb.apply_PC(x)
+    rel = np.linalg.norm(pc_after - pc_before) / np.linalg.norm(pc_before)
+    assert rel < 1e-2                                             # the kept factors of q serve q + delta U ...
+    rb.set_config(Xn, Qn)                                         # ... while a fresh build at the same configuration differs from
+    fresh = rb.apply_PC(x)                                        #     the kept one only by O(delta)
+    assert np.linalg.norm(fresh - pc_after) / np.linalg.norm(fresh) < 1e-2
+    with pytest.raises(RuntimeError):
+        rb.M_RFD_from_U(U[:-1], W)

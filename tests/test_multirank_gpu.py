@@ -106,6 +106,20 @@ def test_two_rank_sharded_brownian_step_matches_single_process(monkeypatch, nati
     assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10
 
 
+@pytest.mark.parametrize("split,allreduce_only", [("1", "0"), ("0", "1"), ("1", "1")])
+def test_two_rank_step_with_row_split_and_with_the_allreduce_only_callbacks(monkeypatch, split, allreduce_only):
+    """the library's sharded step with the ROW split (own bodies' geometry + all-gather of positions, ordered-pair kernel on own
+    rows + all-gather of U; per-body results completed by the all-gather callback) and with the round-2/3 callback form
+    (rbl_set_comm: all-reduce only, per-body results zero-padded and summed) against the single-process step"""
+    monkeypatch.setenv("RBL_CHECK_SPLIT", split)
+    monkeypatch.setenv("RBL_CHECK_ALLREDUCE_ONLY", allreduce_only)
+    monkeypatch.setenv("RBL_CHECK_BLOCK_PC", "1")
+    monkeypatch.setenv("RBL_CHECK_BODIES", "7")
+    p = _torchrun(2, ["tools/check_sharded_brownian.py"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10
+
+
 @pytest.mark.parametrize("block_pc", ["0", "1"])
 def test_three_rank_uneven_split_brownian_step(monkeypatch, block_pc):
     """7 bodies over 3 ranks (3 + 2 + 2): per-rank body ranges of the block factors -- of the preconditioned square root

@@ -43,6 +43,12 @@ def main():
             cls = ShardedBrownianStepper if native else TorchShardedBrownianStepper
             st = cls(ctx, ShardedMobility(nb, nblb, device=dev, ctx=ctx), nb, nblb, dev, c["a"], wall, kBT,
                      c["dt"], lanczos_tol=ltol, lanczos_max_iter=255)
+            if native:                # work split of the library's sharded products: 0 tile pairs + all-reduce, 1 rows + all-gather
+                ctx.set_option("comm_split", int(os.environ.get("RBL_CHECK_SPLIT", "0")))
+                if os.environ.get("RBL_CHECK_ALLREDUCE_ONLY", "0") == "1":      # the round-2/3 callback form: zero-padded sums instead of all-gathers
+                    from rigid_body_light_amd._lib import lib as _lib
+                    import ctypes as _C
+                    _lib().rbl_set_comm(ctx.h, rank, world, _C.cast(ctx._comm_cb, _C.c_void_p), None)
             dump = os.environ.get("RBL_CHECK_DUMP", "")
             if dump and rank == 0:        # for the test's ORACLE check of the sharded solve: system, solution and the predictor configuration it lives at
                 solve = st.saddle_solve
