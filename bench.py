@@ -127,6 +127,7 @@ def self_launch(args, argv):
     ok = rc2 == 0 and bool(l2)
     if ok:
         line["timestep"] = json.loads(l2[-1])
+        line["timesteps_per_sec"] = headline_timesteps(line["timestep"])
     else:
         line["timestep"] = {"error": "the time-step job did not finish (%s)" % (why2 or ("exit status %d" % rc2))}
     print(json.dumps(line), flush=True)
@@ -745,22 +746,26 @@ def dropin_block(dev):
             return rb.apply_saddle(rb.apply_PC(y))
 
         A = spla.LinearOperator((nsys, nsys), matvec=op, dtype=np.float64)
-        t0 = time.perf_counter()
-        y, info = spla.gmres(A, rhs, rtol=1e-8, atol=0.0, restart=100, maxiter=2)
-        xs = rb.apply_PC(y)
-        t_solve = time.perf_counter() - t0
+        for attempt in range(2):                                 # timed on the second solve (SciPy's own first-call set-up left out)
+            count[0] = 0
+            t0 = time.perf_counter()
+            y, info = spla.gmres(A, rhs, rtol=1e-8, atol=0.0, restart=40, maxiter=5)
+            xs = rb.apply_PC(y)
+            t_solve = time.perf_counter() - t0
         res = float(np.linalg.norm(rb.apply_saddle(xs) - rhs) / np.linalg.norm(rhs))
         # the library's own solver on the same system (device-resident vectors, rbl_step_deterministic without the update)
-        t0 = time.perf_counter()
-        m_lib, r_lib = rb.cb.solve_saddle(rhs, 200, 1e-8)[1:]
-        t_lib = time.perf_counter() - t0
+        for attempt in range(2):
+            t0 = time.perf_counter()
+            m_lib, r_lib = rb.cb.solve_saddle(rhs, 200, 1e-8)[1:]
+            t_lib = time.perf_counter() - t0
         out[name] = {"workload": "%d x shell_N_%d, %s, %s PC" % (nb, nblb, "wall-corrected" if wall else "free-space", "block" if block else "diagonal"),
                      "apply_saddle_ms": t_sad * 1e3, "apply_PC_ms": t_pc * 1e3,
                      "scipy_gmres": {"ms": t_solve * 1e3, "operator_calls": count[0], "info": int(info), "true_residual": res},
                      "rbl_gmres_saddle": {"ms": t_lib * 1e3, "iterations": int(m_lib), "residual_estimate": float(r_lib)}}
     out["note"] = ("host-pointer API through `import Rigid`-compatible RigidBody: every call uploads its argument and downloads its result "
                    "(apply_saddle = ONE boundary crossing, rbl_apply_saddle; the reference composes it from four).  scipy_gmres = "
-                   "scipy.sparse.linalg.gmres on A P^-1 (right preconditioning with apply_PC as the reference defines it), rtol 1e-8; "
+                   "scipy.sparse.linalg.gmres (restart 40) on A P^-1 (right preconditioning with apply_PC as the reference defines it), rtol 1e-8, "
+                   "second of two solves; "
                    "rbl_gmres_saddle = the library's device-resident solver on the same right-hand side, host vectors in and out")
     return out
 

@@ -452,7 +452,11 @@ enum {
   RBL_OPT_RELAXED_GAP_RATIO = 26,  /* [0] relaxed product: a far tile pair is swept in single precision when the extents of its boxes,
                                       d_I + 2 d_J, are at most this many times their gap (0 = the library's default); smaller = fewer
                                       pairs relaxed, smaller product error (6e-8 (1 + ratio) of a separation)                        */
-  RBL_OPT_COUNT = 27
+  RBL_OPT_SYM_WAVE_UNITS = 27,     /* [1] mid-size systems (one row per lane, < 128 blob tiles): work units owned by single waves, four
+                                      independent waves per workgroup, column sums rotating through the lanes in registers
+                                      (k_apply_M_symw); 0: the round-3 kernel (one workgroup per unit, column sums by LDS atomics).
+                                      Same slabs and reduction either way                                                          */
+  RBL_OPT_COUNT = 28
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

@@ -62,6 +62,7 @@ struct RblSymTune {        // per-context tuning of the symmetric matvec kernels
   int sw = 0;              // > 0: waves per workgroup (0 = heuristic; experiments)
   int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (rbl_set_tuning 93); 0: work queue there (94)
   int gap_ratio = 0;       // relaxed product: a tile pair is swept in single precision when (d_I + 2 d_J) <= gap_ratio x gap (0 = default; RBL_OPT_RELAXED_GAP_RATIO)
+  int wave_units = 0;      // < 0: mid-size systems on the round-3 kernel (one workgroup per unit, column sums by LDS atomics); 0: wave-owned units (RBL_OPT_SYM_WAVE_UNITS)
   int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
 

@@ -560,6 +560,132 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 }
 
 // ---------------------------------------------------------------------------
+// Mid-size systems (one row per lane: fewer than 128 blob tiles per rank -- BASELINE configs[1], 8 100 blobs): the same
+// work decomposition and the SAME slabs as k_apply_M_sym<WALL, 1, 1, 0>, re-shaped for what limits that size (round 4):
+//   * a work unit belongs to ONE WAVE, and IW independent waves share a workgroup (own LDS image each, no workgroup
+//     barrier -- a wave's DS instructions execute in order).  Single-wave workgroups stop at 16 per CU = 4 waves per SIMD
+//     (profiles/r03_cfg2_wave_timeline.md); with four waves per workgroup eight waves per SIMD are resident, which is what
+//     hides the staging loads and the fp64 latency chain of a unit that lasts only 5 us of issue;
+//   * the column sums M_ji F_i stay in VGPRs and ROTATE with the column index: at step s lane l pairs its row with column
+//     (l + s) & 63, so the accumulator of that column moves one lane down per step -- `v_mov_b32_dpp wave_rol:1`, six dword
+//     moves, folded into the pair's own FMA chain (the rotated sum is the addend).  The three ds_add_f64 per step of the
+//     LDS form (24 of its 47 LDS clocks, as much LDS time as VALU time at one row per lane) are gone, and after 64 steps
+//     every accumulator is back in its own lane: the 64 sums go to the slab straight from registers;
+//   * only the existing units are launched (closed-form index -> (row tile, chunk)), never the dead half of the rectangle.
+// Sums per column are formed in step order, like the LDS atomics before them: bitwise reproducible run to run.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_rol1(double v)            // lane l takes lane (l + 1) & 63's value
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// live units of row tile e (i_step == 1, NI == 1): chunks e / C .. nch - 1.  units before row e:
+__host__ __device__ __forceinline__ long symw_prefix(int e, int C, int nch)
+{
+  const long q = e / C, rem = e - q * C;
+  return (long)e * nch - ((long)C * (q * (q - 1) / 2) + q * rem);
+}
+
+#ifndef RBL_SYMW_WAVES_FREE
+#define RBL_SYMW_WAVES_FREE 6     // waves per SIMD the register allocator is held to (HIP's second launch bound): 80 VGPRs, no spill
+#endif
+#ifndef RBL_SYMW_WAVES_WALL
+#define RBL_SYMW_WAVES_WALL 4     // 116 VGPRs (80 would spill 136 bytes per lane)
+#endif
+#ifndef RBL_SYMW_UNROLL
+#define RBL_SYMW_UNROLL 2
+#endif
+#ifndef RBL_SYMW_IW
+#define RBL_SYMW_IW 4             // independent waves (= work units in flight) per workgroup
+#endif
+template <bool WALL, int IW>
+__global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
+                                                        double *__restrict__ slabI, double *__restrict__ slabJ, long N,
+                                                        SymLayout L, RblParams P, unsigned *err, long n_units)
+{
+  __shared__ double2_t sP0[IW][TS], sP1[IW][TS], sP2[IW][TS];   // (x,y) (z,fx) (fy,fz) of a wave's current column tile
+  const int lane = threadIdx.x & (TS - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long u = (long)blockIdx.x * IW + wave;
+  if (u >= n_units) return;
+  const int T = L.T, C = L.C;
+  int e, c;
+  if (L.tri) {                       // u -> (row tile, chunk) through the closed-form prefix count (scalar work)
+    int lo = 0, hi = L.rowsI;        // largest e with prefix(e) <= u
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (symw_prefix(mid, C, L.nch) <= u) lo = mid; else hi = mid;
+    }
+    e = lo; c = e / C + (int)(u - symw_prefix(e, C, L.nch));
+  } else {                           // a multi-GPU shard: the rectangle (row, chunk), dead units leave at once
+    c = (int)(u / L.rowsI);
+    e = (int)((u - (long)c * L.rowsI + c) % L.rowsI);
+  }
+  const int I = sym_row_of(e, L.i_first, L.i_step, 1);
+  if (I >= T) return;
+  int J0 = c * C;
+  const int J1 = (J0 + C < T) ? J0 + C : T;
+  if (J0 < I) J0 = I;
+  if (J0 >= J1) return;
+  unsigned flags = 0;
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
+    if (idx < N) {
+      x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
+      double d = 1.0;
+      if (WALL) {
+        if (z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+        d = damp_of(P, z);
+      }
+      x *= P.inv_a; y *= P.inv_a; z *= P.inv_a;
+      fx = d * F[3 * idx]; fy = d * F[3 * idx + 1]; fz = d * F[3 * idx + 2];
+    } else {  // padding blob: zero force, far from everything (and from every other pad)
+      x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0; fx = 0.0; fy = 0.0; fz = 0.0;
+    }
+  };
+  double xi, yi, zi, Fix, Fiy, Fiz, uix = 0.0, uiy = 0.0, uiz = 0.0;
+  load_blob((long)I * TS + lane, xi, yi, zi, Fix, Fiy, Fiz);
+  for (int J = J0; J < J1; ++J) {
+    {
+      double xj, yj, zj, Fjx, Fjy, Fjz;
+      load_blob((long)J * TS + lane, xj, yj, zj, Fjx, Fjy, Fjz);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // the previous tile's reads are done (in-order DS queue)
+      sP0[wave][lane] = (double2_t){xj, yj};
+      sP1[wave][lane] = (double2_t){zj, Fjx};
+      sP2[wave][lane] = (double2_t){Fjy, Fjz};
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (J == I) {                    // the diagonal tile: ordered sweep with the index-equality self term
+#pragma unroll 2
+      for (int jj = 0; jj < TS; ++jj) {
+        const double2_t pa = sP0[wave][jj], pb = sP1[wave][jj], pd = sP2[wave][jj];
+        rbl_pair_accum<WALL, true, true>(Pu, xi, yi, zi, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane, uix, uiy, uiz, flags);
+      }
+      continue;
+    }
+    double ax = 0.0, ay = 0.0, az = 0.0;                            // column sums of column (lane + s) & 63, travelling
+    unsigned off16 = (unsigned)lane * 16u;
+    const char *b0 = (const char *)sP0[wave], *b1 = (const char *)sP1[wave], *b2 = (const char *)sP2[wave];
+#pragma unroll RBL_SYMW_UNROLL
+    for (int s = 0; s < TS; ++s) {
+      const double2_t pa = *(const double2_t *)(b0 + off16), pb = *(const double2_t *)(b1 + off16), pd = *(const double2_t *)(b2 + off16);
+      off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
+      rbl_pair_sym<WALL, true, true>(Pu, xi, yi, zi, Fix, Fiy, Fiz, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix, uiy, uiz, ax, ay, az, flags, WK);
+      ax = wave_rol1(ax); ay = wave_rol1(ay); az = wave_rol1(az);
+    }
+    double *q = slabJ + sym_idxJ(L, e, 0, (long)J * TS + lane);     // 64 rotations: lane l holds column l again
+    q[0] = ax; q[1] = ay; q[2] = az;
+  }
+  double *p_ = slabI + sym_idxI(L, c, 0, (long)I * TS + lane);
+  p_[0] = uix; p_[1] = uiy; p_[2] = uiz;
+  if (flags) atomicOr(err, flags);
+}
+
+// ---------------------------------------------------------------------------
 // The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
 // coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back.
 // ---------------------------------------------------------------------------
@@ -1590,6 +1716,17 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
     if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
     else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
 #endif
+  } else if (nrhs == 1 && L.SW == 1 && tune.wave_units >= 0) {
+    // mid-size systems: wave-owned units, column sums rotating through the lanes (k_apply_M_symw), same slabs + reduction
+    constexpr int IW = RBL_SYMW_IW;
+    const long n_units = L.tri ? symw_prefix(L.rowsI, L.C, L.nch) : (long)L.rowsI * L.nch;
+    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
+    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    const int64_t n = 3 * n_blobs;
+    dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
+    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
+    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
   } else {
     if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
     else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);

@@ -34,6 +34,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->sym_tune.sw = (int)v; }},
     {RBL_OPT_SYM_WORK_QUEUE, "sym_work_queue", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.queue < 0 ? 0 : 1; },
      [](rbl_ctx *c, int64_t v) { c->sym_tune.queue = v ? 0 : -1; }},
+    {RBL_OPT_SYM_WAVE_UNITS, "sym_wave_units", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.wave_units < 0 ? 0 : 1; },
+     [](rbl_ctx *c, int64_t v) { c->sym_tune.wave_units = v ? 0 : -1; }},
     {RBL_OPT_GMRES_PC_SIGN_FIX, "gmres_pc_sign_fix", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->gmres_pc_sign_fix; },
      [](rbl_ctx *c, int64_t v) { c->gmres_pc_sign_fix = v != 0; }},
     {RBL_OPT_GMRES_ONE_KERNEL, "gmres_one_kernel", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->gmres_small; },

@@ -1455,7 +1455,7 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     assert torch.equal(again, ref)                                   # the switch is transient and exact when off
     err = float(torch.linalg.norm(rel_ - ref) / torch.linalg.norm(ref))
     rows = (rel_ - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
-    assert 0.0 < err < 3e-6 and float(rows.max()) < 3e-5, (err, float(rows.max()))
+    assert 0.0 < err < 1e-6 and float(rows.max()) < 3e-6, (err, float(rows.max()))      # (measured 1.1e-7 / 4.6e-7 at cfg 3)
     # multi-GPU shards (one wave per workgroup, every i_step-th row super-tile) have it too: three relaxed shards add up
     ctx.set_option("relaxed_always", 1)
     acc = torch.zeros_like(x)
@@ -1465,7 +1465,7 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
         acc += pshard
     ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
-    assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 3e-6
+    assert float(torch.linalg.norm(acc - ref) / torch.linalg.norm(ref)) < 1e-6
     # the two-vector kernel (lock-step Lanczos) has the same relaxed form
     X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
     R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
@@ -1477,7 +1477,7 @@ def test_relaxed_product_accuracy(nb, nblb, wall):
     assert float(torch.linalg.norm(R2[0] - ref) / torch.linalg.norm(ref)) < 1e-13
     for k in range(2):
         e2 = float(torch.linalg.norm(S2[k] - R2[k]) / torch.linalg.norm(R2[k]))
-        assert 0.0 < e2 < 3e-6, (k, e2)
+        assert 0.0 < e2 < 1e-6, (k, e2)
     ctx.close()
 
 
@@ -1513,7 +1513,7 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     ctx.sync_check()
     err = float(torch.linalg.norm(rlx - ref) / torch.linalg.norm(ref))
     rows = (rlx - ref).view(-1, 3).norm(dim=1) / ref.view(-1, 3).norm(dim=1).mean()
-    assert 0.0 < err < 6e-6 and float(rows.max()) < 6e-5, (err, float(rows.max()))      # (measured 3.2e-6 / 3.3e-5; 1e-3 with one origin per workgroup)
+    assert 0.0 < err < 1e-6 and float(rows.max()) < 3e-6, (err, float(rows.max()))      # (measured 1.4e-8 / 1.6e-7, tools/sweep_relaxed_gap.py; 1e-3 with one origin per workgroup)
     X2 = torch.stack([x, torch.from_numpy(np.random.default_rng(13).standard_normal(3 * N)).to(dev)]).contiguous()
     R2 = torch.empty_like(X2); S2 = torch.empty_like(X2)
     ctx.apply_M_multi(X2.data_ptr(), r.data_ptr(), N, 2, R2.data_ptr())
@@ -1522,7 +1522,7 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     ctx.set_option("relaxed_always", 0)
     ctx.sync_check()
     for k in range(2):
-        assert float(torch.linalg.norm(S2[k] - R2[k]) / torch.linalg.norm(R2[k])) < 6e-6
+        assert float(torch.linalg.norm(S2[k] - R2[k]) / torch.linalg.norm(R2[k])) < 1e-6
     # inexact Krylov on top of it: the converged solution satisfies the fp64 system
     lib().rbl_set_blk_pc(ctx.h, 1)
     nsys = 3 * N + 6 * nb

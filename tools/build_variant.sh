@@ -8,7 +8,7 @@ here=$(cd "$(dirname "$0")/.." && pwd)
 src=$here/rigid_body_light_amd/csrc
 out=$here/rigid_body_light_amd/build/variants
 mkdir -p $out/$name
-for f in rbl_kernels.hip rbl_dense.hip rbl_body_dev.hip rbl_small.hip rbl_api.hip rbl_host.cpp; do
+for f in $(cd $src && ls rbl_*.hip) rbl_host.cpp; do
   o=$out/$name/${f%.*}.o
   if true; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -Wno-unused-function "$@" -c $src/$f -o $o &
