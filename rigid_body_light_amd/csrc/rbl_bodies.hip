@@ -212,7 +212,7 @@ int bf_build(rbl_ctx *c)
   if ((rc = rbl_launch_cholesky_batched(c->stream, Lb, m, 1, msz, c->d_err, (double *)c->d_bfLinv.p)))
     return rbl_fail(c, rc, "body-frame cholesky launch failed");
   c->bf_inv = false; c->bf_tables = false;
-  if (c->blk_explicit && m > 512 && c->blk_large != 0) {   // large bodies: ONE explicit inverse for all bodies and all time
+  if (c->blk_explicit && rbl_block_inverse_large_fits(m) && c->blk_large != 0) {   // large bodies: ONE explicit inverse for all bodies and all time
     int chunk = 1;
     if ((rc = rbl_dev_reserve(c, c->d_bfX, rbl_block_inverse_bytes(m, 1)))) return rc;
     if ((rc = rbl_dev_reserve(c, c->d_blkAug, rbl_block_inverse_large_aug_bytes(m, 1, &chunk)))) return rc;
@@ -377,7 +377,7 @@ int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int
   }
   if (mode == 3 && d_in == d_out) return rbl_fail(c, RBL_ERR_ARG, "block_solve_dev: mode 3 does not work in place");
   rc = mode == 3 ? blk_trmv(c, body_begin, nb, d_in, d_out) : blk_solve(c, body_begin, nb, d_in, d_out, 1, 0, mode);
-  if (rc) return rbl_fail(c, rc, "block_solve_dev: bodies with more than 2730 blobs are not supported");
+  if (rc) return rbl_fail(c, rc, "block_solve_dev: the per-body factor application failed");
   return RBL_OK;
 }
 
@@ -473,7 +473,7 @@ int pc_block_factors(rbl_ctx *c, int b0, int b1)
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
   c->blk_inv_valid = false; c->blk_f32_valid = false;
-  if (c->blk_explicit && m > 512 && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)))) {
+  if (c->blk_explicit && rbl_block_inverse_large_fits(m) && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)))) {
     // large bodies (shell_N_642 / 2562): explicit inverses through the factorisation's own MFMA kernels -- a rank's few
     // bodies are then applied by batched triangular matrix-vector products over the whole chip instead of one latency
     // chain of 3 N_blb / 32 steps per body on one CU each
@@ -527,7 +527,7 @@ static int pc_block_build(rbl_ctx *c)
   if (nbo <= 0) return RBL_OK;
   // ... solved in place, three per pass over the factors (the sweeps are latency chains: 6 single solves cost 10 ms at cfg 3)
   if ((rc = blk_solve(c, b0, nbo, MK, MK, 6, n3, 0)))
-    return rbl_fail(c, rc, "block-diagonal PC: bodies with more than 2730 blobs are not supported on the device");
+    return rbl_fail(c, rc, "block-diagonal PC: the per-body factor application failed");
   for (int cc = 0; cc < 6; ++cc)
     rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p + off, MK + (size_t)cc * n3 + off, S.N_blb, nbo,
                         cols + (size_t)cc * 6 * S.N_bod + (size_t)6 * b0);

@@ -808,21 +808,27 @@ constexpr int BS_T = 1024;   // threads per matrix: the sweeps are latency-bound
 
 // NV right-hand sides per matrix (vector v of body b at in + v * rhs_pitch + b * vec_stride): L is streamed ONCE for
 // all of them -- the sweeps are latency chains, so NV vectors cost about what one does.
-template <int NV>
+// GLOBAL (bodies whose vector does not fit the 64 KB of LDS a workgroup gets: more than 2 730 blobs): the working vector is
+// the OUTPUT vector itself in HBM / L2 -- one workgroup owns it, its waves share the CU's vector L1, and __syncthreads() orders
+// their global accesses -- only the IB-entry scratch stays in LDS.  Same operation order per row, no size limit.
+template <int NV, bool GLOBAL = false>
 __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
                                                      const double *in, double *out, long vec_stride, long rhs_pitch,
                                                      int mode /* 0: L L^T, 1: L only, 2: L^T only */)
 {
-  extern __shared__ double y[];                      // NV x n doubles + NV x IB scratch
-  double *tbuf = y + (size_t)NV * n;                 // tbuf[v * IB + m]
+  extern __shared__ double y_lds[];                  // NV x n doubles + NV x IB scratch (GLOBAL: the scratch only)
   const int b = blockIdx.x, t = threadIdx.x;
+  double *const y = GLOBAL ? out + (size_t)b * (size_t)vec_stride : y_lds;     // vector v at y + v * ypitch
+  const size_t ypitch = GLOBAL ? (size_t)rhs_pitch : (size_t)n;
+  double *tbuf = GLOBAL ? y_lds : y_lds + (size_t)NV * n;                      // tbuf[v * IB + m]
   const double *Lb = L + (size_t)b * (size_t)strideA;
   const double *Lib = Linv + (size_t)b * (size_t)strideL;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-    for (long e = t; e < n; e += BS_T) y[(size_t)v * n + e] = vin[e];
+    if (!GLOBAL || vin != y + (size_t)v * ypitch)
+      for (long e = t; e < n; e += BS_T) y[(size_t)v * ypitch + e] = vin[e];
   }
   __syncthreads();
   const int nsteps = (int)((n + IB - 1) / IB);
@@ -833,13 +839,13 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     const double *Li = Lib + (size_t)s * IB * IB;
     if (t < IB * NV) {
       double acc = 0.0;
-      const double *yv = y + (size_t)tv * n + k;
+      const double *yv = y + (size_t)tv * ypitch + k;
       if (tt < nb)
         for (int m = 0; m <= tt; ++m) acc = __builtin_fma(Li[tt * IB + m], yv[m], acc);
       tbuf[t] = acc;
     }
     __syncthreads();
-    if (t < IB * NV && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
+    if (t < IB * NV && tt < nb) y[(size_t)tv * ypitch + k + tt] = tbuf[t];
     if (nb == IB) {   // full block: 32 independent strided loads per row are issued back to back
       for (long r = k + IB + t; r < n; r += BS_T) {
         const double *col = Lb + (size_t)k * (size_t)n + r;
@@ -848,13 +854,13 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
         for (int m = 0; m < IB; ++m) lv[m] = col[(size_t)m * n];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          double a0 = y[(size_t)v * n + r], a1 = 0.0;
+          double a0 = y[(size_t)v * ypitch + r], a1 = 0.0;
 #pragma unroll
           for (int m = 0; m < IB; m += 2) {
             a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
             a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
           }
-          y[(size_t)v * n + r] = a0 + a1;
+          y[(size_t)v * ypitch + r] = a0 + a1;
         }
       }
     } else {
@@ -862,9 +868,9 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
         const double *col = Lb + (size_t)k * (size_t)n + r;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          double acc = y[(size_t)v * n + r];
+          double acc = y[(size_t)v * ypitch + r];
           for (int m = 0; m < nb; ++m) acc = __builtin_fma(-col[(size_t)m * n], tbuf[v * IB + m], acc);
-          y[(size_t)v * n + r] = acc;
+          y[(size_t)v * ypitch + r] = acc;
         }
       }
     }
@@ -876,13 +882,13 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     const double *Li = Lib + (size_t)s * IB * IB;
     if (t < IB * NV) {
       double acc = 0.0;
-      const double *yv = y + (size_t)tv * n + k;
+      const double *yv = y + (size_t)tv * ypitch + k;
       if (tt < nb)
         for (int m = tt; m < nb; ++m) acc = __builtin_fma(Li[m * IB + tt], yv[m], acc);   // Linv^T
       tbuf[t] = acc;
     }
     __syncthreads();
-    if (t < IB * NV && tt < nb) y[(size_t)tv * n + k + tt] = tbuf[t];
+    if (t < IB * NV && tt < nb) y[(size_t)tv * ypitch + k + tt] = tbuf[t];
     if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
       // The 32 entries of a column are one 256-byte run.  Sixteen lanes share a column (16 bytes = two rows each), so a
       // wave's load instruction covers four whole runs -- eight cache lines for 1 KB, as coalesced as the forward sweep --
@@ -914,7 +920,7 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
               a += dpp_row<0x4E>(a);                               // quad_perm [2,3,0,1]
               a += dpp_row<0x141>(a);                              // row_half_mirror
               a += dpp_row<0x140>(a);                              // row_mirror: every lane of the row holds the sum
-              if (h == 0) y[(size_t)v * n + c] -= a;
+              if (h == 0) y[(size_t)v * ypitch + c] -= a;
             }
           }
         }
@@ -924,18 +930,19 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
         const double *row = Lb + (size_t)c * (size_t)n + k;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          double acc = y[(size_t)v * n + c];
+          double acc = y[(size_t)v * ypitch + c];
           for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], tbuf[v * IB + m], acc);
-          y[(size_t)v * n + c] = acc;
+          y[(size_t)v * ypitch + c] = acc;
         }
       }
     }
     __syncthreads();
   }
+  if (GLOBAL) return;                                // the working vector WAS the output
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-    for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * n + e];
+    for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * ypitch + e];
   }
 }
 
@@ -1370,6 +1377,9 @@ __global__ void k_rotate_bodies(const double *__restrict__ Q, const double *in, 
 // measured (tools/bench_block_solve.py, both sweeps): n = 486 x 50 bodies 124 -> 43 us; n = 126 x 400 and n = 36 x 2000 are
 // chains of 4 and 2 steps only, where the substitution kernel (23 us) beats two matrix-vector launches
 bool rbl_block_inverse_fits(int64_t n) { return n > 192 && n <= BSS_T; }
+// explicit inverses of LARGE bodies are applied with one vector of the body in LDS: up to 2 666 blobs (beyond: substitution, whose
+// working vector lives in HBM then)
+bool rbl_block_inverse_large_fits(int64_t n) { return n > BSS_T && sizeof(double) * ((size_t)n + 64 * BIA_W) <= 65536; }
 // leading dimension of the two layouts of an explicit inverse: n for small bodies (k_trtri_small), a multiple of 32 entries
 // (128 bytes of fp32, 256 of fp64) for large ones so that 64-row segments of a column are whole cache lines
 int64_t rbl_block_inverse_ld(int64_t n) { return n <= BSS_T ? n : ((n + 31) / 32) * 32; }
@@ -1573,16 +1583,21 @@ void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d
 
 // y_b = L_b x_b for every matrix of the batch (lower-triangular product): one workgroup per matrix, x in LDS,
 // column sweep with rows spread over the threads.
+// (GLOBAL: bodies of more than 2 730 blobs -- x is read where it lies, through the CU's caches)
+template <bool GLOBAL>
 __global__ __launch_bounds__(BS_T) void k_block_trmv(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ in, double *__restrict__ out,
                                                      long vec_stride)
 {
-  extern __shared__ double x[];
+  extern __shared__ double x_lds[];
   const int b = blockIdx.x, t = threadIdx.x;
   const double *Lb = L + (size_t)b * (size_t)strideA;
   const double *v = in + (size_t)b * (size_t)vec_stride;
-  for (long e = t; e < n; e += BS_T) x[e] = v[e];
-  __syncthreads();
+  const double *x = GLOBAL ? v : x_lds;
+  if (!GLOBAL) {
+    for (long e = t; e < n; e += BS_T) x_lds[e] = v[e];
+    __syncthreads();
+  }
   double *o = out + (size_t)b * (size_t)vec_stride;
   for (long r = t; r < n; r += BS_T) {
     double a0 = 0.0, a1 = 0.0;
@@ -1600,9 +1615,11 @@ __global__ __launch_bounds__(BS_T) void k_block_trmv(const double *__restrict__ 
 int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                           double *d_out, int64_t vec_stride)
 {
-  if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
-  hipLaunchKernelGGL(k_block_trmv, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)n, st, d_L, (long)n, (long)strideA,
-                     d_in, d_out, (long)vec_stride);
+  if (n > SOLVE_MAXN)
+    hipLaunchKernelGGL(k_block_trmv<true>, dim3(batch), dim3(BS_T), 0, st, d_L, (long)n, (long)strideA, d_in, d_out, (long)vec_stride);
+  else
+    hipLaunchKernelGGL(k_block_trmv<false>, dim3(batch), dim3(BS_T), sizeof(double) * (size_t)n, st, d_L, (long)n, (long)strideA,
+                       d_in, d_out, (long)vec_stride);
   return RBL_OK;
 }
 
@@ -1613,7 +1630,6 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
                                  int64_t rhs_pitch, int mode, const double *d_Q)
 {
   // d_Q (with | 0x100 and n <= 512 only): the shared factor is a body-frame one, G_b = R_b L -- rotations fused into the sweep
-  if (n > SOLVE_MAXN) return RBL_ERR_SIZE;
   const int64_t nsteps = (n + IB - 1) / IB;
   const bool shared = (mode & 0x100) != 0;           // one factor for every body of the batch (strideA = 0 by the caller)
   mode &= 0xff;
@@ -1624,6 +1640,13 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     const size_t lds = sizeof(double) * (size_t)g * (size_t)(n + IB);
     const double *in = d_in + (size_t)v0 * (size_t)rhs_pitch;
     double *out = d_out + (size_t)v0 * (size_t)rhs_pitch;
+    if (lds > 65536) {         // one vector of a body does not fit LDS (> 2 730 blobs): the output vector in HBM is the working vector
+      if (d_Q) return RBL_ERR_ARG;
+      hipLaunchKernelGGL((k_block_solve<1, true>), dim3(batch), dim3(BS_T), sizeof(double) * IB, st, d_L, (long)n, (long)strideA, d_Linv,
+                         strideL, in, out, (long)vec_stride, (long)rhs_pitch, mode);
+      v0 += 1;
+      continue;
+    }
     if (d_Q && !(shared && n <= BSS_T)) return RBL_ERR_ARG;
     if (n <= BSS_T) {          // small bodies: one row per thread, factor entries prefetched a step ahead
       const int th = (int)(n <= 128 ? 128 : ((n + 63) / 64) * 64);

@@ -237,6 +237,7 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
                           double *d_out, int64_t vec_stride);
 // explicit per-body inverses for small bodies (3 N_blb <= 512): substitution sweeps become triangular matrix-vector products
 bool rbl_block_inverse_fits(int64_t n);
+bool rbl_block_inverse_large_fits(int64_t n);
 size_t rbl_block_inverse_bytes(int64_t n, int batch);
 int64_t rbl_block_inverse_ld(int64_t n);
 int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,

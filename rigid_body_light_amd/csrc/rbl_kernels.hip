@@ -597,6 +597,9 @@ __host__ __device__ __forceinline__ long symw_prefix(int e, int C, int nch)
 #ifndef RBL_SYMW_UNROLL
 #define RBL_SYMW_UNROLL 2
 #endif
+#ifndef RBL_SYMW_LDSACC
+#define RBL_SYMW_LDSACC 0         // column-sum components kept in LDS (atomics) instead of rotating registers
+#endif
 #ifndef RBL_SYMW_IW
 #define RBL_SYMW_IW 4             // independent waves (= work units in flight) per workgroup
 #endif
@@ -606,6 +609,10 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
                                                         SymLayout L, RblParams P, unsigned *err, long n_units)
 {
   __shared__ double2_t sP0[IW][TS], sP1[IW][TS], sP2[IW][TS];   // (x,y) (z,fx) (fy,fz) of a wave's current column tile
+  // RBL_SYMW_LDSACC of the three column-sum components go through LDS atomics instead of the rotating registers: the DPP
+  // moves are VALU work, the atomics LDS work, and the kernel is bound by whichever pipe carries more (measured)
+  constexpr int NL = RBL_SYMW_LDSACC;
+  __shared__ double sU[IW][NL > 0 ? NL : 1][TS];
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long u = (long)blockIdx.x * IW + wave;
@@ -668,14 +675,31 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
       continue;
     }
     double ax = 0.0, ay = 0.0, az = 0.0;                            // column sums of column (lane + s) & 63, travelling
+    if (NL > 0) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) sU[wave][k][lane] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
     unsigned off16 = (unsigned)lane * 16u;
     const char *b0 = (const char *)sP0[wave], *b1 = (const char *)sP1[wave], *b2 = (const char *)sP2[wave];
 #pragma unroll RBL_SYMW_UNROLL
     for (int s = 0; s < TS; ++s) {
       const double2_t pa = *(const double2_t *)(b0 + off16), pb = *(const double2_t *)(b1 + off16), pd = *(const double2_t *)(b2 + off16);
+      const int jj = (int)(off16 >> 4);
       off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
-      rbl_pair_sym<WALL, true, true>(Pu, xi, yi, zi, Fix, Fiy, Fiz, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix, uiy, uiz, ax, ay, az, flags, WK);
-      ax = wave_rol1(ax); ay = wave_rol1(ay); az = wave_rol1(az);
+      double vx = (NL > 0) ? 0.0 : ax, vy = (NL > 1) ? 0.0 : ay, vz = (NL > 2) ? 0.0 : az;
+      rbl_pair_sym<WALL, true, true>(Pu, xi, yi, zi, Fix, Fiy, Fiz, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix, uiy, uiz, vx, vy, vz, flags, WK);
+      if (NL > 0) __hip_atomic_fetch_add(&sU[wave][0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else ax = wave_rol1(vx);
+      if (NL > 1) __hip_atomic_fetch_add(&sU[wave][NL > 1 ? 1 : 0][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else ay = wave_rol1(vy);
+      if (NL > 2) __hip_atomic_fetch_add(&sU[wave][NL > 2 ? 2 : 0][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else az = wave_rol1(vz);
+    }
+    if (NL > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      ax = sU[wave][0][lane];
+      if (NL > 1) ay = sU[wave][NL > 1 ? 1 : 0][lane];
+      if (NL > 2) az = sU[wave][NL > 2 ? 2 : 0][lane];
     }
     double *q = slabJ + sym_idxJ(L, e, 0, (long)J * TS + lane);     // 64 rotations: lane l holds column l again
     q[0] = ax; q[1] = ay; q[2] = az;

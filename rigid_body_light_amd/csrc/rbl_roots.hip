@@ -187,7 +187,7 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       }
       if (comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(d_tmp, 0, vbytes, c->stream));
       if ((rc = blk_solve(c, b0, b1 - b0, src, d_tmp, nvec, n, 2, lz32)))
-        return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+        return rbl_fail(c, rc, "preconditioned square root: the per-body factor application failed");
       if ((rc = comm_allgather_bodies(c, d_tmp, 0, mb, nvec, n))) return rc;
       c->no_damp = true;
       rc = apply_M_multi_enqueue(c, c->S.wall, d_tmp, d_r, nbl, nvec, d_y);
@@ -203,7 +203,7 @@ static int apply_A_dev(rbl_ctx *c, const RblParams &P, const double *d_r, int64_
       if ((rc = tl_apply(c, d_x, d_y, nvec, n, 2))) return rc;
       rc = blk_solve(c, 0, c->S.N_bod, d_y, d_tmp, nvec, n, 2, lz32);
     } else rc = blk_solve(c, 0, c->S.N_bod, d_x, d_tmp, nvec, n, 2, lz32);   // both vectors in one pass over L
-    if (rc) return rbl_fail(c, rc, "preconditioned square root: bodies with more than 2730 blobs are not supported");
+    if (rc) return rbl_fail(c, rc, "preconditioned square root: the per-body factor application failed");
     double *prod = d_y;                                // explicit inverses do not work in place: product into their scratch
     if (c->blk_inv_valid || (bf_on(c) && c->bf_inv)) {
       if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n))) return rc;

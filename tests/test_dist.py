@@ -82,6 +82,36 @@ def test_two_rank_body_sharded_apply_M(n_bodies, wall):
     assert ret["parts"][0][0] == 0 and ret["parts"][-1][1] == n_bodies
 
 
+def _gather_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rigid_body_light_amd.dist import ShardedMobility
+        sm = ShardedMobility(7, 12)                        # 7 bodies over 2 ranks: 4 + 3 (ragged segments)
+        n = 7 * 36
+        buf = torch.full((n + 10,), -1.0, dtype=torch.float64)
+        offs = [5 + 36 * b for b, _ in sm.parts]
+        cnts = [36 * (e - b) for b, e in sm.parts]
+        buf[offs[rank]:offs[rank] + cnts[rank]] = torch.arange(cnts[rank], dtype=torch.float64) + 1000.0 * (rank + 1)
+        sm.all_gather_segments(lambda a, k: buf[a:a + k], offs, cnts)      # what librbl's all-gather callback does
+        want = torch.full((n + 10,), -1.0, dtype=torch.float64)
+        for r_ in range(world):
+            want[offs[r_]:offs[r_] + cnts[r_]] = torch.arange(cnts[r_], dtype=torch.float64) + 1000.0 * (r_ + 1)
+        ret[rank] = bool(torch.equal(buf, want)) and sm.n_all_gather == 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_in_place_all_gather_of_ragged_segments():
+    """the all-gather librbl asks its communicator for (owners' segments of ONE vector, in place, ragged: rbl_allgatherv_fn) as the
+    gloo rehearsals implement it (ShardedMobility.all_gather_segments); the native communicator does it with ncclAllGather /
+    grouped ncclBroadcast on the GPU box"""
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
+
+
 def test_partition():
     from rigid_body_light_amd.dist import body_partition
     assert body_partition(200, 8) == [(25 * i, 25 * i + 25) for i in range(8)]

@@ -592,17 +592,54 @@ def test_cfg2_full_size_lanczos_square_roots():
     ctx.close()
 
 
-def test_block_pc_rejects_bodies_over_the_lds_limit():
-    """the block-diagonal preconditioner keeps a body's substitution vector in 64 KB of LDS: bodies of more than
-    2730 blobs are refused with a message, not silently mis-solved"""
+@pytest.mark.parametrize("wall", [False, True])
+def test_block_pc_for_a_body_beyond_the_lds_limit(orc, wall):
+    """Bodies of more than 2 730 blobs do not fit a workgroup's 64 KB of LDS with their substitution vector (rounds 1-3 refused them
+    with an error): the substitution kernel then works on the vector in HBM.  Block-diagonal preconditioner and per-body factor
+    operations for a 2 800-blob body (free space: the shared body-frame factor; wall: the per-configuration factor) against dense
+    numpy solves on the oracle's mobility; the reference's Block_diag_invM (:461-487) has no size limit either."""
+    import torch
+    from oracle import oracle as O
     from rigid_body_light_amd import RigidBody
-    nblb = 2731
+    from rigid_body_light_amd._lib import DeviceContext
+    nblb = 2800
     k = np.arange(nblb) + 0.5
     phi = np.arccos(1.0 - 2.0 * k / nblb); th = np.pi * (1.0 + 5.0 ** 0.5) * k
     cfg = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)   # Fibonacci sphere, radius 1
-    rb = RigidBody(cfg, np.array([[0.0, 0.0, 40.0]]), np.array([[1.0, 0, 0, 0]]), 0.02, 1.0, 0.01, block_PC=True)
-    with pytest.raises(RuntimeError, match="2730"):
-        rb.apply_PC(np.ones(3 * nblb + 6))
+    a, eta = 0.02, 1.0
+    X = np.array([[0.0, 0.0, 3.0]]); Q = np.array([[0.8, 0.2, -0.4, 0.4]]); Q /= np.linalg.norm(Q)
+    n = 3 * nblb
+    r = orc.multi_body_pos(X, Q, cfg - cfg.mean(axis=0))
+    M = orc.rotne_prager_tensor(r, a, eta, wall)                 # undamped body mobility (the block the reference inverts)
+    rng = np.random.default_rng(8)
+    # per-body factor operations through the device API
+    dev = torch.device("cuda:0")
+    ctx = DeviceContext(a, eta, wall, cfg=cfg, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(X, Q)
+    v = rng.standard_normal(n)
+    dv = torch.from_numpy(v).to(dev)
+
+    def bsolve(vec, mode):
+        out = torch.empty_like(vec)
+        ctx.block_solve(vec.contiguous().data_ptr(), out.data_ptr(), mode)
+        ctx.sync_check()
+        return out
+
+    x0 = bsolve(dv, 0).cpu().numpy()                             # (G G^T)^-1 v = M^-1 v
+    assert np.linalg.norm(M @ x0 - v) < 1e-9 * np.linalg.norm(v)
+    y1 = bsolve(dv, 1)                                           # G^-1 v ...
+    x2 = bsolve(y1, 2).cpu().numpy()                             # ... then G^-T of it: the same solve in two halves
+    assert np.linalg.norm(x2 - x0) < 1e-11 * np.linalg.norm(x0)
+    assert abs(float(y1 @ y1) - float(v @ x0)) < 1e-10 * abs(float(v @ x0))      # |G^-1 v|^2 = v^T M^-1 v
+    back = bsolve(y1, 3).cpu().numpy()                           # G (G^-1 v) = v   (mode 3: the factor itself, x read from HBM)
+    assert np.linalg.norm(back - v) < 1e-10 * np.linalg.norm(v)
+    ctx.close()
+    # the block-diagonal preconditioner through the drop-in surface against the oracle's dense restatement
+    rb = RigidBody(cfg, X, Q, a, eta, 0.01, wall_PC=wall, block_PC=True)
+    b = np.concatenate([rng.standard_normal(n), rng.standard_normal(6)])
+    got = rb.apply_PC(b)
+    ref = O.apply_PC(orc, b, X, Q, cfg - cfg.mean(axis=0), a, eta, wall, True)      # dense numpy restatement of :589-616 with :461-487
+    assert np.linalg.norm(got - ref) < 1e-8 * np.linalg.norm(ref)
 
 
 def test_cholesky_cfg2_size_property():

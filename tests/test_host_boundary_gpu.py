@@ -95,3 +95,36 @@ def test_rfd_family_vs_numpy_restatements(orc, wall):
     assert np.linalg.norm(fresh - pc_after) / np.linalg.norm(fresh) < 1e-2
     with pytest.raises(RuntimeError):
         rb.M_RFD_from_U(U[:-1], W)
+
+
+@pytest.mark.parametrize("wall", [True, False])
+def test_overlapped_convergence_test_changes_nothing_but_the_schedule(wall):
+    """RBL_OPT_GMRES_OVERLAP_CHECK (large systems: the host reads iteration j's Hessenberg column while the GPU already applies
+    iteration j + 1's preconditioner): same iterations, bitwise the same solution as the drain-then-continue schedule, and the
+    solve ends at the first iteration that passes (36 x shell_N_642 = 23 112 blobs, block PC, 1e-9)."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, nblb = 36, 642
+    c = make_config(nb, nblb, wall)
+    dev = torch.device("cuda:0")
+    nsys = 3 * nb * nblb + 6 * nb
+    rhs = torch.zeros(nsys, dtype=torch.float64, device=dev)
+    rhs[3 * nb * nblb:] = torch.from_numpy(-np.tile([0.0, 0.1, -1.0, 0.0, 0.0, 0.3], nb)).to(dev)
+    out = {}
+    for overlap in (0, 1):
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_option("gmres_overlap_check", overlap)
+        assert ctx.get_option("gmres_overlap_check") == overlap
+        x = torch.empty_like(rhs)
+        m, res = ctx.gmres_saddle(rhs.data_ptr(), 100, 1e-9, x.data_ptr())
+        ctx.sync_check()
+        chk = torch.empty_like(rhs)
+        ctx.apply_saddle(x.data_ptr(), chk.data_ptr()); ctx.sync_check()
+        out[overlap] = (m, res, x.clone(), float(torch.linalg.norm(chk - rhs) / torch.linalg.norm(rhs)))
+        ctx.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and 3 < out[1][0] < 60
+    assert torch.equal(out[0][2], out[1][2])
+    assert out[1][3] < 2e-9

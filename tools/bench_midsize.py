@@ -10,13 +10,17 @@ from rigid_body_light_amd._lib import DeviceContext
 
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
-print("library:", os.environ.get("RBL_LIBRARY", "default"))
+print("library:", os.environ.get("RBL_LIBRARY", "default"), " chunk:", os.environ.get("CHUNK", "heuristic"))
 for name, nb, nblb, wall in (("cfg2 50x162 free", 50, 162, False), ("50x162 wall", 50, 162, True), ("37x162 free", 37, 162, False),
                              ("25x162 free", 25, 162, False), ("12x642 wall", 12, 642, True), ("cfg1 10x12 free", 10, 12, False)):
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        continue
     c = make_config(nb, nblb, wall)
     N = nb * nblb
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=st.cuda_stream)
     ctx.set_config(c["X"], c["Q"])
+    if os.environ.get("CHUNK"):
+        ctx.set_option("sym_chunk", int(os.environ["CHUNK"]))
     r = torch.empty(3 * N, dtype=torch.float64, device=dev)
     ctx.blob_positions(0, nb, r.data_ptr())
     F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev)
