@@ -431,7 +431,7 @@ def brownian_mode(args, dev, world, rank):
         dist.destroy_process_group()
 
 
-def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier):
+def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier, multi=None):
     """Time steps built on the hot path (the reference has no driver; SURVEY.md 8d defines them).  Every variant is timed
     over args.timestep_steps consecutive steps and carries its GMRES residuals and iteration counts.
       deterministic_fixed : 20 right-preconditioned GMRES iterations (diagonal PC) = 21 apply_M + K ops + evolve
@@ -440,6 +440,8 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
                             GMRES to 1e-8 from a zero guess, square root by block-Jacobi preconditioned Lanczos to 1e-3 / 1e-6."""
     from rigid_body_light_amd._lib import DeviceContext, lib
     from rigid_body_light_amd.krylov import DeterministicStepper, ShardedDeterministicStepper, BrownianStepper, ShardedBrownianStepper
+    if multi is None:
+        multi = world > 1          # (--force-comm: the N-rank code path with one rank)
     K = args.timestep_steps
     Fb = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], nb)
 
@@ -466,7 +468,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         return d
 
     out = {}
-    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev, set_comm=False) if world > 1 else DeterministicStepper(ctx, nb, nblb, dev))
+    stp = (ShardedDeterministicStepper(ctx, sm, nb, nblb, dev, set_comm=False) if multi else DeterministicStepper(ctx, nb, nblb, dev))
     stp.step(Fb, 20)
     d = timed(lambda k: stp.step(Fb, 20), tctx=ctx)
     d.update({"apply_M_per_timestep": 21, "definition": "deterministic fixed-work step (SURVEY.md 8d): 20 GMRES iterations on the saddle "
@@ -475,7 +477,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
     out.update({k: d[k] for k in ("timesteps_per_sec", "ms_per_timestep", "apply_M_per_timestep", "steps_timed")})
     out["definition"] = d["definition"]
     out["gmres_residual"] = d["gmres_residual_last"]
-    if world == 1:
+    if not multi:
         lib().rbl_set_blk_pc(ctx.h, 1)
         stp.warm_start = True; stp.extrapolate = 2     # initial guess 3 x_n - 3 x_{n-1} + x_{n-2}
         ctx.set_block_refresh(4)                       # per-body factors rebuilt every 4th configuration
@@ -496,7 +498,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
     # stochastic midpoint step, converged: BASELINE configs[3] (on N GPUs: `--mode timestep --kBT 1 --gpus N`)
     bro = {}
     variants = [(1e-3, False, False, 0), (1e-6, False, False, 0), (1e-3, True, False, 0), (1e-3, False, True, 0)]
-    if world > 1:
+    if multi:
         variants.append((1e-3, False, False, 1))       # the same step with the row split (all-gather of positions and U)
     for ltol, relaxed, energy, split in variants:
         bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
@@ -508,9 +510,9 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             bctx.set_option("relaxed_krylov", 1)
         if energy:                     # stop the root on its energy-norm estimate (RBL_OPT_LANCZOS_EUCLID_NORM = 0): see `lanczos_norm` below
             bctx.set_option("lanczos_euclid_norm", 0)
-        if world > 1:
+        if multi:
             from rigid_body_light_amd.dist import ShardedMobility
-            bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
+            bst = ShardedBrownianStepper(bctx, ShardedMobility(nb, nblb, device=dev, ctx=bctx, force_collectives=args.force_comm), nb, nblb, dev, c["a"], wall, 1.0, c["dt"],
                                          lanczos_tol=ltol, lanczos_max_iter=200)
             bctx.set_option("comm_split", split)
             one = lambda k: bst.step(Fb, seed=k, iters=200, rtol=1e-8)
@@ -523,10 +525,10 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         d = timed(one, 1, tctx=bctx)
         d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz(), "lanczos_error_estimate_last_step": bctx.lanczos_report()[1],
                   "relaxed_products": relaxed})
-        if world == 1:                 # measured, outside the timed region: one more pair of roots + one product
+        if not multi:                  # measured, outside the timed region: one more pair of roots + one product
             d["root_identity_error"] = root_identity_error(bctx, nb, nblb, c["a"], dev)
         d["lanczos_stopping_norm"] = "energy" if energy else "euclidean"
-        d["comm_split"] = ["tile pairs + all-reduce", "rows by body index + all-gather"][split] if world > 1 else None
+        d["comm_split"] = ["tile pairs + all-reduce", "rows by body index + all-gather"][split] if multi else None
         bro["lanczos_%g%s%s%s" % (ltol, "_relaxed" if relaxed else "", "_energy_norm" if energy else "", "_rows" if split else "")] = d
         del bst
         bctx.close()
@@ -879,6 +881,8 @@ def main():
                     "instead of the fixed 20 iterations")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="rbl_set_option switches for A/B runs "
                     "(include/rbl.h RBL_OPT_*: gmres_pc_sign_fix=0, sym_work_queue=0, comm_split=1, ...), repeatable")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1 only: run the N > 1 code path (process group of one rank, the library's "
+                    "communicator with one share, both work splits) -- a one-GPU rehearsal of exactly what the N-rank job executes")
     ap.add_argument("--dump-check", default="", help="write a row sample of the result to PATH.rank<r>.npz (tests compare it with the CPU oracle)")
     args = ap.parse_args()
 
@@ -897,8 +901,15 @@ def main():
     dev_index = local_rank % max(ndev, 1)     # several ranks may share a GPU only in a gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    multi = world > 1 or args.force_comm
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                    # --force-comm without torchrun: a rendezvous of our own
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -921,7 +932,7 @@ def main():
     if args.jsplit or args.variant:
         ctx.set_tuning(args.jsplit, args.variant)        # (kernel choice + its split: the one call the old switchboard keeps)
     apply_opts(ctx, args)
-    sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx)
+    sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx, force_collectives=args.force_comm)
     nrows = sm.row1 - sm.row0
     guard = LineGuard(world, rank, limit_s=500)      # below the 600 s after which the RCCL watchdog aborts a stuck rank
     kname_w = "true" if wall else "false"
@@ -968,7 +979,7 @@ def main():
         return roof
 
     partitionings = None
-    if world == 1:
+    if not multi:
         # ---- one GPU: blob positions -> U = B M B F, the kernel bracketed by events on its own stream ------------------------
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -1042,7 +1053,8 @@ def main():
             ctx.sync_check()
             tm = ctx.timings()
             el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            if world > 1:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
             el = float(el.item())
             pr = gather_ranks([tm["product"][0] / args.steps, tm["collective"][0] / args.steps, tm["collective"][1] / args.steps], dev, world)
             k_ms = float(pr[:, 0].max())
@@ -1078,7 +1090,7 @@ def main():
 
     phase = os.environ.get("RBL_BENCH_PHASE", "all")       # set by self_launch: main | timestep | all
     if phase == "timestep":                                  # second job of a self-launched N-rank run: only the time steps
-        tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
+        tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier, multi)
         if rank == 0:
             print(json.dumps(tstep), flush=True)
         if world > 1:
@@ -1125,7 +1137,7 @@ def main():
         try:
             if os.environ.get("RBL_BENCH_INJECT_FAILURE") == str(rank):     # tests/test_multirank_gpu.py: the guard itself
                 raise RuntimeError("injected failure (test hook)")
-            tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier)
+            tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier, multi)
         except Exception as e:                               # the hot-path line must not be lost to the time-step part ...
             if world > 1:
                 guard.rank_failed(e)                         # rank 0 prints the line with the reason; status 4
@@ -1170,7 +1182,7 @@ def main():
             if tstep is not None and "error" not in tstep:
                 line["cpu_baseline_timestep"] = cpu_timestep_baseline(tstep, cb)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         ctx.close()                                          # (destroys the library's communicator before the process group goes)
         dist.destroy_process_group()
     if failed:

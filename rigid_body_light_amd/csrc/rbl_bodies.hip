@@ -644,8 +644,20 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
   const RblBodyState &S = c->S;
   const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
   if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3))) return rc;
-  if ((rc = apply_M_enqueue(c, S.wall, d_x, (const double *)c->d_pos.p, N, 0, N, (double *)c->d_sad.p))) return rc;
-  if (c->ktl_arm && c->ktl_of == d_x) {      // GMRES: d_x came out of the block preconditioner together with its K^T Lambda
+  const bool have_ktl = c->ktl_arm && c->ktl_of == d_x;   // GMRES: d_x came out of the block preconditioner together with its K^T Lambda
+  c->fuse_done = false;
+  if (have_ktl && c->fused_krylov && !comm_on(c)) {
+    // one launch fewer per iteration: the slab reduction of the product writes  out = [M lambda - K U ; K^T lambda]  itself
+    RblSaddleFuse f;
+    f.lever = (const double *)c->d_lever.p; f.U = d_x + n3; f.ktl = (const double *)c->d_ktl.p; f.w = d_out;
+    f.N_blb = S.N_blb; f.nb6 = 6 * S.N_bod;
+    c->sym_tune.fuse = f;
+  }
+  rc = apply_M_enqueue(c, S.wall, d_x, (const double *)c->d_pos.p, N, 0, N, (double *)c->d_sad.p);
+  c->sym_tune.fuse = RblSaddleFuse();
+  if (rc) return rc;
+  if (c->fuse_done) { c->fuse_done = false; return RBL_OK; }
+  if (have_ktl) {
     rbl_launch_saddle_tail(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, S.N_bod, d_out,
                            (const double *)c->d_sad.p, (const double *)c->d_ktl.p);
     return RBL_OK;

@@ -55,6 +55,16 @@ struct RblDevBuf {
   size_t bytes = 0;
 };
 
+// saddle epilogue fused into the slab reduction of a symmetric product (launch-bound systems, RBL_OPT_FUSED_KRYLOV): besides
+// out = B M B F the reduction also leaves  w_top = out - K U  and  w_bot = ktl  (the K^T lambda the block preconditioner left)
+struct RblSaddleFuse {
+  const double *lever = nullptr;   // nullptr: off
+  const double *U = nullptr;       // 6 N_bod
+  const double *ktl = nullptr;     // 6 N_bod
+  double *w = nullptr;             // 3 N + 6 N_bod
+  int N_blb = 0, nb6 = 0;
+};
+
 struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
   int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
@@ -63,6 +73,8 @@ struct RblSymTune {        // per-context tuning of the symmetric matvec kernels
   int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (rbl_set_tuning 93); 0: work queue there (94)
   int gap_ratio = 0;       // relaxed product: a tile pair is swept in single precision when (d_I + 2 d_J) <= gap_ratio x gap (0 = default; RBL_OPT_RELAXED_GAP_RATIO)
   int wave_units = 0;      // < 0: mid-size systems on the round-3 kernel (one workgroup per unit, column sums by LDS atomics); 0: wave-owned units (RBL_OPT_SYM_WAVE_UNITS)
+  unsigned *queue_mem = nullptr;   // the context's work-queue counter (4 bytes of device memory, zero between products) for the wave-unit kernel
+  RblSaddleFuse fuse;      // transient: see RblSaddleFuse
   int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
 
@@ -114,6 +126,7 @@ struct rbl_ctx {
   int blk_b0 = 0, blk_b1 = 0;   // ... for the bodies [blk_b0, blk_b1) (a multi-GPU driver factors only its own bodies)
   int blk_refresh = 1, blk_age = 0;   // rbl_set_block_refresh: keep the factors for blk_refresh configuration changes
   unsigned *d_err = nullptr;
+  unsigned *d_queue = nullptr;  // work-queue counter of the mid-size pair kernel (sym_tune.queue_mem)
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
   void *h_pin = nullptr;      // pinned, 1 MB: target of the small device-to-host reads of the solver loops (read_back)
@@ -141,6 +154,7 @@ struct rbl_ctx {
   void *comm_nccl = nullptr;                        // ncclComm_t of the native communicator
   int comm_split = 0;                               // RBL_OPT_COMM_SPLIT: 0 unordered tile pairs + all-reduce(U), 1 rows by body index + all-gather (north_star)
   std::vector<int64_t> comm_offs, comm_cnts;        // scratch of the all-gather calls
+  bool fuse_done = false; // the last full product honoured sym_tune.fuse (rbl_apply_saddle_dev)
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs

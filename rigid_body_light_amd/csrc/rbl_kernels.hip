@@ -576,8 +576,9 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_rol1(double v)            // lane l takes lane (l + 1) & 63's value
 {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+  // (mov_dpp: no `old` operand to initialise -- every lane of a wave rotate has a source; update_dpp(0, ...) cost a v_mov per half)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -606,7 +607,7 @@ __host__ __device__ __forceinline__ long symw_prefix(int e, int C, int nch)
 template <bool WALL, int IW>
 __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
                                                         double *__restrict__ slabI, double *__restrict__ slabJ, long N,
-                                                        SymLayout L, RblParams P, unsigned *err, long n_units)
+                                                        SymLayout L, RblParams P, unsigned *err, long n_units, unsigned *queue)
 {
   __shared__ double2_t sP0[IW][TS], sP1[IW][TS], sP2[IW][TS];   // (x,y) (z,fx) (fy,fz) of a wave's current column tile
   // RBL_SYMW_LDSACC of the three column-sum components go through LDS atomics instead of the rotating registers: the DPP
@@ -615,9 +616,12 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
   __shared__ double sU[IW][NL > 0 ? NL : 1][TS];
   const int lane = threadIdx.x & (TS - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long u = (long)blockIdx.x * IW + wave;
-  if (u >= n_units) return;
   const int T = L.T, C = L.C;
+  unsigned flags = 0;
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  // one work unit of this wave (`return` ends the unit)
+  auto sweep_unit = [&](const long u) {
   int e, c;
   if (L.tri) {                       // u -> (row tile, chunk) through the closed-form prefix count (scalar work)
     int lo = 0, hi = L.rowsI;        // largest e with prefix(e) <= u
@@ -636,9 +640,6 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
   const int J1 = (J0 + C < T) ? J0 + C : T;
   if (J0 < I) J0 = I;
   if (J0 >= J1) return;
-  unsigned flags = 0;
-  const RblParams Pu = unit_params(P);
-  const RblWallK WK = rbl_wall_k_resident();
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
       x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
@@ -706,6 +707,23 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
   }
   double *p_ = slabI + sym_idxI(L, c, 0, (long)I * TS + lane);
   p_[0] = uix; p_[1] = uiy; p_[2] = uiz;
+  };
+  if (!queue) {
+    const long u = (long)blockIdx.x * IW + wave;
+    if (u < n_units) sweep_unit(u);
+  } else {
+    // WORK QUEUE: the launch holds as many waves as stay resident and every wave draws units from one counter until it runs
+    // dry.  8 128 equal units on 6 144 resident waves otherwise run as one full round and a 32 % round at two waves per SIMD,
+    // which cannot fill the fp64 pipe; with the queue every SIMD keeps its waves until the units are gone.  The slabs are
+    // addressed by unit: results do not depend on who swept what.  (The counter is reset by the slab reduction that follows.)
+    for (;;) {
+      unsigned t = 0;
+      if (lane == 0) t = atomicAdd(queue, 1u);
+      const long u = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      if (u >= n_units) break;
+      sweep_unit(u);
+    }
+  }
   if (flags) atomicOr(err, flags);
 }
 
@@ -928,10 +946,11 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
                                                        const double *__restrict__ slabJ,
                                                        const double *__restrict__ r,
                                                        double *__restrict__ out, long N, SymLayout L, RblParams P,
-                                                       unsigned *err)
+                                                       unsigned *err, unsigned *queue_reset, RblSaddleFuse fuse)
 {
   // blockIdx.y = right-hand side (out is [gridDim.y][3N])
   const int v = blockIdx.y;
+  if (queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue_reset = 0u;   // the pair kernel's work queue, for the next product
   out += (size_t)v * (size_t)(3 * N);
   __shared__ double sh[RG][64];
   const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -966,7 +985,17 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
     if (WALL) sc *= damp_of(P, r[3 * j + 2]);
     out[idx] = sc * t;
     if (!isfinite(t)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
+    if (fuse.lever) {                                    // saddle epilogue: w = M lambda - K U  (k_saddle_tail's arithmetic)
+      const int b = (int)(j / fuse.N_blb);
+      const double *u = fuse.U + 6 * b, *om = u + 3, *l = fuse.lever + 3 * j;
+      const double ku = (k == 0) ? u[0] + l[2] * om[1] - l[1] * om[2]
+                      : (k == 1) ? u[1] + l[0] * om[2] - l[2] * om[0]
+                                 : u[2] + l[1] * om[0] - l[0] * om[1];
+      fuse.w[idx] = sc * t - ku;
+    }
   }
+  if (fuse.lever && blockIdx.x == 0 && blockIdx.y == 0)   // ... and its body rows: K^T lambda as the preconditioner left it
+    for (int i = threadIdx.x; i < fuse.nb6; i += 64 * RG) fuse.w[3 * N + i] = fuse.ktl[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1679,7 +1708,7 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
 template <bool WALL, int NI, int SW>
 static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, const double *d_r, int64_t n_blobs,
                        double *d_out, double *slabI, double *slabJ, const SymLayout &L, unsigned *d_err, bool relaxed,
-                       int n_cu, bool use_queue, double gap_ratio)
+                       int n_cu, bool use_queue, double gap_ratio, const RblSaddleFuse &fuse)
 {
   const int T = L.T, nrhs = L.nrhs;
   dim3 grid((unsigned)L.rowsG, (unsigned)L.nch), block(TS * SW);
@@ -1715,7 +1744,7 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
   else
     hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap, queue);
-  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
+  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, nrhs == 1 ? fuse : RblSaddleFuse());
 }
 
 // nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...)
@@ -1730,30 +1759,35 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   const bool relaxed = tune.relaxed != 0;
   const double gr = tune.gap_ratio > 0 ? (double)tune.gap_ratio : 15.0;
   if (L.NI == 2 && L.SW == SW_LARGE) {
-    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
-    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
+    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
+    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
   } else if (L.NI == 2) {
-    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
-    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr);
+    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
+    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
 #ifdef RBL_WAVE_TRACE
   } else if (L.SW == 2) {                  // experiment (tools/wave_trace.hip): one row per lane, two waves per workgroup
-    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
-    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
+    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
+    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
 #endif
   } else if (nrhs == 1 && L.SW == 1 && tune.wave_units >= 0) {
     // mid-size systems: wave-owned units, column sums rotating through the lanes (k_apply_M_symw), same slabs + reduction
     constexpr int IW = RBL_SYMW_IW;
     const long n_units = L.tri ? symw_prefix(L.rowsI, L.C, L.nch) : (long)L.rowsI * L.nch;
-    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
-    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    long nwg = (n_units + IW - 1) / IW;
+    // more units than resident waves: a fixed set of workgroups draws them from the context's counter (zero between products)
+    const long resident = (long)(n_cu > 0 ? n_cu : 256) * 4 * (wall ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) / IW;
+    unsigned *queue = (tune.queue >= 0 && tune.queue_mem && nwg > resident) ? tune.queue_mem : nullptr;
+    if (queue) nwg = resident;
+    const dim3 grid((unsigned)nwg), block(TS * IW);
+    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units, queue);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units, queue);
     const int64_t n = 3 * n_blobs;
     dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
-    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
-    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err);
+    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, queue, tune.fuse);
+    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, queue, tune.fuse);
   } else {
-    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
-    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr);
+    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
+    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
   }
 }
 

@@ -47,6 +47,7 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
   if (full && comm_on(c)) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, c->sym_tune)))) return rc;
     RblSymTune tune = c->sym_tune;
+    tune.fuse = RblSaddleFuse();                      // (a shard's sum is partial: the epilogue waits for the all-reduce)
     if (c->force_relaxed) tune.relaxed = 1;
     {
       RblPhase ph(c, RBL_T_PRODUCT);
@@ -62,6 +63,7 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
     if (c->force_relaxed) tune.relaxed = 1;
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
                            c->d_err, 1, tune);
+    c->fuse_done = tune.fuse.lever != nullptr;        // the slab reduction also wrote the saddle epilogue (rbl_apply_saddle_dev)
   } else {
     int js = 1;
     const size_t pb = rbl_apply_M_part_bytes(nbl, row_end - row_begin, c->n_cu, c->tune_jsplit, &js);

@@ -201,3 +201,39 @@ def test_cpp_only_host_drives_rccl_inside_librbl(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         assert "HOST OK" in p.stdout and "communicator kind 2" in p.stdout and p.stdout.count("GMRES iterations") == 3
+
+
+def test_bench_n_rank_code_path_on_one_rank_over_rccl(orc, tmp_path):
+    """`bench.py --force-comm`: the code path of the driver's N = 2, 4, 8 runs -- nccl process group, RCCL inside librbl, both work
+    splits timed, the sharded time steps -- with ONE rank on the one GPU there is: the line carries both partitionings with their
+    rooflines and per-rank phases, and the product it timed matches the CPU oracle."""
+    import json
+    import numpy as np
+    from rigid_body_light_amd import make_config
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "RBL_BENCH_PHASE"):
+        env.pop(k, None)
+    dump = str(tmp_path / "chk")
+    p = subprocess.run([sys.executable, "bench.py", "--force-comm", "--config", "cfg2", "--steps", "3", "--warmup", "1", "--cpu-budget", "0",
+                        "--timestep-steps", "1", "--dump-check", dump], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "RCCL inside librbl" in d["config"]["parallelism"]
+    for name, kernel in (("tile_pairs", "k_apply_M_sym<false,1>"), ("rows", "k_apply_M<false>")):
+        part = d["partitionings"][name]
+        assert part["roofline"]["kernel"] == kernel and 0.0 < part["roofline"]["frac"] <= 1.0
+        assert part["per_rank"]["kernel_ms"]["max"] > 0.0 and part["per_rank"]["collectives_per_step"] >= 1.0
+    t = d["timestep"]
+    assert "error" not in t and t["brownian_converged"]["lanczos_0.001"]["gmres_residual_max"] < 1e-8
+    assert t["brownian_converged"]["lanczos_0.001_rows"]["gmres_residual_max"] < 1e-8
+    assert d["timesteps_per_sec"]["brownian_converged"] > 0.0
+    nb, nblb, wall = 50, 162, False
+    c = make_config(nb, nblb, wall)
+    F = np.random.default_rng(2).standard_normal(3 * nb * nblb)
+    r = orc.multi_body_pos(c["X"], c["Q"], c["cfg"] - c["cfg"].mean(axis=0))
+    z = np.load("%s.rank0.npz" % dump)
+    b0 = int(z["row0"])
+    Uo = orc.apply_M_rows(F, r, b0, b0 + 8, c["a"], c["eta"], wall, nthreads=8)
+    assert np.linalg.norm(z["values"] - Uo) / np.linalg.norm(Uo) < 1e-11

@@ -10,7 +10,7 @@ from rigid_body_light_amd._lib import DeviceContext
 
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
-print("library:", os.environ.get("RBL_LIBRARY", "default"), " chunk:", os.environ.get("CHUNK", "heuristic"))
+print("library:", os.environ.get("RBL_LIBRARY", "default"), " chunk:", os.environ.get("CHUNK", "heuristic"), " queue:", os.environ.get("QUEUE", "default"))
 for name, nb, nblb, wall in (("cfg2 50x162 free", 50, 162, False), ("50x162 wall", 50, 162, True), ("37x162 free", 37, 162, False),
                              ("25x162 free", 25, 162, False), ("12x642 wall", 12, 642, True), ("cfg1 10x12 free", 10, 12, False)):
     if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
@@ -19,6 +19,8 @@ for name, nb, nblb, wall in (("cfg2 50x162 free", 50, 162, False), ("50x162 wall
     N = nb * nblb
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], stream_ptr=st.cuda_stream)
     ctx.set_config(c["X"], c["Q"])
+    if os.environ.get("QUEUE"):
+        ctx.set_option("sym_work_queue", int(os.environ["QUEUE"]))
     if os.environ.get("CHUNK"):
         ctx.set_option("sym_chunk", int(os.environ["CHUNK"]))
     r = torch.empty(3 * N, dtype=torch.float64, device=dev)
