@@ -55,9 +55,6 @@ int rbl_dev_init(rbl_ctx *c)
   RBL_HIP(c, hipMalloc((void **)&c->d_err, sizeof(unsigned)));
   RBL_HIP(c, hipHostMalloc((void **)&c->h_err, sizeof(unsigned), hipHostMallocDefault));
   RBL_HIP(c, hipMemset(c->d_err, 0, sizeof(unsigned)));
-  RBL_HIP(c, hipMalloc((void **)&c->d_queue, 64));
-  RBL_HIP(c, hipMemset(c->d_queue, 0, 64));
-  c->sym_tune.queue_mem = c->d_queue;
   // auxiliary stream + events for the Cholesky lookahead (optional: failure just disables it)
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
@@ -291,7 +288,6 @@ void rbl_destroy(rbl_ctx *c)
     for (const rbl_ctx::TimedSpan &sp : c->ev_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
-    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_err2) (void)hipFree(c->d_err2);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

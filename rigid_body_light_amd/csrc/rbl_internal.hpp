@@ -73,7 +73,6 @@ struct RblSymTune {        // per-context tuning of the symmetric matvec kernels
   int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (rbl_set_tuning 93); 0: work queue there (94)
   int gap_ratio = 0;       // relaxed product: a tile pair is swept in single precision when (d_I + 2 d_J) <= gap_ratio x gap (0 = default; RBL_OPT_RELAXED_GAP_RATIO)
   int wave_units = 0;      // < 0: mid-size systems on the round-3 kernel (one workgroup per unit, column sums by LDS atomics); 0: wave-owned units (RBL_OPT_SYM_WAVE_UNITS)
-  unsigned *queue_mem = nullptr;   // the context's work-queue counter (4 bytes of device memory, zero between products) for the wave-unit kernel
   RblSaddleFuse fuse;      // transient: see RblSaddleFuse
   int relaxed = 0;         // transient: far tile pairs in packed single precision (inexact Krylov iterations only)
 };
@@ -126,7 +125,6 @@ struct rbl_ctx {
   int blk_b0 = 0, blk_b1 = 0;   // ... for the bodies [blk_b0, blk_b1) (a multi-GPU driver factors only its own bodies)
   int blk_refresh = 1, blk_age = 0;   // rbl_set_block_refresh: keep the factors for blk_refresh configuration changes
   unsigned *d_err = nullptr;
-  unsigned *d_queue = nullptr;  // work-queue counter of the mid-size pair kernel (sym_tune.queue_mem)
   unsigned *h_err = nullptr;  // pinned
   void *h_stage = nullptr;    // pinned staging for large pageable host copies
   void *h_pin = nullptr;      // pinned, 1 MB: target of the small device-to-host reads of the solver loops (read_back)

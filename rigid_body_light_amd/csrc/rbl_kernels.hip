@@ -572,6 +572,8 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 //     LDS form (24 of its 47 LDS clocks, as much LDS time as VALU time at one row per lane) are gone, and after 64 steps
 //     every accumulator is back in its own lane: the 64 sums go to the slab straight from registers;
 //   * only the existing units are launched (closed-form index -> (row tile, chunk)), never the dead half of the rectangle.
+// Measured at cfg 2 (tools/bench_midsize.py, one box, alternating): 70.1 us per product against 73.9-75.4 (-6 %); PMC passes of both
+// kernels in profiles/r04_cfg2_kernel_pmc.md.
 // Sums per column are formed in step order, like the LDS atomics before them: bitwise reproducible run to run.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_rol1(double v)            // lane l takes lane (l + 1) & 63's value
@@ -607,7 +609,7 @@ __host__ __device__ __forceinline__ long symw_prefix(int e, int C, int nch)
 template <bool WALL, int IW>
 __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
                                                         double *__restrict__ slabI, double *__restrict__ slabJ, long N,
-                                                        SymLayout L, RblParams P, unsigned *err, long n_units, unsigned *queue)
+                                                        SymLayout L, RblParams P, unsigned *err, long n_units)
 {
   __shared__ double2_t sP0[IW][TS], sP1[IW][TS], sP2[IW][TS];   // (x,y) (z,fx) (fy,fz) of a wave's current column tile
   // RBL_SYMW_LDSACC of the three column-sum components go through LDS atomics instead of the rotating registers: the DPP
@@ -708,22 +710,11 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
   double *p_ = slabI + sym_idxI(L, c, 0, (long)I * TS + lane);
   p_[0] = uix; p_[1] = uiy; p_[2] = uiz;
   };
-  if (!queue) {
-    const long u = (long)blockIdx.x * IW + wave;
-    if (u < n_units) sweep_unit(u);
-  } else {
-    // WORK QUEUE: the launch holds as many waves as stay resident and every wave draws units from one counter until it runs
-    // dry.  8 128 equal units on 6 144 resident waves otherwise run as one full round and a 32 % round at two waves per SIMD,
-    // which cannot fill the fp64 pipe; with the queue every SIMD keeps its waves until the units are gone.  The slabs are
-    // addressed by unit: results do not depend on who swept what.  (The counter is reset by the slab reduction that follows.)
-    for (;;) {
-      unsigned t = 0;
-      if (lane == 0) t = atomicAdd(queue, 1u);
-      const long u = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
-      if (u >= n_units) break;
-      sweep_unit(u);
-    }
-  }
+  // (A work queue -- a resident set of waves drawing units from one counter, or from eight per-XCD counters -- was measured and
+  // dropped: 179 and 119 us per product at cfg 2 against 70 with one unit per wave, gpurun_out/r04f, r04g: a wave that sweeps
+  // units back to back pays every unit's staging latency in series.)
+  const long u = (long)blockIdx.x * IW + wave;
+  if (u < n_units) sweep_unit(u);
   if (flags) atomicOr(err, flags);
 }
 
@@ -950,7 +941,7 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
 {
   // blockIdx.y = right-hand side (out is [gridDim.y][3N])
   const int v = blockIdx.y;
-  if (queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *queue_reset = 0u;   // the pair kernel's work queue, for the next product
+  if (queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) queue_reset[32 * threadIdx.x] = 0u;   // the pair kernel's per-XCD work queues, for the next product
   out += (size_t)v * (size_t)(3 * N);
   __shared__ double sh[RG][64];
   const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1773,18 +1764,13 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
     // mid-size systems: wave-owned units, column sums rotating through the lanes (k_apply_M_symw), same slabs + reduction
     constexpr int IW = RBL_SYMW_IW;
     const long n_units = L.tri ? symw_prefix(L.rowsI, L.C, L.nch) : (long)L.rowsI * L.nch;
-    long nwg = (n_units + IW - 1) / IW;
-    // more units than resident waves: a fixed set of workgroups draws them from the context's counter (zero between products)
-    const long resident = (long)(n_cu > 0 ? n_cu : 256) * 4 * (wall ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) / IW;
-    unsigned *queue = (tune.queue >= 0 && tune.queue_mem && nwg > resident) ? tune.queue_mem : nullptr;
-    if (queue) nwg = resident;
-    const dim3 grid((unsigned)nwg), block(TS * IW);
-    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units, queue);
-    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units, queue);
+    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
+    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
     const int64_t n = 3 * n_blobs;
     dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
-    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, queue, tune.fuse);
-    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, queue, tune.fuse);
+    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
+    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
   } else {
     if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
     else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);

@@ -112,6 +112,44 @@ def main():
         per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]   # a transcendental counted as ONE flop
         res["%s<%s,%d>" % (kern, "true" if wall else "false", ni)] = {
             "block": best[0], "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
+    # the wave-unit kernel of mid-size systems, k_apply_M_symw<WALL, IW>: its sweep is a loop of a few basic blocks (the rare overlap
+    # branch splits it), column sums rotating through the lanes by v_mov_b32_dpp wave_rol:1 -- summed from the loop header to the
+    # block that branches back to it; pair steps per trip = v_rsq_f64 / (2 with the wall term, 1 without)
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*?14k_apply_M_symwILb([01])ELi(\d+)EE\S*):", l)
+        if not m:
+            continue
+        wall = m.group(2) == "1"
+        end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+        name_k = "k_apply_M_symw<%s>" % ("true" if wall else "false")
+        instances[name_k] = isa_hash(lines, i, end)
+        labels, raw = [], []
+        for k in range(i + 1, end):
+            if re.match(r"^\.LBB\d+_\d+:", lines[k]):
+                labels.append(lines[k].split(":")[0]); raw.append([])
+            elif raw:
+                raw[-1].append(lines[k])
+        for b, body in enumerate(raw):
+            txt = "\n".join(body)
+            back = re.search(r"s_cbranch_scc0 (\.LBB\d+_\d+)", txt)
+            if "wave_rol" not in txt or not back or back.group(1) not in labels[:b + 1]:
+                continue
+            h = labels.index(back.group(1))
+            ops = {}
+            for body2 in raw[h:b + 1]:
+                for ln in body2:
+                    t = ln.strip().split(" ")[0].split("\t")[0] if ln.strip() else ""
+                    if t and not t.startswith(";") and not t.startswith("."):
+                        ops[t] = ops.get(t, 0) + 1
+            c = classify(ops)
+            pairs = c["rsq"] / (2.0 if wall else 1.0)
+            if pairs <= 0:
+                continue
+            per = {k: c[k] / pairs for k in ("fma", "mul", "add", "trans", "f64", "valu", "valu_other", "lds", "salu")}
+            per["dpp_mov"] = sum(v for k, v in ops.items() if k.startswith("v_mov_b32_dpp")) / pairs
+            per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]
+            res[name_k] = {"block": "%s .. %s" % (labels[h], labels[b]), "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
+            break
     # the ordered-rows kernel k_apply_M<WALL> (row-sharded multi-GPU split): its sweep is a run of one-pair head blocks (distance,
     # rsq, three ds_read_b128 broadcasts of the staged j blob) followed by ONE body block that finishes those pairs together
     for i, l in enumerate(lines):
