@@ -49,6 +49,25 @@ PEAK_CLOCK_GHZ = 2.4                          # the clock that peak is quoted at
 N_SIMD = 1024                                 # 256 CUs x 4 SIMDs; one wave64 fp64 VALU instruction occupies a SIMD for 4 cycles
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to fd 1 when a
+    communicator is created): keep a private handle on the real stdout for the line and point fd 1 at stderr for everybody else."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(text):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(text + "\n")
+    out.flush()
+
+
 def visible_gpus():
     """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of a self-launched job must not
     initialise the GPU before it starts its ranks): GPU nodes of the KFD topology, cut down by the *_VISIBLE_DEVICES lists."""
@@ -370,7 +389,7 @@ def timestep_mode(args, dev, world=1, rank=0):
             extra["lanczos_iterations_last_step"] = lanczos_its()
             n_prod += sum(extra["lanczos_iterations_last_step"]) * (1 if len(extra["lanczos_iterations_last_step"]) > 1 else 2)
         extra["apply_M_per_step"] = n_prod
-    print(json.dumps({
+    emit(json.dumps({
         "metric": "timesteps/sec (%s: %d GMRES iterations (%s, %s PC) = %d apply_M + PC + K ops + evolve), "
                   "%d x shell_N_%d, %s, fp64" % (kind, iters, "fixed work" if rtol is None else "converged to %g" % rtol, args.pc,
                                                  iters + 1, nb, nblb, "wall-corrected" if wall else "free-space"),
@@ -380,7 +399,7 @@ def timestep_mode(args, dev, world=1, rank=0):
         "mf_gflops": extra.get("apply_M_per_step", iters + 1) * 18.0 * float(N) ** 2 / sec / 1e9, "gmres_residual": res[-1], "gmres_iterations": used,
         "block_refresh": args.block_refresh, "initial_guess": (["previous solution", "2 x_n - x_{n-1}", "3 x_n - 3 x_{n-1} + x_{n-2}"][args.extrapolate]
                           if (args.warm_start or args.extrapolate) and not brownian else "zero"),
-        "phases": phases, **extra}), flush=True)
+        "phases": phases, **extra}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -426,7 +445,7 @@ def brownian_mode(args, dev, world, rank):
     if rank == 0:
         sec = float(sec.item())
         pc = args.mhalf == "lanczos_pc"
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "Brownian increments/sec (M^{1/2} W by %s to %g, %d iterations), %d x shell_N_%d, %s, fp64"
                       % ("block-Jacobi preconditioned Lanczos" if pc else "Lanczos", args.lanczos_tol, its, nb, nblb,
                          "wall-corrected" if wall else "free-space"),
@@ -435,7 +454,7 @@ def brownian_mode(args, dev, world, rank):
             "data": "synthetic", "config": {"workload": "BASELINE.json configs[3]" if args.config == "cfg3" else args.config,
                                             "bodies": nb, "blobs_per_body": nblb, "n_blobs": N, "wall": wall,
                                             "parallelism": "tile-pair-sharded x%d, all-reduce(U) per Lanczos iteration" % world},
-            "lanczos_iterations": its, "lanczos_error_estimate": est, "mf_gflops": its * 18.0 * float(N) ** 2 / sec / 1e9}), flush=True)
+            "lanczos_iterations": its, "lanczos_error_estimate": est, "mf_gflops": its * 18.0 * float(N) ** 2 / sec / 1e9}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -831,7 +850,7 @@ class LineGuard:
         with self.lock:
             if self.line is not None:
                 self.line["timestep"] = {"error": why}
-                print(json.dumps(self.line), flush=True)
+                emit(json.dumps(self.line))
                 self.line = None
             sys.stderr.write("bench.py: time-step part failed: %s\n" % why)
             sys.stderr.flush()
@@ -899,6 +918,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args, sys.argv[1:])       # never returns
+    protect_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1101,7 +1121,7 @@ def main():
     if phase == "timestep":                                  # second job of a self-launched N-rank run: only the time steps
         tstep = timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barrier, multi)
         if rank == 0:
-            print(json.dumps(tstep), flush=True)
+            emit(json.dumps(tstep))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1190,7 +1210,7 @@ def main():
             line["speedup_vs_cpu_allcores"] = line["value"] / cb["allcores"]["value"]
             if tstep is not None and "error" not in tstep:
                 line["cpu_baseline_timestep"] = cpu_timestep_baseline(tstep, cb)
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
     if multi:
         ctx.close()                                          # (destroys the library's communicator before the process group goes)
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
 """A/B of launch-level switches on the cfg 2 Brownian step (50 x shell_N_162, free space; bench.py's `configs.cfg2` entry):
-    python tools/bench_cfg2_step.py [tuning_a tuning_b] [steps]      default: 91 92 (GMRES convergence-test placement)
+    python tools/bench_cfg2_step.py [options_a options_b] [steps]    options: comma-separated name=value (include/rbl.h RBL_OPT_*)
+    default: "fused_krylov=0,sym_wave_units=0" against "fused_krylov=1,sym_wave_units=1" (the round-3 kernels against round 4's)
 Both settings run on the same context, interleaved in blocks of `steps` steps, three rounds."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,9 +10,15 @@ from rigid_body_light_amd import make_config
 from rigid_body_light_amd._lib import DeviceContext, lib
 from rigid_body_light_amd.krylov import BrownianStepper
 
-ta = int(sys.argv[1]) if len(sys.argv) > 2 else 91
-tb = int(sys.argv[2]) if len(sys.argv) > 2 else 92
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+ta = sys.argv[1] if len(sys.argv) > 2 else "fused_krylov=0,sym_wave_units=0"
+tb = sys.argv[2] if len(sys.argv) > 2 else "fused_krylov=1,sym_wave_units=1"
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+
+
+def apply(spec):
+    for kv in spec.split(","):
+        k, _, v = kv.partition("=")
+        ctx.set_option(k.strip(), int(v))
 nb, nblb = 50, 162
 c = make_config(nb, nblb, False)
 dev = torch.device("cuda:0")
@@ -26,7 +33,7 @@ for _ in range(3):
     seed += 1; bst.step(Fb, seed=seed, method=2, iters=200, rtol=1e-8)
 for rnd in range(3):
     for t in (ta, tb):
-        ctx.set_tuning(0, t)
+        apply(t)
         X, Q = ctx.get_config(nb)
         seed0 = 100 * rnd                                   # the same noise and the same start for both settings
         ctx.set_config(c["X"], c["Q"])
@@ -36,7 +43,7 @@ for rnd in range(3):
         for k in range(steps):
             m, r = bst.step(Fb, seed=seed0 + 1 + k, method=2, iters=200, rtol=1e-8); its.append(m)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-        print("round %d tuning %d: %.3f ms per step, GMRES iterations %s" % (rnd, t, dt * 1e3, its), flush=True)
+        print("round %d [%s]: %.3f ms per step, GMRES iterations %s" % (rnd, t, dt * 1e3, its), flush=True)
     # the same steps through the one-call C entry point (rbl_step_brownian): no Python between the pieces of a step
     ctx.set_config(c["X"], c["Q"])
     its = []
@@ -45,4 +52,4 @@ for rnd in range(3):
     for k in range(steps):
         m, r = ctx.step_brownian(Fb, 200, 1e-8, seed=100 * rnd + 1 + k, method=2); its.append(m)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    print("round %d one-call entry (tuning %d): %.3f ms per step, GMRES iterations %s" % (rnd, tb, dt * 1e3, its), flush=True)
+    print("round %d one-call entry [%s]: %.3f ms per step, GMRES iterations %s" % (rnd, tb, dt * 1e3, its), flush=True)
