@@ -4,10 +4,12 @@
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/multi_gpu_brownian.py
 
 Every rank holds the same (replicated) body state and calls the same library entry points with the same arguments;
-`DeviceContext.set_comm` (C ABI: rbl_set_comm) makes librbl's own Lanczos / GMRES loops multi-GPU: each mobility product
-is this rank's share of the unordered blob-tile pairs followed by one all-reduce (RCCL through torch.distributed with the
-`nccl` backend), per-body factors and substitutions are done for the rank's own bodies only.  With one visible GPU and
-several ranks it falls back to the `gloo` backend (host-staged collectives) -- a rehearsal, not a speed-up."""
+`DeviceContext.set_comm` makes librbl's own Lanczos / GMRES loops multi-GPU: with an `nccl` process group it creates an
+RCCL communicator INSIDE librbl (C ABI: rbl_comm_unique_id on rank 0, broadcast through the group, rbl_comm_init_rccl) --
+each mobility product is this rank's share of the unordered blob-tile pairs followed by one ncclAllReduce on the context's
+stream, per-body factors and substitutions are done for the rank's own bodies only and completed by an all-gather; no Python
+runs inside a solve.  With one visible GPU and several ranks it falls back to the `gloo` backend (callbacks, host-staged
+collectives) -- a rehearsal, not a speed-up.  The same thing without Python: examples/host_rccl_step.cpp."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

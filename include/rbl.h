@@ -456,7 +456,10 @@ enum {
                                       independent waves per workgroup, column sums rotating through the lanes in registers
                                       (k_apply_M_symw); 0: the round-3 kernel (one workgroup per unit, column sums by LDS atomics).
                                       Same slabs and reduction either way                                                          */
-  RBL_OPT_COUNT = 28
+  RBL_OPT_SHARED_GEMM = 28,        /* [1] free space, bodies of <= 170 blobs: the ONE body-frame inverse / preconditioner table is applied to
+                                      all bodies' vectors as a matrix-matrix product on the fp64 matrix cores (the table read once);
+                                      0: batched matrix-vector products (every body re-reads it)                                    */
+  RBL_OPT_COUNT = 29
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

@@ -264,10 +264,11 @@ int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv
       const double *pi = in + (size_t)v0 * (size_t)pitch + off;
       double *po = out + (size_t)v0 * (size_t)pitch + off;
       if (c->bf_inv) {                                  // small bodies: X = L^-1 explicit, rotations fused into the products
-        if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, 0, tmp + off, dQ);
-        else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, mode, nullptr, dQ);
+        const int form = c->shared_gemm ? 0 : 2;          // (bit 1 of the last argument: batched matrix-vector form instead of the MFMA product)
+        if (mode == 0) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, 0, tmp + off, dQ, form);
+        else if (pi != po) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, po, m, g, pitch, mode, nullptr, dQ, form);
         else {
-          rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr, dQ);
+          rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_bfX.p, m, nbo, pi, tmp + off, m, g, pitch, mode, nullptr, dQ, form);
           for (int v = 0; v < g && !rc; ++v)
             RBL_HIP(c, hipMemcpyAsync(po + (size_t)v * (size_t)pitch, tmp + off + (size_t)v * (size_t)pitch,
                                       sizeof(double) * (size_t)m * (size_t)nbo, hipMemcpyDeviceToDevice, c->stream));
@@ -561,7 +562,7 @@ static int pc_block_apply_local(rbl_ctx *c, const double *d_in, double *d_out, b
       if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n3))) return rc;
       if ((rc = rbl_launch_pc_bodyframe(c->stream, T, T + (size_t)(m * m), T + (size_t)(m * m) + 6 * (size_t)m, (const double *)c->d_cfg.p,
                                         (const double *)c->d_XQ.p + 3 * (size_t)S.N_bod, m, b0, nbo, d_in, n3, c->pc_fsign, d_out, ktl,
-                                        (double *)c->d_blkTmp.p)))
+                                        (double *)c->d_blkTmp.p, c->shared_gemm ? 1 : 0)))
         return rbl_fail(c, rc, "body-frame preconditioner launch failed");
       if (ktl) c->ktl_of = d_out;
     }

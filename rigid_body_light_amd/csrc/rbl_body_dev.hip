@@ -318,7 +318,7 @@ __global__ void k_saddle_tail(const double *__restrict__ lever, const double *__
   out[3 * idx] = sub[3 * idx] - k0; out[3 * idx + 1] = sub[3 * idx + 1] - k1; out[3 * idx + 2] = sub[3 * idx + 2] - k2;
 }
 
-// ---- free space, small bodies: the WHOLE block preconditioner in the body frame (see bf_build in rbl_api.hip) ----------
+// ---- free space, small bodies: the WHOLE block preconditioner in the body frame (see bf_build in rbl_bodies.hip) ----------
 // M_b = (I x R) M_body (I x R)^T and K_b = (I x R) K_body blkdiag(R^T, R^T), so with s' = R^T slip, F' = (R^T F, R^T T):
 //   y1' = M_body^-1 s',  f' = K_body^T y1',  U' = N_body^-1 (fsign F' - f'),  Lambda' = y1' + (M_body^-1 K_body) U',
 //   Lambda = R Lambda',  U = (R U'_lin, R U'_ang),  K^T Lambda = (R, R) K_body^T Lambda'
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__
   }
 }
 
-// ---- two-level factor of the preconditioned Lanczos root (round 3; rbl_api.hip: tl_build) ----------------------------
+// ---- two-level factor of the preconditioned Lanczos root (round 3; rbl_roots.hip: tl_build) ----------------------------
 // The block-Jacobi factor L leaves the body-body far field to the Krylov iteration; in the Euclidean norm of the increment
 // what converges last are the collective translations of the bodies.  Monopole model of the far field:
 //     M~ = D + K_t C K_t^T = L (I + Q E Q^T) L^T,    Z_b = L_b^-1 K_t,b  (3 columns per body),  R_b = Z_b^T Z_b = C_b C_b^T,
@@ -706,11 +706,19 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
 // d_y1: scratch, n doubles per body (laid out like the blob vector)
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl, double *d_y1)
+                            double *d_out, double *d_ktl, double *d_y1, int gemm)
 {
   if (n > BFT || !d_y1) return RBL_ERR_SIZE;
   if (b_count <= 0) return RBL_OK;
-  for (int q0 = 0; q0 < b_count; q0 += 65535) {      // bodies ride in gridDim.y
+  // y1' = M_body^-1 R^T slip for every body: ONE table, many vectors -- a matrix-matrix product on the fp64 matrix cores
+  // (rbl_launch_shared_gemm; round 4) or, RBL_OPT_SHARED_GEMM = 0, a matrix-vector product per body that re-reads the table
+  const bool use_gemm = gemm && rbl_shared_gemm_fits(n) && b_count <= 65535;
+  if (use_gemm) {
+    const int rc = rbl_launch_shared_gemm(st, d_Minv, n, n, 0, d_in + (size_t)b_begin * (size_t)n, d_y1 + (size_t)b_begin * (size_t)n, n, 0,
+                                          b_count, 1, d_Q + 4 * (size_t)b_begin, 1);
+    if (rc) return rc;
+  }
+  for (int q0 = 0; q0 < b_count && !use_gemm; q0 += 65535) {      // bodies ride in gridDim.y
     const int nb = b_count - q0 < 65535 ? b_count - q0 : 65535;
     const dim3 grid((unsigned)((n + BFG - 1) / BFG), nb);
     const size_t lds = sizeof(double) * ((size_t)n + 2 * 64 * BFW);

@@ -976,7 +976,7 @@ __global__ __launch_bounds__(BSS_T) void k_block_solve_small(const double *__res
                                                              const double *__restrict__ Q, int rot)
 {
   // Q, rot: body-frame factor shared by all bodies (strideA = strideL = 0): rot & 1 rotates the input into the body frame
-  // (v_k <- R_b^T v_k per blob), rot & 2 the result back (x_k <- R_b x_k) -- see bf_build in rbl_api.hip
+  // (v_k <- R_b^T v_k per blob), rot & 2 the result back (x_k <- R_b x_k) -- see bf_build in rbl_bodies.hip
   extern __shared__ double y[];                      // NV x n doubles + NV x IB scratch
   double *tbuf = y + (size_t)NV * n;                 // tbuf[v * IB + m]
   const int b = blockIdx.x, t = threadIdx.x;
@@ -1259,7 +1259,7 @@ constexpr int BIA_W = 4;      // waves per workgroup of k_block_inv_apply: BIA_R
 constexpr int BIA_RQ = 63;    // outputs per workgroup of the rotated forms: 21 whole blobs (the output rotation needs whole blobs)
 
 // mstride: doubles between the matrices of consecutive bodies (2 n^2; 0 = ONE body-frame matrix shared by all bodies, see
-// the body-frame factors in rbl_api.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
+// the body-frame factors in rbl_bodies.hip).  rot & 1: the input is rotated into the body frame first (v_k <- R_b^T v_k per
 // blob), rot & 2: the output is rotated back (x_k <- R_b x_k); Q: quaternions of the bodies (4 per body, relative to b = 0).
 // TM: storage type of the matrix (double; float = the single-precision copy of the explicit inverses of large bodies:
 // half the bytes, converted on load, sums in fp64).  The row blocks with the longest sums are dealt first (revx).
@@ -1543,12 +1543,145 @@ static int block_inv_apply_t(hipStream_t st, const TM *d_X, int64_t n, int batch
   return RBL_OK;
 }
 
+// ---------------------------------------------------------------------------
+// ONE matrix, many vectors (round 4): in free space every body's factor / inverse is the SAME body-frame matrix seen through
+// the body's rotation, so applying it to the N_bod x nv vectors of a sweep is a matrix-MATRIX product  Y = Op [x_1 .. x_C]  with
+// C = N_bod nv columns -- 2 n^2 C flops, the matrix read ONCE.  The batched matrix-vector kernel above re-read the 1.9 MB table
+// for every body (98 MB through L2 per application at 50 x 486: 12.8 us at 7.6 TB/s); this kernel is the same operation on the
+// fp64 matrix cores: workgroup = 48 rows (16 whole blobs: the output rotation needs whole blobs) x 16 columns, the rotated
+// input panel staged in LDS once, K split over the four waves (v_mfma_f64_16x16x4, three row tiles per wave), partial tiles
+// added in wave order, rotated back per blob and stored.  Op = A restricted to k <= m (TRI = 1: X = L^-1, column-major),
+// k >= m (TRI = 2: X^T, read from the row-major copy) or full (TRI = 0: the symmetric M_body^-1 table).
+// rot & 1: x <- R_b^T x per blob before, rot & 2: y <- R_b y after.  Column c = b nv + v reads in + v rhs_pitch + b vec_stride.
+// ---------------------------------------------------------------------------
+constexpr int SG_M = 48, SG_N = 16;
+
+template <int TRI>
+__global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ A, long n, long lda, const double *in, double *out,
+                                                     long vec_stride, long rhs_pitch, int ncol, int nv,
+                                                     const double *__restrict__ Q, int rot)
+{
+  extern __shared__ double sg[];                     // rotated inputs sB[k][16], k < kpad; afterwards red[4][48][16]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const long m0 = (long)blockIdx.x * SG_M;
+  const int c0 = (int)blockIdx.y * SG_N;
+  // rows of the input this row tile multiplies: [klo, khi), widened to whole blobs and to multiples of 4
+  long klo = (TRI == 2) ? m0 : 0, khi = (TRI == 1) ? ((m0 + SG_M < n) ? m0 + SG_M : n) : n;
+  klo = (klo / 12) * 12;
+  const long kpad = ((khi - klo + 3) / 4) * 4;
+  const int col = t & 15;                            // this thread's column while staging and while storing
+  const int c = c0 + col;
+  const bool live = c < ncol;
+  const int b = live ? c / nv : 0, v = live ? c - b * nv : 0;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (rot && live) quat_rot_d(Q + 4 * (size_t)b, R);
+  const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+  for (long q = klo / 3 + (t >> 4); 3 * q < klo + kpad; q += 16) {       // blob q of column `col`
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (live && 3 * q + 2 < n) { a0 = vin[3 * q]; a1 = vin[3 * q + 1]; a2 = vin[3 * q + 2]; }
+    double d0 = a0, d1 = a1, d2 = a2;
+    if (rot & 1) {                                   // R^T a
+      d0 = R[0] * a0 + R[3] * a1 + R[6] * a2;
+      d1 = R[1] * a0 + R[4] * a1 + R[7] * a2;
+      d2 = R[2] * a0 + R[5] * a1 + R[8] * a2;
+    }
+    const long r0 = 3 * q - klo;
+    if (r0 < kpad) sg[r0 * SG_N + col] = d0;
+    if (r0 + 1 < kpad) sg[(r0 + 1) * SG_N + col] = d1;
+    if (r0 + 2 < kpad) sg[(r0 + 2) * SG_N + col] = d2;
+  }
+  __syncthreads();
+  double4_t acc[3];
+#pragma unroll
+  for (int ti = 0; ti < 3; ++ti) acc[ti] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const long nks = kpad / 4;
+  constexpr int UK = 4;                              // k steps in flight per wave: 12 loads before the first MFMA
+  for (long s0 = w; s0 < nks; s0 += 4 * UK) {
+    double a[UK][3], bb[UK];
+#pragma unroll
+    for (int u = 0; u < UK; ++u) {
+      const long ks = s0 + 4 * u;
+      const long k = klo + 4 * ks + l4;              // this lane's row of the input = column of Op
+      const bool kin = ks < nks && k < n;
+#pragma unroll
+      for (int ti = 0; ti < 3; ++ti) {
+        const long m = m0 + 16 * ti + l15;
+        const bool ok = kin && m < n && (TRI == 0 || (TRI == 1 ? k <= m : k >= m));
+        const double x = A[(size_t)(kin ? k : 0) * (size_t)lda + (m < n ? m : 0)];   // unconditional (clamped) load, masked after
+        a[u][ti] = ok ? x : 0.0;
+      }
+      bb[u] = ks < nks ? sg[(4 * ks + l4) * SG_N + l15] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UK; ++u)
+#pragma unroll
+      for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], bb[u], acc[ti], 0, 0, 0);
+  }
+  __syncthreads();                                   // the input panel is dead: its LDS holds the four partial tiles now
+  double *red = sg;                                  // red[w][row][col]
+#pragma unroll
+  for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) red[((size_t)w * SG_M + 16 * ti + l4 + 4 * vv) * SG_N + l15] = acc[ti][vv];   // D: row = l4 + 4 v, col = l15
+  __syncthreads();
+  const int q = t >> 4;                              // blob q of the tile (rows 3 q .. 3 q + 2), column `col`
+  if (live && m0 + 3 * q + 2 < n) {
+    double y[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double sum = red[(size_t)(3 * q + d) * SG_N + col];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) sum += red[((size_t)ww * SG_M + 3 * q + d) * SG_N + col];
+      y[d] = sum;
+    }
+    double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride + m0 + 3 * q;
+    if (rot & 2) {                                   // R y
+      o[0] = R[0] * y[0] + R[1] * y[1] + R[2] * y[2];
+      o[1] = R[3] * y[0] + R[4] * y[1] + R[5] * y[2];
+      o[2] = R[6] * y[0] + R[7] * y[1] + R[8] * y[2];
+    } else { o[0] = y[0]; o[1] = y[1]; o[2] = y[2]; }
+  }
+}
+
+// tri: 0 full, 1 lower (k <= m), 2 upper (k >= m).  n a multiple of 3, n <= 512 (the input panel of a row tile in 64 KB of LDS)
+bool rbl_shared_gemm_fits(int64_t n) { return n % 3 == 0 && n >= 48 && (size_t)(((n + 3) / 4) * 4) * SG_N * sizeof(double) <= 65536; }
+
+int rbl_launch_shared_gemm(hipStream_t st, const double *d_A, int64_t n, int64_t lda, int tri, const double *d_in, double *d_out,
+                           int64_t vec_stride, int64_t rhs_pitch, int nbod, int nv, const double *d_Q, int rot)
+{
+  if (!rbl_shared_gemm_fits(n) || d_in == d_out) return RBL_ERR_ARG;
+  const int ncol = nbod * nv;
+  if (ncol <= 0) return RBL_OK;
+  const dim3 grid((unsigned)((n + SG_M - 1) / SG_M), (unsigned)((ncol + SG_N - 1) / SG_N));
+  size_t lds = (size_t)(((n + 3) / 4) * 4 + 12) * SG_N * sizeof(double);
+  const size_t red = (size_t)4 * SG_M * SG_N * sizeof(double);
+  if (lds < red) lds = red;
+  if (lds > 65536) lds = 65536;
+  if (tri == 1) hipLaunchKernelGGL(k_shared_gemm<1>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  else if (tri == 2) hipLaunchKernelGGL(k_shared_gemm<2>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  else hipLaunchKernelGGL(k_shared_gemm<0>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  return RBL_OK;
+}
+
 int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int batch, const double *d_in, double *d_out,
                                int64_t vec_stride, int nv, int64_t rhs_pitch, int mode, double *d_tmp, const double *d_Q, int f32)
 {
   if (sizeof(double) * ((size_t)n + 64 * BIA_W) > 65536) return RBL_ERR_SIZE;      // one vector + partial sums in LDS
   if (mode == 0 && !d_tmp) return RBL_ERR_ARG;
   if (mode != 0 && d_in == d_out) return RBL_ERR_ARG;
+  const bool no_gemm = (f32 & 2) != 0;               // RBL_OPT_SHARED_GEMM = 0: the batched matrix-vector form
+  f32 &= 1;
+  if (d_Q && !f32 && !no_gemm && rbl_shared_gemm_fits(n) && vec_stride == n) {
+    // ONE body-frame matrix for every body (free space): the sweep is a matrix-matrix product on the fp64 matrix cores
+    const int64_t ldx = rbl_block_inverse_ld(n);
+    const double *XL = d_X, *XU = d_X + (size_t)(ldx * n);
+    if (mode == 0) {
+      int rc = rbl_launch_shared_gemm(st, XL, n, ldx, 1, d_in, d_tmp, vec_stride, rhs_pitch, batch, nv, d_Q, 1);
+      return rc ? rc : rbl_launch_shared_gemm(st, XU, n, ldx, 2, d_tmp, d_out, vec_stride, rhs_pitch, batch, nv, d_Q, 2);
+    }
+    return mode == 1 ? rbl_launch_shared_gemm(st, XL, n, ldx, 1, d_in, d_out, vec_stride, rhs_pitch, batch, nv, d_Q, 1)
+                     : rbl_launch_shared_gemm(st, XU, n, ldx, 2, d_in, d_out, vec_stride, rhs_pitch, batch, nv, d_Q, 2);
+  }
   if (f32) return block_inv_apply_t<float>(st, (const float *)d_X, n, batch, d_in, d_out, vec_stride, nv, rhs_pitch, mode, d_tmp, d_Q);
   return block_inv_apply_t<double>(st, d_X, n, batch, d_in, d_out, vec_stride, nv, rhs_pitch, mode, d_tmp, d_Q);
 }

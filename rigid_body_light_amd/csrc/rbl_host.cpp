@@ -199,7 +199,7 @@ int rbl_chol6(double *A)
 // invM * v for the cached preconditioner mobility inverse
 static void apply_invM(const RblBodyState &S, const double *v, double *out)
 {
-  // diagonal preconditioner only: the block-diagonal one lives on the GPU (rbl_api.hip)
+  // diagonal preconditioner only: the block-diagonal one lives on the GPU (rbl_bodies.hip)
   const int nb = S.N_bod, nl = S.N_blb;
   for (size_t i = 0; i < (size_t)nb * nl; ++i) {
     const double *B = &S.invM_diag[9 * i];
@@ -210,7 +210,7 @@ static void apply_invM(const RblBodyState &S, const double *v, double *out)
   }
 }
 
-// apply_PC, c_rigid_obj.cpp:589-616, diagonal PC.  The caller (rbl_api) fills invM_diag
+// apply_PC, c_rigid_obj.cpp:589-616, diagonal PC.  The caller (rbl_bodies.hip) fills invM_diag
 // beforehand when !pc_set (diag_invM :489-543).
 int rbl_body_apply_PC(RblBodyState &S, const double *in, double *out, std::string &err)
 {

@@ -99,7 +99,7 @@ struct rbl_ctx {
                                                     // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- rbl_set_tuning 63 / 64 / 65
   bool blk_f32 = false, blk_f32_valid = false;      // rbl_set_tuning 83 / 84: apply them from a single-precision copy (half the bytes)
   bool bf_tables = false;                           // d_bfPC holds the body-frame preconditioner tables (small bodies)
-  // two-level factor of the preconditioned Lanczos root (rbl_api.hip: tl_build): G = L (I + Q (L_E - I) Q^T)
+  // two-level factor of the preconditioned Lanczos root (rbl_roots.hip: tl_build): G = L (I + Q (L_E - I) Q^T)
   RblDevBuf d_tlQ, d_tlCb, d_tlCs, d_tlA, d_tlLinv, d_tlX, d_tlT, d_tlZ;
   bool tl_on = true, tl_valid = false, tl_ok = false;   // rbl_set_tuning 87 / 88; built for the current configuration; usable (SPD)
   unsigned *d_err2 = nullptr;                       // error word of the two-level build: a failure there is not an error, only "not usable"
@@ -112,6 +112,7 @@ struct rbl_ctx {
   bool bf_wall_approx = false;                                   // rbl_set_tuning 73 / 74 (experiment)
   RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
   bool ktl_arm = false; const double *ktl_of = nullptr;   // armed by the GMRES loop only; ktl_of = the vector d_ktl belongs to
+  bool shared_gemm = true;                          // RBL_OPT_SHARED_GEMM: the ONE body-frame matrix of free space applied to all bodies' vectors as a matrix-matrix product (MFMA)
   bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
@@ -250,6 +251,10 @@ int rbl_launch_block_trmv(hipStream_t st, const double *d_L, int64_t n, int batc
 // explicit per-body inverses for small bodies (3 N_blb <= 512): substitution sweeps become triangular matrix-vector products
 bool rbl_block_inverse_fits(int64_t n);
 bool rbl_block_inverse_large_fits(int64_t n);
+// one matrix shared by all bodies applied to N_bod x nv vectors as a matrix-matrix product on the fp64 matrix cores
+bool rbl_shared_gemm_fits(int64_t n);
+int rbl_launch_shared_gemm(hipStream_t st, const double *d_A, int64_t n, int64_t lda, int tri, const double *d_in, double *d_out,
+                           int64_t vec_stride, int64_t rhs_pitch, int nbod, int nv, const double *d_Q, int rot);
 size_t rbl_block_inverse_bytes(int64_t n, int batch);
 int64_t rbl_block_inverse_ld(int64_t n);
 int rbl_launch_block_inverse(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
@@ -321,7 +326,7 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
                           double *d_NL, unsigned *d_err);
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl, double *d_y1);
+                            double *d_out, double *d_ktl, double *d_y1, int gemm);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 // two-level factor of the preconditioned Lanczos root (rbl_body_dev.hip: k_tl_*)
 void rbl_launch_tl_unit(hipStream_t st, int64_t n3, double *d_out);

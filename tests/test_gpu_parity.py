@@ -1354,7 +1354,7 @@ def test_restart_from_get_config_reproduces_the_trajectory_bitwise(shell12, gene
 
 def test_gmres_convergence_tests_follow_the_previous_solve():
     """launch-bound systems: the first convergence test of a solve waits until two iterations before the previous solve's
-    count, later ones follow the residual's rate (rbl_api.hip: gmres_saddle_core_) -- WHEN the tests happen must not change
+    count, later ones follow the residual's rate (rbl_solvers.hip: gmres_saddle_core_) -- WHEN the tests happen must not change
     the answer: repeated solves return the count and the solution of the first (which had no history), an easier system
     after a harder one still stops at its own first passing iteration, and a harder one after an easy one runs on"""
     import torch
@@ -1707,7 +1707,7 @@ def test_M_half_W_preconditioned_lanczos_vs_dense(orc, shell12, wall):
         G = (B[:, None] * Lf) @ Sh                                    # the square root this method realises
         assert np.linalg.norm(G @ G.T - (B[:, None] * M) * B[None, :]) < 1e-10 * np.linalg.norm(M)
 
-    # default: the TWO-LEVEL factor L (I + Q (L_E - I) Q^T) (csrc/rbl_api.hip tl_build), restated in numpy: Z = L^-1 K_t,
+    # default: the TWO-LEVEL factor L (I + Q (L_E - I) Q^T) (csrc/rbl_roots.hip tl_build), restated in numpy: Z = L^-1 K_t,
     # R_b = Z_b^T Z_b = C_b C_b^T, Q_b = Z_b C_b^-T, E = blockdiag(C_b^T) C blockdiag(C_b) with C the pair tensor of spheres
     # of the bodies' outer radius at the body centres (off-diagonal blocks; the wall term when no sphere reaches the wall)
     c0 = np.asarray(shell12, dtype=np.float64) - np.asarray(shell12, dtype=np.float64).mean(axis=0)

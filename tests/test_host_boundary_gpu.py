@@ -128,3 +128,52 @@ def test_overlapped_convergence_test_changes_nothing_but_the_schedule(wall):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and 3 < out[1][0] < 60
     assert torch.equal(out[0][2], out[1][2])
     assert out[1][3] < 2e-9
+
+
+@pytest.mark.parametrize("nb,nblb", [(50, 162), (7, 162), (23, 42)])
+def test_shared_matrix_product_on_the_matrix_cores_equals_the_batched_form(nb, nblb):
+    """Free space: ONE body-frame inverse / preconditioner table serves every body, so a sweep over all bodies is a matrix-matrix
+    product (k_shared_gemm on the fp64 MFMA, RBL_OPT_SHARED_GEMM = 1, default) instead of a matrix-vector product per body that
+    re-reads the table (= 0).  Every user of it -- the three factor operations, the block preconditioner, the preconditioned
+    Lanczos root (two vectors in lock step), a GMRES solve -- must give the same answer either way (column groups of 16 that end
+    inside a body, a last row tile of 6 rows at 162 blobs, 42-blob bodies)."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    c = make_config(nb, nblb, False)
+    N = nb * nblb; n3 = 3 * N; nsys = n3 + 6 * nb
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    v = torch.from_numpy(rng.standard_normal(n3)).to(dev)
+    xs = torch.from_numpy(rng.standard_normal(nsys)).to(dev)
+    W = torch.from_numpy(rng.standard_normal(n3)).to(dev)
+    res = {}
+    for gemm in (0, 1):
+        ctx = DeviceContext(c["a"], c["eta"], False, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_option("shared_gemm", gemm)
+        out = []
+        for mode in (0, 1, 2):
+            o = torch.empty_like(v)
+            ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
+            out.append(o)
+        o = torch.empty_like(xs)
+        ctx.apply_PC(xs.data_ptr(), o.data_ptr()); ctx.sync_check()
+        out.append(o)
+        r = torch.empty(n3, dtype=torch.float64, device=dev)
+        ctx.blob_positions(0, nb, r.data_ptr())
+        ctx.set_lanczos(100, 1e-10)
+        o = torch.empty_like(W)
+        ctx.M_half_W(r.data_ptr(), N, W.data_ptr(), "lanczos_pc", o.data_ptr()); ctx.sync_check()
+        out.append(o)
+        sol = torch.empty_like(xs)
+        m, rr = ctx.gmres_saddle(xs.data_ptr(), 100, 1e-10, sol.data_ptr()); ctx.sync_check()
+        out.append(sol)
+        res[gemm] = (out, m)
+        ctx.close()
+    names = ("(G G^T)^-1 v", "G^-1 v", "G^-T v", "apply_PC", "M_half_W lanczos_pc", "gmres solution")
+    for name, a, b in zip(names, res[0][0], res[1][0]):
+        err = float(torch.linalg.norm(a - b) / torch.linalg.norm(a))
+        assert err < (1e-9 if name in ("M_half_W lanczos_pc", "gmres solution") else 1e-12), (name, err)
+    assert abs(res[0][1] - res[1][1]) <= 1
