@@ -1549,19 +1549,20 @@ static int block_inv_apply_t(hipStream_t st, const TM *d_X, int64_t n, int batch
 // C = N_bod nv columns -- 2 n^2 C flops, the matrix read ONCE.  The batched matrix-vector kernel above re-read the 1.9 MB table
 // for every body (98 MB through L2 per application at 50 x 486: 12.8 us at 7.6 TB/s); this kernel is the same operation on the
 // fp64 matrix cores: workgroup = 48 rows (16 whole blobs: the output rotation needs whole blobs) x 16 columns, the rotated
-// input panel staged in LDS once, K split over the four waves (v_mfma_f64_16x16x4, three row tiles per wave), partial tiles
+// input panel staged in LDS once, K split over eight waves (v_mfma_f64_16x16x4, three row tiles per wave, every operand load
+// in flight before the first wait), partial tiles
 // added in wave order, rotated back per blob and stored.  Op = A restricted to k <= m (TRI = 1: X = L^-1, column-major),
 // k >= m (TRI = 2: X^T, read from the row-major copy) or full (TRI = 0: the symmetric M_body^-1 table).
 // rot & 1: x <- R_b^T x per blob before, rot & 2: y <- R_b y after.  Column c = b nv + v reads in + v rhs_pitch + b vec_stride.
 // ---------------------------------------------------------------------------
-constexpr int SG_M = 48, SG_N = 16;
+constexpr int SG_M = 48, SG_N = 16, SG_W = 8, SG_KW = 16;     // 8 waves per workgroup, <= 16 k steps (64 rows of the input) per wave
 
 template <int TRI>
-__global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ A, long n, long lda, const double *in, double *out,
-                                                     long vec_stride, long rhs_pitch, int ncol, int nv,
-                                                     const double *__restrict__ Q, int rot)
+__global__ __launch_bounds__(64 * SG_W) void k_shared_gemm(const double *__restrict__ A, long n, long lda, const double *in, double *out,
+                                                          long vec_stride, long rhs_pitch, int ncol, int nv,
+                                                          const double *__restrict__ Q, int rot)
 {
-  extern __shared__ double sg[];                     // rotated inputs sB[k][16], k < kpad; afterwards red[4][48][16]
+  extern __shared__ double sg[];                     // rotated inputs sB[k][16], k < kpad; afterwards red[SG_W][48][16]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l15 = lane & 15, l4 = lane >> 4;
   const long m0 = (long)blockIdx.x * SG_M;
   const int c0 = (int)blockIdx.y * SG_N;
@@ -1569,6 +1570,24 @@ __global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ 
   long klo = (TRI == 2) ? m0 : 0, khi = (TRI == 1) ? ((m0 + SG_M < n) ? m0 + SG_M : n) : n;
   klo = (klo / 12) * 12;
   const long kpad = ((khi - klo + 3) / 4) * 4;
+  const long nks = kpad / 4;                         // k steps of the tile, dealt to the waves round-robin: wave w takes w, w + 8, ...
+  // A operands first: EVERY load of this wave is in flight before anything waits (the whole kernel is two memory round trips:
+  // these and the input panel below; a loop of load -> MFMA batches was one round trip per batch and no faster than the
+  // matrix-vector form it replaces)
+  double a[SG_KW][3];
+#pragma unroll
+  for (int u = 0; u < SG_KW; ++u) {
+    const long ks = w + (long)SG_W * u;
+    const long k = klo + 4 * ks + l4;                // this lane's row of the input = column of Op
+    const bool kin = ks < nks && k < n;
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+      const long m = m0 + 16 * ti + l15;
+      const bool ok = kin && m < n && (TRI == 0 || (TRI == 1 ? k <= m : k >= m));
+      const double x = A[(size_t)(kin ? k : 0) * (size_t)lda + (m < n ? m : 0)];     // unconditional (clamped) load, masked after
+      a[u][ti] = ok ? x : 0.0;
+    }
+  }
   const int col = t & 15;                            // this thread's column while staging and while storing
   const int c = c0 + col;
   const bool live = c < ncol;
@@ -1576,7 +1595,7 @@ __global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ 
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (rot && live) quat_rot_d(Q + 4 * (size_t)b, R);
   const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
-  for (long q = klo / 3 + (t >> 4); 3 * q < klo + kpad; q += 16) {       // blob q of column `col`
+  for (long q = klo / 3 + (t >> 4); 3 * q < klo + kpad; q += 4 * SG_W) {   // blob q of column `col`
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (live && 3 * q + 2 < n) { a0 = vin[3 * q]; a1 = vin[3 * q + 1]; a2 = vin[3 * q + 2]; }
     double d0 = a0, d1 = a1, d2 = a2;
@@ -1594,30 +1613,14 @@ __global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ 
   double4_t acc[3];
 #pragma unroll
   for (int ti = 0; ti < 3; ++ti) acc[ti] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const long nks = kpad / 4;
-  constexpr int UK = 4;                              // k steps in flight per wave: 12 loads before the first MFMA
-  for (long s0 = w; s0 < nks; s0 += 4 * UK) {
-    double a[UK][3], bb[UK];
 #pragma unroll
-    for (int u = 0; u < UK; ++u) {
-      const long ks = s0 + 4 * u;
-      const long k = klo + 4 * ks + l4;              // this lane's row of the input = column of Op
-      const bool kin = ks < nks && k < n;
+  for (int u = 0; u < SG_KW; ++u) {
+    const long ks = w + (long)SG_W * u;
+    const double bb = ks < nks ? sg[(4 * ks + l4) * SG_N + l15] : 0.0;
 #pragma unroll
-      for (int ti = 0; ti < 3; ++ti) {
-        const long m = m0 + 16 * ti + l15;
-        const bool ok = kin && m < n && (TRI == 0 || (TRI == 1 ? k <= m : k >= m));
-        const double x = A[(size_t)(kin ? k : 0) * (size_t)lda + (m < n ? m : 0)];   // unconditional (clamped) load, masked after
-        a[u][ti] = ok ? x : 0.0;
-      }
-      bb[u] = ks < nks ? sg[(4 * ks + l4) * SG_N + l15] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < UK; ++u)
-#pragma unroll
-      for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], bb[u], acc[ti], 0, 0, 0);
+    for (int ti = 0; ti < 3; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], bb, acc[ti], 0, 0, 0);
   }
-  __syncthreads();                                   // the input panel is dead: its LDS holds the four partial tiles now
+  __syncthreads();                                   // the input panel is dead: its LDS holds the partial tiles now
   double *red = sg;                                  // red[w][row][col]
 #pragma unroll
   for (int ti = 0; ti < 3; ++ti)
@@ -1625,13 +1628,13 @@ __global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ 
     for (int vv = 0; vv < 4; ++vv) red[((size_t)w * SG_M + 16 * ti + l4 + 4 * vv) * SG_N + l15] = acc[ti][vv];   // D: row = l4 + 4 v, col = l15
   __syncthreads();
   const int q = t >> 4;                              // blob q of the tile (rows 3 q .. 3 q + 2), column `col`
-  if (live && m0 + 3 * q + 2 < n) {
+  if (q < SG_M / 3 && live && m0 + 3 * q + 2 < n) {
     double y[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       double sum = red[(size_t)(3 * q + d) * SG_N + col];
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) sum += red[((size_t)ww * SG_M + 3 * q + d) * SG_N + col];
+      for (int ww = 1; ww < SG_W; ++ww) sum += red[((size_t)ww * SG_M + 3 * q + d) * SG_N + col];   // waves in fixed order
       y[d] = sum;
     }
     double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride + m0 + 3 * q;
@@ -1644,7 +1647,7 @@ __global__ __launch_bounds__(256) void k_shared_gemm(const double *__restrict__ 
 }
 
 // tri: 0 full, 1 lower (k <= m), 2 upper (k >= m).  n a multiple of 3, n <= 512 (the input panel of a row tile in 64 KB of LDS)
-bool rbl_shared_gemm_fits(int64_t n) { return n % 3 == 0 && n >= 48 && (size_t)(((n + 3) / 4) * 4) * SG_N * sizeof(double) <= 65536; }
+bool rbl_shared_gemm_fits(int64_t n) { return n % 3 == 0 && n >= 48 && (n + 3) / 4 <= (int64_t)SG_W * SG_KW && (size_t)(((n + 3) / 4) * 4) * SG_N * sizeof(double) <= 65536; }
 
 int rbl_launch_shared_gemm(hipStream_t st, const double *d_A, int64_t n, int64_t lda, int tri, const double *d_in, double *d_out,
                            int64_t vec_stride, int64_t rhs_pitch, int nbod, int nv, const double *d_Q, int rot)
@@ -1654,12 +1657,12 @@ int rbl_launch_shared_gemm(hipStream_t st, const double *d_A, int64_t n, int64_t
   if (ncol <= 0) return RBL_OK;
   const dim3 grid((unsigned)((n + SG_M - 1) / SG_M), (unsigned)((ncol + SG_N - 1) / SG_N));
   size_t lds = (size_t)(((n + 3) / 4) * 4 + 12) * SG_N * sizeof(double);
-  const size_t red = (size_t)4 * SG_M * SG_N * sizeof(double);
+  const size_t red = (size_t)SG_W * SG_M * SG_N * sizeof(double);
   if (lds < red) lds = red;
   if (lds > 65536) lds = 65536;
-  if (tri == 1) hipLaunchKernelGGL(k_shared_gemm<1>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
-  else if (tri == 2) hipLaunchKernelGGL(k_shared_gemm<2>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
-  else hipLaunchKernelGGL(k_shared_gemm<0>, grid, dim3(256), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  if (tri == 1) hipLaunchKernelGGL(k_shared_gemm<1>, grid, dim3(64 * SG_W), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  else if (tri == 2) hipLaunchKernelGGL(k_shared_gemm<2>, grid, dim3(64 * SG_W), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
+  else hipLaunchKernelGGL(k_shared_gemm<0>, grid, dim3(64 * SG_W), lds, st, d_A, (long)n, (long)lda, d_in, d_out, (long)vec_stride, (long)rhs_pitch, ncol, nv, d_Q, rot);
   return RBL_OK;
 }
 
