@@ -712,7 +712,9 @@ int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *
   if (b_count <= 0) return RBL_OK;
   // y1' = M_body^-1 R^T slip for every body: ONE table, many vectors -- a matrix-matrix product on the fp64 matrix cores
   // (rbl_launch_shared_gemm; round 4) or, RBL_OPT_SHARED_GEMM = 0, a matrix-vector product per body that re-reads the table
-  const bool use_gemm = gemm && rbl_shared_gemm_fits(n) && b_count <= 65535;
+  // (measured, tools/bench_shared_gemm.py: 14.9 -> 16.0 us at 50 bodies of 162 blobs, 28.7 -> 16.1 at 200: the full table is twice the
+  // triangular factor's work per row tile, so the product only pays once there are enough columns to share it)
+  const bool use_gemm = gemm && rbl_shared_gemm_fits(n) && b_count >= 64 && b_count <= 65535;
   if (use_gemm) {
     const int rc = rbl_launch_shared_gemm(st, d_Minv, n, n, 0, d_in + (size_t)b_begin * (size_t)n, d_y1 + (size_t)b_begin * (size_t)n, n, 0,
                                           b_count, 1, d_Q + 4 * (size_t)b_begin, 1);

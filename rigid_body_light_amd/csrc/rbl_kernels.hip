@@ -1673,6 +1673,11 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
+  // four-wave workgroups draw their units from a work queue (large systems): balance no longer needs thousands of short units,
+  // and a shard's row sums are written once per chunk -- at 8 ranks the rule above gave 3-tile chunks (669 row-sum slabs per owned
+  // row against 126 on one GPU); 8-tile chunks: 2.64 ms per rank instead of 2.74 (tools/bench_shard_kernel.py, CHUNK = 3 .. 16)
+  // (only while 8-tile chunks still leave >= 4 units per resident workgroup slot: mid-size systems keep their short chunks)
+  if (sw > 1 && i_step > 1 && c < 8 && ((long)(rowsI / sw) * (long)((t + 7) / 8)) / 2 >= 4L * 3 * (n_cu > 0 ? n_cu : 256)) c = 8;
   if (tune.chunk > 0) c = tune.chunk;
   L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
   L.SW = sw;
