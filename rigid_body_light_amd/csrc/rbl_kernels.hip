@@ -1673,11 +1673,15 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   int c = (int)(pairs / target_units);
   if (c < 1) c = 1;
   if (c > 16) c = 16;
-  // four-wave workgroups draw their units from a work queue (large systems): balance no longer needs thousands of short units,
-  // and a shard's row sums are written once per chunk -- at 8 ranks the rule above gave 3-tile chunks (669 row-sum slabs per owned
-  // row against 126 on one GPU); 8-tile chunks: 2.64 ms per rank instead of 2.74 (tools/bench_shard_kernel.py, CHUNK = 3 .. 16)
-  // (only while 8-tile chunks still leave >= 4 units per resident workgroup slot: mid-size systems keep their short chunks)
-  if (sw > 1 && i_step > 1 && c < 8 && ((long)(rowsI / sw) * (long)((t + 7) / 8)) / 2 >= 4L * 3 * (n_cu > 0 ? n_cu : 256)) c = 8;
+  // Shards of large systems (four-wave workgroups drawing their units from the work queue: balance no longer needs thousands of
+  // short units, and a shard's row sums are written once per chunk).  Measured per rank at cfg 3, tools/bench_shard_kernel.py with
+  // CHUNK forced, two runs each on one box: 8 ranks (the rule above gives 3): C = 3 / 6 / 8 / 12 / 16 -> 2.75 / 2.74 / 2.64 / 2.70 /
+  // 2.67 ms; 4 ranks (rule: 7): 7 / 8 / 16 -> 5.15 / 5.32 / 5.26; 2 ranks (rule: 15): 8 / 15 / 16 -> 10.25 / 10.53 / 10.68.  So: at
+  // most 8 tiles per chunk, and 8 instead of anything below 7 while that still leaves >= 4 units per resident workgroup slot.
+  if (sw > 1 && i_step > 1) {
+    if (c > 8) c = 8;
+    else if (c < 7 && ((long)(rowsI / sw) * (long)((t + 7) / 8)) / 2 >= 4L * 3 * (n_cu > 0 ? n_cu : 256)) c = 8;
+  }
   if (tune.chunk > 0) c = tune.chunk;
   L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
   L.SW = sw;

@@ -5,7 +5,7 @@ measured on ONE GPU (no 8-GPU node is available to the builder; the driver measu
   2. rank by rank (r = 0 .. P-1), the pieces a rank executes: its share of the tile pairs of a one- and of a two-vector
      product (rbl_apply_M_sym[_multi]_dev(r, P)), the applications of ITS 25 bodies' factors / inverses, their build;
   3. budget = counts of the real step x the slowest rank's piece + the replicated part, before collectives.
-usage: bench_step_budget_p8.py [P] [tuning switches ...]   (e.g. 8 64 84)"""
+usage: bench_step_budget_p8.py [P] [old tuning codes ...]   (e.g. 8 64 84: through the rbl_set_tuning shim)"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from rigid_body_light_amd import make_config
@@ -74,6 +74,9 @@ x2 = torch.randn(2 * n3, dtype=torch.float64, device=dev)
 o2 = torch.empty_like(x2)
 v = torch.randn(n3, dtype=torch.float64, device=dev); o = torch.empty_like(v)
 base, rem = divmod(nb, P)
+ctx.set_option("block_explicit_large", 1)
+ctx.block_solve(v.data_ptr(), o.data_ptr(), 0, 0, base + (1 if rem else 0))        # first build: also sizes the factor / inverse storage (12 GB of hipMalloc)
+ctx.sync_check()
 rows = []
 for rk in range(P):
     b0 = rk * base + min(rk, rem); b1 = b0 + base + (1 if rk < rem else 0)
