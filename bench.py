@@ -760,6 +760,8 @@ def dropin_block(dev):
         x = np.random.default_rng(11).standard_normal(nsys)
         rb.apply_saddle(x); rb.apply_PC(x)                     # builds the preconditioner, sizes the workspaces
         reps = 200 if name == "cfg1" else 20 if name == "cfg2" else 5
+        for _ in range(reps):                                    # untimed: the first small calls after cfg 5's 189 GB were freed run ~6x slow
+            rb.apply_saddle(x)
         t0 = time.perf_counter()
         for _ in range(reps):
             rb.apply_saddle(x)
