@@ -25,6 +25,16 @@ print("M^(1/2) W :", np.linalg.norm(cb.M_half_W(seed=7)))    # Brownian incremen
 print("M_RFD     :", np.linalg.norm(cb.M_RFD(seed=8)))       # thermal drift by random finite differences
 cb.evolve_rigid_bodies(np.tile([0, 0, -1.0, 0, 0, 0], 3))
 print("new X     :", cb.get_config()[0])
+# the reference's usage model: an external Krylov solver over apply_saddle / apply_PC (src/Rigid.py:69-80) ...
+import scipy.sparse.linalg as spla
+rhs = np.concatenate([np.zeros(r.size), -np.tile([0, 0, 1.0, 0, 0, 0], 3)])
+A = spla.LinearOperator((rhs.size, rhs.size), matvec=lambda y: cb.apply_saddle(cb.apply_PC(y)), dtype=np.float64)
+y, info = spla.gmres(A, rhs, rtol=1e-8, atol=0.0, restart=60, maxiter=3)
+xs = cb.apply_PC(y)                                          # right preconditioning: x = P^-1 y
+# ... or the library's own solver on the same system (every iteration on the GPU)
+xn, its, res = cb.solve_saddle(rhs, rtol=1e-8)
+print("solve     : SciPy info %d, native %d iterations (%.1e); |x_scipy - x_native| / |x| = %.1e" % (
+    info, its, res, np.linalg.norm(xs - xn) / np.linalg.norm(xn)))
 # beyond the reference's surface: whole time steps inside the library (GMRES on the saddle system + evolve)
 its, res = cb.step_deterministic(np.tile([0, 0, 1.0, 0, 0, 0], 3), rtol=1e-8)
 print("det. step :", its, "GMRES iterations, residual %.1e" % res, "-> z =", cb.get_config()[0][:, 2])

@@ -23,7 +23,7 @@ def _run(script, timeout=600):
 
 def test_quickstart_drop_in_surface():
     out = _run("quickstart.py")
-    for key in ("apply_M", "saddle", "apply_PC", "M^(1/2) W", "M_RFD", "new X", "det. step"):
+    for key in ("apply_M", "saddle", "apply_PC", "M^(1/2) W", "M_RFD", "new X", "solve", "det. step"):
         assert key in out
     assert "nan" not in out.lower()
 

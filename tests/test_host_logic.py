@@ -213,3 +213,32 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert p.returncode != 0
     assert "needs 2 visible GPUs" in (p.stdout + p.stderr)
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def test_bench_line_helpers():
+    """the pieces of bench.py's line that are pure host logic: the top-level `timesteps_per_sec` / `cpu_baseline_timestep` blocks
+    (BASELINE's metric is timesteps/sec + M.F GFLOP/s), the product count of a Brownian step, the --opt parser"""
+    import bench
+    b = {"timesteps_per_sec": 1.6, "gmres_iterations": [17, 17, 18], "lanczos_iterations_last_step": [5]}
+    t = {"deterministic_fixed": {"timesteps_per_sec": 2.4, "gmres_residual_max": 2e-4},
+         "converged": {"timesteps_per_sec": 15.0, "gmres_iterations": [2, 1, 1]},
+         "brownian_converged": {"lanczos_0.001": b}}
+    assert abs(bench.brownian_products(b) - (52.0 / 3 + 2 + 10)) < 1e-12
+    h = bench.headline_timesteps(t)
+    assert h["deterministic_fixed_work"] == 2.4 and h["deterministic_converged"] == 15.0 and h["brownian_converged"] == 1.6
+    assert h["deterministic_fixed_work_residual"] == 2e-4 and "SURVEY" in h["definition"]
+    cb = {"1core": {"seconds_per_step": 500.0, "cores": 1}, "allcores": {"seconds_per_step": 30.0, "cores": 16}}
+    c = bench.cpu_timestep_baseline(t, cb)
+    assert abs(c["1core"]["deterministic_fixed_work"] - 1.0 / (21 * 500.0)) < 1e-18
+    assert abs(c["allcores"]["brownian_converged"] - 1.0 / (bench.brownian_products(b) * 30.0)) < 1e-18
+    assert abs(c["allcores"]["deterministic_converged"] - 1.0 / ((4.0 / 3 + 1) * 30.0)) < 1e-15 and c["kind"] == "port"
+
+    class Ctx:
+        def __init__(self): self.seen = []
+        def set_option(self, k, v): self.seen.append((k, v))
+
+    class Args:
+        opt = ["comm_split=1", " sym_work_queue = 0"]
+    ctx = Ctx()
+    bench.apply_opts(ctx, Args())
+    assert ctx.seen == [("comm_split", 1), ("sym_work_queue", 0)]
