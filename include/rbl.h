@@ -417,7 +417,7 @@ enum {
   RBL_OPT_SYM_CHUNK = 3,           /* [0] column tiles per work unit of the symmetric kernels (0 = heuristic)                         */
   RBL_OPT_SYM_ROWS_PER_LANE = 4,   /* [0] rows per lane of the one-vector symmetric kernel: 0 heuristic, 1, 2 (experiments)            */
   RBL_OPT_SYM2_ROWS_PER_LANE = 5,  /* [0] the same for the two-vector kernel                                                          */
-  RBL_OPT_SYM_WAVES = 6,           /* [0] waves per workgroup of the symmetric kernels (0 = heuristic; experiments)                   */
+  RBL_OPT_SYM_WAVES = 6,           /* [0] waves per workgroup of the symmetric kernels: 0 heuristic, 1 or 4 (other values: heuristic)         */
   RBL_OPT_SYM_WORK_QUEUE = 7,      /* [1] large systems (four-wave workgroups): 1 a fixed set of resident workgroups draws work units
                                       from a counter (an XCD that runs faster takes more), 0 one unit per workgroup in launch order;
                                       the slabs are addressed by unit, so results are bitwise the same either way                   */

@@ -1661,7 +1661,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // workgroups of SW_LARGE waves (= units of SW_LARGE consecutive super-tiles, see sym_row_of) for large systems; a shard
   // keeps them as long as every rank still gets >= 8 units
   int sw = (ni == 2 && tsup >= SW_LARGE * i_step * 8) ? SW_LARGE : 1;
-  if (tune.sw > 0) sw = tune.sw;
+  if (tune.sw == 1 || tune.sw == SW_LARGE) sw = tune.sw;        // (the only workgroup shapes the product build instantiates)
   const int tunits = (tsup + sw - 1) / sw;
   const int rowsI = ((tunits + i_step - 1) / i_step) * sw;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
