@@ -652,12 +652,18 @@ int rbl_apply_saddle_dev(rbl_ctx *c, const double *d_x, double *d_out)
     RblSaddleFuse f;
     f.lever = (const double *)c->d_lever.p; f.U = d_x + n3; f.ktl = (const double *)c->d_ktl.p; f.w = d_out;
     f.N_blb = S.N_blb; f.nb6 = 6 * S.N_bod;
+    const int64_t np = (n3 + 63) / 64 + 1;              // one partial per block of the reduction + the body rows
+    if (c->fuse_dotK > 0 && c->fuse_dotV && c->fuse_dotPart && np <= rbl_gmres_p1_capacity()) {
+      f.dotV = c->fuse_dotV; f.dotStride = (long)(n3 + 6 * S.N_bod); f.dotK = c->fuse_dotK; f.dotNp = (int)np; f.dotPart = c->fuse_dotPart;
+    }
     c->sym_tune.fuse = f;
   }
+  c->fuse_dots_np = 0;
+  const int dots_np = c->sym_tune.fuse.dotK > 0 ? c->sym_tune.fuse.dotNp : 0;
   rc = apply_M_enqueue(c, S.wall, d_x, (const double *)c->d_pos.p, N, 0, N, (double *)c->d_sad.p);
   c->sym_tune.fuse = RblSaddleFuse();
   if (rc) return rc;
-  if (c->fuse_done) { c->fuse_done = false; return RBL_OK; }
+  if (c->fuse_done) { c->fuse_done = false; c->fuse_dots_np = dots_np; return RBL_OK; }
   if (have_ktl) {
     rbl_launch_saddle_tail(c->stream, (const double *)c->d_lever.p, d_x + n3, S.N_blb, N, S.N_bod, d_out,
                            (const double *)c->d_sad.p, (const double *)c->d_ktl.p);

@@ -650,6 +650,46 @@ __global__ void k_tl_addq(const double *__restrict__ Q, long n3, int N_blb, cons
   wo[(size_t)v * wpitch + k] = w[(size_t)v * wpitch + k] + Q[k] * (s[0] - t[0]) + Q[n3 + k] * (s[1] - t[1]) + Q[2 * n3 + k] * (s[2] - t[2]);
 }
 
+// k_tl_addq with the small triangular operator applied in the same launch (one workgroup per body and vector): rows
+// e = 3 b + c of s = Op t, then wo_b = w_b + sum_c Q_c,b (s_e - t_e).   Op (nt x nt, `ld` doubles between columns):
+//   kind 0: s = A t,   A lower triangular, column-major (the Cholesky factor L_E):  s_e = sum_{q <= e} A[q ld + e] t_q
+//   kind 1: s = X t    from the layout whose COLUMN e holds row e of X (second half of an explicit inverse): q <= e
+//   kind 2: s = X^T t  from the layout whose column e holds column e of X (first half):                    q >= e
+__global__ __launch_bounds__(BT) void k_tl_eaddq(const double *__restrict__ Q, long n3, int N_blb, const double *__restrict__ Op, long nt,
+                                                 long ld, int kind, const double *__restrict__ tt, long tpitch, const double *w, double *wo,
+                                                 long wpitch)
+{
+  __shared__ double s[3][BT];
+  const int b = blockIdx.x, v = blockIdx.y, t = threadIdx.x;
+  const double *tv = tt + (size_t)v * tpitch;
+  double f[3] = {0, 0, 0};
+  if (kind == 0) {
+    for (long q = t; q <= 3L * b + 2; q += BT) {
+      const double x = tv[q];
+      const double *a = Op + (size_t)q * ld + 3 * b;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (q <= 3L * b + c) f[c] += a[c] * x;
+    }
+  } else {
+    const long lo = kind == 1 ? 0 : 3L * b, hi = kind == 1 ? 3L * b + 3 : nt;
+    for (long q = lo + t; q < hi; q += BT) {
+      const double x = tv[q];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long e = 3L * b + c;
+        if (kind == 1 ? q <= e : q >= e) f[c] += Op[(size_t)e * ld + q] * x;
+      }
+    }
+  }
+  block_reduce<3>(f, s, t);
+  const double d0 = f[0] - tv[3 * b], d1 = f[1] - tv[3 * b + 1], d2 = f[2] - tv[3 * b + 2];
+  const long o = 3L * b * N_blb, m = 3L * N_blb;
+  const double *wv = w + (size_t)v * wpitch + o;
+  double *wov = wo + (size_t)v * wpitch + o;
+  for (long k = t; k < m; k += BT) wov[k] = wv[k] + Q[o + k] * d0 + Q[n3 + o + k] * d1 + Q[2 * n3 + o + k] * d2;
+}
+
 // K_t: unit translation of every body in direction d -> vector d of out ([3][n3])
 __global__ void k_tl_unit(long n3, double *__restrict__ out)
 {
@@ -800,6 +840,12 @@ void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, 
                       double *d_t, int64_t tpitch)
 {
   hipLaunchKernelGGL(k_tl_qt, dim3(N_bod, nvec), dim3(BT), 0, st, d_Q, (long)n3, N_blb, d_w, (long)wpitch, d_t, (long)tpitch);
+}
+void rbl_launch_tl_eaddq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_Op, int64_t nt, int64_t ld,
+                         int kind, const double *d_t, int64_t tpitch, const double *d_w, double *d_wo, int64_t wpitch, int nvec)
+{
+  hipLaunchKernelGGL(k_tl_eaddq, dim3(N_bod, nvec), dim3(BT), 0, st, d_Q, (long)n3, N_blb, d_Op, (long)nt, (long)ld, kind, d_t, (long)tpitch,
+                     d_w, d_wo, (long)wpitch);
 }
 void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
                         const double *d_w, double *d_wo, int64_t wpitch, int nvec)

@@ -63,6 +63,12 @@ struct RblSaddleFuse {
   const double *ktl = nullptr;     // 6 N_bod
   double *w = nullptr;             // 3 N + 6 N_bod
   int N_blb = 0, nb6 = 0;
+  // ... and the first Gram-Schmidt pass of the Arnoldi step that follows: partial sums of V_k . w over each block's 64 entries,
+  // dotPart[k][dotNp] (block order; slot dotNp - 1 = the body rows) -- what k_mdot_partial would leave for k_arnoldi_upd
+  const double *dotV = nullptr;    // basis, dotStride doubles between vectors; dotK of them (0: off)
+  long dotStride = 0;
+  int dotK = 0, dotNp = 0;
+  double *dotPart = nullptr;
 };
 
 struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
@@ -154,6 +160,8 @@ struct rbl_ctx {
   int comm_split = 0;                               // RBL_OPT_COMM_SPLIT: 0 unordered tile pairs + all-reduce(U), 1 rows by body index + all-gather (north_star)
   std::vector<int64_t> comm_offs, comm_cnts;        // scratch of the all-gather calls
   bool fuse_done = false; // the last full product honoured sym_tune.fuse (rbl_apply_saddle_dev)
+  const double *fuse_dotV = nullptr; double *fuse_dotPart = nullptr;   // GMRES -> rbl_apply_saddle_dev: also leave the partials of V^T w ...
+  int fuse_dotK = 0, fuse_dots_np = 0;                                  // ... for dotK basis vectors; answer: partials per vector (0 = not done)
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
   // tuning
   size_t sym_workspace_budget = (size_t)24 << 30;   // bytes the symmetric kernel may use for its slabs
@@ -279,8 +287,9 @@ void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const dou
                      int64_t n, double *d_out2);  // out[0]=x.y out[1]=x.z (z may be null)
 int rbl_gmres_max_vectors(void);
 size_t rbl_gmres_part_doubles(void);
+int rbl_gmres_p1_capacity(void);          // partial sums per vector the first Gram-Schmidt pass may be handed
 void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
-                             double *part);
+                             double *part, int fused_np = 0);
 size_t rbl_lanczos_part_doubles(void);
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
                              double *part);
@@ -291,8 +300,15 @@ void rbl_launch_lanczos_step_reorth(hipStream_t st, int64_t n, int k, double *u,
                                     double *beta_out, int64_t scal_stride, double *hcol, int64_t hcol_stride, double *part, int nvec);
 void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, const double *coef, int m,
                                 double *out, int64_t stride = 0);
+void rbl_launch_lanczos_combine_xd(hipStream_t st, int64_t n, const double *V, int64_t stride, int64_t vsep, const double *coef,
+                                   int64_t csep, int m, double *zx, double *zd, int64_t osep, int nvec);
+constexpr int RBL_SQNORM_BLOCKS = 128;
+int rbl_launch_damp_sqnorm(hipStream_t st, const RblParams &P, const double *d_r, int64_t n_blobs, double *o, int64_t pitch, int nv,
+                           double *part);
 void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, double b,
                       const double *y, double *out);
+void rbl_launch_rhs_combine(hipStream_t st, int64_t n, const double *x, double a, const double *y, double b, const double *z,
+                            const double *w, double *out);
 void rbl_launch_scale_by_damp(hipStream_t st, const RblParams &P, const double *d_r,
                               int64_t n_blobs, const double *in, double *out);
 
@@ -334,6 +350,8 @@ void rbl_launch_tl_orth(hipStream_t st, double *d_Z, int64_t n3, int N_blb, int 
 void rbl_launch_tl_E(hipStream_t st, const double *d_Cs, const double *d_Cb, int N_bod, double *d_A);
 void rbl_launch_tl_qt(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_w, int64_t wpitch, int nvec,
                       double *d_t, int64_t tpitch);
+void rbl_launch_tl_eaddq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, int N_bod, const double *d_Op, int64_t nt, int64_t ld,
+                         int kind, const double *d_t, int64_t tpitch, const double *d_w, double *d_wo, int64_t wpitch, int nvec);
 void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
                         const double *d_w, double *d_wo, int64_t wpitch, int nvec);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,

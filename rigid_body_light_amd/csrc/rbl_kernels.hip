@@ -932,6 +932,13 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 // fixed order.  Many short independent load streams instead of one long one per entry.
 constexpr int RG = 16;
 
+__device__ __forceinline__ double wave_sum64(double v)    // sum over the 64 lanes (every lane gets it), fixed order
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 template <bool WALL>
 __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict__ slabI,
                                                        const double *__restrict__ slabJ,
@@ -968,6 +975,7 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
   for (; e < nJ; e += RG) s += slabJ[sym_idxJ(L, e, v, j) + k];
   sh[q][tx] = s;
   __syncthreads();
+  double wtop = 0.0;                                     // this thread's entry of the fused saddle product (q == 0)
   if (q == 0 && live) {
     double t = sh[0][tx];
 #pragma unroll
@@ -982,11 +990,29 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
       const double ku = (k == 0) ? u[0] + l[2] * om[1] - l[1] * om[2]
                       : (k == 1) ? u[1] + l[0] * om[2] - l[2] * om[0]
                                  : u[2] + l[1] * om[0] - l[0] * om[1];
-      fuse.w[idx] = sc * t - ku;
+      wtop = sc * t - ku;
+      fuse.w[idx] = wtop;
     }
   }
   if (fuse.lever && blockIdx.x == 0 && blockIdx.y == 0)   // ... and its body rows: K^T lambda as the preconditioner left it
     for (int i = threadIdx.x; i < fuse.nb6; i += 64 * RG) fuse.w[3 * N + i] = fuse.ktl[i];
+  if (fuse.dotK > 0) {                                     // (uniform) first Gram-Schmidt pass: this block's share of V_k . w, wave q the vectors q, q + RG, ...
+    if (q == 0) sh[0][tx] = live ? wtop : 0.0;             // (the wave that read sh[1..] above is the one that overwrites sh[0])
+    __syncthreads();
+    const double wv = sh[0][tx];
+    for (int kk = q; kk < fuse.dotK; kk += RG) {
+      double a = live ? fuse.dotV[(size_t)kk * (size_t)fuse.dotStride + idx] * wv : 0.0;
+      a = wave_sum64(a);
+      if (tx == 0) fuse.dotPart[(size_t)kk * fuse.dotNp + blockIdx.x] = a;
+    }
+    if (blockIdx.x == 0)                                   // the body rows' share, last slot
+      for (int kk = q; kk < fuse.dotK; kk += RG) {
+        double a = 0.0;
+        for (int i = tx; i < fuse.nb6; i += 64) a = __builtin_fma(fuse.dotV[(size_t)kk * (size_t)fuse.dotStride + 3 * N + i], fuse.ktl[i], a);
+        a = wave_sum64(a);
+        if (tx == 0) fuse.dotPart[(size_t)kk * fuse.dotNp + fuse.dotNp - 1] = a;
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1328,6 +1354,17 @@ __global__ void k_axpby(long n, double a, const double *x, double b, const doubl
   if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
 }
 
+// out = x - a y - b z + (w ? b w : 0): the right-hand side of the stochastic step in one launch (rbl_RHS_and_Midpoint_dev)
+__global__ void k_rhs_combine(long n, const double *x, double a, const double *y, double b, const double *z, const double *w, double *out)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = x[i] - a * y[i];                              // (the order of the three separate updates it replaces)
+  r = r - b * z[i];
+  if (w) r = r + b * w[i];
+  out[i] = r;
+}
+
 // ---- Lanczos recurrence without host round trips -------------------------------------------
 // The three-term recurrence needs two inner products per iteration; here they stay on the device:
 // a kernel leaves per-block partial sums, the NEXT kernel's every block re-adds them in the same
@@ -1422,6 +1459,43 @@ __global__ __launch_bounds__(256) void k_lz_combine(long n, const double *__rest
   double a = 0.0;
   for (int p = 0; p < m; ++p) a = __builtin_fma(coef[p], V[(size_t)p * stride + i], a);
   out[i] = a;
+}
+
+// The estimate and its last correction in ONE pass over the basis: zx = V coef[0..m), zd = V coef[m..2m)  (the stopping
+// test of the preconditioned root in the norm of the increment).  blockIdx.y = recurrence of a lock-step pair: basis
+// vsep, coefficients csep, outputs osep doubles further.  zx is k_lz_combine's sum, term for term.
+__global__ __launch_bounds__(256) void k_lz_combine_xd(long n, const double *__restrict__ V, long stride, long vsep,
+                                                       const double *__restrict__ coef, long csep, int m,
+                                                       double *__restrict__ zx, double *__restrict__ zd, long osep)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  V += (size_t)blockIdx.y * (size_t)vsep; coef += (size_t)blockIdx.y * (size_t)csep;
+  double a = 0.0, b = 0.0;
+  for (int p = 0; p < m; ++p) {
+    const double v = V[(size_t)p * stride + i];
+    a = __builtin_fma(coef[p], v, a);
+    b = __builtin_fma(coef[m + p], v, b);
+  }
+  zx[(size_t)blockIdx.y * (size_t)osep + i] = a;
+  zd[(size_t)blockIdx.y * (size_t)osep + i] = b;
+}
+
+// o_v <- B o_v in place and the per-block partial sums of |B o_v|^2   (blockIdx.y = vector, `pitch` doubles apart;
+// part[v][gridDim.x], added up by the host in block order)
+__global__ __launch_bounds__(256) void k_damp_sqnorm(RblParams P, const double *__restrict__ r, long n_blobs,
+                                                     double *__restrict__ o, long pitch, double *__restrict__ part)
+{
+  __shared__ double sh[256];
+  o += (size_t)blockIdx.y * (size_t)pitch;
+  double a = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 3 * n_blobs; i += (long)gridDim.x * 256) {
+    const double x = damp_of(P, r[3 * (i / 3) + 2]) * o[i];
+    o[i] = x;
+    a = __builtin_fma(x, x, a);
+  }
+  a = lz_block_sum(a, sh);
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = a;
 }
 
 // ---- Arnoldi orthogonalisation (GMRES) --------------------------------------------------------
@@ -1902,6 +1976,13 @@ void rbl_launch_axpby(hipStream_t st, int64_t n, double a, const double *x, doub
                      b, y, out);
 }
 
+void rbl_launch_rhs_combine(hipStream_t st, int64_t n, const double *x, double a, const double *y, double b, const double *z,
+                            const double *w, double *out)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_rhs_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (long)n, x, a, y, b, z, w, out);
+}
+
 static int lz_grid(int64_t n)
 {
   int g = (int)std::min<int64_t>(LZ_BLOCKS, (n + 255) / 256);
@@ -1946,14 +2027,35 @@ void rbl_launch_lanczos_combine(hipStream_t st, int64_t n, const double *V, cons
                      (long)(stride > 0 ? stride : n));
 }
 
+void rbl_launch_lanczos_combine_xd(hipStream_t st, int64_t n, const double *V, int64_t stride, int64_t vsep, const double *coef,
+                                   int64_t csep, int m, double *zx, double *zd, int64_t osep, int nvec)
+{
+  if (n <= 0 || nvec <= 0) return;
+  hipLaunchKernelGGL(k_lz_combine_xd, dim3((unsigned)((n + 255) / 256), nvec), dim3(256), 0, st, (long)n, V, (long)stride, (long)vsep, coef,
+                     (long)csep, m, zx, zd, (long)osep);
+}
+
+// returns the number of partial sums per vector (part: nv x that many doubles, at most RBL_SQNORM_BLOCKS each)
+int rbl_launch_damp_sqnorm(hipStream_t st, const RblParams &P, const double *d_r, int64_t n_blobs, double *o, int64_t pitch, int nv,
+                           double *part)
+{
+  if (n_blobs <= 0 || nv <= 0) return 0;
+  int g = (int)std::min<int64_t>(RBL_SQNORM_BLOCKS, (3 * n_blobs + 255) / 256);
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_damp_sqnorm, dim3(g, nv), dim3(256), 0, st, P, d_r, (long)n_blobs, o, (long)pitch, part);
+  return g;
+}
+
 int rbl_gmres_max_vectors(void) { return GM_MAXK; }
 constexpr int AR_BLOCKS = 1024;
-size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * 128 + (size_t)GM_MAXK * AR_BLOCKS + AR_BLOCKS; }
+constexpr int AR_P1 = 528;          // partial sums per vector of the first pass: 128 from k_mdot_partial, up to this many from a fused product
+int rbl_gmres_p1_capacity(void) { return AR_P1; }
+size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * AR_P1 + (size_t)GM_MAXK * AR_BLOCKS + AR_BLOCKS; }
 
 // one Arnoldi step after w = A P^-1 v_j: classical Gram-Schmidt twice against V[0..k), then Hcol[k] = |w| and
 // vnext = w / |w|  (four launches, see k_arnoldi_upd)
 void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
-                             double *part)
+                             double *part, int fused_np)
 {
   if (k <= 0 || n <= 0) return;
   int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
@@ -1961,8 +2063,9 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
   const int64_t gneed = (n + 256 * AR_EPT - 1) / (256 * AR_EPT);          // AR_EPT entries per thread ...
   int g = (int)std::max<int64_t>(gneed, std::min<int64_t>(256, (n + 255) / 256));    // ... fewer in small systems: more blocks
   if (g > AR_BLOCKS) g = AR_BLOCKS;                                        // beyond 1 048 576 entries the kernels take several passes
-  double *p1 = part, *p2 = part + (size_t)GM_MAXK * 128, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
-  hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, p1, (long)n, 0L, 0L, 0L);
+  double *p1 = part, *p2 = part + (size_t)GM_MAXK * AR_P1, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
+  if (fused_np > 0) nb = fused_np;                     // (the product's slab reduction left part[k][fused_np]: RblSaddleFuse)
+  else hipLaunchKernelGGL(k_mdot_partial, dim3(nb, k), dim3(256), 0, st, V, (long)n, (const double *)w, p1, (long)n, 0L, 0L, 0L);
   hipLaunchKernelGGL(k_arnoldi_upd<false>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p1, nb, Hcol, p2, (long)n, 0L,
                      0L, 0L, 0L);
   hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn, (long)n, 0L, 0L,
@@ -1989,7 +2092,7 @@ void rbl_launch_lanczos_step_reorth(hipStream_t st, int64_t n, int k, double *u,
   int g = (int)std::max<int64_t>(gneed, std::min<int64_t>(256, (n + 255) / 256));
   if (g > AR_BLOCKS) g = AR_BLOCKS;
   const long pp = (long)rbl_gmres_part_doubles(), ph = (long)hcol_stride, vstr = (long)nvec * (long)n, pn_ = (long)n;
-  double *p1 = part, *p2 = part + (size_t)GM_MAXK * 128, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
+  double *p1 = part, *p2 = part + (size_t)GM_MAXK * AR_P1, *pn = p2 + (size_t)GM_MAXK * AR_BLOCKS;
   // more than GM_MAXK basis vectors: one group of GM_MAXK after the other (classical Gram-Schmidt twice inside a group,
   // the groups in sequence); the norm partials of the last group's second pass belong to the final vector
   for (int c0 = 0; c0 < k; c0 += GM_MAXK) {

@@ -104,16 +104,19 @@ int tl_build(rbl_ctx *c)
   if ((rc = rbl_dev_reserve(c, c->d_tlX, rbl_block_inverse_bytes(nt, 1)))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_tlT, sizeof(double) * 2 * 3 * (size_t)nt))) return rc;
   double *Q = (double *)c->d_tlQ.p;
-  rbl_launch_tl_unit(c->stream, n3, Q);                                  // K_t: one vector per direction holds that column of every body
+  if ((rc = rbl_dev_reserve(c, c->d_tlZ, sizeof(double) * 3 * (size_t)n3))) return rc;
+  double *t = (double *)c->d_tlZ.p;
   if (comm_on(c)) {
+    rbl_launch_tl_unit(c->stream, n3, Q);                                // K_t: one vector per direction holds that column of every body
     int b0, b1; comm_body_range(c, &b0, &b1);
-    if ((rc = rbl_dev_reserve(c, c->d_tlZ, sizeof(double) * 3 * (size_t)n3))) return rc;
-    double *t = (double *)c->d_tlZ.p;
     if (comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(t, 0, sizeof(double) * 3 * (size_t)n3, c->stream));
     if ((rc = blk_solve(c, b0, b1 - b0, Q, t, 3, n3, 1, false))) return rc;
     if ((rc = comm_allgather_bodies(c, t, 0, 3 * (int64_t)S.N_blb, 3, n3))) return rc;      // owners' segments, in place
     RBL_HIP(c, hipMemcpyAsync(Q, t, sizeof(double) * 3 * (size_t)n3, hipMemcpyDeviceToDevice, c->stream));
-  } else if ((rc = blk_solve(c, 0, Nb, Q, Q, 3, n3, 1, false))) return rc;   // Z = L^-1 K_t (G^-1 K_t with body-frame factors)
+  } else {                                                               // Z = L^-1 K_t (G^-1 K_t with body-frame factors), out of place
+    rbl_launch_tl_unit(c->stream, n3, t);
+    if ((rc = blk_solve(c, 0, Nb, t, Q, 3, n3, 1, false))) return rc;
+  }
   rbl_launch_tl_orth(c->stream, Q, n3, S.N_blb, Nb, (double *)c->d_tlCb.p, c->d_err2);
   // far-field model: the pair tensor of spheres of the bodies' outer radius at the body centres; the wall term only when no
   // sphere reaches the wall (any SPD model keeps the root exact -- it only has to resemble the true coupling)
@@ -148,18 +151,16 @@ int tl_apply(rbl_ctx *c, const double *w, double *wo, int nvec, int64_t pitch, i
   const int Nb = S.N_bod;
   const int64_t nt = 3 * (int64_t)Nb, n3 = 3 * (int64_t)Nb * S.N_blb;
   const double *Q = (const double *)c->d_tlQ.p;
-  double *t = (double *)c->d_tlT.p, *sv = t + 3 * nt;                     // (up to three vectors at a time)
+  double *t = (double *)c->d_tlT.p;                                       // (up to three vectors at a time)
+  // the small operator by its rows, in the launch that adds the correction: L_E itself (op 0), or the explicit inverse in the
+  // layout that holds the wanted rows contiguously (rbl_block_inverse_*: first half columns of X, second half its rows)
+  const int64_t ldx = rbl_block_inverse_ld(nt);
+  const double *Op = op == 0 ? (const double *)c->d_tlA.p : (const double *)c->d_tlX.p + (op == 1 ? (size_t)(ldx * nt) : 0);
   for (int v0 = 0; v0 < nvec; v0 += 3) {
     const int g = nvec - v0 >= 3 ? 3 : nvec - v0;
     const double *wv = w + (size_t)v0 * (size_t)pitch;
     rbl_launch_tl_qt(c->stream, Q, n3, S.N_blb, Nb, wv, pitch, g, t, nt);
-    int rc = RBL_OK;
-    if (op != 0) rc = rbl_launch_block_inv_apply(c->stream, (const double *)c->d_tlX.p, nt, 1, t, sv, nt, g, nt, op, nullptr);   // all g vectors in one pass
-    else
-      for (int v = 0; v < g && !rc; ++v)
-        rc = rbl_launch_block_trmv_small(c->stream, (const double *)c->d_tlA.p, nt, 1, 0, t + (size_t)v * nt, sv + (size_t)v * nt, 0, nullptr);
-    if (rc) return rbl_fail(c, rc, "two-level factor: application failed");
-    rbl_launch_tl_addq(c->stream, Q, n3, S.N_blb, sv, t, nt, wv, wo + (size_t)v0 * (size_t)pitch, pitch, g);
+    rbl_launch_tl_eaddq(c->stream, Q, n3, S.N_blb, Nb, Op, nt, op == 0 ? nt : ldx, op, t, nt, wv, wo + (size_t)v0 * (size_t)pitch, pitch, g);
   }
   return RBL_OK;
 }
@@ -275,7 +276,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   const size_t nsc = (size_t)4 * maxit + 1;                            // alpha, beta, |W|, coef (two sets: estimate, correction)
   const size_t nh = (size_t)maxit + 2;
   const bool out_norm = precond && c->lanczos_out_norm;                // stopping estimate in the norm of the increment itself
-  const size_t ndot = 2 + 2 * 512;                                     // rbl_launch_dot2 scratch
+  const size_t ndot = 2 + 2 * 512;                                     // partial sums of the increment-norm test (4 vectors x RBL_SQNORM_BLOCKS)
   const size_t npart = reorth ? (size_t)nvec * rbl_gmres_part_doubles() + rbl_lanczos_part_doubles() : rbl_lanczos_part_doubles();
   if ((rc = rbl_dev_reserve(c, c->d_tmp, vbytes * (size_t)(maxit + 1) * nvec))) return rc;
   if ((rc = rbl_dev_reserve(c, c->d_tmp2, vbytes * (out_norm ? 4 : 2) * nvec + sizeof(double) * (nsc * nvec + nh * nvec + npart + ndot)))) return rc;
@@ -305,7 +306,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
     return yn > 0.0 ? std::sqrt(dn / yn) : 0.0;
   };
   int m = 0, next_check = check_every;
-  bool done = false;
+  bool done = false, out_ready = false;
   static const bool trace = std::getenv("RBL_LANCZOS_TRACE") != nullptr;      // diagnostic: the estimate's history on stderr
   for (int it = 0; it < maxit && !done; ++it) {
     // inexact Krylov: an estimate wanted to lanczos_tol >= 1e-4 does not notice a product error of ~1e-6
@@ -364,38 +365,39 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
       // 3e-4).  So once the cheap estimate has passed, the last correction is evaluated where the caller sees it:
       // d = |B L V (y_m - y_{m-1})| / |B L V y_m|, extrapolated with the same rho; a few combinations and factor products
       // per test, only near convergence.
+      // All of it in one batch: the 2 nvec vectors (estimates, then corrections) go through H, the body factors and B
+      // together, their norms come back in one read; and the estimate that passes IS the result (out_ready).
       int b0 = 0, b1 = c->S.N_bod;
       if (comm_on(c)) comm_body_range(c, &b0, &b1);
+      const int nz = 2 * nvec;
       std::vector<double> cf((size_t)2 * m);
-      double worst = 0.0;
       for (int v = 0; v < nvec; ++v) {
-        if (!(wnorm[v] > 0.0)) continue;
         const std::vector<double> &yc = y_cur[v];
         std::vector<double> yp;
         const int mv = m_last[v] > 1 ? m_last[v] : m;
         alpha.assign(hs.data() + nsc * v, hs.data() + nsc * v + m);
         beta.assign(hs.data() + nsc * v + maxit, hs.data() + nsc * v + maxit + m);
-        if ((rc = lanczos_coeffs(c, alpha, beta, mv - 1, wnorm[v], yp))) return rc;
+        if (wnorm[v] > 0.0 && (rc = lanczos_coeffs(c, alpha, beta, mv - 1, wnorm[v], yp))) return rc;
         for (int p_ = 0; p_ < m; ++p_) { cf[p_] = yc[p_]; cf[m + p_] = yc[p_] - (p_ < (int)yp.size() ? yp[p_] : 0.0); }
-        RBL_HIP(c, hipMemcpyAsync(d_coef(v), cf.data(), sizeof(double) * 2 * (size_t)m, hipMemcpyHostToDevice, c->stream));
-        RBL_HIP(c, hipStreamSynchronize(c->stream));                 // (pageable source; two tests per solve at most)
-        double *zx = u + (size_t)v * n, *zd = tmp + (size_t)v * n, *ox = ex + (size_t)(2 * v) * n, *od = ox + n;
-        rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v), m, zx, (int64_t)nvec * n);
-        rbl_launch_lanczos_combine(c->stream, n, Vp(0, v), d_coef(v) + m, m, zd, (int64_t)nvec * n);
-        for (int w = 0; w < 2; ++w) {
-          double *zin = w ? zd : zx, *o = w ? od : ox;
-          if (c->tl_ok && (rc = tl_apply(c, zin, zin, 1, n, 0))) return rc;
-          if (comm_on(c) && comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(o, 0, sizeof(double) * (size_t)n, c->stream));
-          if ((rc = blk_trmv(c, b0, b1 - b0, zin, o))) return rc;
-          if (comm_on(c) && (rc = comm_allgather_bodies(c, o, 0, 3 * (int64_t)c->S.N_blb, 1, n))) return rc;
-          rbl_launch_scale_by_damp(c->stream, P, d_r, nbl, o, o);
-        }
-        double h2[2] = {0.0, 0.0}, hx[2] = {0.0, 0.0};
-        rbl_launch_dot2(c->stream, od, od, nullptr, n, d_dot);
-        if ((rc = read_back(c, h2, d_dot, sizeof(double) * 2))) return rc;
-        rbl_launch_dot2(c->stream, ox, ox, nullptr, n, d_dot);
-        if ((rc = read_back(c, hx, d_dot, sizeof(double) * 2))) return rc;
-        const double dout = hx[0] > 0.0 ? std::sqrt(h2[0] / hx[0]) : 0.0;
+        if ((rc = upload_coef(c, d_coef(v), cf.data(), 2 * m, v))) return rc;   // (the stream is idle: hs has just been read)
+      }
+      rbl_launch_lanczos_combine_xd(c->stream, n, V, (int64_t)nvec * n, n, d_coef(0), (int64_t)nsc, m, u, tmp, n, nvec);   // u | tmp: x_0.. d_0..
+      if (c->tl_ok && (rc = tl_apply(c, u, u, nz, n, 0))) return rc;
+      for (int k = 0; k < nz; ++k) {
+        double *o = ex + (size_t)k * n;
+        if (comm_on(c) && comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(o, 0, sizeof(double) * (size_t)n, c->stream));
+        if ((rc = blk_trmv(c, b0, b1 - b0, u + (size_t)k * n, o))) return rc;
+        if (comm_on(c) && (rc = comm_allgather_bodies(c, o, 0, 3 * (int64_t)c->S.N_blb, 1, n))) return rc;
+      }
+      const int gq = rbl_launch_damp_sqnorm(c->stream, P, d_r, nbl, ex, n, nz, d_dot);
+      std::vector<double> hq((size_t)gq * nz);
+      if ((rc = read_back(c, hq.data(), d_dot, sizeof(double) * hq.size()))) return rc;
+      auto sq = [&](int k) { double t = 0.0; for (int g_ = 0; g_ < gq; ++g_) t += hq[(size_t)k * gq + g_]; return t; };
+      double worst = 0.0;
+      for (int v = 0; v < nvec; ++v) {
+        if (!(wnorm[v] > 0.0)) continue;
+        const double hx = sq(v), h2 = sq(nvec + v);
+        const double dout = hx > 0.0 ? std::sqrt(h2 / hx) : 0.0;
         // rho of the coefficient sequence (same contraction, other norm); resid[v] = d_m rho / (1 - rho) in the energy norm
         const double ratio = d_last[v] > 0.0 ? resid[v] / d_last[v] : 1.0;
         const double est = dout * ratio;
@@ -403,12 +405,17 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
         resid[v] = est;
         worst = std::max(worst, est);
       }
-      if (!(worst < c->lanczos_tol) && m < maxit) all_conv = false;
+      out_ready = true;                                    // ex[0..nvec) = B G V y_m: the increments themselves if the test passes
+      if (!(worst < c->lanczos_tol) && m < maxit) { all_conv = false; out_ready = false; }
     }
     if (all_conv) done = true;
   }
   c->lanczos_iters = m;
   c->lanczos_resid = *std::max_element(resid.begin(), resid.end());
+  if (out_ready) {                                         // the last test evaluated exactly these vectors
+    RBL_HIP(c, hipMemcpyAsync(d_out, ex, vbytes * (size_t)nvec, hipMemcpyDeviceToDevice, c->stream));
+    return RBL_OK;
+  }
   // d_out_v = V_v[:, :m] y_v
   for (int v = 0; v < nvec; ++v) {
     if ((int)y_cur[v].size() < m) y_cur[v].resize(m, 0.0);

@@ -179,13 +179,16 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
     // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
     c->sym_tune.relaxed = (c->gmres_relax && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
+    c->fuse_dotV = V; c->fuse_dotK = j + 1; c->fuse_dotPart = part;   // (small systems: the product's last kernel starts the Gram-Schmidt pass)
     rc = rbl_apply_saddle_dev(c, z, w);
+    const int fused_np = c->fuse_dots_np;
+    c->fuse_dotV = nullptr; c->fuse_dotK = 0; c->fuse_dotPart = nullptr; c->fuse_dots_np = 0;
     c->sym_tune.relaxed = 0;
     c->ktl_arm = false; c->ktl_of = nullptr;
     if (rc) return rc;
     double *Hcol = H + (size_t)j * ldh;
-    // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches
-    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part);
+    // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches (three when the product left the first sums)
+    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part, fused_np);
     used = j + 1;
     if (rtol > 0.0 && (used >= next_check || used == m)) {
       const size_t hb = sizeof(double) * (1 + (size_t)ldh * used);

@@ -138,6 +138,30 @@ int m_rfd_core(rbl_ctx *c, const double *d_W, const double *Wh, double delta, do
   return m_rfd_dir(c, d_W, uom.data(), delta, d_out, d_r, d_work);
 }
 
+// uom_v = Kinv V_v = (K^T K)^-1 K^T V_v for nv device vectors: the sums over the blobs on the device (one launch each), the
+// 6 x 6 blocks on the host after ONE small read-back -- instead of bringing the 3 N-vectors to the host (reference :408)
+static int kinv_dev(rbl_ctx *c, const double *const *d_V, int nv, double *d_t, std::vector<double> *uom)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const size_t nb6 = (size_t)6 * S.N_bod;
+  for (int v = 0; v < nv; ++v) rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, d_V[v], S.N_blb, S.N_bod, d_t + (size_t)v * nb6);
+  std::vector<double> t(nb6 * (size_t)nv);
+  if ((rc = read_back(c, t.data(), d_t, sizeof(double) * t.size()))) return rc;
+  for (int v = 0; v < nv; ++v) {
+    uom[v].assign(nb6, 0.0);
+    for (int b = 0; b < S.N_bod; ++b) {
+      const double *B = &S.KTKinv[(size_t)36 * b], *tb = t.data() + (size_t)v * nb6 + 6 * (size_t)b;
+      for (int p = 0; p < 6; ++p) {
+        double s = 0.0;
+        for (int q = 0; q < 6; ++q) s += B[6 * p + q] * tb[q];
+        uom[v][6 * (size_t)b + p] = s;
+      }
+    }
+  }
+  return RBL_OK;
+}
+
 // M_RFD(), c_rigid_obj.cpp:769-796.  The two products run on the GPU at the two displaced configurations.
 int rbl_M_RFD(rbl_ctx *c, const double *W, uint64_t seed, double delta, double *out)
 {
@@ -199,10 +223,10 @@ int rbl_RHS_and_Midpoint_dev(rbl_ctx *c, const double *d_Slip, const double *d_F
   }
   if (!(S.dt > 0.0) || !(delta > 0.0)) return rbl_fail(c, RBL_ERR_ARG, "RHS_and_Midpoint: dt and delta must be positive");
   // workspace: [W1 | W2 | W_rfd] (when drawn here), M^{1/2}W1, M^{1/2}W2, M_RFD, positions, 2 scratch
-  if ((rc = rbl_dev_reserve(c, c->d_bd, 9 * vb))) return rc;
+  if ((rc = rbl_dev_reserve(c, c->d_bd, 9 * vb + 2 * sizeof(double) * (size_t)nb6))) return rc;
   double *base = (double *)c->d_bd.p;
   double *dWown = base, *dMW = base + 3 * n3 /* 2 vectors */, *dRFD = base + 5 * n3, *dr = base + 6 * n3,
-         *dwork = base + 7 * n3;
+         *dwork = base + 7 * n3, *dt6 = base + 9 * n3;
   if (!d_W) {                                                                          // rand_vector (:730-741)
     rbl_launch_normal(c->stream, seed, 0, 3 * n3, dWown);
     d_W = dWown;
@@ -210,20 +234,17 @@ int rbl_RHS_and_Midpoint_dev(rbl_ctx *c, const double *d_Slip, const double *d_F
   const int nvec = split_rand ? 2 : 1;
   if ((rc = positions_dev(c, 0, S.N_bod, dr))) return rc;                              // multi_body_pos (:662)
   if ((rc = mhalf_dev_multi(c, dr, N, d_W, nvec, method, dMW))) return rc;             // M_half_W1/2 (:927-936)
-  std::vector<double> Wh((size_t)n3), mw1((size_t)n3);
-  if ((rc = copy_d2h(c, Wh.data(), d_W + 2 * n3, vb))) return rc;
-  if ((rc = copy_d2h(c, mw1.data(), dMW, vb))) return rc;
-  RBL_HIP(c, hipStreamSynchronize(c->stream));
-  if ((rc = m_rfd_core(c, d_W + 2 * n3, Wh.data(), delta, dRFD, dr, dwork))) return rc;  // M_RFD (:940)
+  // Kinv of the RFD noise (M_RFD's direction, :776) and of M^{1/2}W1 (the predictor, :955): blob sums on the device, one read-back
+  const double *kv[2] = {d_W + 2 * n3, dMW};
+  std::vector<double> uoms[2];
+  if ((rc = kinv_dev(c, kv, 2, dt6, uoms))) return rc;
+  if ((rc = m_rfd_dir(c, d_W + 2 * n3, uoms[0].data(), delta, dRFD, dr, dwork))) return rc;  // M_RFD (:940)
   const double c1 = split_rand ? 2.0 * std::sqrt(S.kBT / S.dt) : std::sqrt(2.0 * S.kBT / S.dt);   // :945-952
   const double c2 = split_rand ? std::sqrt(S.kBT / S.dt) : std::sqrt(2.0 * S.kBT / S.dt);
   // Slip -= kBT M_RFD + BI,  BI = c2 (M^{1/2}W1 - M^{1/2}W2)  or  c2 M^{1/2}W1   (:948,953,963)
-  rbl_launch_axpby(c->stream, n3, 1.0, d_Slip, -S.kBT, dRFD, d_RHS);
-  rbl_launch_axpby(c->stream, n3, 1.0, d_RHS, -c2, dMW, d_RHS);
-  if (split_rand) rbl_launch_axpby(c->stream, n3, 1.0, d_RHS, c2, dMW + n3, d_RHS);
+  rbl_launch_rhs_combine(c->stream, n3, d_Slip, S.kBT, dRFD, c2, dMW, split_rand ? dMW + n3 : nullptr, d_RHS);
   // predictor: q^{n+1/2} = q^n displaced by (dt/2) Kinv (c1 M^{1/2}W1)   (:955-959)
-  std::vector<double> uom((size_t)nb6), Xo, Qo;
-  rbl_body_Kinv_x_V(S, mw1.data(), uom.data());
+  std::vector<double> &uom = uoms[1], Xo, Qo;
   for (double &u : uom) u *= 0.5 * S.dt * c1;
   rbl_body_update_X_Q(S, uom.data(), Xo, Qo);
   std::memcpy(X_half, Xo.data(), sizeof(double) * Xo.size());
