@@ -459,7 +459,11 @@ enum {
   RBL_OPT_SHARED_GEMM = 28,        /* [1] free space, bodies of <= 170 blobs: the ONE body-frame inverse / preconditioner table is applied to
                                       all bodies' vectors as a matrix-matrix product on the fp64 matrix cores (the table read once);
                                       0: batched matrix-vector products (every body re-reads it)                                    */
-  RBL_OPT_COUNT = 29
+  RBL_OPT_TWO_LEVEL_REFRESH = 29,  /* [1] two-level factor of the preconditioned root: keep the factored coarse (body-centre) operator for this
+                                      many configuration changes; the bodies' coarse basis Q follows every change.  The root stays exact
+                                      for ANY coarse operator (H^-1 is the exact inverse of H whatever L_E is); a stale one costs at most
+                                      a Lanczos iteration and saves its 3 N_bod-square Cholesky factor + inverse per step             */
+  RBL_OPT_COUNT = 30
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

@@ -345,6 +345,25 @@ int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out)
                                out + off, m);
 }
 
+// the same for nv vectors `pitch` doubles apart: ONE launch on the matrix cores where every body shares the body-frame factor
+int blk_trmv_multi(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch)
+{
+  if (nbo <= 0 || nv <= 0) return RBL_OK;
+  const int64_t m = 3 * (int64_t)c->S.N_blb;
+  if (nv > 1 && bf_on(c) && c->shared_gemm && rbl_shared_gemm_fits(m)) {
+    RblPhase ph(c, RBL_T_PERBODY);
+    int rc = ensure_xq_dev(c); if (rc) return rc;
+    const size_t off = (size_t)b0 * (size_t)m;
+    const double *dQ0 = (const double *)c->d_XQ.p + 3 * (size_t)c->S.N_bod + 4 * (size_t)b0;
+    return rbl_launch_shared_gemm(c->stream, (const double *)c->d_bfL.p, m, m, 1, in + off, out + off, m, pitch, nbo, nv, dQ0, 2);   // y_b = R_b (L x_b)
+  }
+  for (int v = 0; v < nv; ++v) {
+    const int rc = blk_trmv(c, b0, nbo, in + (size_t)v * (size_t)pitch, out + (size_t)v * (size_t)pitch);
+    if (rc) return rc;
+  }
+  return RBL_OK;
+}
+
 // ---- per-body (block-Jacobi) Cholesky factors of the object's own configuration, for callers that compose the
 // preconditioned square root themselves (the multi-GPU driver): L L^T = M_body (wall term per wall_PC, undamped)
 int rbl_block_solve_range_dev(rbl_ctx *c, const double *d_in, double *d_out, int mode, int body_begin, int body_end)
@@ -417,7 +436,8 @@ int sync_bodies(rbl_ctx *c)
   c->dev_bodies_valid = true;
   if (c->pc_keep_once) { c->pc_keep_once = false; return RBL_OK; }   // rbl_evolve_X_Q_RFD (:892): the preconditioner of q serves q + delta U
   c->dev_pc_valid = false;
-  c->tl_valid = false;
+  if (c->tl_valid && c->tl_ok && ++c->tl_age < c->tl_refresh) c->tl_q_stale = true;   // coarse operator kept (RBL_OPT_TWO_LEVEL_REFRESH), its basis not
+  else c->tl_valid = false;
   // the per-body Cholesky factors follow every configuration change unless the caller asked to keep them for a few
   // (rbl_set_block_refresh): as a preconditioner, or as the L of B L (L^-1 M L^-T)^{1/2} W, any nearby factor serves
   if (c->dev_blk_valid && ++c->blk_age >= c->blk_refresh) c->dev_blk_valid = false;   // blk_age: changes since the build
@@ -497,7 +517,10 @@ int pc_block_factors(rbl_ctx *c, int b0, int b1)
     c->blk_inv_valid = true;
   }
   c->dev_blk_valid = true; c->blk_b0 = b0; c->blk_b1 = b1; c->blk_age = 0;
-  c->tl_valid = false;
+  // new per-body factors: the two-level factor's basis Q = orth(L^-1 K_t) follows; its coarse operator may stay (any does) while
+  // RBL_OPT_TWO_LEVEL_REFRESH keeps it (sync_bodies did the counting)
+  if (c->tl_valid && c->tl_ok && c->tl_refresh > 1) c->tl_q_stale = true;
+  else c->tl_valid = false;
   return RBL_OK;
 }
 

@@ -107,6 +107,8 @@ struct rbl_ctx {
   bool bf_tables = false;                           // d_bfPC holds the body-frame preconditioner tables (small bodies)
   // two-level factor of the preconditioned Lanczos root (rbl_roots.hip: tl_build): G = L (I + Q (L_E - I) Q^T)
   RblDevBuf d_tlQ, d_tlCb, d_tlCs, d_tlA, d_tlLinv, d_tlX, d_tlT, d_tlZ;
+  int tl_refresh = 1, tl_age = 0;     // RBL_OPT_TWO_LEVEL_REFRESH: configuration changes the factored coarse operator is kept for
+  bool tl_q_stale = false;            // ... while its basis Q (rotations, per-body factors) is rebuilt at every change
   bool tl_on = true, tl_valid = false, tl_ok = false;   // rbl_set_tuning 87 / 88; built for the current configuration; usable (SPD)
   unsigned *d_err2 = nullptr;                       // error word of the two-level build: a failure there is not an error, only "not usable"
   double body_radius = 0.0;                         // max |c_k| + a: the sphere the far-field model gives a body

@@ -1548,6 +1548,31 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
   pin += (size_t)blockIdx.y * (size_t)pp; pout += (size_t)blockIdx.y * (size_t)pp; Hcol += (size_t)blockIdx.y * (size_t)ph;
   // h_v = sum of the previous kernel's partials: a 16-lane row per vector (one thread per vector walked npin dependent
   // loads: at 97 partials that prologue WAS the kernel)
+  if (npin > 128) {
+    // hundreds of partials per vector (the fused product leaves one per 64 entries): a WAVE per vector, four vectors of a wave
+    // in flight, all loads issued before the first add (16 lanes walking 24 dependent loads each doubled this kernel's time)
+    const int wv = t >> 6, lane = t & 63;
+    for (int v0 = wv; v0 < k; v0 += 16) {
+      double x[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int v = v0 + 4 * u, b = lane + 64 * e;
+          x[u][e] = (v < k && b < npin) ? pin[(size_t)v * npin + b] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = v0 + 4 * u;
+        double a = ((x[u][0] + x[u][1]) + (x[u][2] + x[u][3])) + ((x[u][4] + x[u][5]) + (x[u][6] + x[u][7]));
+        a = wave_sum64(a);
+        if (lane == 0 && v < k) {
+          h[v] = a;
+          if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
+        }
+      }
+    }
+  } else
   for (int v = t >> 4; v < k; v += 16) {
     double a = 0.0;
     for (int b = t & 15; b < npin; b += 16) a += pin[(size_t)v * npin + b];
@@ -2048,7 +2073,7 @@ int rbl_launch_damp_sqnorm(hipStream_t st, const RblParams &P, const double *d_r
 
 int rbl_gmres_max_vectors(void) { return GM_MAXK; }
 constexpr int AR_BLOCKS = 1024;
-constexpr int AR_P1 = 528;          // partial sums per vector of the first pass: 128 from k_mdot_partial, up to this many from a fused product
+constexpr int AR_P1 = 512;          // partial sums per vector of the first pass: 128 from k_mdot_partial, up to this many from a fused product (k_arnoldi_upd: 8 x 64)
 int rbl_gmres_p1_capacity(void) { return AR_P1; }
 size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * AR_P1 + (size_t)GM_MAXK * AR_BLOCKS + AR_BLOCKS; }
 

@@ -74,6 +74,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->comm_split = (int)v; c->dev_bodies_valid = false; }},
     {RBL_OPT_SHARED_GEMM, "shared_gemm", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->shared_gemm; },
      [](rbl_ctx *c, int64_t v) { c->shared_gemm = v != 0; }},
+    {RBL_OPT_TWO_LEVEL_REFRESH, "two_level_refresh", 1, 1 << 20, 1, [](const rbl_ctx *c) -> int64_t { return c->tl_refresh; },
+     [](rbl_ctx *c, int64_t v) { c->tl_refresh = (int)v; c->tl_age = 0; c->tl_valid = false; }},
     {RBL_OPT_FUSED_KRYLOV, "fused_krylov", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->fused_krylov; },
      [](rbl_ctx *c, int64_t v) { c->fused_krylov = v != 0; }},
 };

@@ -84,8 +84,10 @@ static bool tridiag_ql(std::vector<double> &d, std::vector<double> &e_in, std::v
 // Not usable (tl_ok = false: plain block-Jacobi) when I + E is not positive definite or the small system does not fit.
 int tl_build(rbl_ctx *c)
 {
-  if (c->tl_valid) return RBL_OK;
-  c->tl_valid = true; c->tl_ok = false;
+  if (c->tl_valid && !c->tl_q_stale) return RBL_OK;
+  const bool keep_E = c->tl_valid && c->tl_ok;          // a configuration change within RBL_OPT_TWO_LEVEL_REFRESH: only Q is rebuilt
+  c->tl_q_stale = false;
+  if (!keep_E) { c->tl_valid = true; c->tl_ok = false; c->tl_age = 0; }
   const RblBodyState &S = c->S;
   const int Nb = S.N_bod;
   const int64_t nt = 3 * (int64_t)Nb, n3 = 3 * (int64_t)Nb * S.N_blb;
@@ -117,7 +119,8 @@ int tl_build(rbl_ctx *c)
     rbl_launch_tl_unit(c->stream, n3, t);
     if ((rc = blk_solve(c, 0, Nb, t, Q, 3, n3, 1, false))) return rc;
   }
-  rbl_launch_tl_orth(c->stream, Q, n3, S.N_blb, Nb, (double *)c->d_tlCb.p, c->d_err2);
+  rbl_launch_tl_orth(c->stream, Q, n3, S.N_blb, Nb, (double *)c->d_tlCb.p, keep_E ? c->d_err : c->d_err2);
+  if (keep_E) return RBL_OK;                             // (a failed orthonormalisation now surfaces with the step's error word)
   // far-field model: the pair tensor of spheres of the bodies' outer radius at the body centres; the wall term only when no
   // sphere reaches the wall (any SPD model keeps the root exact -- it only has to resemble the true coupling)
   double zmin = 1.0e300;
@@ -383,12 +386,9 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
       }
       rbl_launch_lanczos_combine_xd(c->stream, n, V, (int64_t)nvec * n, n, d_coef(0), (int64_t)nsc, m, u, tmp, n, nvec);   // u | tmp: x_0.. d_0..
       if (c->tl_ok && (rc = tl_apply(c, u, u, nz, n, 0))) return rc;
-      for (int k = 0; k < nz; ++k) {
-        double *o = ex + (size_t)k * n;
-        if (comm_on(c) && comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(o, 0, sizeof(double) * (size_t)n, c->stream));
-        if ((rc = blk_trmv(c, b0, b1 - b0, u + (size_t)k * n, o))) return rc;
-        if (comm_on(c) && (rc = comm_allgather_bodies(c, o, 0, 3 * (int64_t)c->S.N_blb, 1, n))) return rc;
-      }
+      if (comm_on(c) && comm_gather_needs_zero(c)) RBL_HIP(c, hipMemsetAsync(ex, 0, sizeof(double) * (size_t)n * nz, c->stream));
+      if ((rc = blk_trmv_multi(c, b0, b1 - b0, u, ex, nz, n))) return rc;
+      if (comm_on(c) && (rc = comm_allgather_bodies(c, ex, 0, 3 * (int64_t)c->S.N_blb, nz, n))) return rc;
       const int gq = rbl_launch_damp_sqnorm(c->stream, P, d_r, nbl, ex, n, nz, d_dot);
       std::vector<double> hq((size_t)gq * nz);
       if ((rc = read_back(c, hq.data(), d_dot, sizeof(double) * hq.size()))) return rc;

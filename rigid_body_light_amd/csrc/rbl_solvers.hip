@@ -165,7 +165,8 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   // the stream never runs dry at a test -- on N GPUs no rank drains per iteration.  A solve that ends at j has applied one
   // preconditioner too many (0.2 ms at cfg 3 against a 20 ms product; enqueuing the whole next iteration would waste a product).
   const size_t pin_need = sizeof(double) * (1 + (size_t)ldh * m);
-  const bool overlap_ok = c->gmres_overlap && check_every == 1 && pin_need <= ((size_t)1 << 20);
+  // (launch-bound systems too, round 4: a test's round trip costs 40-50 us there, the preconditioner it hides behind 18)
+  const bool overlap_ok = c->gmres_overlap && pin_need <= ((size_t)1 << 20);
   if (overlap_ok && !c->ev_check) RBL_HIP(c, hipEventCreateWithFlags(&c->ev_check, hipEventDisableTiming));
   if (overlap_ok && !c->h_pin) RBL_HIP(c, hipHostMalloc(&c->h_pin, (size_t)1 << 20, hipHostMallocDefault));
   bool z_ready = false;                                // z = P^-1 V_j is already enqueued (by the previous iteration's test)

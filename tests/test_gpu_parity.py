@@ -2077,3 +2077,59 @@ def test_two_level_factor_of_the_preconditioned_root(orc, wall, nb, nblb):
         ctx.set_option("lanczos_two_level", 0); root(W); its_bj = ctx.lanczos_report()[0]; ctx.set_option("lanczos_two_level", 1)
         assert e < 10.0 * tol and its <= its_bj, (tol, e, its, its_bj)
     ctx.close()
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_two_level_refresh_keeps_the_root_exact(wall):
+    """RBL_OPT_TWO_LEVEL_REFRESH > 1: after a configuration change only the coarse basis Q of the two-level factor is rebuilt, the
+    factored coarse operator L_E is the previous configuration's.  H^-1 = I + Q (L_E^-1 - I) Q^T inverts H = I + Q (L_E - I) Q^T for
+    ANY L_E, so the factor is still consistent (G^-1 G = I, adjoint identity) and the root identity holds to 10 x tolerance; the
+    stale operator may cost an iteration, not more."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext
+    nb, nblb = 30, 42
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb; n = 3 * N
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    X1 = c["X"] + 0.05 * c["a"] * rng.standard_normal(c["X"].shape) * ([1.0, 1.0, 0.0] if wall else [1.0, 1.0, 1.0])
+    Q1 = c["Q"] + 0.03 * rng.standard_normal(c["Q"].shape); Q1 /= np.linalg.norm(Q1, axis=-1, keepdims=True)
+    x = torch.from_numpy(rng.standard_normal(n)).to(dev); y = torch.from_numpy(rng.standard_normal(n)).to(dev)
+    W = torch.from_numpy(rng.standard_normal(n)).to(dev)
+    res = {}
+    for refresh in (1, 4):
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_option("two_level_refresh", refresh)
+        assert ctx.get_option("two_level_refresh") == refresh
+        ctx.set_lanczos(200, 1e-6)
+
+        def op(vec, mode):
+            out = torch.empty_like(vec)
+            ctx.block_solve(vec.contiguous().data_ptr(), out.data_ptr(), mode); ctx.sync_check()
+            return out
+
+        r = torch.empty(n, dtype=torch.float64, device=dev)
+
+        def root(vec):
+            out = torch.empty_like(vec)
+            ctx.M_half_W(r.data_ptr(), N, vec.contiguous().data_ptr(), "lanczos_pc", out.data_ptr()); ctx.sync_check()
+            return out
+
+        ctx.set_config(c["X"], c["Q"]); ctx.blob_positions(0, nb, r.data_ptr()); ctx.sync_check()
+        root(W)                                                                          # builds the factor at the first configuration
+        ctx.set_config(X1, Q1); ctx.blob_positions(0, nb, r.data_ptr()); ctx.sync_check()  # one change: within the refresh window of 4
+        xx = root(W); its = ctx.lanczos_report()[0]
+        assert rel(op(op(x, 7), 5).cpu().numpy(), x.cpu().numpy()) < 1e-11             # G^-1 G = I with the kept coarse operator
+        assert abs(float(y @ op(x, 5)) - float(op(y, 6) @ x)) < 1e-11 * float(x.norm() * op(y, 6).norm())
+        z_ = r.view(-1, 3)[:, 2]
+        B = torch.where(z_ >= c["a"], torch.ones_like(z_), z_ / c["a"]).repeat_interleave(3)
+        s_ = op(xx / B, 5); v = op(W, 6)
+        Mv = torch.empty_like(v)
+        ctx.set_no_damp(True); ctx.apply_M(v.data_ptr(), r.data_ptr(), N, 0, N, Mv.data_ptr()); ctx.set_no_damp(False); ctx.sync_check()
+        e = float(torch.linalg.norm(root(s_) - B * Mv) / torch.linalg.norm(B * Mv))
+        assert e < 1e-5, (refresh, e)
+        res[refresh] = (its, op(x, 5).cpu().numpy())
+        ctx.close()
+    assert res[4][0] <= res[1][0] + 1, res[1][0:1] + res[4][0:1]
+    assert not np.array_equal(res[1][1], res[4][1])                                     # the kept operator really is another one
