@@ -426,8 +426,8 @@ enum {
   RBL_OPT_GMRES_ONE_KERNEL = 9,    /* [1] small systems (<= 256 blobs, diagonal PC, <= 255 iterations): whole solve in ONE launch    */
   RBL_OPT_GMRES_PREDICT_CHECKS = 10, /* [1] launch-bound systems (<= 20 000 blobs): convergence tests placed by the previous solve's
                                       count and the residual's rate; 0: every 4th iteration                                         */
-  RBL_OPT_GMRES_OVERLAP_CHECK = 11, /* [1] large systems: the host reads the Hessenberg column of iteration j while the GPU already
-                                      applies the preconditioner of iteration j + 1 (no idle stream at the test); 0: drain, then go on */
+  RBL_OPT_GMRES_OVERLAP_CHECK = 11, /* [1] the host reads the Hessenberg columns of a convergence test while the GPU already applies the
+                                      preconditioner of the next iteration (no idle stream at the test); 0: drain, then go on          */
   RBL_OPT_RELAXED_KRYLOV = 12,     /* [0] inexact Krylov: once GMRES's residual estimate is below rtol x 1e5 (and in Lanczos runs to
                                       tolerances >= 1e-4) far tile pairs are evaluated in packed single precision (relative product
                                       error <= 3e-6, ~1.8x faster); the solution still satisfies the fp64 system to rtol             */
@@ -447,8 +447,9 @@ enum {
   RBL_OPT_NO_DAMP = 23,            /* [0] transient: the matvec entry points apply the plain wall-corrected M, no damping B          */
   RBL_OPT_COMM_SPLIT = 24,         /* [0] multi-GPU contexts: 0 unordered tile pairs + all-reduce(U), 1 rows by body index +
                                       all-gather(positions, U) -- see "multi-GPU" above                                             */
-  RBL_OPT_FUSED_KRYLOV = 25,       /* [1] launch-bound systems: the small kernels of a GMRES / Lanczos iteration fused (slab sums +
-                                      saddle tail + Gram-Schmidt passes in cooperative kernels); 0: one kernel per operation        */
+  RBL_OPT_FUSED_KRYLOV = 25,       /* [1] launch-bound systems: the product's slab reduction also writes the saddle tail and the partial
+                                      sums of the Arnoldi step's first Gram-Schmidt pass (two launches fewer per GMRES iteration);
+                                      0: one kernel per operation                                                                  */
   RBL_OPT_RELAXED_GAP_RATIO = 26,  /* [0] relaxed product: a far tile pair is swept in single precision when the extents of its boxes,
                                       d_I + 2 d_J, are at most this many times their gap (0 = the library's default); smaller = fewer
                                       pairs relaxed, smaller product error (6e-8 (1 + ratio) of a separation)                        */

@@ -294,7 +294,7 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
                              double *part, int fused_np = 0);
 size_t rbl_lanczos_part_doubles(void);
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
-                             double *part);
+                             double *part, int nvec = 1, int64_t scal_stride = 0);
 void rbl_launch_lanczos_step(hipStream_t st, int64_t n, double *u, const double *v, const double *vprev,
                              const double *beta_prev, double *alpha_out, double *beta_out, double *vnext,
                              double *part, int nvec = 1, int64_t vec_stride = 0, int64_t scal_stride = 0);

@@ -1553,19 +1553,24 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
     // in flight, all loads issued before the first add (16 lanes walking 24 dependent loads each doubled this kernel's time)
     const int wv = t >> 6, lane = t & 63;
     for (int v0 = wv; v0 < k; v0 += 16) {
-      double x[4][8];
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int base = 0; base < npin; base += 512) {     // (512 partials per round; the second pass of a large system hands over 1024)
+        double x[4][8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int v = v0 + 4 * u, b = lane + 64 * e;
-          x[u][e] = (v < k && b < npin) ? pin[(size_t)v * npin + b] : 0.0;
-        }
+          for (int e = 0; e < 8; ++e) {
+            const int v = v0 + 4 * u, b = base + lane + 64 * e;
+            x[u][e] = (v < k && b < npin) ? pin[(size_t)v * npin + b] : 0.0;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          acc[u] += ((x[u][0] + x[u][1]) + (x[u][2] + x[u][3])) + ((x[u][4] + x[u][5]) + (x[u][6] + x[u][7]));
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int v = v0 + 4 * u;
-        double a = ((x[u][0] + x[u][1]) + (x[u][2] + x[u][3])) + ((x[u][4] + x[u][5]) + (x[u][6] + x[u][7]));
-        a = wave_sum64(a);
+        double a = wave_sum64(acc[u]);
         if (lane == 0 && v < k) {
           h[v] = a;
           if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
@@ -2017,13 +2022,15 @@ static int lz_grid(int64_t n)
 size_t rbl_lanczos_part_doubles(void) { return 4 * (size_t)LZ_BLOCKS; }      // two partial-sum arrays for each vector of a pair
 
 // V0 = W / |W|, *wnorm_out = |W|
+// (nvec vectors in the same two launches: vector k of d_W / V0 is k n doubles further, its norm k * scal_stride)
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
-                             double *part)
+                             double *part, int nvec, int64_t scal_stride)
 {
   const int g = lz_grid(n);
-  hipLaunchKernelGGL(k_lz_a, dim3(g), dim3(256), 0, st, (long)n, const_cast<double *>(d_W), d_W,
-                     (const double *)nullptr, (const double *)nullptr, part, 0L, 0L, 0L);
-  hipLaunchKernelGGL(k_lz_c, dim3(g), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0, 0L, 0L, 0L,
+  const long vs = nvec > 1 ? (long)n : 0L, ss = nvec > 1 ? (long)scal_stride : 0L, ps = nvec > 1 ? 2L * LZ_BLOCKS : 0L;
+  hipLaunchKernelGGL(k_lz_a, dim3(g, nvec), dim3(256), 0, st, (long)n, const_cast<double *>(d_W), d_W,
+                     (const double *)nullptr, (const double *)nullptr, part, vs, ss, ps);
+  hipLaunchKernelGGL(k_lz_c, dim3(g, nvec), dim3(256), 0, st, (long)n, d_W, (const double *)part, g, wnorm_out, V0, vs, ss, ps,
                      (const double *)nullptr, 0L, 0L);
 }
 

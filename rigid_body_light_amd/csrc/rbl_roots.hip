@@ -293,7 +293,7 @@ static int mhalf_lanczos_dev(rbl_ctx *c, const double *d_r, int64_t nbl, const d
   auto d_wn = [&](int v) { return sc + nsc * v + 2 * maxit; };
   auto d_coef = [&](int v) { return sc + nsc * v + 2 * maxit + 1; };
   auto Vp = [&](int it, int v) { return V + ((size_t)it * nvec + v) * n; };
-  for (int v = 0; v < nvec; ++v) rbl_launch_lanczos_init(c->stream, n, d_W + (size_t)v * n, d_wn(v), Vp(0, v), d_part_init);
+  rbl_launch_lanczos_init(c->stream, n, d_W, d_wn(0), Vp(0, 0), d_part_init, nvec, (int64_t)nsc);   // both recurrences of a pair in the same launches
   const int check_every = (nbl > 20000) ? 1 : 4;
   std::vector<double> hs(nsc * nvec), alpha, beta, y_prev, y_pp;
   std::vector<std::vector<double>> y_cur(nvec);

@@ -119,7 +119,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   // (beta sits in FRONT of H: a convergence test reads back 1 + ldh * used doubles, not the whole ldh x m array)
   double *V = (double *)c->d_gm.p, *w = V + (size_t)(m + 1) * nsys, *z = w + nsys, *d_beta = z + nsys, *H = d_beta + 1,
          *d_y = H + (size_t)ldh * m, *part = d_y + m, *part2 = part + rbl_gmres_part_doubles();
-  RBL_HIP(c, hipMemsetAsync(H, 0, sizeof(double) * (size_t)ldh * m, c->stream));
+  // (H is not cleared: the least-squares solve reads rows 0 .. j + 1 of column j only, all written by the Arnoldi step)
   rbl_launch_lanczos_init(c->stream, nsys, d_rhs, d_beta, V, part2);                    // V_0 = b/|b|, beta = |b|
   std::vector<double> Hh((size_t)ldh * m + 1), y;
   // convergence test: every iteration when an iteration is expensive.  When it is launch-bound a test (copy + stream

@@ -10,8 +10,9 @@ from rigid_body_light_amd._lib import DeviceContext
 
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
-variants = [("default", {}), ("sw=1", {"sym_waves": 1}), ("sw=2", {"sym_waves": 2})]
-for nb in (19, 25, 37, 51, 80, 200):
+variants = [("default", {}), ("symw", {"sym_waves": 1, "sym_rows_per_lane": 1}), ("sw=1", {"sym_waves": 1}),
+            ("C=2", {"sym_chunk": 2}), ("C=3", {"sym_chunk": 3}), ("C=4", {"sym_chunk": 4})]
+for nb in (13, 16, 19, 25, 37, 51, 80):
     nblb, wall = 642, True
     c = make_config(nb, nblb, wall)
     N = nb * nblb
@@ -23,7 +24,7 @@ for nb in (19, 25, 37, 51, 80, 200):
     U = torch.empty_like(F); ref = None
     out = []
     for name, opts in variants:
-        for k in ("sym_waves", "sym_chunk"):
+        for k in ("sym_waves", "sym_chunk", "sym_rows_per_lane"):
             ctx.set_option(k, 0)
         for k, v in opts.items():
             ctx.set_option(k, v)
