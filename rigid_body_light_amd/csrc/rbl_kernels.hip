@@ -1763,8 +1763,11 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   if (nrhs == 1 && tune.ni1 > 0) ni = tune.ni1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
   // workgroups of SW_LARGE waves (= units of SW_LARGE consecutive super-tiles, see sym_row_of) for large systems; a shard
-  // keeps them as long as every rank still gets >= 8 units
-  int sw = (ni == 2 && tsup >= SW_LARGE * i_step * 8) ? SW_LARGE : 1;
+  // keeps them as long as every rank still gets >= 8 units.  On one GPU they start at 160 super-tiles (20 480 blobs): below,
+  // single-wave workgroups fill the chip a little better (tools/bench_midrange.py, wall, one box, forced shapes back to back:
+  // 8 346 / 12 198 / 16 050 blobs 0.142 / 0.244 / 0.384 ms with four waves against 0.132 / 0.232 / 0.371 with one; 23 754: 0.778 /
+  // 0.783; 32 742: 1.41 / 1.49; the two-vector product is indifferent below 24 000 blobs and 9 % better with four waves above)
+  int sw = (ni == 2 && tsup >= SW_LARGE * i_step * (i_step > 1 ? 8 : 40)) ? SW_LARGE : 1;
   if (tune.sw == 1 || tune.sw == SW_LARGE) sw = tune.sw;        // (the only workgroup shapes the product build instantiates)
   const int tunits = (tsup + sw - 1) / sw;
   const int rowsI = ((tunits + i_step - 1) / i_step) * sw;

@@ -171,6 +171,30 @@ def test_apply_M_cfg2_size_vs_oracle_rows(orc):
     assert np.array_equal(rb.apply_M(F, r), rb.apply_M(F, r))
 
 
+@pytest.mark.parametrize("nb,nblb,wall", [(19, 642, True), (25, 642, True), (37, 642, False)])
+def test_apply_M_between_cfg2_and_cfg3_vs_oracle_rows(orc, nb, nblb, wall):
+    """12 198 / 16 050 / 23 754 blobs: the sizes between BASELINE cfg 2 and cfg 3, where the symmetric kernel runs two rows per lane
+    in single-wave workgroups (below 160 row super-tiles; four-wave workgroups above -- sym_geometry).  Oracle on row samples that
+    include the ragged last tile, every workgroup shape the options can force agrees to rounding, and the result is bitwise
+    reproducible."""
+    from rigid_body_light_amd import RigidBody, make_config
+    c = make_config(nb, nblb, wall)
+    rb = RigidBody(c["cfg"], c["X"], c["Q"], c["a"], c["eta"], c["dt"], wall_PC=wall)
+    r = rb.get_blob_positions()
+    N = nb * nblb
+    F = np.random.default_rng(nb).standard_normal(r.size)
+    U = rb.apply_M(F, r)
+    U3 = U.reshape(-1, 3)
+    for (b, e) in ((0, 48), (N // 2 - 7, N // 2 + 41), (N - 48, N)):
+        Uo = orc.apply_M_rows(F, r, b, e, c["a"], c["eta"], wall, nthreads=8)
+        assert rel(U3[b:e].ravel(), Uo) < 1e-12
+    assert np.array_equal(rb.apply_M(F, r), U)
+    for waves, rows in ((1, 0), (4, 0), (1, 1)):           # single-wave / four-wave workgroups, the wave-unit kernel
+        rb.cb.set_option("sym_waves", waves); rb.cb.set_option("sym_rows_per_lane", rows)
+        assert rel(rb.apply_M(F, r), U) < 1e-13
+    rb.cb.set_option("sym_waves", 0); rb.cb.set_option("sym_rows_per_lane", 0)
+
+
 @pytest.mark.parametrize("wall", [False, True])
 @pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 16, 19])      # 2, 3: two-vector symmetric kernel; >= 4: MFMA kernel
 def test_apply_M_multi_mfma_vs_oracle(orc, wall, nrhs):
