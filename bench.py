@@ -229,13 +229,10 @@ def cpu_baseline(c, nb, nblb, wall, budget_s):
     return out
 
 
-def sym_kernel_name(ctx, wall, ni):
-    """the instantiation a one-vector symmetric product launches: mid-size systems (one row per lane) run the wave-unit kernel
-    unless RBL_OPT_SYM_WAVE_UNITS is off"""
-    w = "true" if wall else "false"
-    if ni == 1 and ctx.get_option("sym_wave_units") == 1:
-        return "k_apply_M_symw<%s>" % w
-    return "k_apply_M_sym<%s,%d>" % (w, ni)
+def sym_kernel_name(ctx, wall, n_blobs, i_step=1):
+    """the instantiation a one-vector symmetric product of that size launches under the context's options (rbl_apply_M_sym_kernel:
+    the library's own launch decisions), in the naming of librbl.isa.json"""
+    return ctx.apply_M_sym_kernel(int(n_blobs), wall, i_step=i_step)
 
 
 def apply_opts(ctx, args):
@@ -615,7 +612,7 @@ def other_configs(dev, stream):
         ctx.sync_check()
         t = wall_time(one, 200)
         ni, _, _ = ctx.apply_M_sym_info(N, 1, 1)
-        kname = sym_kernel_name(ctx, wall, ni)
+        kname = sym_kernel_name(ctx, wall, N)
         isa = isa_counts(kname)
         d = {"workload": "%d x shell_N_%d, %s" % (nb, nblb, "wall-corrected" if wall else "free-space"),
              "apply_M_us": t * 1e6, "mf_gflops": 18.0 * float(N) ** 2 / t / 1e9}
@@ -1056,7 +1053,7 @@ def main():
                    "note": "three passes of --steps steps each; `value` / `ms_per_step` are the first (the contract's timed region)"}
         if use_sym:
             ni, chunk, wbytes = ctx.apply_M_sym_info(N, 1, 1)
-            kname = sym_kernel_name(ctx, wall, ni)
+            kname = sym_kernel_name(ctx, wall, N)
             roof = roofline_of(kname, 0.5 * float(N) * float(N), False, kern_ms, args.config)
             roof["launch"] = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
         else:
@@ -1098,7 +1095,7 @@ def main():
             k_ms = float(pr[:, 0].max())
             if split == 0:
                 ni, chunk, wbytes = ctx.apply_M_sym_info(N, world, 1)
-                rf = roofline_of(sym_kernel_name(ctx, wall, ni), 0.5 * float(N) * float(N) / world, False, k_ms)
+                rf = roofline_of(sym_kernel_name(ctx, wall, N, world), 0.5 * float(N) * float(N) / world, False, k_ms)
                 rf["launch"] = {"rows_per_lane": ni, "column_tiles_per_unit": chunk, "slab_workspace_bytes": wbytes}
                 what = ("unordered tile pairs dealt over the ranks (positions replicated: a 5 us kernel per rank instead of a collective), "
                         "partial U completed by ONE sum all-reduce of 24 N bytes")

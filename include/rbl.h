@@ -248,6 +248,10 @@ int rbl_apply_M_sym_multi_dev(rbl_ctx *ctx, const double *d_F, const double *d_r
 int rbl_apply_M_sym_info(rbl_ctx *ctx, int64_t n_blobs, int i_step, int nrhs, int *rows_per_lane, int *chunk_tiles,
                          int64_t *workspace_bytes);
 
+/* ... and the kernel instantiation a one- or two-vector symmetric product of that size launches under the context's options
+ * ("k_apply_M_sym<true,2>", "k_apply_M_symw<false>", ...; name: >= 40 bytes) */
+int rbl_apply_M_sym_kernel(rbl_ctx *ctx, int64_t n_blobs, int i_step, int nrhs, int wall, char *name, int name_len);
+
 /* blob positions of bodies [body_begin, body_end) into d_out
  * (3*N_blb*(body_end-body_begin)); uses the host-side configuration. */
 int rbl_blob_positions_dev(rbl_ctx *ctx, int body_begin, int body_end, double *d_out);

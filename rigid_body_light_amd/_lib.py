@@ -44,6 +44,7 @@ def lib():
         L.rbl_apply_M_sym_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, vp]
         L.rbl_apply_M_sym_multi_dev.argtypes = [vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp]
         L.rbl_apply_M_sym_info.argtypes = [vp, i64, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64)]
+        L.rbl_apply_M_sym_kernel.argtypes = [vp, i64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
         L.rbl_blob_positions_dev.argtypes = [vp, C.c_int, C.c_int, vp]
         L.rbl_rotne_prager_tensor_dev.argtypes = [vp, vp, i64, C.c_int, vp]
         L.rbl_cholesky_lower_dev.argtypes = [vp, vp, i64, C.c_int]
@@ -360,6 +361,12 @@ class DeviceContext:
         ni, ch, wb = C.c_int(0), C.c_int(0), C.c_int64(0)
         self._chk(self.L.rbl_apply_M_sym_info(self.h, n_blobs, i_step, nrhs, C.byref(ni), C.byref(ch), C.byref(wb)))
         return ni.value, ch.value, wb.value
+
+    def apply_M_sym_kernel(self, n_blobs, wall, i_step=1, nrhs=1):
+        """name of the kernel instantiation a symmetric product of that size launches under this context's options"""
+        buf = C.create_string_buffer(64)
+        self._chk(self.L.rbl_apply_M_sym_kernel(self.h, n_blobs, i_step, nrhs, 1 if wall else 0, buf, 64))
+        return buf.value.decode()
 
     def blob_positions(self, body_begin, body_end, dout):
         self._chk(self.L.rbl_blob_positions_dev(self.h, body_begin, body_end, dout))

@@ -228,6 +228,7 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
                         int variant, unsigned *d_err);
 size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune,
                              int *NI_out = nullptr, int *C_out = nullptr);
+void rbl_apply_M_sym_kernel_name(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, bool wall, char *out, size_t len);
 // nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); workspace rbl_apply_M_sym_bytes(..., nrhs)
 void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                             const double *d_r, int64_t n_blobs, int i_first, int i_step,

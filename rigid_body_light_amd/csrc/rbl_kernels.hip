@@ -20,6 +20,7 @@
 #include "rbl_pair_pk.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
 #include <cmath>
 
@@ -606,8 +607,26 @@ __host__ __device__ __forceinline__ long symw_prefix(int e, int C, int nch)
 #ifndef RBL_SYMW_IW
 #define RBL_SYMW_IW 4             // independent waves (= work units in flight) per workgroup
 #endif
-template <bool WALL, int IW>
-__global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE) void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
+#ifndef RBL_SYMW2_WAVES_FREE
+#define RBL_SYMW2_WAVES_FREE 4    // two rows per lane: waves per SIMD the allocator is held to (free space / wall)
+#endif
+#ifndef RBL_SYMW2_WAVES_WALL
+#define RBL_SYMW2_WAVES_WALL 3
+#endif
+// live units of row super-tile e with NI rows per lane: chunks (NI e) / C .. nch - 1.  Closed form for NI = 1, and for NI = 2 with
+// C = 1 or C even (floor(2 e / C) = floor(e / (C / 2)); sym_geometry keeps C that way for these kernels)
+__host__ __device__ __forceinline__ long symw_prefix_ni(int e, int C, int nch, int ni)
+{
+  if (ni == 1) return symw_prefix(e, C, nch);
+  if (C == 1) return (long)e * nch - (long)e * (e - 1);
+  return symw_prefix(e, C / 2, nch);
+}
+// NI = 2 (round 4, 8 200 - 20 480 blobs and whatever sym_geometry sends here): a lane owns the same two row tiles as in
+// k_apply_M_sym<WALL, 2, 1, 0> and the SAME slabs come out; the column data read from LDS and the three travelling column sums
+// (six DPP moves per step) are shared by the two pair evaluations of a step.
+template <bool WALL, int NI, int IW>
+__global__ __launch_bounds__(TS *IW, NI == 2 ? (WALL ? RBL_SYMW2_WAVES_WALL : RBL_SYMW2_WAVES_FREE) : (WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES_FREE))
+void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
                                                         double *__restrict__ slabI, double *__restrict__ slabJ, long N,
                                                         SymLayout L, RblParams P, unsigned *err, long n_units)
 {
@@ -625,22 +644,23 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
   // one work unit of this wave (`return` ends the unit)
   auto sweep_unit = [&](const long u) {
   int e, c;
-  if (L.tri) {                       // u -> (row tile, chunk) through the closed-form prefix count (scalar work)
+  if (L.tri) {                       // u -> (row super-tile, chunk) through the closed-form prefix count (scalar work)
     int lo = 0, hi = L.rowsI;        // largest e with prefix(e) <= u
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (symw_prefix(mid, C, L.nch) <= u) lo = mid; else hi = mid;
+      if (symw_prefix_ni(mid, C, L.nch, NI) <= u) lo = mid; else hi = mid;
     }
-    e = lo; c = e / C + (int)(u - symw_prefix(e, C, L.nch));
+    e = lo; c = (NI * e) / C + (int)(u - symw_prefix_ni(e, C, L.nch, NI));
   } else {                           // a multi-GPU shard: the rectangle (row, chunk), dead units leave at once
     c = (int)(u / L.rowsI);
     e = (int)((u - (long)c * L.rowsI + c) % L.rowsI);
   }
   const int I = sym_row_of(e, L.i_first, L.i_step, 1);
-  if (I >= T) return;
+  const int It0 = NI * I;            // first row tile of the lane's NI
+  if (It0 >= T) return;
   int J0 = c * C;
   const int J1 = (J0 + C < T) ? J0 + C : T;
-  if (J0 < I) J0 = I;
+  if (J0 < It0) J0 = It0;
   if (J0 >= J1) return;
   auto load_blob = [&](long idx, double &x, double &y, double &z, double &fx, double &fy, double &fz) {
     if (idx < N) {
@@ -656,8 +676,12 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
       x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0; fx = 0.0; fy = 0.0; fz = 0.0;
     }
   };
-  double xi, yi, zi, Fix, Fiy, Fiz, uix = 0.0, uiy = 0.0, uiz = 0.0;
-  load_blob((long)I * TS + lane, xi, yi, zi, Fix, Fiy, Fiz);
+  double xi[NI], yi[NI], zi[NI], Fix[NI], Fiy[NI], Fiz[NI], uix[NI], uiy[NI], uiz[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a]);   // (a row tile beyond T is padding: zero force)
+    uix[a] = 0.0; uiy[a] = 0.0; uiz[a] = 0.0;
+  }
   for (int J = J0; J < J1; ++J) {
     {
       double xj, yj, zj, Fjx, Fjy, Fjz;
@@ -669,15 +693,33 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (J == I) {                    // the diagonal tile: ordered sweep with the index-equality self term
+    double ax = 0.0, ay = 0.0, az = 0.0;                            // column sums of column (lane + s) & 63, travelling
+    if (J < It0 + NI) {              // J is one of the lane's own row tiles: the ordered diagonal sweep of that row tile ...
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+        if (J == It0 + a) {
 #pragma unroll 2
-      for (int jj = 0; jj < TS; ++jj) {
-        const double2_t pa = sP0[wave][jj], pb = sP1[wave][jj], pd = sP2[wave][jj];
-        rbl_pair_accum<WALL, true, true>(Pu, xi, yi, zi, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane, uix, uiy, uiz, flags);
+          for (int jj = 0; jj < TS; ++jj) {
+            const double2_t pa = sP0[wave][jj], pb = sP1[wave][jj], pd = sP2[wave][jj];
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane, uix[a], uiy[a], uiz[a], flags);
+          }
+        }
+      if (NI == 1 || J == It0) continue;                             // (no earlier row tile of the lane: no column sums)
+      // ... and (NI = 2, J = It0 + 1) the symmetric sweep of row tile It0 against it
+      unsigned off16 = (unsigned)lane * 16u;
+      const char *b0 = (const char *)sP0[wave], *b1 = (const char *)sP1[wave], *b2 = (const char *)sP2[wave];
+#pragma unroll 2
+      for (int s = 0; s < TS; ++s) {
+        const double2_t pa = *(const double2_t *)(b0 + off16), pb = *(const double2_t *)(b1 + off16), pd = *(const double2_t *)(b2 + off16);
+        off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
+        double vx = ax, vy = ay, vz = az;
+        rbl_pair_sym<WALL, true, true>(Pu, xi[0], yi[0], zi[0], Fix[0], Fiy[0], Fiz[0], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix[0], uiy[0], uiz[0], vx, vy, vz, flags, WK);
+        ax = wave_rol1(vx); ay = wave_rol1(vy); az = wave_rol1(vz);
       }
+      double *q = slabJ + sym_idxJ(L, e, 0, (long)J * TS + lane);
+      q[0] = ax; q[1] = ay; q[2] = az;
       continue;
     }
-    double ax = 0.0, ay = 0.0, az = 0.0;                            // column sums of column (lane + s) & 63, travelling
     if (NL > 0) {
 #pragma unroll
       for (int k = 0; k < NL; ++k) sU[wave][k][lane] = 0.0;
@@ -692,7 +734,9 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
       const int jj = (int)(off16 >> 4);
       off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
       double vx = (NL > 0) ? 0.0 : ax, vy = (NL > 1) ? 0.0 : ay, vz = (NL > 2) ? 0.0 : az;
-      rbl_pair_sym<WALL, true, true>(Pu, xi, yi, zi, Fix, Fiy, Fiz, pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix, uiy, uiz, vx, vy, vz, flags, WK);
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+        rbl_pair_sym<WALL, true, true>(Pu, xi[a], yi[a], zi[a], Fix[a], Fiy[a], Fiz[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, uix[a], uiy[a], uiz[a], vx, vy, vz, flags, WK);
       if (NL > 0) __hip_atomic_fetch_add(&sU[wave][0][jj], vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else ax = wave_rol1(vx);
       if (NL > 1) __hip_atomic_fetch_add(&sU[wave][NL > 1 ? 1 : 0][jj], vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else ay = wave_rol1(vy);
       if (NL > 2) __hip_atomic_fetch_add(&sU[wave][NL > 2 ? 2 : 0][jj], vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else az = wave_rol1(vz);
@@ -707,8 +751,12 @@ __global__ __launch_bounds__(TS *IW, WALL ? RBL_SYMW_WAVES_WALL : RBL_SYMW_WAVES
     double *q = slabJ + sym_idxJ(L, e, 0, (long)J * TS + lane);     // 64 rotations: lane l holds column l again
     q[0] = ax; q[1] = ay; q[2] = az;
   }
-  double *p_ = slabI + sym_idxI(L, c, 0, (long)I * TS + lane);
-  p_[0] = uix; p_[1] = uiy; p_[2] = uiz;
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+    if (It0 + a < T) {
+      double *p_ = slabI + sym_idxI(L, c, 0, (long)(It0 + a) * TS + lane);
+      p_[0] = uix[a]; p_[1] = uiy[a]; p_[2] = uiz[a];
+    }
   };
   // (A work queue -- a resident set of waves drawing units from one counter, or from eight per-XCD counters -- was measured and
   // dropped: 179 and 119 us per product at cfg 2 against 70 with one unit per wave, gpurun_out/r04f, r04g: a wave that sweeps
@@ -1759,6 +1807,10 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // 2 rows per lane once there is parallelism to spare: same speed on one GPU (the kernel is
   // VALU-issue bound either way) but half the column-sum slab to write and re-read
   int ni = (t >= 128 * i_step) ? 2 : 1;
+  // one vector on one GPU: two rows per lane from 120 tiles on -- the wave-unit kernel's NI = 2 form shares the column reads and the
+  // rotating column sums between two pairs (43.5 instead of 49 instructions per pair in free space): 8 100 blobs 71 against 74-77 us,
+  // cfg 2's Brownian step -2 to -3 % (tools/bench_cfg2_step.py, interleaved); at 4 860 blobs it is the slower one (38 against 34 us)
+  if (nrhs == 1 && i_step == 1 && t >= 120) ni = 2;
   if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
   if (nrhs == 1 && tune.ni1 > 0) ni = tune.ni1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
@@ -1768,7 +1820,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // 8 346 / 12 198 / 16 050 blobs 0.142 / 0.244 / 0.384 ms with four waves against 0.132 / 0.232 / 0.371 with one; 23 754: 0.778 /
   // 0.783; 32 742: 1.41 / 1.49; the two-vector product is indifferent below 24 000 blobs and 9 % better with four waves above)
   int sw = (ni == 2 && tsup >= SW_LARGE * i_step * (i_step > 1 ? 8 : 40)) ? SW_LARGE : 1;
-  if (tune.sw == 1 || tune.sw == SW_LARGE) sw = tune.sw;        // (the only workgroup shapes the product build instantiates)
+  if (tune.sw == 1 || (tune.sw == SW_LARGE && ni == 2)) sw = tune.sw;   // (the only workgroup shapes the product build instantiates: 1, or 4 with two rows per lane)
   const int tunits = (tsup + sw - 1) / sw;
   const int rowsI = ((tunits + i_step - 1) / i_step) * sw;
   // a unit sweeps <= C column tiles.  Measured (tools/tune_sym_chunk.py): short chunks win -- many
@@ -1789,6 +1841,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
     if (c > 8) c = 8;
     else if (c < 7 && ((long)(rowsI / sw) * (long)((t + 7) / 8)) / 2 >= 4L * 3 * (n_cu > 0 ? n_cu : 256)) c = 8;
   }
+  if (ni == 2 && sw == 1 && c > 1 && (c & 1)) ++c;      // (the wave-unit kernel's closed-form unit index wants C = 1 or even there)
   if (tune.chunk > 0) c = tune.chunk;
   L.Npad = (long)t * TS; L.T = t; L.NI = ni; L.C = c; L.nch = (t + c - 1) / c; L.rowsI = rowsI;
   L.SW = sw;
@@ -1868,6 +1921,17 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   if (L.NI == 2 && L.SW == SW_LARGE) {
     if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
     else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
+  } else if (L.NI == 2 && nrhs == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) {
+    // two rows per lane in single-wave workgroups (8 200 - 20 480 blobs on one GPU): the wave-unit kernel's NI = 2 form
+    constexpr int IW = RBL_SYMW_IW;
+    const long n_units = L.tri ? symw_prefix_ni(L.rowsI, L.C, L.nch, 2) : (long)L.rowsI * L.nch;
+    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
+    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    const int64_t n = 3 * n_blobs;
+    dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
+    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
+    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
   } else if (L.NI == 2) {
     if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
     else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
@@ -1881,8 +1945,8 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
     constexpr int IW = RBL_SYMW_IW;
     const long n_units = L.tri ? symw_prefix(L.rowsI, L.C, L.nch) : (long)L.rowsI * L.nch;
     const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
-    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    else hipLaunchKernelGGL((k_apply_M_symw<false, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
     const int64_t n = 3 * n_blobs;
     dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
     if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
@@ -1891,6 +1955,19 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
     if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
     else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
   }
+}
+
+// the instantiation rbl_launch_apply_M_sym would launch (reporting: bench.py names what it times): same decisions, no launch
+void rbl_apply_M_sym_kernel_name(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, bool wall, char *out, size_t len)
+{
+  const SymLayout L = sym_geometry(n_blobs, n_cu, 0, i_step, nrhs, tune);
+  const char *w = wall ? "true" : "false";
+  const bool relaxed = tune.relaxed != 0;
+  if (nrhs == 2) std::snprintf(out, len, "k_apply_M_sym2<%s,%d,%d>", w, L.NI, L.SW);
+  else if (L.NI == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) std::snprintf(out, len, "k_apply_M_symw<%s,2>", w);
+  else if (L.NI == 2) std::snprintf(out, len, "k_apply_M_sym<%s,2>", w);              // (one or four waves per workgroup: the same sweep)
+  else if (L.SW == 1 && tune.wave_units >= 0) std::snprintf(out, len, "k_apply_M_symw<%s>", w);
+  else std::snprintf(out, len, "k_apply_M_sym<%s,1>", w);
 }
 
 // ---- multi-RHS (MFMA) variant ---------------------------------------------------

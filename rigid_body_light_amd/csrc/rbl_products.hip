@@ -343,6 +343,15 @@ int rbl_apply_M_sym_info(rbl_ctx *c, int64_t n_blobs, int i_step, int nrhs, int 
   return RBL_OK;
 }
 
+int rbl_apply_M_sym_kernel(rbl_ctx *c, int64_t n_blobs, int i_step, int nrhs, int wall, char *name, int name_len)
+{
+  if (!c || n_blobs <= 0 || i_step < 1 || nrhs < 1 || nrhs > 2 || !name || name_len < 40)
+    return rbl_fail(c, RBL_ERR_ARG, "apply_M_sym_kernel: bad arguments (name buffer of >= 40 bytes)");
+  int rc = rbl_dev_init(c); if (rc) return rc;
+  rbl_apply_M_sym_kernel_name(n_blobs, c->n_cu, i_step, nrhs, c->sym_tune, wall != 0, name, (size_t)name_len);
+  return RBL_OK;
+}
+
 int rbl_rotne_prager_tensor_dev(rbl_ctx *c, const double *d_r, int64_t n_blobs, int scale_damp,
                                 double *d_out)
 {

@@ -221,9 +221,9 @@ def test_bench_n_rank_code_path_on_one_rank_over_rccl(orc, tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "RCCL inside librbl" in d["config"]["parallelism"]
-    for name, kernel in (("tile_pairs", "k_apply_M_symw<false>"), ("rows", "k_apply_M<false>")):
+    for name, kernel in (("tile_pairs", "k_apply_M_symw<false"), ("rows", "k_apply_M<false>")):   # (the wave-unit kernel, whichever rows per lane)
         part = d["partitionings"][name]
-        assert part["roofline"]["kernel"] == kernel and 0.0 < part["roofline"]["frac"] <= 1.0
+        assert part["roofline"]["kernel"].startswith(kernel) and 0.0 < part["roofline"]["frac"] <= 1.0
         assert part["per_rank"]["kernel_ms"]["max"] > 0.0 and part["per_rank"]["collectives_per_step"] >= 1.0
     t = d["timestep"]
     assert "error" not in t and t["brownian_converged"]["lanczos_0.001"]["gmres_residual_max"] < 1e-8

@@ -116,12 +116,13 @@ def main():
     # branch splits it), column sums rotating through the lanes by v_mov_b32_dpp wave_rol:1 -- summed from the loop header to the
     # block that branches back to it; pair steps per trip = v_rsq_f64 / (2 with the wall term, 1 without)
     for i, l in enumerate(lines):
-        m = re.match(r"^(_ZN\S*?14k_apply_M_symwILb([01])ELi(\d+)EE\S*):", l)
+        m = re.match(r"^(_ZN\S*?14k_apply_M_symwILb([01])ELi(\d+)ELi(\d+)EE\S*):", l)
         if not m:
             continue
         wall = m.group(2) == "1"
+        ni = int(m.group(3))
         end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
-        name_k = "k_apply_M_symw<%s>" % ("true" if wall else "false")
+        name_k = ("k_apply_M_symw<%s>" if ni == 1 else "k_apply_M_symw<%%s,%d>" % ni) % ("true" if wall else "false")
         instances[name_k] = isa_hash(lines, i, end)
         labels, raw = [], []
         for k in range(i + 1, end):
@@ -131,7 +132,7 @@ def main():
                 raw[-1].append(lines[k])
         for b, body in enumerate(raw):
             txt = "\n".join(body)
-            back = re.search(r"s_cbranch_scc0 (\.LBB\d+_\d+)", txt)
+            back = re.search(r"s_cbranch_scc[01] (\.LBB\d+_\d+)", txt)
             if "wave_rol" not in txt or not back or back.group(1) not in labels[:b + 1]:
                 continue
             h = labels.index(back.group(1))
@@ -148,8 +149,8 @@ def main():
             per = {k: c[k] / pairs for k in ("fma", "mul", "add", "trans", "f64", "valu", "valu_other", "lds", "salu")}
             per["dpp_mov"] = sum(v for k, v in ops.items() if k.startswith("v_mov_b32_dpp")) / pairs
             per["flop"] = 2 * per["fma"] + per["mul"] + per["add"] + per["trans"]
-            res[name_k] = {"block": "%s .. %s" % (labels[h], labels[b]), "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
-            break
+            if name_k not in res or res[name_k]["unordered_pairs_per_trip"] < pairs:   # (NI = 2: the one-row sweep of the lane's own second tile comes first)
+                res[name_k] = {"block": "%s .. %s" % (labels[h], labels[b]), "unordered_pairs_per_trip": pairs, "per_unordered_pair": per}
     # the ordered-rows kernel k_apply_M<WALL> (row-sharded multi-GPU split): its sweep is a run of one-pair head blocks (distance,
     # rsq, three ds_read_b128 broadcasts of the staged j blob) followed by ONE body block that finishes those pairs together
     for i, l in enumerate(lines):
