@@ -764,7 +764,7 @@ def dropin_block(dev):
         x = np.random.default_rng(11).standard_normal(nsys)
         rb.apply_saddle(x); rb.apply_PC(x)                     # builds the preconditioner, sizes the workspaces
         reps = 200 if name == "cfg1" else 20 if name == "cfg2" else 5
-        for _ in range(reps):                                    # untimed: the first small calls after cfg 5's 189 GB were freed run ~6x slow
+        for _ in range(reps):                                    # untimed warm-up
             rb.apply_saddle(x)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -1184,6 +1184,13 @@ def main():
     others = None
     dropin = None
     if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
+        try:                                                 # (before cfg 5 maps 189 GB: small host-boundary calls measured after it run several times slower)
+            dropin = dropin_block(dev)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            dropin = {"error": repr(e)}
+            failed = failed or "drop-in part failed"
         try:
             others = other_configs(dev, stream)
         except Exception as e:
@@ -1191,13 +1198,6 @@ def main():
             traceback.print_exc()
             others = {"error": repr(e)}
             failed = failed or "other-configs part failed"
-        try:
-            dropin = dropin_block(dev)
-        except Exception as e:
-            import traceback
-            traceback.print_exc()
-            dropin = {"error": repr(e)}
-            failed = failed or "drop-in part failed"
 
     if rank == 0:
         if tstep is not None:
