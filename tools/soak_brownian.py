@@ -1,5 +1,6 @@
 """Soak test: 3 200 stochastic midpoint steps of 50 x shell_N_162 above a wall through rbl_step_brownian; free device memory
-and host RSS before / after the last 3 000 (no growth: 293 704 MiB and 1 401 MiB on both sides, 6.4 ms per step, round 3)."""
+and host RSS before / after the last 3 000 (no growth: 293 704 MiB and 1 401 MiB on both sides, 6.4 ms per step, round 3; 293 706 / 1 180 MiB, 6.0 ms per step at the end
+of round 4)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch, psutil
