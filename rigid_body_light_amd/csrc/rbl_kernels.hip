@@ -980,11 +980,27 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 // fixed order.  Many short independent load streams instead of one long one per entry.
 constexpr int RG = 16;
 
-__device__ __forceinline__ double wave_sum64(double v)    // sum over the 64 lanes (every lane gets it), fixed order
+template <int CTRL>
+__device__ __forceinline__ double ws_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes (every lane gets it), fixed order: the four 16-lane rows by DPP (a __shfl_xor butterfly on doubles is
+// twelve dependent ds_bpermute round trips), then the rows' sums through four scalar reads
+__device__ __forceinline__ double wave_sum64(double v)
+{
+  v += ws_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += ws_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += ws_dpp<0x141>(v);      // row_half_mirror
+  v += ws_dpp<0x140>(v);      // row_mirror
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 template <bool WALL>
