@@ -1827,6 +1827,8 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // rotating column sums between two pairs (43.5 instead of 49 instructions per pair in free space): 8 100 blobs 71 against 74-77 us,
   // cfg 2's Brownian step -2 to -3 % (tools/bench_cfg2_step.py, interleaved); at 4 860 blobs it is the slower one (38 against 34 us)
   if (nrhs == 1 && i_step == 1 && t >= 120) ni = 2;
+  // two vectors: one row per lane a little longer (8 346 wall blobs 175 against 186 us, 8 100 free 110 against 124; 12 960: 259 / 253)
+  if (nrhs == 2 && t < 176 * i_step) ni = 1;
   if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
   if (nrhs == 1 && tune.ni1 > 0) ni = tune.ni1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles

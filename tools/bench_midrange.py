@@ -15,7 +15,8 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream()
 variants = [("default", {}), ("wave units, 1 row/lane", {"sym_waves": 1, "sym_rows_per_lane": 1}),
             ("wave units, 2 rows/lane", {"sym_waves": 1, "sym_rows_per_lane": 2}),
-            ("round-3 kernel, 1 wave", {"sym_waves": 1, "sym_rows_per_lane": 2, "sym_wave_units": 0}), ("4 waves", {"sym_waves": 4, "sym_rows_per_lane": 2})]
+            ("round-3 kernel, 1 wave", {"sym_waves": 1, "sym_rows_per_lane": 2, "sym_wave_units": 0}), ("4 waves", {"sym_waves": 4, "sym_rows_per_lane": 2}),
+            ("pair: 2 rows/lane", {"sym2_rows_per_lane": 2}), ("pair: 1 row/lane", {"sym2_rows_per_lane": 1})]
 sizes = [(50, 162, False), (80, 162, False)] + [(nb, 642, True) for nb in (13, 16, 19, 25, 37, 51)]
 if os.environ.get("SIZES"):
     sizes = [tuple(int(x) for x in t.split("x")[:2]) + (t.split("x")[2] == "w",) for t in os.environ["SIZES"].split(",")]
@@ -34,7 +35,7 @@ for nb, nblb, wall in sizes:
         ctx.apply_M(F.data_ptr(), r.data_ptr(), N, 0, N, U.data_ptr())
     ctx.sync_check()
     for name, opts in variants:
-        for k in ("sym_waves", "sym_chunk", "sym_rows_per_lane"):
+        for k in ("sym_waves", "sym_chunk", "sym_rows_per_lane", "sym2_rows_per_lane"):
             ctx.set_option(k, 0)
         ctx.set_option("sym_wave_units", 1)
         for k, v in opts.items():
