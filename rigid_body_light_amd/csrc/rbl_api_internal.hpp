@@ -57,6 +57,7 @@ int bf_build(rbl_ctx *c);
 int blk_prepare(rbl_ctx *c, int b0, int b1);
 int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch, int mode, bool allow_f32 = true);
 int blk_trmv(rbl_ctx *c, int b0, int nbo, const double *in, double *out);
+bool pc_can_fold(rbl_ctx *c);
 int blk_trmv_multi(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv, int64_t pitch);
 
 // ---- rbl_roots.hip ------------------------------------------------------------------------------------------------

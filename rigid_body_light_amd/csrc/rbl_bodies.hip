@@ -585,8 +585,9 @@ static int pc_block_apply_local(rbl_ctx *c, const double *d_in, double *d_out, b
       if ((rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * (size_t)n3))) return rc;
       if ((rc = rbl_launch_pc_bodyframe(c->stream, T, T + (size_t)(m * m), T + (size_t)(m * m) + 6 * (size_t)m, (const double *)c->d_cfg.p,
                                         (const double *)c->d_XQ.p + 3 * (size_t)S.N_bod, m, b0, nbo, d_in, n3, c->pc_fsign, d_out, ktl,
-                                        (double *)c->d_blkTmp.p, c->shared_gemm ? 1 : 0)))
+                                        (double *)c->d_blkTmp.p, c->shared_gemm ? 1 : 0, c->pc_fold.part ? &c->pc_fold : nullptr)))
         return rbl_fail(c, rc, "body-frame preconditioner launch failed");
+      c->pc_fold = RblNormFold();
       if (ktl) c->ktl_of = d_out;
     }
     return RBL_OK;
@@ -617,10 +618,20 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   return comm_allgather_bodies2(c, d_out, 0, 3 * (int64_t)c->S.N_blb, d_out, n3, 6);
 }
 
+// may the next rbl_apply_PC_dev be handed an un-normalised Arnoldi vector (rbl_ctx::pc_fold)?  Only the free-space body-frame tables
+// in their matrix-vector form on one GPU take it; the preconditioner must have been built (the first application builds it)
+bool pc_can_fold(rbl_ctx *c)
+{
+  const RblBodyState &S = c->S;
+  return c->gmres_fold_norm && c->fused_krylov && S.block_pc && c->dev_pc_valid && !comm_on(c) && bf_on(c) && c->bf_tables &&
+         rbl_pc_bodyframe_folds(S.N_bod, c->shared_gemm ? 1 : 0);
+}
+
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
 {
   int rc = sync_bodies(c); if (rc) return rc;
   const RblBodyState &S = c->S;
+  if (c->pc_fold.part && !pc_can_fold(c)) { c->pc_fold = RblNormFold(); return rbl_fail(c, RBL_ERR_ARG, "apply_PC: this preconditioner does not normalise its input"); }
   if (S.block_pc) {
     if (!c->dev_pc_valid) {
       if ((rc = pc_block_build(c))) return rc;

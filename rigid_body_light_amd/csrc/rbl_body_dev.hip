@@ -426,6 +426,22 @@ __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], dou
   __syncthreads();
 }
 
+// |w| and 1 / |w| (0 for a vanishing vector, like k_lz_c) from the partial sums of |w|^2: every wave of every workgroup adds them in
+// the same order (lanes strided, 16-lane rows by DPP, the four rows by scalar reads) -- one value everywhere, no barrier
+__device__ __forceinline__ void bf_fold_norm(const RblNormFold &nf, int lane, double &nrm, double &inv)
+{
+  double a = 0.0;
+  for (int i = lane; i < nf.np; i += 64) a += nf.part[i];
+  a += bf_dpp<0xB1>(a); a += bf_dpp<0x4E>(a); a += bf_dpp<0x141>(a); a += bf_dpp<0x140>(a);
+  const int lo = __double2loint(a), hi = __double2hiint(a);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  nrm = sqrt((r0 + r1) + (r2 + r3));
+  inv = nrm > 1e-300 ? 1.0 / nrm : 0.0;
+}
+
 // y1' = M_body^-1 R^T slip, 128 outputs per workgroup: a body's product spread over ceil(n / 128) CUs (one workgroup per
 // body pulled the whole 1.9 MB table through ONE CU: 14 of that kernel's 35 us at n = 486).  Four waves split the sum
 // (interleaved, fixed-order LDS reduction), a lane owns TWO adjacent outputs and reads them with one 16-byte load: the
@@ -433,8 +449,10 @@ __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], dou
 constexpr int BFG = 128;                             // outputs per workgroup
 constexpr int BFW = 4;                               // waves per workgroup
 template <bool PAIR>
+// nf (RblNormFold): `in` is an un-normalised Arnoldi vector -- the product is linear, so the OUTPUT is scaled by 1 / |w| (the sum
+// of the partials runs beside the main loop), and the first row block of every body stores its blobs of w / |w|
 __global__ __launch_bounds__(64 * BFW) void k_bf_gemv(const double *__restrict__ Minv, const double *__restrict__ Q, long n,
-                                                      int b_begin, const double *__restrict__ in, double *__restrict__ y1)
+                                                      int b_begin, const double *__restrict__ in, double *__restrict__ y1, RblNormFold nf)
 {
   extern __shared__ double sv[];                     // s'[n] | partial sums [BFW][128]
   double *red = sv + n;
@@ -473,12 +491,19 @@ __global__ __launch_bounds__(64 * BFW) void k_bf_gemv(const double *__restrict__
       a1 = __builtin_fma(m1[u], s, a1);
     }
   }
+  double nrm = 1.0, inv = 1.0;
+  if (nf.part) {
+    bf_fold_norm(nf, lane, nrm, inv);
+    if (blockIdx.x == 0)
+      for (long k = t; k < n; k += 64 * BFW) nf.vnext[(size_t)b * (size_t)n + k] = inv * slip[k];
+  }
   red[(w * 64 + lane) * 2] = a0; red[(w * 64 + lane) * 2 + 1] = a1;
   __syncthreads();
   if (w == 0) {
     double r0 = red[lane * 2], r1 = red[lane * 2 + 1];
 #pragma unroll
     for (int ww = 1; ww < BFW; ++ww) { r0 += red[(ww * 64 + lane) * 2]; r1 += red[(ww * 64 + lane) * 2 + 1]; }
+    r0 *= inv; r1 *= inv;
     double *o = y1 + (size_t)b * (size_t)n;
     if (ec == e0) { if (e0 < n) o[e0] = r0; if (e0 + 1 < n) o[e0 + 1] = r1; }
     else if (e0 < n) o[e0] = (e0 == ec + 1) ? r1 : r0;      // last odd entry: the clamped pair (n - 2, n - 1) holds it second
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(64 * BFW) void k_bf_gemv(const double *__restrict__
 __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__ y1, const double *__restrict__ MK,
                                                       const double *__restrict__ NL, const double *__restrict__ cfg,
                                                       const double *__restrict__ Q, long n, int b_begin, const double *in,
-                                                      long n3, double fsign, double *out, double *__restrict__ ktl)
+                                                      long n3, double fsign, double *out, double *__restrict__ ktl, RblNormFold nf)
 {
   extern __shared__ double sm[];                     // Lambda'[n] | y1'[n]
   __shared__ double red[BFT / 64][6], f6[6], us[6];
@@ -496,6 +521,12 @@ __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__
   const int b = b_begin + blockIdx.x, t = threadIdx.x;
   double R[9];
   quat_rot(Q + 4 * (size_t)b, R);
+  double nrm = 1.0, inv = 1.0;                       // RblNormFold: y1 arrives scaled (k_bf_gemv), the body rows of `in` are scaled here
+  if (nf.part) {
+    bf_fold_norm(nf, t & 63, nrm, inv);
+    if (t < 6) nf.vnext[n3 + 6 * (size_t)b + t] = inv * in[n3 + 6 * (size_t)b + t];
+    if (t == 0 && blockIdx.x == 0) *nf.hout = nrm;
+  }
   if (t < n) yv[t] = y1[(size_t)b * (size_t)n + t];  // y1' = M_body^-1 R^T slip (k_bf_gemv)
   __syncthreads();
   double f[6] = {0, 0, 0, 0, 0, 0};
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(BFT) void k_pc_bodyframe(const double *__restrict__
     const double *F = in + n3 + 6 * (size_t)b;
     double Fb[6], y[6], u[6];
     for (int h = 0; h < 2; ++h)
-      for (int d = 0; d < 3; ++d) Fb[3 * h + d] = R[d] * F[3 * h] + R[3 + d] * F[3 * h + 1] + R[6 + d] * F[3 * h + 2];   // R^T
+      for (int d = 0; d < 3; ++d) Fb[3 * h + d] = inv * (R[d] * F[3 * h] + R[3 + d] * F[3 * h + 1] + R[6 + d] * F[3 * h + 2]);   // R^T
     for (int p = 0; p < 6; ++p) {
       double v = fsign * Fb[p] - f6[p];
       for (int q = 0; q < p; ++q) v -= NL[6 * p + q] * y[q];
@@ -746,10 +777,12 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
 // d_y1: scratch, n doubles per body (laid out like the blob vector)
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl, double *d_y1, int gemm)
+                            double *d_out, double *d_ktl, double *d_y1, int gemm, const RblNormFold *fold)
 {
   if (n > BFT || !d_y1) return RBL_ERR_SIZE;
   if (b_count <= 0) return RBL_OK;
+  const RblNormFold nf = fold ? *fold : RblNormFold();
+  if (nf.part && (b_begin != 0 || !rbl_pc_bodyframe_folds(b_count, gemm))) return RBL_ERR_ARG;   // (all bodies, matrix-vector form: see there)
   // y1' = M_body^-1 R^T slip for every body: ONE table, many vectors -- a matrix-matrix product on the fp64 matrix cores
   // (rbl_launch_shared_gemm; round 4) or, RBL_OPT_SHARED_GEMM = 0, a matrix-vector product per body that re-reads the table
   // (measured, tools/bench_shared_gemm.py: 14.9 -> 16.0 us at 50 bodies of 162 blobs, 28.7 -> 16.1 at 200: the full table is twice the
@@ -765,15 +798,18 @@ int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *
     const dim3 grid((unsigned)((n + BFG - 1) / BFG), nb);
     const size_t lds = sizeof(double) * ((size_t)n + 2 * 64 * BFW);
     if (n % 2 == 0 && (reinterpret_cast<uintptr_t>(d_Minv) & 15) == 0)     // rows start 16-byte aligned: one load per output pair
-      hipLaunchKernelGGL(k_bf_gemv<true>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1);
+      hipLaunchKernelGGL(k_bf_gemv<true>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1, nf);
     else
-      hipLaunchKernelGGL(k_bf_gemv<false>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1);
+      hipLaunchKernelGGL(k_bf_gemv<false>, grid, dim3(64 * BFW), lds, st, d_Minv, d_Q, (long)n, b_begin + q0, d_in, d_y1, nf);
   }
   const int th = (int)(n <= 64 ? 64 : ((n + 63) / 64) * 64);
   hipLaunchKernelGGL(k_pc_bodyframe, dim3(b_count), dim3(th), sizeof(double) * 2 * (size_t)n, st, (const double *)d_y1, d_MK, d_NL,
-                     d_cfg, d_Q, (long)n, b_begin, d_in, (long)n3, fsign, d_out, d_ktl);
+                     d_cfg, d_Q, (long)n, b_begin, d_in, (long)n3, fsign, d_out, d_ktl, nf);
   return RBL_OK;
 }
+
+// the one-launch-pair form above can take an un-normalised input (RblNormFold) when it runs the matrix-vector kernel over all bodies
+bool rbl_pc_bodyframe_folds(int b_count, int gemm) { return b_count > 0 && b_count <= 65535 && !(gemm && b_count >= 64); }
 
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U)
 {

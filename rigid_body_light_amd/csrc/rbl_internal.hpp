@@ -71,6 +71,15 @@ struct RblSaddleFuse {
   double *dotPart = nullptr;
 };
 
+// normalisation of an Arnoldi vector folded into the (linear) preconditioner that consumes it: the kernels take w, the partial sums
+// of |w|^2 its second Gram-Schmidt pass left, apply P^-1 (w / |w|) and store w / |w| and |w| on the side (GMRES, free-space tables)
+struct RblNormFold {
+  const double *part = nullptr;    // np partial sums (nullptr: off)
+  int np = 0;
+  double *vnext = nullptr;         // w / |w|  (3 N + 6 N_bod)
+  double *hout = nullptr;          // |w|
+};
+
 struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
   int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
@@ -162,6 +171,8 @@ struct rbl_ctx {
   int comm_split = 0;                               // RBL_OPT_COMM_SPLIT: 0 unordered tile pairs + all-reduce(U), 1 rows by body index + all-gather (north_star)
   std::vector<int64_t> comm_offs, comm_cnts;        // scratch of the all-gather calls
   bool fuse_done = false; // the last full product honoured sym_tune.fuse (rbl_apply_saddle_dev)
+  RblNormFold pc_fold;              // transient, GMRES -> the next rbl_apply_PC_dev (body-frame tables only; see pc_can_fold)
+  bool gmres_fold_norm = true;      // ... unless switched off with RBL_OPT_FUSED_KRYLOV = 0
   const double *fuse_dotV = nullptr; double *fuse_dotPart = nullptr;   // GMRES -> rbl_apply_saddle_dev: also leave the partials of V^T w ...
   int fuse_dotK = 0, fuse_dots_np = 0;                                  // ... for dotK basis vectors; answer: partials per vector (0 = not done)
   bool no_damp = false;   // transient: matvec kernels skip the damping B (preconditioned square root)
@@ -291,8 +302,10 @@ void rbl_launch_dot2(hipStream_t st, const double *x, const double *y, const dou
 int rbl_gmres_max_vectors(void);
 size_t rbl_gmres_part_doubles(void);
 int rbl_gmres_p1_capacity(void);          // partial sums per vector the first Gram-Schmidt pass may be handed
+// skip_norm: leave out the normalisation launch; *norm_part / *norm_np then say where the partial sums of |w|^2 lie (RblNormFold)
 void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
-                             double *part, int fused_np = 0);
+                             double *part, int fused_np = 0, bool skip_norm = false, const double **norm_part = nullptr,
+                             int *norm_np = nullptr);
 size_t rbl_lanczos_part_doubles(void);
 void rbl_launch_lanczos_init(hipStream_t st, int64_t n, const double *d_W, double *wnorm_out, double *V0,
                              double *part, int nvec = 1, int64_t scal_stride = 0);
@@ -345,7 +358,8 @@ void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cf
                           double *d_NL, unsigned *d_err);
 int rbl_launch_pc_bodyframe(hipStream_t st, const double *d_Minv, const double *d_MK, const double *d_NL, const double *d_cfg,
                             const double *d_Q, int64_t n, int b_begin, int b_count, const double *d_in, int64_t n3, double fsign,
-                            double *d_out, double *d_ktl, double *d_y1, int gemm);
+                            double *d_out, double *d_ktl, double *d_y1, int gemm, const RblNormFold *fold = nullptr);
+bool rbl_pc_bodyframe_folds(int b_count, int gemm);
 void rbl_launch_unit_U(hipStream_t st, int N_bod, int c, double *d_U);
 // two-level factor of the preconditioned Lanczos root (rbl_body_dev.hip: k_tl_*)
 void rbl_launch_tl_unit(hipStream_t st, int64_t n3, double *d_out);

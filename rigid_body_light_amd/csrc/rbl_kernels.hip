@@ -1828,7 +1828,7 @@ static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step
   // cfg 2's Brownian step -2 to -3 % (tools/bench_cfg2_step.py, interleaved); at 4 860 blobs it is the slower one (38 against 34 us)
   if (nrhs == 1 && i_step == 1 && t >= 120) ni = 2;
   // two vectors: one row per lane a little longer (8 346 wall blobs 175 against 186 us, 8 100 free 110 against 124; 12 960: 259 / 253)
-  if (nrhs == 2 && t < 176 * i_step) ni = 1;
+  if (nrhs == 2 && t < 176 * i_step && !tune.relaxed) ni = 1;   // (the relaxed sweep carries the two rows of a lane: it keeps NI = 2)
   if (nrhs == 2 && tune.ni2 > 0) ni = tune.ni2;
   if (nrhs == 1 && tune.ni1 > 0) ni = tune.ni1;
   const int tsup = (t + ni - 1) / ni;                    // row super-tiles
@@ -2185,7 +2185,7 @@ size_t rbl_gmres_part_doubles(void) { return (size_t)GM_MAXK * AR_P1 + (size_t)G
 // one Arnoldi step after w = A P^-1 v_j: classical Gram-Schmidt twice against V[0..k), then Hcol[k] = |w| and
 // vnext = w / |w|  (four launches, see k_arnoldi_upd)
 void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, double *w, double *Hcol, double *vnext,
-                             double *part, int fused_np)
+                             double *part, int fused_np, bool skip_norm, const double **norm_part, int *norm_np)
 {
   if (k <= 0 || n <= 0) return;
   int nb = (int)std::min<int64_t>(128, (n + 1023) / 1024);
@@ -2200,6 +2200,9 @@ void rbl_launch_arnoldi_step(hipStream_t st, const double *V, int64_t n, int k, 
                      0L, 0L, 0L);
   hipLaunchKernelGGL(k_arnoldi_upd<true>, dim3(g), dim3(256), 0, st, V, (long)n, k, w, (const double *)p2, g, Hcol, pn, (long)n, 0L, 0L,
                      0L, 0L);
+  if (norm_part) *norm_part = pn;
+  if (norm_np) *norm_np = g;
+  if (skip_norm) return;                               // (the consumer normalises: RblNormFold)
   hipLaunchKernelGGL(k_lz_c, dim3(lz_grid(n)), dim3(256), 0, st, (long)n, (const double *)w, (const double *)pn, g, Hcol + k,
                      vnext, 0L, 0L, 0L, (const double *)nullptr, 0L, 0L);
 }

@@ -45,10 +45,10 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
     return comm_allgather_rows(c, d_out, bounds.data(), 3);
   }
   if (full && comm_on(c)) {   // multi-GPU: this rank's tile pairs, then the sum over the ranks
-    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, c->sym_tune)))) return rc;
     RblSymTune tune = c->sym_tune;
     tune.fuse = RblSaddleFuse();                      // (a shard's sum is partial: the epilogue waits for the all-reduce)
     if (c->force_relaxed) tune.relaxed = 1;
+    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, tune)))) return rc;   // (the geometry follows the transient switches)
     {
       RblPhase ph(c, RBL_T_PRODUCT);
       rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
@@ -58,9 +58,9 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
   }
   RblPhase ph(c, RBL_T_PRODUCT);
   if (sym) {
-    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, c->sym_tune)))) return rc;
     RblSymTune tune = c->sym_tune;
     if (c->force_relaxed) tune.relaxed = 1;
+    if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, tune)))) return rc;   // (the geometry follows the transient switches)
     rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
                            c->d_err, 1, tune);
     c->fuse_done = tune.fuse.lever != nullptr;        // the slab reduction also wrote the saddle epilogue (rbl_apply_saddle_dev)
@@ -93,9 +93,9 @@ int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double
       return RBL_OK;
     }
     for (; k + 2 <= nrhs; k += 2) {
-      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, c->sym_tune)))) return rc;
       RblSymTune tune = c->sym_tune;
       if (c->force_relaxed) tune.relaxed = 1;
+      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, tune)))) return rc;   // (the geometry follows the transient switches)
       {
         RblPhase ph(c, RBL_T_PRODUCT);
         rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
@@ -112,9 +112,9 @@ int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double
     int k = 0;
     const bool sym2 = c->tune_variant != 1 && rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune) <= c->sym_workspace_budget;
     for (; sym2 && k + 2 <= nrhs; k += 2) {
-      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, c->sym_tune)))) return rc;
       RblSymTune tune = c->sym_tune;
       if (c->force_relaxed) tune.relaxed = 1;
+      if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, tune)))) return rc;   // (the geometry follows the transient switches)
       rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
                              d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
     }
@@ -322,9 +322,9 @@ int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_
   if ((rc = rbl_dev_init(c))) return rc;
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_dev: need n_blobs > 0 and 0 <= i_first < i_step");
-  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, 1, c->sym_tune)))) return rc;
   RblSymTune tune = c->sym_tune;
   if (c->force_relaxed) tune.relaxed = 1;
+  if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, 1, tune)))) return rc;   // (the geometry follows the transient switches)
   rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
                          i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, tune);
   return RBL_OK;

@@ -170,12 +170,21 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   if (overlap_ok && !c->ev_check) RBL_HIP(c, hipEventCreateWithFlags(&c->ev_check, hipEventDisableTiming));
   if (overlap_ok && !c->h_pin) RBL_HIP(c, hipHostMalloc(&c->h_pin, (size_t)1 << 20, hipHostMallocDefault));
   bool z_ready = false;                                // z = P^-1 V_j is already enqueued (by the previous iteration's test)
+  // Normalisation folded into the next preconditioner (launch-bound systems whose preconditioner takes it, pc_can_fold): the Arnoldi
+  // step leaves w and the partial sums of |w|^2; P^-1 is linear, so the kernels that apply it to V_{j+1} = w / |w| read w, scale by
+  // 1 / |w| themselves and store V_{j+1} and H[j+1][j] on the side -- one launch fewer per iteration.  A convergence test that
+  // falls between the two gets |w| from the same partial sums on the host.  The last possible iteration normalises as before.
+  RblNormFold pend;                                    // set: V_j and H[j][j-1] are still to be written, from w
+  auto apply_pc = [&](int jv) -> int {                 // z = P^-1 V_jv
+    c->ktl_arm = true;                                 // the PC's K^T Lambda by-product feeds the product that follows
+    const double *src = V + (size_t)jv * nsys;
+    if (pend.part) { c->pc_fold = pend; src = w; pend = RblNormFold(); }
+    const int r = rbl_apply_PC_dev(c, src, z);
+    if (r) c->ktl_arm = false;
+    return r;
+  };
   for (int j = 0; j < m; ++j) {
-    const double *vj = V + (size_t)j * nsys;
-    if (!z_ready) {
-      c->ktl_arm = true;                               // the PC's K^T Lambda by-product feeds the product that follows
-      if ((rc = rbl_apply_PC_dev(c, vj, z))) { c->ktl_arm = false; return rc; }
-    }
+    if (!z_ready && (rc = apply_pc(j))) return rc;
     z_ready = false;
     // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
     // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
@@ -189,19 +198,33 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     if (rc) return rc;
     double *Hcol = H + (size_t)j * ldh;
     // classical Gram-Schmidt twice, H[j+1][j] = |w|, V_{j+1} = w / |w|: four launches (three when the product left the first sums)
-    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part, fused_np);
+    const bool fold = j + 1 < m && pc_can_fold(c);
+    const double *npart = nullptr; int nnp = 0;
+    rbl_launch_arnoldi_step(c->stream, V, nsys, j + 1, w, Hcol, V + (size_t)(j + 1) * nsys, part, fused_np, fold, &npart, &nnp);
+    if (fold) { pend.part = npart; pend.np = nnp; pend.vnext = V + (size_t)(j + 1) * nsys; pend.hout = Hcol + (j + 1); }
     used = j + 1;
     if (rtol > 0.0 && (used >= next_check || used == m)) {
       const size_t hb = sizeof(double) * (1 + (size_t)ldh * used);
-      if (overlap_ok && used < m) {
+      const size_t pb = fold ? sizeof(double) * (size_t)nnp : 0;       // H[j+1][j] is not on the device yet: its partial sums come along
+      std::vector<double> hp((size_t)(fold ? nnp : 0));
+      if (overlap_ok && used < m && hb + pb <= ((size_t)1 << 20)) {
         RBL_HIP(c, hipMemcpyAsync(c->h_pin, d_beta, hb, hipMemcpyDeviceToHost, c->stream));
+        if (fold) RBL_HIP(c, hipMemcpyAsync((char *)c->h_pin + hb, npart, pb, hipMemcpyDeviceToHost, c->stream));
         RBL_HIP(c, hipEventRecord(c->ev_check, c->stream));
-        c->ktl_arm = true;                             // iteration j + 1's preconditioner, ahead of the host's wait
-        if ((rc = rbl_apply_PC_dev(c, V + (size_t)(j + 1) * nsys, z))) { c->ktl_arm = false; return rc; }
+        if ((rc = apply_pc(j + 1))) return rc;         // iteration j + 1's preconditioner, ahead of the host's wait
         z_ready = true;
         RBL_HIP(c, hipEventSynchronize(c->ev_check));
         std::memcpy(Hh.data(), c->h_pin, hb);
-      } else if ((rc = read_back(c, Hh.data(), d_beta, hb))) return rc;
+        if (fold) std::memcpy(hp.data(), (const char *)c->h_pin + hb, pb);
+      } else {
+        if (fold && (rc = read_back(c, hp.data(), npart, pb))) return rc;
+        if ((rc = read_back(c, Hh.data(), d_beta, hb))) return rc;
+      }
+      if (fold) {
+        double s2 = 0.0;
+        for (double v : hp) s2 += v;
+        Hh[1 + (size_t)j * ldh + (size_t)(j + 1)] = std::sqrt(s2);
+      }
       // the test may have become true anywhere since the last look: take the first k that passes
       int hit = 0;
       double r_before = resid;
