@@ -452,8 +452,9 @@ enum {
   RBL_OPT_COMM_SPLIT = 24,         /* [0] multi-GPU contexts: 0 unordered tile pairs + all-reduce(U), 1 rows by body index +
                                       all-gather(positions, U) -- see "multi-GPU" above                                             */
   RBL_OPT_FUSED_KRYLOV = 25,       /* [1] launch-bound systems: the product's slab reduction also writes the saddle tail and the partial
-                                      sums of the Arnoldi step's first Gram-Schmidt pass (two launches fewer per GMRES iteration);
-                                      0: one kernel per operation                                                                  */
+                                      sums of the Arnoldi step's first Gram-Schmidt pass, and (free-space body-frame preconditioner) the
+                                      normalisation of the new basis vector is done by the preconditioner kernels that consume it
+                                      (three launches fewer per GMRES iteration); 0: one kernel per operation                       */
   RBL_OPT_RELAXED_GAP_RATIO = 26,  /* [0] relaxed product: a far tile pair is swept in single precision when the extents of its boxes,
                                       d_I + 2 d_J, are at most this many times their gap (0 = the library's default); smaller = fewer
                                       pairs relaxed, smaller product error (6e-8 (1 + ratio) of a separation)                        */
