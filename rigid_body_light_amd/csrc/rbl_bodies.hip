@@ -602,7 +602,8 @@ static int pc_block_apply_local(rbl_ctx *c, const double *d_in, double *d_out, b
       ktl = (double *)c->d_ktl.p;
     }
     rbl_launch_pc_block_tail(c->stream, lev, w1, (const double *)c->d_pcMK.p, n3, (const double *)c->d_NL.p, d_in + n3, S.N_blb,
-                             b0, nbo, c->pc_fsign, d_out + n3, d_out, ktl);
+                             b0, nbo, c->pc_fsign, d_out + n3, d_out, ktl, c->pc_fold.part ? &c->pc_fold : nullptr, d_in);
+    c->pc_fold = RblNormFold();
     if (ktl) c->ktl_of = d_out;
   }
   (void)f6; (void)off;
@@ -618,13 +619,15 @@ static int pc_block_apply(rbl_ctx *c, const double *d_in, double *d_out)
   return comm_allgather_bodies2(c, d_out, 0, 3 * (int64_t)c->S.N_blb, d_out, n3, 6);
 }
 
-// may the next rbl_apply_PC_dev be handed an un-normalised Arnoldi vector (rbl_ctx::pc_fold)?  Only the free-space body-frame tables
-// in their matrix-vector form on one GPU take it; the preconditioner must have been built (the first application builds it)
+// may the next rbl_apply_PC_dev be handed an un-normalised Arnoldi vector (rbl_ctx::pc_fold)?  On one GPU, once the preconditioner
+// has been built (its first application builds it): the diagonal one, the per-body factors' tail kernel, and the free-space
+// body-frame tables in their matrix-vector form
 bool pc_can_fold(rbl_ctx *c)
 {
   const RblBodyState &S = c->S;
-  return c->gmres_fold_norm && c->fused_krylov && S.block_pc && c->dev_pc_valid && !comm_on(c) && bf_on(c) && c->bf_tables &&
-         rbl_pc_bodyframe_folds(S.N_bod, c->shared_gemm ? 1 : 0);
+  if (!(c->gmres_fold_norm && c->fused_krylov && c->dev_pc_valid && !comm_on(c) && S.N_bod <= 65535)) return false;
+  if (S.block_pc && bf_on(c) && c->bf_tables) return rbl_pc_bodyframe_folds(S.N_bod, c->shared_gemm ? 1 : 0);
+  return true;
 }
 
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
@@ -649,7 +652,8 @@ int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
     c->dev_pc_valid = true;
   }
   rbl_launch_pc_diag_apply(c->stream, (const double *)c->d_lever.p, (const double *)c->d_invM2.p, (const double *)c->d_NL.p,
-                           S.N_blb, S.N_bod, d_in, d_out, c->pc_fsign);
+                           S.N_blb, S.N_bod, d_in, d_out, c->pc_fsign, c->pc_fold.part ? &c->pc_fold : nullptr);
+  c->pc_fold = RblNormFold();
   return RBL_OK;
 }
 

@@ -80,6 +80,29 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double (*s)[BT], i
   __syncthreads();
 }
 
+template <int CTRL>
+__device__ __forceinline__ double nf_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// RblNormFold: |w| and 1 / |w| (0 for a vanishing vector, like k_lz_c) from the partial sums of |w|^2: every wave of every workgroup
+// adds them in the same order (lanes strided, 16-lane rows by DPP, the four rows by scalar reads) -- one value everywhere, no barrier
+__device__ __forceinline__ void bf_fold_norm(const RblNormFold &nf, int lane, double &nrm, double &inv)
+{
+  double a = 0.0;
+  for (int i = lane; i < nf.np; i += 64) a += nf.part[i];
+  a += nf_dpp<0xB1>(a); a += nf_dpp<0x4E>(a); a += nf_dpp<0x141>(a); a += nf_dpp<0x140>(a);
+  const int lo = __double2loint(a), hi = __double2hiint(a);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  nrm = sqrt((r0 + r1) + (r2 + r3));
+  inv = nrm > 1e-300 ? 1.0 / nrm : 0.0;
+}
+
 // F_b = sum lambda_k, T_b = sum l_k x lambda_k   (:410); one workgroup per body
 __global__ __launch_bounds__(BT) void k_KT_x_Lam(const double *__restrict__ lever,
                                                  const double *__restrict__ lam, int N_blb,
@@ -167,18 +190,24 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
                                                       const double *__restrict__ invM2,
                                                       const double *__restrict__ NL, int N_blb,
                                                       long n3, const double *__restrict__ in,
-                                                      double *__restrict__ out, double fsign)
+                                                      double *__restrict__ out, double fsign, RblNormFold nf)
 {
   __shared__ double s[6][BT];
   __shared__ double Ush[6];
   const int b = blockIdx.x, t = threadIdx.x;
   const double *slip = in, *F = in + n3;
+  double nrm = 1.0, inv = 1.0;                           // RblNormFold: `in` is an un-normalised Arnoldi vector
+  if (nf.part) {
+    bf_fold_norm(nf, t & 63, nrm, inv);
+    if (t < 6) nf.vnext[n3 + 6 * (size_t)b + t] = inv * F[6 * (size_t)b + t];
+    if (t == 0 && b == 0) *nf.hout = nrm;
+  }
   double f[6] = {0, 0, 0, 0, 0, 0};
   for (int k = t; k < N_blb; k += BT) {  // K^T (invM slip)
     const size_t i = (size_t)b * N_blb + k;
     const double *l = lever + 3 * i;
-    const double v0 = invM2[2 * i] * slip[3 * i], v1 = invM2[2 * i] * slip[3 * i + 1],
-                 v2 = invM2[2 * i + 1] * slip[3 * i + 2];
+    const double v0 = invM2[2 * i] * (inv * slip[3 * i]), v1 = invM2[2 * i] * (inv * slip[3 * i + 1]),
+                 v2 = invM2[2 * i + 1] * (inv * slip[3 * i + 2]);
     f[0] += v0; f[1] += v1; f[2] += v2;
     f[3] += l[1] * v2 - l[2] * v1;
     f[4] += l[2] * v0 - l[0] * v2;
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
     const double *L = NL + 36 * (size_t)b;
     double y[6], u[6];
     for (int p = 0; p < 6; ++p) {
-      double v = fsign * F[6 * b + p] - f[p];
+      double v = fsign * (inv * F[6 * b + p]) - f[p];
       for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
       y[p] = v / L[6 * p + p];
     }
@@ -205,9 +234,11 @@ __global__ __launch_bounds__(BT) void k_pc_diag_apply(const double *__restrict__
   for (int k = t; k < N_blb; k += BT) {  // Lambda = invM (slip + K U)   (:610, M_scale = 1)
     const size_t i = (size_t)b * N_blb + k;
     const double *l = lever + 3 * i;
-    out[3 * i] = invM2[2 * i] * (slip[3 * i] + u0 + l[2] * o1 - l[1] * o2);
-    out[3 * i + 1] = invM2[2 * i] * (slip[3 * i + 1] + u1 + l[0] * o2 - l[2] * o0);
-    out[3 * i + 2] = invM2[2 * i + 1] * (slip[3 * i + 2] + u2 + l[1] * o0 - l[0] * o1);
+    const double s0 = inv * slip[3 * i], s1 = inv * slip[3 * i + 1], s2 = inv * slip[3 * i + 2];
+    if (nf.part) { nf.vnext[3 * i] = s0; nf.vnext[3 * i + 1] = s1; nf.vnext[3 * i + 2] = s2; }
+    out[3 * i] = invM2[2 * i] * (s0 + u0 + l[2] * o1 - l[1] * o2);
+    out[3 * i + 1] = invM2[2 * i] * (s1 + u1 + l[0] * o2 - l[2] * o0);
+    out[3 * i + 2] = invM2[2 * i + 1] * (s2 + u2 + l[1] * o0 - l[0] * o1);
   }
 }
 
@@ -246,11 +277,20 @@ __global__ __launch_bounds__(BT) void k_pc_block_tail(const double *__restrict__
                                                       const double *__restrict__ MK, long stride,
                                                       const double *__restrict__ NL, const double *__restrict__ F, int N_blb,
                                                       int b_begin, double fsign, double *__restrict__ U,
-                                                      double *__restrict__ lam, double *__restrict__ ktl)
+                                                      double *__restrict__ lam, double *__restrict__ ktl, RblNormFold nf,
+                                                      const double *__restrict__ win)
 {
   __shared__ double s[6][BT];
   __shared__ double us[6];
   const int b = b_begin + blockIdx.x, t = threadIdx.x;
+  // RblNormFold: y1 = invM w for an un-normalised Arnoldi vector w (win: its blob part, F: its body part) -- every use of y1 and F
+  // below is linear, so they are scaled by 1 / |w| where they are read, and w / |w| goes to nf.vnext
+  double nrm = 1.0, inv = 1.0;
+  if (nf.part) {
+    bf_fold_norm(nf, t & 63, nrm, inv);
+    if (t < 6) nf.vnext[3 * (size_t)gridDim.x * N_blb + 6 * (size_t)b + t] = inv * F[6 * (size_t)b + t];   // (all bodies: b_begin = 0)
+    if (t == 0 && b == 0) *nf.hout = nrm;
+  }
   double f[6] = {0, 0, 0, 0, 0, 0};
   for (int k = t; k < N_blb; k += BT) {
     const size_t idx = 3 * ((size_t)b * N_blb + k);
@@ -265,7 +305,7 @@ __global__ __launch_bounds__(BT) void k_pc_block_tail(const double *__restrict__
     const double *L = NL + 36 * (size_t)b;
     double y[6], u[6];
     for (int p = 0; p < 6; ++p) {
-      double v = fsign * F[6 * b + p] - f[p];
+      double v = inv * (fsign * F[6 * b + p] - f[p]);
       for (int q = 0; q < p; ++q) v -= L[6 * p + q] * y[q];
       y[p] = v / L[6 * p + p];
     }
@@ -283,7 +323,8 @@ __global__ __launch_bounds__(BT) void k_pc_block_tail(const double *__restrict__
     double v[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      double acc = y1[idx + d];
+      if (nf.part) nf.vnext[idx + d] = inv * win[idx + d];
+      double acc = inv * y1[idx + d];
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc = __builtin_fma(MK[(size_t)c * stride + idx + d], us[c], acc);
       v[d] = acc;
@@ -424,22 +465,6 @@ __device__ __forceinline__ void bf_reduce6(double (&v)[6], double (*red)[6], dou
     res[t] = a;
   }
   __syncthreads();
-}
-
-// |w| and 1 / |w| (0 for a vanishing vector, like k_lz_c) from the partial sums of |w|^2: every wave of every workgroup adds them in
-// the same order (lanes strided, 16-lane rows by DPP, the four rows by scalar reads) -- one value everywhere, no barrier
-__device__ __forceinline__ void bf_fold_norm(const RblNormFold &nf, int lane, double &nrm, double &inv)
-{
-  double a = 0.0;
-  for (int i = lane; i < nf.np; i += 64) a += nf.part[i];
-  a += bf_dpp<0xB1>(a); a += bf_dpp<0x4E>(a); a += bf_dpp<0x141>(a); a += bf_dpp<0x140>(a);
-  const int lo = __double2loint(a), hi = __double2hiint(a);
-  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-  nrm = sqrt((r0 + r1) + (r2 + r3));
-  inv = nrm > 1e-300 ? 1.0 / nrm : 0.0;
 }
 
 // y1' = M_body^-1 R^T slip, 128 outputs per workgroup: a body's product spread over ceil(n / 128) CUs (one workgroup per
@@ -749,11 +774,11 @@ void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, d
 
 void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,
                               const double *d_NL, const double *d_F, int N_blb, int b_begin, int b_count, double fsign,
-                              double *d_U, double *d_lam, double *d_ktl)
+                              double *d_U, double *d_lam, double *d_ktl, const RblNormFold *fold, const double *d_win)
 {
   if (b_count <= 0) return;
   hipLaunchKernelGGL(k_pc_block_tail, dim3(b_count), dim3(BT), 0, st, d_lever, d_y1, d_MK, (long)stride, d_NL, d_F, N_blb,
-                     b_begin, fsign, d_U, d_lam, d_ktl);
+                     b_begin, fsign, d_U, d_lam, d_ktl, (fold && b_begin == 0) ? *fold : RblNormFold(), d_win);
 }
 
 void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N, int N_bod,
@@ -852,11 +877,11 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
 }
 
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
-                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign)
+                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign, const RblNormFold *fold)
 {
   if (N_bod <= 0) return;
   hipLaunchKernelGGL(k_pc_diag_apply, dim3(N_bod), dim3(BT), 0, st, d_lever, d_invM2, d_NL, N_blb,
-                     (long)3 * N_blb * N_bod, d_in, d_out, fsign);
+                     (long)3 * N_blb * N_bod, d_in, d_out, fsign, fold ? *fold : RblNormFold());
 }
 
 // ---- two-level factor of the preconditioned Lanczos root (see k_tl_orth) -------------------------------------------------

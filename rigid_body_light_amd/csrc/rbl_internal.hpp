@@ -346,12 +346,12 @@ void rbl_launch_pc_diag_build(hipStream_t st, const RblParams &P, bool wall, con
                               const double *d_pos, int N_blb, int N_bod, double *d_invM2, double *d_NL,
                               unsigned *d_err);
 void rbl_launch_pc_diag_apply(hipStream_t st, const double *d_lever, const double *d_invM2, const double *d_NL,
-                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign);
+                              int N_blb, int N_bod, const double *d_in, double *d_out, double fsign, const RblNormFold *fold = nullptr);
 void rbl_launch_pc_block_ninv(hipStream_t st, const double *d_cols, int N_bod, double *d_NL, unsigned *d_err, int b_begin = 0,
                               int b_end = -1);
 void rbl_launch_pc_block_tail(hipStream_t st, const double *d_lever, const double *d_y1, const double *d_MK, int64_t stride,
                               const double *d_NL, const double *d_F, int N_blb, int b_begin, int b_count, double fsign,
-                              double *d_U, double *d_lam, double *d_ktl);
+                              double *d_U, double *d_lam, double *d_ktl, const RblNormFold *fold = nullptr, const double *d_win = nullptr);
 void rbl_launch_saddle_tail(hipStream_t st, const double *d_lever, const double *d_U, int N_blb, int64_t N, int N_bod,
                             double *d_out, const double *d_sub, const double *d_ktl);
 void rbl_launch_bf_tables(hipStream_t st, const double *d_XU, const double *d_cfg, int64_t n, double *d_Minv, double *d_MK,
