@@ -767,6 +767,137 @@ void k_apply_M_symw(const double *__restrict__ r, const double *__restrict__ F,
 }
 
 // ---------------------------------------------------------------------------
+// The wave-unit kernel for TWO force vectors (the Lanczos pair of mid-size systems, end of round 4): k_apply_M_sym2<WALL, NI, 1>'s
+// decomposition and slabs, k_apply_M_symw's execution -- a unit per wave, the SIX column sums of a step (three per vector) rotating
+// through the lanes in registers instead of six ds_add_f64 (the one-row form of the round-3 kernel is LDS-bound on them: 11 LDS
+// instructions per pair step).  Vector v of F / the slabs as in k_apply_M_sym2.
+// ---------------------------------------------------------------------------
+#ifndef RBL_SYMW2V_WAVES
+#define RBL_SYMW2V_WAVES(WALL, NI) ((NI) == 2 ? ((WALL) ? 2 : 3) : ((WALL) ? 3 : 4))
+#endif
+template <bool WALL, int NI, int IW>
+__global__ __launch_bounds__(TS *IW, RBL_SYMW2V_WAVES(WALL, NI))
+void k_apply_M_symw2v(const double *__restrict__ r, const double *__restrict__ F, double *__restrict__ slabI, double *__restrict__ slabJ,
+                      long N, SymLayout L, RblParams P, unsigned *err, long n_units)
+{
+  __shared__ double2_t sP0[IW][TS], sP1[IW][TS], sP2[IW][TS], sP3[IW][TS], sP4[IW][TS];   // (x,y) (z,f0x) (f0y,f0z) (f1x,f1y) (f1z,-)
+  const int lane = threadIdx.x & (TS - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int T = L.T, C = L.C;
+  const long n3 = 3 * N;
+  unsigned flags = 0;
+  const RblParams Pu = unit_params(P);
+  const RblWallK WK = rbl_wall_k_resident();
+  auto sweep_unit = [&](const long u) {
+  int e, c;
+  if (L.tri) {
+    int lo = 0, hi = L.rowsI;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (symw_prefix_ni(mid, C, L.nch, NI) <= u) lo = mid; else hi = mid;
+    }
+    e = lo; c = (NI * e) / C + (int)(u - symw_prefix_ni(e, C, L.nch, NI));
+  } else {
+    c = (int)(u / L.rowsI);
+    e = (int)((u - (long)c * L.rowsI + c) % L.rowsI);
+  }
+  const int I = sym_row_of(e, L.i_first, L.i_step, 1);
+  const int It0 = NI * I;
+  if (It0 >= T) return;
+  int J0 = c * C;
+  const int J1 = (J0 + C < T) ? J0 + C : T;
+  if (J0 < It0) J0 = It0;
+  if (J0 >= J1) return;
+  auto load_blob = [&](long idx, double &x, double &y, double &z, RblV3 &f0, RblV3 &f1) {
+    if (idx < N) {
+      x = r[3 * idx]; y = r[3 * idx + 1]; z = r[3 * idx + 2];
+      double d = 1.0;
+      if (WALL) {
+        if (z < 0.0) flags |= RBL_FLAG_BELOW_WALL;
+        d = damp_of(P, z);
+      }
+      x *= P.inv_a; y *= P.inv_a; z *= P.inv_a;
+      f0 = RblV3{d * F[3 * idx], d * F[3 * idx + 1], d * F[3 * idx + 2]};
+      f1 = RblV3{d * F[n3 + 3 * idx], d * F[n3 + 3 * idx + 1], d * F[n3 + 3 * idx + 2]};
+    } else {
+      x = 1.0e15 * (double)(2 + (idx - N)); y = 0.0; z = 1.0; f0 = RblV3{0.0, 0.0, 0.0}; f1 = RblV3{0.0, 0.0, 0.0};
+    }
+  };
+  double xi[NI], yi[NI], zi[NI];
+  RblV3 Fi0[NI], Fi1[NI], ui0[NI], ui1[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) {
+    load_blob((long)(It0 + a) * TS + lane, xi[a], yi[a], zi[a], Fi0[a], Fi1[a]);
+    ui0[a] = RblV3{0.0, 0.0, 0.0}; ui1[a] = RblV3{0.0, 0.0, 0.0};
+  }
+  for (int J = J0; J < J1; ++J) {
+    {
+      double xj, yj, zj; RblV3 g0, g1;
+      load_blob((long)J * TS + lane, xj, yj, zj, g0, g1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      sP0[wave][lane] = (double2_t){xj, yj};
+      sP1[wave][lane] = (double2_t){zj, g0.x};
+      sP2[wave][lane] = (double2_t){g0.y, g0.z};
+      sP3[wave][lane] = (double2_t){g1.x, g1.y};
+      sP4[wave][lane] = (double2_t){g1.z, 0.0};
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    RblV3 a0{0.0, 0.0, 0.0}, a1{0.0, 0.0, 0.0};                    // the six travelling column sums
+    const char *b0 = (const char *)sP0[wave], *b1 = (const char *)sP1[wave], *b2 = (const char *)sP2[wave],
+               *b3 = (const char *)sP3[wave], *b4 = (const char *)sP4[wave];
+    auto sym_sweep = [&](const int alo, const int ahi) {           // rows alo .. ahi - 1 of the lane against tile J, column sums rotating
+      unsigned off16 = (unsigned)lane * 16u;
+#pragma unroll 2
+      for (int s = 0; s < TS; ++s) {
+        const double2_t pa = *(const double2_t *)(b0 + off16), pb = *(const double2_t *)(b1 + off16), pd = *(const double2_t *)(b2 + off16),
+                        pe = *(const double2_t *)(b3 + off16), pf = *(const double2_t *)(b4 + off16);
+        off16 = (off16 + 16u) & (unsigned)(TS * 16 - 16);
+        RblV3 v0 = a0, v1 = a1;
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+          if (a >= alo && a < ahi)
+            rbl_pair_sym2<WALL, true, true>(Pu, xi[a], yi[a], zi[a], Fi0[a], Fi1[a], pa.x, pa.y, pb.x, RblV3{pb.y, pd.x, pd.y},
+                                            RblV3{pe.x, pe.y, pf.x}, ui0[a], ui1[a], v0, v1, flags, WK);
+        a0 = RblV3{wave_rol1(v0.x), wave_rol1(v0.y), wave_rol1(v0.z)};
+        a1 = RblV3{wave_rol1(v1.x), wave_rol1(v1.y), wave_rol1(v1.z)};
+      }
+    };
+    if (J < It0 + NI) {              // one of the lane's own row tiles: its ordered diagonal sweep, one vector after the other ...
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+        if (J == It0 + a) {
+#pragma unroll 2
+          for (int jj = 0; jj < TS; ++jj) {
+            const double2_t pa = sP0[wave][jj], pb = sP1[wave][jj], pd = sP2[wave][jj], pe = sP3[wave][jj], pf = sP4[wave][jj];
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pb.y, pd.x, pd.y, jj == lane,
+                                             ui0[a].x, ui0[a].y, ui0[a].z, flags);
+            rbl_pair_accum<WALL, true, true>(Pu, xi[a], yi[a], zi[a], pa.x, pa.y, pb.x, pe.x, pe.y, pf.x, jj == lane,
+                                             ui1[a].x, ui1[a].y, ui1[a].z, flags);
+          }
+        }
+      if (NI == 1 || J == It0) continue;
+      sym_sweep(0, 1);               // ... and (NI = 2, J = It0 + 1) row tile It0 against it
+    } else
+      sym_sweep(0, NI);
+    double *q0 = slabJ + sym_idxJ(L, e, 0, (long)J * TS + lane), *q1 = slabJ + sym_idxJ(L, e, 1, (long)J * TS + lane);
+    q0[0] = a0.x; q0[1] = a0.y; q0[2] = a0.z;
+    q1[0] = a1.x; q1[1] = a1.y; q1[2] = a1.z;
+  }
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+    if (It0 + a < T) {
+      double *p0 = slabI + sym_idxI(L, c, 0, (long)(It0 + a) * TS + lane), *p1 = slabI + sym_idxI(L, c, 1, (long)(It0 + a) * TS + lane);
+      p0[0] = ui0[a].x; p0[1] = ui0[a].y; p0[2] = ui0[a].z;
+      p1[0] = ui1[a].x; p1[1] = ui1[a].y; p1[2] = ui1[a].z;
+    }
+  };
+  const long u = (long)blockIdx.x * IW + wave;
+  if (u < n_units) sweep_unit(u);
+  if (flags) atomicOr(err, flags);
+}
+
+// ---------------------------------------------------------------------------
 // The symmetric product for TWO force vectors at once (F, out: [2][3N]): same work decomposition, the pair
 // coefficients are evaluated once for both (rbl_pair_sym2).  Slabs hold the two vectors back to back.
 // ---------------------------------------------------------------------------
@@ -1936,7 +2067,23 @@ void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const
   double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
   const bool relaxed = tune.relaxed != 0;
   const double gr = tune.gap_ratio > 0 ? (double)tune.gap_ratio : 15.0;
-  if (L.NI == 2 && L.SW == SW_LARGE) {
+  if (nrhs == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.NI == 1 || L.C == 1 || (L.C & 1) == 0)) {
+    // the Lanczos pair of mid-size systems: wave-owned units, six column sums rotating in registers (k_apply_M_symw2v)
+    constexpr int IW = RBL_SYMW_IW;
+    const long n_units = L.tri ? symw_prefix_ni(L.rowsI, L.C, L.nch, L.NI) : (long)L.rowsI * L.nch;
+    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
+    if (L.NI == 2) {
+      if (wall) hipLaunchKernelGGL((k_apply_M_symw2v<true, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+      else hipLaunchKernelGGL((k_apply_M_symw2v<false, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    } else {
+      if (wall) hipLaunchKernelGGL((k_apply_M_symw2v<true, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+      else hipLaunchKernelGGL((k_apply_M_symw2v<false, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
+    }
+    const int64_t n = 3 * n_blobs;
+    dim3 g2((unsigned)((n + 63) / 64), 2u), b2(64 * RG);
+    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, RblSaddleFuse());
+    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, RblSaddleFuse());
+  } else if (L.NI == 2 && L.SW == SW_LARGE) {
     if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
     else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
   } else if (L.NI == 2 && nrhs == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) {
@@ -1981,7 +2128,9 @@ void rbl_apply_M_sym_kernel_name(int64_t n_blobs, int n_cu, int i_step, int nrhs
   const SymLayout L = sym_geometry(n_blobs, n_cu, 0, i_step, nrhs, tune);
   const char *w = wall ? "true" : "false";
   const bool relaxed = tune.relaxed != 0;
-  if (nrhs == 2) std::snprintf(out, len, "k_apply_M_sym2<%s,%d,%d>", w, L.NI, L.SW);
+  if (nrhs == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.NI == 1 || L.C == 1 || (L.C & 1) == 0))
+    std::snprintf(out, len, "k_apply_M_symw2v<%s,%d>", w, L.NI);
+  else if (nrhs == 2) std::snprintf(out, len, "k_apply_M_sym2<%s,%d,%d>", w, L.NI, L.SW);
   else if (L.NI == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) std::snprintf(out, len, "k_apply_M_symw<%s,2>", w);
   else if (L.NI == 2) std::snprintf(out, len, "k_apply_M_sym<%s,2>", w);              // (one or four waves per workgroup: the same sweep)
   else if (L.SW == 1 && tune.wave_units >= 0) std::snprintf(out, len, "k_apply_M_symw<%s>", w);
