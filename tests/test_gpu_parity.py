@@ -2157,3 +2157,41 @@ def test_two_level_refresh_keeps_the_root_exact(wall):
         ctx.close()
     assert res[4][0] <= res[1][0] + 1, res[1][0:1] + res[4][0:1]
     assert not np.array_equal(res[1][1], res[4][1])                                     # the kept operator really is another one
+
+
+@pytest.mark.parametrize("wall", [False, True])
+def test_symmetric_kernels_at_the_geometry_thresholds_equal_the_ordered_kernel(wall):
+    """The launch geometry of the symmetric products switches shape with the number of 64-blob tiles T: one / two rows per lane at
+    T = 120 (one vector) and 176 (two vectors), wave units / four-wave workgroups at 320, and every shape has ragged last tiles.
+    Random blob clouds (apply_M takes any positions) of sizes on both sides of each switch: the default product of one vector and
+    of a pair against the ordered-rows kernel, which shares nothing with them but the pair arithmetic."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    dev = torch.device("cuda:0")
+    a, eta = 0.5, 1.3
+    ctx = DeviceContext(a, eta, wall, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(17)
+    seen = set()
+    for N in (64 * 118 + 5, 64 * 120, 64 * 120 + 1, 64 * 127 + 63, 64 * 128, 64 * 175 + 10, 64 * 176, 64 * 176 + 33, 64 * 319 + 1, 64 * 320):
+        side = int(np.ceil(N ** (1.0 / 3.0)))
+        g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), axis=-1).reshape(-1, 3)[:N].astype(float)
+        pos = 2.3 * a * g + 0.1 * a * rng.standard_normal((N, 3))                      # some pairs closer than 2a, none overlapping
+        if wall:
+            pos[:, 2] += 0.6 * a                                                        # the lowest layer inside the damping zone
+        r = torch.from_numpy(pos.reshape(-1)).to(dev)
+        F2 = torch.from_numpy(rng.standard_normal((2, 3 * N))).to(dev).contiguous()
+        ref = torch.empty_like(F2); U1 = torch.empty(3 * N, dtype=torch.float64, device=dev); U2 = torch.empty_like(F2)
+        ctx.set_option("matvec_kernel", 1)
+        for v in range(2):
+            ctx.apply_M(F2[v].data_ptr(), r.data_ptr(), N, 0, N, ref[v].data_ptr())
+        ctx.set_option("matvec_kernel", 0)
+        ctx.apply_M(F2[0].data_ptr(), r.data_ptr(), N, 0, N, U1.data_ptr())
+        ctx.apply_M_multi(F2.data_ptr(), r.data_ptr(), N, 2, U2.data_ptr())
+        ctx.sync_check()
+        seen.add(ctx.apply_M_sym_kernel(N, wall)); seen.add(ctx.apply_M_sym_kernel(N, wall, nrhs=2))
+        assert float(torch.linalg.norm(U1 - ref[0]) / torch.linalg.norm(ref[0])) < 1e-12, N
+        assert float(torch.linalg.norm(U2 - ref) / torch.linalg.norm(ref)) < 1e-12, N
+    w = "true" if wall else "false"
+    assert {"k_apply_M_symw<%s>" % w, "k_apply_M_symw<%s,2>" % w, "k_apply_M_sym<%s,2>" % w, "k_apply_M_symw2v<%s,1>" % w,
+            "k_apply_M_symw2v<%s,2>" % w, "k_apply_M_sym2<%s,2,4>" % w} <= seen, seen
+    ctx.close()
