@@ -2191,6 +2191,17 @@ def test_symmetric_kernels_at_the_geometry_thresholds_equal_the_ordered_kernel(w
         seen.add(ctx.apply_M_sym_kernel(N, wall)); seen.add(ctx.apply_M_sym_kernel(N, wall, nrhs=2))
         assert float(torch.linalg.norm(U1 - ref[0]) / torch.linalg.norm(ref[0])) < 1e-12, N
         assert float(torch.linalg.norm(U2 - ref) / torch.linalg.norm(ref)) < 1e-12, N
+        if N in (64 * 127 + 63, 64 * 176 + 33):                                        # multi-GPU shards of the same products (rectangular unit index)
+            for step in (2, 3):
+                acc1 = torch.zeros_like(U1); acc2 = torch.zeros_like(U2)
+                for first in range(step):
+                    p1 = torch.empty_like(U1); p2 = torch.empty_like(U2)
+                    ctx.apply_M_sym(F2[0].data_ptr(), r.data_ptr(), N, first, step, p1.data_ptr())
+                    ctx.apply_M_sym_multi(F2.data_ptr(), r.data_ptr(), N, 2, first, step, p2.data_ptr())
+                    acc1 += p1; acc2 += p2
+                ctx.sync_check()
+                assert float(torch.linalg.norm(acc1 - ref[0]) / torch.linalg.norm(ref[0])) < 1e-12, (N, step)
+                assert float(torch.linalg.norm(acc2 - ref) / torch.linalg.norm(ref)) < 1e-12, (N, step)
     w = "true" if wall else "false"
     assert {"k_apply_M_symw<%s>" % w, "k_apply_M_symw<%s,2>" % w, "k_apply_M_sym<%s,2>" % w, "k_apply_M_symw2v<%s,1>" % w,
             "k_apply_M_symw2v<%s,2>" % w, "k_apply_M_sym2<%s,2,4>" % w} <= seen, seen
