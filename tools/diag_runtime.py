@@ -1,3 +1,5 @@
+"""Which HIP / HSA runtime libraries end up mapped into the process depending on the import order (torch first or librbl first):
+    python tools/diag_runtime.py torch_first | rbl_first   (diagnostic of round 1's duplicate-runtime question)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def maps(tag):

@@ -1,3 +1,5 @@
+"""apply_M time against the chunk length C of the symmetric kernel (RBL_OPT_SYM_CHUNK) at cfg 2 (free / wall), cfg 5 and cfg 3:
+    python tools/tune_sym_chunk.py   (the measurements behind sym_geometry's chunk rule)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
