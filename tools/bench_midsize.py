@@ -23,6 +23,8 @@ for name, nb, nblb, wall in (("cfg2 50x162 free", 50, 162, False), ("50x162 wall
         ctx.set_option("sym_work_queue", int(os.environ["QUEUE"]))
     if os.environ.get("CHUNK"):
         ctx.set_option("sym_chunk", int(os.environ["CHUNK"]))
+    if os.environ.get("ROWS"):                               # rows per lane of the one-vector kernels (default: the library's rule)
+        ctx.set_option("sym_rows_per_lane", int(os.environ["ROWS"]))
     r = torch.empty(3 * N, dtype=torch.float64, device=dev)
     ctx.blob_positions(0, nb, r.data_ptr())
     F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev)
