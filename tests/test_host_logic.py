@@ -242,3 +242,35 @@ def test_bench_line_helpers():
     ctx = Ctx()
     bench.apply_opts(ctx, Args())
     assert ctx.seen == [("comm_split", 1), ("sym_work_queue", 0)]
+
+
+def test_bench_slim_line_ends_with_the_whole_metric():
+    """The driver records the parsed contract keys and the LAST 2 000 characters of stdout: the one line must be
+    small, carry no prose, and END with a `summary` that holds both halves of BASELINE's metric -- time steps per second with the CPU
+    port's figures beside them and the M.F rate -- plus every configuration's roofline fraction.  Replayed on round 4's full record."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.loads(open(os.path.join(root, "profiles", "r04_bench_line_final.json")).read().strip().splitlines()[-1])
+    line = bench.slim_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4500 and list(line)[-1] == "summary"
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert line[k] == full[k]
+    assert set(line["roofline"]) == set(bench.ROOFLINE_KEYS) and 0.0 < line["roofline"]["frac"] <= 1.0
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample", "seconds_per_step"}
+    tail = text[-2000:]
+    start = tail.index('"summary"')
+    s = json.loads(tail[start + len('"summary": '):-1])       # the whole summary sits inside the recorded tail
+    ts = s["timesteps_per_sec"]
+    assert ts["deterministic_fixed_work"] > 2.0 and ts["deterministic_converged"] > 10.0 and 1.0 < ts["brownian_converged"] < 3.0
+    cpu = s["cpu_timesteps_per_sec"]
+    assert cpu["1core"]["cores"] == 1 and cpu["allcores"]["brownian_converged"] < 1.0
+    assert s["mf_gflops"] > 1.0e4 and set(s["roofline_frac"]) >= {"cfg3_apply_M", "cfg1_apply_M", "cfg2_apply_M", "cfg5_build_hbm",
+                                                                  "cfg5_cholesky_mfma", "cfg5_LW_hbm"}
+    assert s["dropin_cfg3_ms"]["scipy_gmres"] > s["dropin_cfg3_ms"]["rbl_gmres_saddle"]
+    assert not any(isinstance(v, str) and len(v) > 120 for v in json.loads(text)["summary"].values())
+    # every prose key of the old line now lives in the notes, and the notes explain every block of the summary
+    for k in ("timesteps_per_sec", "cpu_timesteps_per_sec", "roofline_frac", "dropin_cfg3_ms", "brownian_gmres_rtol_matched_to_root"):
+        assert "summary." + k in bench.NOTES

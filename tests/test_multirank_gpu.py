@@ -37,10 +37,12 @@ def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
     from rigid_body_light_amd import make_config
     dump = str(tmp_path / "chk")
     p = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3", "--warmup", "1",
-                      "--dump-check", dump, "--cpu-budget", "0", "--timestep-steps", "1"])
+                      "--dump-check", dump, "--cpu-budget", "0", "--timestep-steps", "1", "--detail", dump + ".json"])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["timestep"]["apply_M_per_timestep"] == 21
+    full = json.load(open(dump + ".json"))                 # the sidecar: the full record behind the slim line
+    assert d["n_gpus"] == 2 and full["timestep"]["apply_M_per_timestep"] == 21
+    assert list(d)[-1] == "summary" and d["summary"]["timesteps_per_sec"]["brownian_converged"] > 0.0
     nb, nblb, wall = 50, 162, False                       # cfg2, as bench.py builds it
     c = make_config(nb, nblb, wall)
     F = np.random.default_rng(2).standard_normal(3 * nb * nblb)
@@ -53,7 +55,7 @@ def test_two_rank_sharded_apply_M_matches_oracle(orc, tmp_path):
 
 
 @pytest.mark.parametrize("timestep_steps", ["0", "1"])
-def test_bench_self_launches_two_ranks(timestep_steps):
+def test_bench_self_launches_two_ranks(timestep_steps, tmp_path):
     """`python bench.py --gpus 2` WITHOUT torchrun (the way the driver calls it): bench.py starts the two ranks itself
     (a child torchrun, before touching the GPU) and the ONE line it prints says n_gpus = 2.  With time steps requested they
     run as a second 2-rank job (native sharded GMRES / Lanczos through rbl_set_comm) whose result is merged into the line."""
@@ -62,16 +64,18 @@ def test_bench_self_launches_two_ranks(timestep_steps):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RBL_BENCH_PHASE"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--config", "cfg2", "--steps", "3",
-                        "--warmup", "1", "--cpu-budget", "0", "--timestep-steps", timestep_steps], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--cpu-budget", "0", "--timestep-steps", timestep_steps, "--detail", str(tmp_path / "d.json")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "x2" in d["config"]["parallelism"]
     assert 0.0 < d["roofline"]["frac"] <= 1.0
+    assert len(lines[0]) < 4500 and list(d)[-1] == "summary"
     if timestep_steps != "0":
-        t = d["timestep"]
+        t = json.load(open(str(tmp_path / "d.json")))["timestep"]
+        assert d["summary"]["timesteps_per_sec"]["deterministic_fixed_work"] > 0.0
         assert "error" not in t and t["apply_M_per_timestep"] == 21
         assert t["brownian_converged"]["lanczos_0.001"]["gmres_residual_max"] < 1e-8
 
@@ -89,7 +93,8 @@ def test_headline_line_survives_a_failing_time_step_part(monkeypatch, failing_ra
     assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and 0.0 < d["roofline"]["frac"] <= 1.0
-    assert "rank %s" % failing_rank in d["timestep"]["error"] and "injected failure" in d["timestep"]["error"]
+    assert "rank %s" % failing_rank in d["timestep_error"] and "injected failure" in d["timestep_error"]
+    assert d["summary"]["failed_parts"] == ["timestep"]
 
 
 def _max_diff(stdout, world):
@@ -215,12 +220,15 @@ def test_bench_n_rank_code_path_on_one_rank_over_rccl(orc, tmp_path):
         env.pop(k, None)
     dump = str(tmp_path / "chk")
     p = subprocess.run([sys.executable, "bench.py", "--force-comm", "--config", "cfg2", "--steps", "3", "--warmup", "1", "--cpu-budget", "0",
-                        "--timestep-steps", "1", "--dump-check", dump], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--timestep-steps", "1", "--dump-check", dump, "--detail", dump + ".json"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and "RCCL inside librbl" in d["config"]["parallelism"]
+    slim = json.loads(lines[0])
+    assert slim["n_gpus"] == 1 and "RCCL inside librbl" in slim["config"]["parallelism"] and len(lines[0]) < 4500
+    assert slim["partitionings"]["rows"]["kernel"].startswith("k_apply_M<false>") and slim["partitionings"]["tile_pairs"]["collectives_per_step"] >= 1.0
+    d = json.load(open(dump + ".json"))                    # the full record
     for name, kernel in (("tile_pairs", "k_apply_M_symw<false"), ("rows", "k_apply_M<false>")):   # (the wave-unit kernel, whichever rows per lane)
         part = d["partitionings"][name]
         assert part["roofline"]["kernel"].startswith(kernel) and 0.0 < part["roofline"]["frac"] <= 1.0
