@@ -469,7 +469,9 @@ enum {
                                       many configuration changes; the bodies' coarse basis Q follows every change.  The root stays exact
                                       for ANY coarse operator (H^-1 is the exact inverse of H whatever L_E is); a stale one costs at most
                                       a Lanczos iteration and saves its 3 N_bod-square Cholesky factor + inverse per step             */
-  RBL_OPT_COUNT = 30
+  RBL_OPT_BLOCK_TILE_FACTOR = 30,  /* [1] per-body factors (and explicit inverses) of bodies with 3 N_blb > 512 built by ONE dataflow launch over
+                                      128 x 128 tiles (rbl_tilechol.hip); 0: the batched panel kernels of rounds 1-4 (12 + 12 launches)      */
+  RBL_OPT_COUNT = 31
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

@@ -18,9 +18,9 @@ OBJ = os.path.join(HERE, "build")
 ARCH = os.environ.get("RBL_OFFLOAD_ARCH", "gfx950")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_body_dev.hip", "rbl_small.hip", "rbl_core.hip", "rbl_options.hip", "rbl_comm.hip",
+HIP_SOURCES = ["rbl_kernels.hip", "rbl_dense.hip", "rbl_tilechol.hip", "rbl_body_dev.hip", "rbl_small.hip", "rbl_core.hip", "rbl_options.hip", "rbl_comm.hip",
                "rbl_products.hip", "rbl_bodies.hip", "rbl_roots.hip", "rbl_solvers.hip", "rbl_steps.hip", "rbl_host.cpp"]
-HEADERS = ["rbl_internal.hpp", "rbl_api_internal.hpp", "rbl_pair.hpp", "rbl_pair_pk.hpp", os.path.join("..", "..", "include", "rbl.h")]
+HEADERS = ["rbl_internal.hpp", "rbl_api_internal.hpp", "rbl_pair.hpp", "rbl_pair_pk.hpp", "rbl_dense_dev.hpp", os.path.join("..", "..", "include", "rbl.h")]
 
 
 def lib_path():

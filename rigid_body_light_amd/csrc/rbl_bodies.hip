@@ -491,13 +491,27 @@ int pc_block_factors(rbl_ctx *c, int b0, int b1)
   for (int q0 = b0; q0 < b1; q0 += 65535)               // bodies ride in gridDim.z
     rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p + (size_t)q0 * (size_t)m, S.N_blb,
                                (b1 - q0 < 65535) ? b1 - q0 : 65535, Lb + (size_t)(q0 - b0) * (size_t)msz, msz, c->d_err);
+  const bool want_inv = c->blk_explicit && rbl_block_inverse_large_fits(m) && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)));
+  c->blk_inv_valid = false; c->blk_f32_valid = false;
+  if (c->blk_tile && rbl_tile_cholesky_fits(m)) {
+    // large bodies (shell_N_642 / 2562): factor and -- where wanted -- explicit inverse in ONE dataflow launch over 128 x 128 tiles
+    double *Xb = nullptr; float *Xf = nullptr;
+    if (want_inv) {
+      if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;
+      if (c->blk_f32 && (rc = rbl_dev_reserve(c, c->d_blkXf, rbl_block_inverse_bytes(m, S.N_bod) / 2))) return rc;
+      Xb = (double *)c->d_blkX.p + (size_t)b0 * 2 * (size_t)(rbl_block_inverse_ld(m) * m);
+      if (c->blk_f32) Xf = (float *)c->d_blkXf.p + (size_t)b0 * 2 * (size_t)(rbl_block_inverse_ld(m) * m);
+    }
+    if ((rc = rbl_dev_reserve(c, c->d_blkAug, rbl_tile_cholesky_work_bytes(m, b1 - b0)))) return rc;
+    rc = rbl_launch_tile_cholesky(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride, Xb, Xf,
+                                  c->d_blkAug.p, c->n_cu);
+    if (rc) return rbl_fail(c, rc, "tile cholesky launch failed");
+    if (want_inv) { c->blk_inv_valid = true; c->blk_f32_valid = c->blk_f32; }
+  } else {
   rc = rbl_launch_cholesky_batched(c->stream, Lb, m, b1 - b0, msz, c->d_err, (double *)c->d_blkLinv.p + (size_t)b0 * lstride);
   if (rc) return rbl_fail(c, rc, "batched cholesky launch failed");
-  c->blk_inv_valid = false; c->blk_f32_valid = false;
-  if (c->blk_explicit && rbl_block_inverse_large_fits(m) && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)))) {
-    // large bodies (shell_N_642 / 2562): explicit inverses through the factorisation's own MFMA kernels -- a rank's few
-    // bodies are then applied by batched triangular matrix-vector products over the whole chip instead of one latency
-    // chain of 3 N_blb / 32 steps per body on one CU each
+  if (want_inv) {
+    // the round-3 form: explicit inverses through the factorisation's own MFMA kernels on an augmented matrix [L ; I]
     int chunk = 1;
     if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;
     if (c->blk_f32 && (rc = rbl_dev_reserve(c, c->d_blkXf, rbl_block_inverse_bytes(m, S.N_bod) / 2))) return rc;
@@ -508,6 +522,7 @@ int pc_block_factors(rbl_ctx *c, int b0, int b1)
                                              (double *)c->d_blkAug.p)))
       return rbl_fail(c, rc, "block inverse (large bodies) launch failed");
     c->blk_inv_valid = true; c->blk_f32_valid = c->blk_f32;
+  }
   }
   if (c->blk_explicit && rbl_block_inverse_fits(m)) {     // small bodies: explicit L^-1, sweeps become matrix-vector products
     if ((rc = rbl_dev_reserve(c, c->d_blkX, rbl_block_inverse_bytes(m, S.N_bod)))) return rc;

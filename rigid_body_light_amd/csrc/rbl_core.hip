@@ -34,6 +34,8 @@ int rbl_flags_to_status(rbl_ctx *c, unsigned f)
     return rbl_fail(c, RBL_ERR_OVERLAP, "ERROR: TWO BLOBS ARE OVERLAPPING OR TOO CLOSELY POSITIONED.");
   if (f & RBL_FLAG_NOT_SPD)
     return rbl_fail(c, RBL_ERR_NOT_SPD, "Cholesky: matrix is not positive definite");
+  if (f & RBL_FLAG_INTERNAL)
+    return rbl_fail(c, RBL_ERR_HIP, "internal: a tile of the per-body factorisation waited for its dependencies longer than the time limit");
   return rbl_fail(c, RBL_ERR_NONFINITE, "mobility product produced a non-finite value");
 }
 

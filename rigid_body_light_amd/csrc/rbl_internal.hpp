@@ -110,6 +110,7 @@ struct rbl_ctx {
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 (two layouts), scratch of their application
   RblDevBuf d_blkXf, d_blkAug;                      // large bodies: single-precision copy of the inverses; scratch of their inversion
+  bool blk_tile = true;                             // RBL_OPT_BLOCK_TILE_FACTOR: large bodies factored (and inverted) by the dataflow tile kernel
   int blk_large = 2;                                // explicit inverses of bodies with 3 N_blb > 512: 0 never, 1 always, 2 when it pays
                                                     // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- rbl_set_tuning 63 / 64 / 65
   bool blk_f32 = false, blk_f32_valid = false;      // rbl_set_tuning 83 / 84: apply them from a single-precision copy (half the bytes)
@@ -288,6 +289,11 @@ int rbl_launch_block_inv_apply(hipStream_t st, const double *d_X, int64_t n, int
 size_t rbl_block_inverse_large_aug_bytes(int64_t n, int batch, int *chunk_out);
 int rbl_launch_block_inverse_large(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_Linv,
                                    double *d_X, float *d_Xf, double *d_aug);
+// per-body factors and explicit inverses of large bodies as ONE dataflow launch over 128 x 128 tiles (rbl_tilechol.hip)
+bool rbl_tile_cholesky_fits(int64_t n);
+size_t rbl_tile_cholesky_work_bytes(int64_t n, int batch);
+int rbl_launch_tile_cholesky(hipStream_t st, double *d_M, int64_t n, int batch, int64_t strideA, unsigned *d_err, double *d_Linv,
+                             double *d_X, float *d_Xf, void *d_work, int n_cu);
 int rbl_launch_block_trmv_small(hipStream_t st, const double *d_L, int64_t n, int batch, int64_t strideA, const double *d_in,
                                 double *d_out, int64_t vec_stride, const double *d_Q);
 void rbl_launch_rotate_bodies(hipStream_t st, const double *d_Q, const double *d_in, double *d_out, int N_blb, int batch, int nv,

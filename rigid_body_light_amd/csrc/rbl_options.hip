@@ -76,6 +76,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->shared_gemm = v != 0; }},
     {RBL_OPT_TWO_LEVEL_REFRESH, "two_level_refresh", 1, 1 << 20, 1, [](const rbl_ctx *c) -> int64_t { return c->tl_refresh; },
      [](rbl_ctx *c, int64_t v) { c->tl_refresh = (int)v; c->tl_age = 0; c->tl_valid = false; }},
+    {RBL_OPT_BLOCK_TILE_FACTOR, "block_tile_factor", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->blk_tile; },
+     [](rbl_ctx *c, int64_t v) { c->blk_tile = v != 0; drop_factors(c); c->tl_valid = false; }},
     {RBL_OPT_FUSED_KRYLOV, "fused_krylov", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->fused_krylov; },
      [](rbl_ctx *c, int64_t v) { c->fused_krylov = v != 0; }},
 };

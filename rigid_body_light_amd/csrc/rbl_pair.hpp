@@ -21,6 +21,7 @@
 #define RBL_FLAG_BELOW_WALL 2
 #define RBL_FLAG_NONFINITE 4
 #define RBL_FLAG_NOT_SPD 8
+#define RBL_FLAG_INTERNAL 16   // a bounded wait between workgroups ran out (rbl_tilechol.hip): never expected, never a hang
 
 struct RblParams {
   double a;        // blob radius

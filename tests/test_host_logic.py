@@ -274,3 +274,28 @@ def test_bench_slim_line_ends_with_the_whole_metric():
     # every prose key of the old line now lives in the notes, and the notes explain every block of the summary
     for k in ("timesteps_per_sec", "cpu_timesteps_per_sec", "roofline_frac", "dropin_cfg3_ms", "brownian_gmres_rtol_matched_to_root"):
         assert "summary." + k in bench.NOTES
+
+
+@pytest.mark.parametrize("NT", [1, 2, 3, 5, 16, 17, 61])
+def test_tile_factorisation_queue_order_is_a_topological_order(NT):
+    """The dataflow tile factorisation (csrc/rbl_tilechol.hip) claims its tasks in a fixed order per body and lets a claimed task WAIT
+    for the tiles it reads.  That cannot deadlock iff every task comes after everything it waits for -- checked here on the host, on
+    the very function the kernel decodes its queue slots with: every CHOL(i, j) and INV(j, i) tile exactly once, the K-panel tiles,
+    the diagonal tile of the column and (for the inverse) the complete row of L before it."""
+    import ctypes as C
+    from rigid_body_light_amd._lib import lib
+    L = lib()
+    out = (C.c_int * (3 * (NT + 1) * (NT + 1)))()
+    assert L.rbl_debug_tile_order(NT, out) == 0
+    order = [tuple(out[3 * k: 3 * k + 3]) for k in range((NT + 1) * (NT + 1))]
+    order = [t for t in order if t[0] != 0]
+    pos = {t: k for k, t in enumerate(order)}
+    assert len(pos) == len(order)
+    expect = {(1, i, j) for j in range(NT) for i in range(j, NT)} | {(2, jj, i) for i in range(NT) for jj in range(i + 1)}
+    assert set(order) == expect
+    for (kind, a, b), p in pos.items():
+        if kind == 1:       # CHOL(i = a, j = b): rows i and j of L in the columns before j, then the diagonal tile of column j
+            deps = [(1, a, k) for k in range(b)] + [(1, b, k) for k in range(b)] + ([(1, b, b)] if a != b else [])
+        else:               # INV(row jj = a, column i = b): row i of L complete, Y(jj, jj .. i - 1)
+            deps = [(1, b, k) for k in range(b + 1)] + [(2, a, k) for k in range(a, b)]
+        assert all(pos[d] < p for d in deps)
