@@ -1190,8 +1190,9 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=stream.cuda_stream)
     ctx.set_config(c["X"], c["Q"])
-    if args.jsplit or args.variant:
-        ctx.set_tuning(args.jsplit, args.variant)        # (kernel choice + its split: the one call the old switchboard keeps)
+    if args.jsplit or args.variant:                      # (kernel choice + its split)
+        ctx.set_option("matvec_kernel", args.variant)
+        ctx.set_option("sym_chunk" if args.variant == 2 else "ordered_jsplit", args.jsplit)
     apply_opts(ctx, args)
     sm = ShardedMobility(nb, nblb, device=dev, ctx=ctx, force_collectives=args.force_comm)
     nrows = sm.row1 - sm.row0

@@ -421,7 +421,8 @@ enum {
   RBL_OPT_SYM_CHUNK = 3,           /* [0] column tiles per work unit of the symmetric kernels (0 = heuristic)                         */
   RBL_OPT_SYM_ROWS_PER_LANE = 4,   /* [0] rows per lane of the one-vector symmetric kernel: 0 heuristic, 1, 2 (experiments)            */
   RBL_OPT_SYM2_ROWS_PER_LANE = 5,  /* [0] the same for the two-vector kernel                                                          */
-  RBL_OPT_SYM_WAVES = 6,           /* [0] waves per workgroup of the symmetric kernels: 0 heuristic, 1 or 4 (other values: heuristic)         */
+  RBL_OPT_SYM_WAVES = 6,           /* [0] waves per workgroup of the symmetric kernels: 0 heuristic, 1 or 4 (4 needs two rows per lane; any other
+                                      value, or a combination no kernel has, is RBL_ERR_ARG -- at the call or at the product)            */
   RBL_OPT_SYM_WORK_QUEUE = 7,      /* [1] large systems (four-wave workgroups): 1 a fixed set of resident workgroups draws work units
                                       from a counter (an XCD that runs faster takes more), 0 one unit per workgroup in launch order;
                                       the slabs are addressed by unit, so results are bitwise the same either way                   */
@@ -471,20 +472,15 @@ enum {
                                       a Lanczos iteration and saves its 3 N_bod-square Cholesky factor + inverse per step             */
   RBL_OPT_BLOCK_TILE_FACTOR = 30,  /* [1] per-body factors (and explicit inverses) of bodies with 3 N_blb > 512 built by ONE dataflow launch over
                                       128 x 128 tiles (rbl_tilechol.hip); 0: the batched panel kernels of rounds 1-4 (12 + 12 launches)      */
-  RBL_OPT_COUNT = 31
+  RBL_OPT_COMM_FORCE_STAGED = 31,  /* [0] test hook: the in-place all-gathers of a native (RCCL) communicator take the STAGED form (segments
+                                      padded to the largest share, one ncclAllGather, unpacked) even when the shares are equal -- what a job
+                                      with N_bod % world != 0 runs, exercised with one rank                                                 */
+  RBL_OPT_COUNT = 32
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);
 int rbl_option_info(int option, const char **name, int64_t *min_value, int64_t *max_value, int64_t *default_value);
 int rbl_option_key(const char *name);
-
-/* DEPRECATED (rounds 1-3; kept for one more round): the switchboard of magic integers, now a shim over rbl_set_option.
- * variant 0..3 = RBL_OPT_MATVEC_KERNEL (jsplit: RBL_OPT_ORDERED_JSPLIT, or RBL_OPT_SYM_CHUNK with variant 2);
- * off / on pairs: 21/22 SYM2_ROWS_PER_LANE 1/2, 31/32 GMRES_PC_SIGN_FIX, 41/42 GMRES_ONE_KERNEL, 51/52 RELAXED_KRYLOV,
- * 53/54 RELAXED_ALWAYS, 61/62 BLOCK_EXPLICIT_SMALL, 63/64/65 BLOCK_EXPLICIT_LARGE 0/1/2, 71/72 BODYFRAME_FACTOR,
- * 73/74 BODYFRAME_WALL_APPROX, 81/82 LANCZOS_REORTH, 83/84 BLOCK_INVERSE_F32, 85/86 LANCZOS_EUCLID_NORM,
- * 87/88 LANCZOS_TWO_LEVEL, 91/92 GMRES_PREDICT_CHECKS, 93/94 SYM_WORK_QUEUE; anything else: RBL_ERR_ARG. */
-int rbl_set_tuning(rbl_ctx *ctx, int jsplit, int variant);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,6 @@ def lib():
         L.rbl_trmv_lower_dev.argtypes = [vp, vp, i64, vp, vp]
         L.rbl_M_half_W_dev.argtypes = [vp, vp, i64, vp, C.c_int, vp]
         L.rbl_sync_check.argtypes = [vp]
-        L.rbl_set_tuning.argtypes = [vp, C.c_int, C.c_int]
         L.rbl_set_lanczos.argtypes = [vp, C.c_int, dbl]
         L.rbl_get_lanczos_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_update_X_Q.argtypes = [vp, vp, vp, vp]
@@ -234,10 +233,6 @@ class DeviceContext:
         ms, calls = (C.c_double * n)(), (C.c_int64 * n)()
         self._chk(self.L.rbl_get_timings(self.h, ms, calls))
         return {k: (ms[i], calls[i]) for i, k in enumerate(self.TIMING_PHASES)}
-
-    def set_tuning(self, jsplit=0, variant=0):
-        """deprecated switchboard of rounds 1-3 (a shim over set_option inside librbl)"""
-        self._chk(self.L.rbl_set_tuning(self.h, jsplit, variant))
 
     def apply_M(self, dF, dr, n_blobs, row_begin, row_end, dout):
         """dF, dr, dout: integer device addresses (tensor.data_ptr())."""

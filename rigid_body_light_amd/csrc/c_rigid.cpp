@@ -415,7 +415,6 @@ struct CManyBodies {
     if (!key || rbl_get_option(ctx, key, &v)) throw std::runtime_error("get_option: unknown option '" + name + "'");
     return v;
   }
-  void set_tuning(int jsplit, int variant) { check(rbl_set_tuning(ctx, jsplit, variant)); }   // deprecated shim
   uintptr_t handle() const { return (uintptr_t)ctx; }
 };
 
@@ -471,7 +470,6 @@ PYBIND11_MODULE(c_rigid, m)
       .def("evolve_X_Q_RFD", &CManyBodies::evolve_X_Q_RFD, py::arg("U"))
       .def("set_option", &CManyBodies::set_option, py::arg("name"), py::arg("value"))
       .def("get_option", &CManyBodies::get_option, py::arg("name"))
-      .def("set_tuning", &CManyBodies::set_tuning, py::arg("jsplit") = 0, py::arg("variant") = 0)
       .def("handle", &CManyBodies::handle, "address of the underlying rbl_ctx (for the ctypes device API)")
       .def_property_readonly_static("precision", [](py::object) { return std::string(rbl_precision()); },
                                     "Compilation precision, a string holding either single or double.");

@@ -1,6 +1,6 @@
 // rbl_api_internal.hpp -- internals shared by the translation units that implement include/rbl.h:
 //   rbl_core.hip      context, errors, device buffers, copies, timings, parameters / configuration
-//   rbl_options.hip   named options (rbl_set_option / rbl_get_option) + the rbl_set_tuning shim
+//   rbl_options.hip   named options (rbl_set_option / rbl_get_option)
 //   rbl_comm.hip      multi-GPU communicator: RCCL inside the library, or the caller's callbacks
 //   rbl_products.hip  mobility products (kernel choice, launches), positions, dense entry points
 //   rbl_bodies.hip    K operators, preconditioners, per-body factors, saddle operator

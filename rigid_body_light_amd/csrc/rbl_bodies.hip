@@ -181,7 +181,7 @@ int rbl_evolve_X_Q(rbl_ctx *c, const double *U)
   rbl_body_update_X_Q(S, Udt.data(), Xo, Qo);
   S.X.swap(Xo);
   S.Q.swap(Qo);
-  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false;
+  c->dev_bodies_valid = false; c->dev_pc_valid = false; c->dev_xq_valid = false; c->pc_keep_once = false;
   rc = rbl_body_set_K(S, c->last_error);                          // :876
   S.pc_set = false;                                               // :877
   return rc;
@@ -294,7 +294,7 @@ int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv
   if (c->blk_inv_valid) {
     const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
     int rc = rbl_dev_reserve(c, c->d_blkTmp, sizeof(double) * 3 * tmpn); if (rc) return rc;
-    // the single-precision copy (large bodies, rbl_set_tuning 84) serves whoever tolerates a factor that is exact to 6e-8 only
+    // the single-precision copy (large bodies, RBL_OPT_BLOCK_INVERSE_F32) serves whoever tolerates a factor that is exact to 6e-8 only
     const int f32 = (c->blk_f32_valid && allow_f32) ? 1 : 0;
     const size_t xsz = 2 * (size_t)(rbl_block_inverse_ld(m) * m);              // entries of one body's two layouts
     const double *X = f32 ? (const double *)((const float *)c->d_blkXf.p + (size_t)b0 * xsz)
@@ -647,6 +647,11 @@ bool pc_can_fold(rbl_ctx *c)
 
 int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
 {
+  struct FoldGuard {                                     // whatever happens, the request to fold a normalisation dies with this call
+    rbl_ctx *c;
+    explicit FoldGuard(rbl_ctx *c_) : c(c_) {}
+    ~FoldGuard() { c->pc_fold = RblNormFold(); }
+  } guard(c);
   int rc = sync_bodies(c); if (rc) return rc;
   const RblBodyState &S = c->S;
   if (c->pc_fold.part && !pc_can_fold(c)) { c->pc_fold = RblNormFold(); return rbl_fail(c, RBL_ERR_ARG, "apply_PC: this preconditioner does not normalise its input"); }

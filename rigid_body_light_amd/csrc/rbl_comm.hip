@@ -2,7 +2,7 @@
 //
 // One process per GPU.  Two ways to give a context its collectives:
 //   * rbl_comm_init_rccl: RCCL inside the library.  ncclCommInitRank from a unique id the host distributes by whatever means
-//     it has (MPI, a file, torch.distributed), then ncclAllReduce / ncclAllGather / grouped ncclBroadcast on the CONTEXT'S
+//     it has (MPI, a file, torch.distributed), then ncclAllReduce / ncclAllGather (ragged segments through a padded staging buffer) on the CONTEXT'S
 //     stream -- a C or C++ host (which is what the reference is, c_rigid_obj.cpp:997-1027) runs N GPUs without Python, and
 //     no host frame sits between two products of a solve.  librccl is opened at run time (dlopen by soname): in a process
 //     that already holds PyTorch's bundled copy that very copy is found, so the process keeps ONE RCCL and one HIP runtime;
@@ -36,7 +36,6 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -66,7 +65,7 @@ const RcclApi *rccl()
   if (!h) { const char *e = dlerror(); g_rccl.error = std::string("cannot open librccl: ") + (e ? e : "?"); return nullptr; }
   const bool ok = load_sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && load_sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
                   load_sym(h, "ncclCommDestroy", g_rccl.CommDestroy) && load_sym(h, "ncclAllReduce", g_rccl.AllReduce) &&
-                  load_sym(h, "ncclAllGather", g_rccl.AllGather) && load_sym(h, "ncclBroadcast", g_rccl.Broadcast) &&
+                  load_sym(h, "ncclAllGather", g_rccl.AllGather) &&
                   load_sym(h, "ncclGroupStart", g_rccl.GroupStart) && load_sym(h, "ncclGroupEnd", g_rccl.GroupEnd) &&
                   load_sym(h, "ncclGetErrorString", g_rccl.GetErrorString);
   if (!ok) { g_rccl.error = "librccl lacks an expected entry point"; dlclose(h); return nullptr; }
@@ -113,6 +112,35 @@ int comm_allreduce(rbl_ctx *c, double *d_buf, int64_t count)
 
 bool comm_gather_needs_zero(const rbl_ctx *c) { return c->comm_kind == 1 && c->comm_gather_fn == nullptr; }
 
+// ---- in-place all-gather of per-rank segments: ONE RCCL shape ----------------------------------------------------------------
+// Equal, back-to-back segments are an in-place ncclAllGather.  Ragged ones (N_bod % world != 0, uneven row bounds) take the SAME
+// collective through a staging buffer: every rank's segment padded to the largest share, own part packed in, one in-place
+// ncclAllGather of the padded slots, everything unpacked to where it belongs.  Round 4 issued a group of in-place ncclBroadcasts
+// there -- a branch that no run had ever executed (a communicator of one rank is always "even"); the staged form is exercised
+// with one rank by RBL_OPT_COMM_FORCE_STAGED.  Pack and unpack are one small kernel each per set.
+namespace {
+
+constexpr int SEG_MAX_RANKS = 64;
+struct SegCopy {
+  int W;
+  long slot;                     // doubles per padded slot of the staging buffer
+  long off[SEG_MAX_RANKS];       // offsets of the ranks' segments in the vector
+  long cnt[SEG_MAX_RANKS];
+};
+
+// unpack = 1: vec[off[r] + e] = stage[r * slot + e] for every rank r (blockIdx.y) ; unpack = 0: the reverse, rank `only` alone
+__global__ __launch_bounds__(256) void k_seg_copy(double *__restrict__ vec, double *__restrict__ stage, SegCopy S, int unpack, int only)
+{
+  const int r = unpack ? (int)blockIdx.y : only;
+  const long n = S.cnt[r];
+  double *v = vec + S.off[r], *s = stage + (size_t)r * (size_t)S.slot;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    if (unpack) v[e] = s[e]; else s[e] = v[e];
+  }
+}
+
+}  // namespace
+
 // `nsets` sets of segments: in set s rank r owns bufs[s][offs[s * world + r] .. + cnts[s * world + r]); every set is
 // completed in place, all of them in ONE fused RCCL group.  Fallback (callbacks without an all-gather): the caller has
 // zeroed what it does not own, one sum all-reduce per set over the span of its segments.
@@ -124,20 +152,58 @@ static int comm_allgatherv(rbl_ctx *c, int nsets, double *const *bufs, const int
     const RcclApi *R = rccl();
     if (!R) return rbl_fail(c, RBL_ERR_COMM, g_rccl.error);
     ncclComm_t comm = (ncclComm_t)c->comm_nccl;
-    RBL_NCCL(c, R, R->GroupStart());
+    // which sets are staged, and where in the staging buffer
+    std::vector<char> staged((size_t)nsets, 0);
+    std::vector<int64_t> slot((size_t)nsets, 0), base((size_t)nsets, 0);
+    int64_t stage_doubles = 0;
     for (int s = 0; s < nsets; ++s) {
       const int64_t *o = offs + (size_t)s * W, *n = cnts + (size_t)s * W;
-      double *d_buf = bufs[s];
-      bool even = true;                                   // equal, back-to-back segments: the plain in-place all-gather
+      bool even = !c->comm_force_staged;                   // equal, back-to-back segments: the plain in-place all-gather
       for (int r = 0; r < W; ++r) even = even && n[r] == n[0] && o[r] == o[0] + (int64_t)r * n[0];
-      if (even) {
-        RBL_NCCL(c, R, R->AllGather(d_buf + o[c->comm_rank], d_buf + o[0], (size_t)n[0], ncclDouble, comm, c->stream));
-      } else {                                            // ragged: one broadcast per owner, fused by the group
-        for (int r = 0; r < W; ++r)
-          if (n[r] > 0) RBL_NCCL(c, R, R->Broadcast(d_buf + o[r], d_buf + o[r], (size_t)n[r], ncclDouble, r, comm, c->stream));
-      }
+      if (even) continue;
+      if (W > SEG_MAX_RANKS) return rbl_fail(c, RBL_ERR_COMM, "ragged all-gather: more than 64 ranks");
+      staged[(size_t)s] = 1;
+      for (int r = 0; r < W; ++r) slot[(size_t)s] = std::max(slot[(size_t)s], n[r]);
+      base[(size_t)s] = stage_doubles;
+      stage_doubles += slot[(size_t)s] * W;
     }
-    RBL_NCCL(c, R, R->GroupEnd());
+    int rc;
+    if (stage_doubles > 0 && (rc = rbl_dev_reserve(c, c->d_commStage, sizeof(double) * (size_t)stage_doubles))) return rc;
+    double *stage = (double *)c->d_commStage.p;
+    auto seg = [&](int s) {
+      SegCopy S; S.W = W; S.slot = (long)slot[(size_t)s];
+      for (int r = 0; r < W; ++r) { S.off[r] = (long)offs[(size_t)s * W + r]; S.cnt[r] = (long)cnts[(size_t)s * W + r]; }
+      return S;
+    };
+    for (int s = 0; s < nsets; ++s)                        // pack the own segment of every staged set
+      if (staged[(size_t)s] && cnts[(size_t)s * W + c->comm_rank] > 0) {
+        const unsigned g = (unsigned)std::min<int64_t>((cnts[(size_t)s * W + c->comm_rank] + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_seg_copy, dim3(g, 1), dim3(256), 0, c->stream, bufs[s], stage + base[(size_t)s], seg(s), 0, c->comm_rank);
+      }
+    // ONE group, and the group is always closed: a failure inside is reported after ncclGroupEnd (a return between
+    // GroupStart and GroupEnd would leave the thread's group open and every later RCCL call of this thread queued in it)
+    ncclResult_t first = R->GroupStart();
+    const char *what = "ncclGroupStart";
+    if (first == ncclSuccess) {
+      for (int s = 0; s < nsets && first == ncclSuccess; ++s) {
+        const int64_t *o = offs + (size_t)s * W, *n = cnts + (size_t)s * W;
+        if (staged[(size_t)s]) {
+          double *sb = stage + base[(size_t)s];
+          first = R->AllGather(sb + (size_t)c->comm_rank * (size_t)slot[(size_t)s], sb, (size_t)slot[(size_t)s], ncclDouble, comm, c->stream);
+        } else {
+          first = R->AllGather(bufs[s] + o[c->comm_rank], bufs[s] + o[0], (size_t)n[0], ncclDouble, comm, c->stream);
+        }
+        if (first != ncclSuccess) what = "ncclAllGather";
+      }
+      const ncclResult_t end = R->GroupEnd();
+      if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
+    }
+    if (first != ncclSuccess) return nccl_fail(c, R, first, what);
+    for (int s = 0; s < nsets; ++s)                        // unpack every rank's segment of every staged set
+      if (staged[(size_t)s] && slot[(size_t)s] > 0) {
+        const unsigned g = (unsigned)std::min<int64_t>((slot[(size_t)s] + 255) / 256, 256);
+        hipLaunchKernelGGL(k_seg_copy, dim3(g, (unsigned)W), dim3(256), 0, c->stream, bufs[s], stage + base[(size_t)s], seg(s), 1, 0);
+      }
     return RBL_OK;
   }
   for (int s = 0; s < nsets; ++s) {
@@ -206,6 +272,7 @@ void comm_release(rbl_ctx *c)
 static void comm_invalidate(rbl_ctx *c)
 {
   c->dev_blk_valid = false; c->blk_inv_valid = false; c->dev_pc_valid = false; c->tl_valid = false; c->dev_bodies_valid = false;
+  c->pc_keep_once = false;
 }
 
 int rbl_set_comm_ops(rbl_ctx *c, int rank, int world, rbl_allreduce_fn allreduce, rbl_allgatherv_fn allgatherv, void *user)

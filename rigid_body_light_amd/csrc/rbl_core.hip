@@ -278,7 +278,7 @@ void rbl_destroy(rbl_ctx *c)
     if (c->ev_check) (void)hipEventDestroy(c->ev_check);
     RblDevBuf *bufs[] = {&c->d_r, &c->d_F, &c->d_U, &c->d_part, &c->d_W, &c->d_cfg,
                          &c->d_XQ, &c->d_mat, &c->d_tmp, &c->d_tmp2, &c->d_chol,
-                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_blkXf, &c->d_blkAug, &c->d_tlQ, &c->d_tlCb, &c->d_tlCs, &c->d_tlA, &c->d_tlLinv, &c->d_tlX, &c->d_tlT, &c->d_tlZ, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
+                         &c->d_lever, &c->d_pos, &c->d_invM2, &c->d_NL, &c->d_sad, &c->d_blkL, &c->d_blkLinv, &c->d_blkX, &c->d_blkTmp, &c->d_blkXf, &c->d_blkAug, &c->d_commStage, &c->d_tlQ, &c->d_tlCb, &c->d_tlCs, &c->d_tlA, &c->d_tlLinv, &c->d_tlX, &c->d_tlT, &c->d_tlZ, &c->d_ktl, &c->d_bfL, &c->d_bfLinv, &c->d_bfX, &c->d_bfPC, &c->d_pcw, &c->d_pcMK, &c->d_bd, &c->d_bd2, &c->d_gm, &c->d_step, &c->d_hist};
     for (RblDevBuf *b : bufs)
       if (b->p) (void)hipFree(b->p);
     if (c->chol_aux.stream) {
@@ -322,7 +322,7 @@ int rbl_set_parameters(rbl_ctx *c, double a, double dt, double kBT, double eta, 
     rmax2 = std::max(rmax2, p_[0] * p_[0] + p_[1] * p_[1] + p_[2] * p_[2]);
   }
   c->body_radius = std::sqrt(rmax2) + a;               // the sphere the two-level factor's far-field model gives a body
-  c->tl_valid = false;
+  c->tl_valid = false; c->pc_keep_once = false;
   S.N_blb = N_blb;
   S.params_set = true;
   S.M_scale = 1.0;
@@ -339,7 +339,8 @@ int rbl_set_config(rbl_ctx *c, const double *X, const double *Q, int N_bod)
 {
   if (!c || !X || !Q || N_bod <= 0) return rbl_fail(c, RBL_ERR_ARG, "setConfig: bad arguments");
   RblBodyState &S = c->S;
-  if (S.N_bod != N_bod) c->dev_blk_valid = false;
+  if (S.N_bod != N_bod) { c->dev_blk_valid = false; c->tl_valid = false; c->tl_age = 0; }   // (a kept coarse operator of another body count is not even the right size)
+  c->pc_keep_once = false;                               // (the promise of rbl_evolve_X_Q_RFD was about the configuration it committed)
   S.N_bod = N_bod;
   S.X.assign(X, X + (size_t)3 * N_bod);
   S.Q.resize((size_t)4 * N_bod);

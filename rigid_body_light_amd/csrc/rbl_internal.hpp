@@ -80,12 +80,12 @@ struct RblNormFold {
   double *hout = nullptr;          // |w|
 };
 
-struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (rbl_set_tuning)
+struct RblSymTune {        // per-context tuning of the symmetric matvec kernels (RBL_OPT_SYM_*)
   int chunk = 0;           // > 0: column tiles per work unit (0 = heuristic)
   int ni2 = 0;             // > 0: rows per lane of the two-vector kernel (0 = same rule as one vector)
   int ni1 = 0;             // > 0: rows per lane of the one-vector kernel (0 = heuristic; experiments)
   int sw = 0;              // > 0: waves per workgroup (0 = heuristic; experiments)
-  int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (rbl_set_tuning 93); 0: work queue there (94)
+  int queue = 0;           // < 0: one unit per workgroup in launch order also for large systems (RBL_OPT_SYM_WORK_QUEUE = 0); 0: work queue there
   int gap_ratio = 0;       // relaxed product: a tile pair is swept in single precision when (d_I + 2 d_J) <= gap_ratio x gap (0 = default; RBL_OPT_RELAXED_GAP_RATIO)
   int wave_units = 0;      // < 0: mid-size systems on the round-3 kernel (one workgroup per unit, column sums by LDS atomics); 0: wave-owned units (RBL_OPT_SYM_WAVE_UNITS)
   RblSaddleFuse fuse;      // transient: see RblSaddleFuse
@@ -109,29 +109,31 @@ struct rbl_ctx {
   RblDevBuf d_lever, d_pos, d_invM2, d_NL, d_sad;   // device-resident body state (rbl_sync_bodies_dev)
   RblDevBuf d_blkL, d_blkLinv, d_pcw, d_pcMK;       // block-diagonal PC: per-body Cholesky factors, work, invM K
   RblDevBuf d_blkX, d_blkTmp;                       // explicit L_b^-1 (two layouts), scratch of their application
+  RblDevBuf d_commStage;                            // padded slots of a ragged in-place all-gather (rbl_comm.hip)
   RblDevBuf d_blkXf, d_blkAug;                      // large bodies: single-precision copy of the inverses; scratch of their inversion
+  bool comm_force_staged = false;                   // RBL_OPT_COMM_FORCE_STAGED (test hook)
   bool blk_tile = true;                             // RBL_OPT_BLOCK_TILE_FACTOR: large bodies factored (and inverted) by the dataflow tile kernel
   int blk_large = 2;                                // explicit inverses of bodies with 3 N_blb > 512: 0 never, 1 always, 2 when it pays
-                                                    // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- rbl_set_tuning 63 / 64 / 65
-  bool blk_f32 = false, blk_f32_valid = false;      // rbl_set_tuning 83 / 84: apply them from a single-precision copy (half the bytes)
+                                                    // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- RBL_OPT_BLOCK_EXPLICIT_LARGE
+  bool blk_f32 = false, blk_f32_valid = false;      // RBL_OPT_BLOCK_INVERSE_F32: apply them from a single-precision copy (half the bytes)
   bool bf_tables = false;                           // d_bfPC holds the body-frame preconditioner tables (small bodies)
   // two-level factor of the preconditioned Lanczos root (rbl_roots.hip: tl_build): G = L (I + Q (L_E - I) Q^T)
   RblDevBuf d_tlQ, d_tlCb, d_tlCs, d_tlA, d_tlLinv, d_tlX, d_tlT, d_tlZ;
   int tl_refresh = 1, tl_age = 0;     // RBL_OPT_TWO_LEVEL_REFRESH: configuration changes the factored coarse operator is kept for
   bool tl_q_stale = false;            // ... while its basis Q (rotations, per-body factors) is rebuilt at every change
-  bool tl_on = true, tl_valid = false, tl_ok = false;   // rbl_set_tuning 87 / 88; built for the current configuration; usable (SPD)
+  bool tl_on = true, tl_valid = false, tl_ok = false;   // RBL_OPT_LANCZOS_TWO_LEVEL; built for the current configuration; usable (SPD)
   unsigned *d_err2 = nullptr;                       // error word of the two-level build: a failure there is not an error, only "not usable"
   double body_radius = 0.0;                         // max |c_k| + a: the sphere the far-field model gives a body
   // free space: M_b = (I x R_b) M_body (I x R_b)^T with ONE body-frame matrix for all bodies and all time: its factor
   // (d_bfL, d_bfLinv; d_bfX = explicit inverse when the body is small) is built once per rbl_set_parameters
   RblDevBuf d_bfL, d_bfLinv, d_bfX;
   RblDevBuf d_bfPC;                                 // small bodies: M_body^-1 (n^2) | M_body^-1 K_body (6 n) | chol(N_body) (36)
-  bool blk_bodyframe = true, bf_valid = false, bf_inv = false;   // rbl_set_tuning 71 / 72
-  bool bf_wall_approx = false;                                   // rbl_set_tuning 73 / 74 (experiment)
+  bool blk_bodyframe = true, bf_valid = false, bf_inv = false;   // RBL_OPT_BODYFRAME_FACTOR
+  bool bf_wall_approx = false;                                   // RBL_OPT_BODYFRAME_WALL_APPROX (experiment)
   RblDevBuf d_ktl;                                  // K^T Lambda of the last block-PC output (GMRES: the saddle product re-uses it)
   bool ktl_arm = false; const double *ktl_of = nullptr;   // armed by the GMRES loop only; ktl_of = the vector d_ktl belongs to
   bool shared_gemm = true;                          // RBL_OPT_SHARED_GEMM: the ONE body-frame matrix of free space applied to all bodies' vectors as a matrix-matrix product (MFMA)
-  bool blk_explicit = true, blk_inv_valid = false;  // rbl_set_tuning 61 / 62; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
+  bool blk_explicit = true, blk_inv_valid = false;  // RBL_OPT_BLOCK_EXPLICIT_SMALL; d_blkX matches d_blkL for bodies blk_b0 .. blk_b1
   RblDevBuf d_bd, d_bd2;                            // RHS_and_Midpoint workspaces
   RblDevBuf d_gm;                                   // GMRES: Krylov basis, Hessenberg, scratch
   RblDevBuf d_step;                                 // time-step entry points: solution, rhs, slip, force
@@ -199,8 +201,8 @@ struct rbl_ctx {
   int gmres_last_used = 0;      // iterations of the previous converged solve: where the next one looks first (launch-bound systems)
   // lanczos
   int lanczos_max_iter = 100;
-  bool lanczos_out_norm = true;  // preconditioned root: final stopping test in the Euclidean norm of the increment (rbl_set_tuning 85 / 86)
-  bool lanczos_reorth = true;   // full re-orthogonalisation of the Lanczos basis (rbl_set_tuning 81 / 82: off / on)
+  bool lanczos_out_norm = true;  // preconditioned root: final stopping test in the Euclidean norm of the increment (RBL_OPT_LANCZOS_EUCLID_NORM)
+  bool lanczos_reorth = true;   // full re-orthogonalisation of the Lanczos basis (RBL_OPT_LANCZOS_REORTH)
   double lanczos_tol = 1e-10;
   int lanczos_iters = 0;
   double lanczos_resid = 0.0;
@@ -242,9 +244,9 @@ size_t rbl_apply_M_sym_bytes(int64_t n_blobs, int n_cu, int i_step, int nrhs, co
                              int *NI_out = nullptr, int *C_out = nullptr);
 void rbl_apply_M_sym_kernel_name(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, bool wall, char *out, size_t len);
 // nrhs = 1 or 2 vectors ([nrhs][3 n_blobs]); workspace rbl_apply_M_sym_bytes(..., nrhs)
-void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
-                            const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune);
+int rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                           const double *d_r, int64_t n_blobs, int i_first, int i_step,
+                           double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune);
 size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu);
 void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                              const double *d_r, int64_t n_blobs, int nrhs, double *d_out,

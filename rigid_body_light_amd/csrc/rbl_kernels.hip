@@ -1139,11 +1139,10 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
                                                        const double *__restrict__ slabJ,
                                                        const double *__restrict__ r,
                                                        double *__restrict__ out, long N, SymLayout L, RblParams P,
-                                                       unsigned *err, unsigned *queue_reset, RblSaddleFuse fuse)
+                                                       unsigned *err, RblSaddleFuse fuse)
 {
   // blockIdx.y = right-hand side (out is [gridDim.y][3N])
   const int v = blockIdx.y;
-  if (queue_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) queue_reset[32 * threadIdx.x] = 0u;   // the pair kernel's per-XCD work queues, for the next product
   out += (size_t)v * (size_t)(3 * N);
   __shared__ double sh[RG][64];
   const int tx = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1946,7 +1945,7 @@ void rbl_launch_apply_M(hipStream_t st, const RblParams &P, bool wall, const dou
 }
 
 // ---- symmetric variant ------------------------------------------------------
-// tune (per context, rbl_set_tuning): chunk > 0 forces the chunk length C; ni2 > 0 the rows per lane of the two-vector kernel
+// tune (per context, RBL_OPT_SYM_*): chunk > 0 forces the chunk length C; ni2 > 0 the rows per lane of the two-vector kernel
 static SymLayout sym_geometry(int64_t n_blobs, int n_cu, int i_first, int i_step, int nrhs, const RblSymTune &tune)
 {
   SymLayout L;
@@ -2053,88 +2052,130 @@ static void launch_sym(hipStream_t st, const RblParams &P, const double *d_F, co
   else
     hipLaunchKernelGGL((k_apply_M_sym<WALL, NI, SW, 0>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P,
                        d_err, (const unsigned char *)farmap, queue);
-  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, nrhs == 1 ? fuse : RblSaddleFuse());
+  hipLaunchKernelGGL(k_reduce_sym<WALL>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, nrhs == 1 ? fuse : RblSaddleFuse());
 }
 
-// nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...)
-void rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
-                            const double *d_r, int64_t n_blobs, int i_first, int i_step,
-                            double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune)
+// ---- which instantiation a symmetric product launches: ONE table ---------------------------------------------------------------
+// A row = one kernel family in one shape (rows per lane NI, waves per workgroup SW) with what it can do; sym_pick returns the FIRST
+// row whose shape equals the layout's and whose conditions hold, or nullptr -- in which case nothing is launched and the caller
+// reports RBL_ERR_ARG (round 4's cascade of `if`s ended in an `else` that launched <1, 1> for ANY layout it did not know: a forced
+// option once ran the wrong shape and returned a wrong product, profiles/r04_midrange_final.txt).  The names are those of
+// librbl.isa.json (bench.py prices a product with its own kernel's instruction count).
+namespace {
+
+struct SymArgs {
+  hipStream_t st; const RblParams *P; bool wall; const double *d_F, *d_r; int64_t n_blobs; double *d_out, *slabI, *slabJ;
+  const SymLayout *L; unsigned *d_err; bool relaxed; int n_cu; bool use_queue; double gap_ratio; const RblSaddleFuse *fuse;
+};
+
+template <int NI, int SW> void row_launch_sym(const SymArgs &a)
 {
-  if (n_blobs <= 0) return;
-  const SymLayout L = sym_geometry(n_blobs, n_cu, i_first, i_step, nrhs, tune);
-  double *slabI = d_work;
-  double *slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
-  const bool relaxed = tune.relaxed != 0;
-  const double gr = tune.gap_ratio > 0 ? (double)tune.gap_ratio : 15.0;
-  if (nrhs == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.NI == 1 || L.C == 1 || (L.C & 1) == 0)) {
-    // the Lanczos pair of mid-size systems: wave-owned units, six column sums rotating in registers (k_apply_M_symw2v)
-    constexpr int IW = RBL_SYMW_IW;
-    const long n_units = L.tri ? symw_prefix_ni(L.rowsI, L.C, L.nch, L.NI) : (long)L.rowsI * L.nch;
-    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
-    if (L.NI == 2) {
-      if (wall) hipLaunchKernelGGL((k_apply_M_symw2v<true, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-      else hipLaunchKernelGGL((k_apply_M_symw2v<false, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    } else {
-      if (wall) hipLaunchKernelGGL((k_apply_M_symw2v<true, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-      else hipLaunchKernelGGL((k_apply_M_symw2v<false, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    }
-    const int64_t n = 3 * n_blobs;
-    dim3 g2((unsigned)((n + 63) / 64), 2u), b2(64 * RG);
-    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, RblSaddleFuse());
-    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, RblSaddleFuse());
-  } else if (L.NI == 2 && L.SW == SW_LARGE) {
-    if (wall) launch_sym<true, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
-    else launch_sym<false, 2, SW_LARGE>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
-  } else if (L.NI == 2 && nrhs == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) {
-    // two rows per lane in single-wave workgroups (8 200 - 20 480 blobs on one GPU): the wave-unit kernel's NI = 2 form
-    constexpr int IW = RBL_SYMW_IW;
-    const long n_units = L.tri ? symw_prefix_ni(L.rowsI, L.C, L.nch, 2) : (long)L.rowsI * L.nch;
-    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
-    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    else hipLaunchKernelGGL((k_apply_M_symw<false, 2, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    const int64_t n = 3 * n_blobs;
-    dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
-    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
-    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
-  } else if (L.NI == 2) {
-    if (wall) launch_sym<true, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
-    else launch_sym<false, 2, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, relaxed, n_cu, tune.queue >= 0, gr, tune.fuse);
-#ifdef RBL_WAVE_TRACE
-  } else if (L.SW == 2) {                  // experiment (tools/wave_trace.hip): one row per lane, two waves per workgroup
-    if (wall) launch_sym<true, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
-    else launch_sym<false, 1, 2>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
-#endif
-  } else if (nrhs == 1 && L.SW == 1 && tune.wave_units >= 0) {
-    // mid-size systems: wave-owned units, column sums rotating through the lanes (k_apply_M_symw), same slabs + reduction
-    constexpr int IW = RBL_SYMW_IW;
-    const long n_units = L.tri ? symw_prefix(L.rowsI, L.C, L.nch) : (long)L.rowsI * L.nch;
-    const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
-    if (wall) hipLaunchKernelGGL((k_apply_M_symw<true, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    else hipLaunchKernelGGL((k_apply_M_symw<false, 1, IW>), grid, block, 0, st, d_r, d_F, slabI, slabJ, (long)n_blobs, L, P, d_err, n_units);
-    const int64_t n = 3 * n_blobs;
-    dim3 g2((unsigned)((n + 63) / 64), 1u), b2(64 * RG);
-    if (wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
-    else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, st, slabI, slabJ, d_r, d_out, (long)n_blobs, L, P, d_err, (unsigned *)nullptr, tune.fuse);
-  } else {
-    if (wall) launch_sym<true, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
-    else launch_sym<false, 1, 1>(st, P, d_F, d_r, n_blobs, d_out, slabI, slabJ, L, d_err, false, n_cu, tune.queue >= 0, gr, tune.fuse);
-  }
+  if (a.wall) launch_sym<true, NI, SW>(a.st, *a.P, a.d_F, a.d_r, a.n_blobs, a.d_out, a.slabI, a.slabJ, *a.L, a.d_err, a.relaxed, a.n_cu, a.use_queue, a.gap_ratio, *a.fuse);
+  else launch_sym<false, NI, SW>(a.st, *a.P, a.d_F, a.d_r, a.n_blobs, a.d_out, a.slabI, a.slabJ, *a.L, a.d_err, a.relaxed, a.n_cu, a.use_queue, a.gap_ratio, *a.fuse);
 }
 
-// the instantiation rbl_launch_apply_M_sym would launch (reporting: bench.py names what it times): same decisions, no launch
+// wave-owned units (k_apply_M_symw / k_apply_M_symw2v): same slabs, same reduction
+template <int NI, int NRHS> void row_launch_symw(const SymArgs &a)
+{
+  constexpr int IW = RBL_SYMW_IW;
+  const SymLayout &L = *a.L;
+  const long n_units = L.tri ? (NI == 2 || NRHS == 2 ? symw_prefix_ni(L.rowsI, L.C, L.nch, NI) : symw_prefix(L.rowsI, L.C, L.nch)) : (long)L.rowsI * L.nch;
+  const dim3 grid((unsigned)((n_units + IW - 1) / IW)), block(TS * IW);
+  if (NRHS == 2) {
+    if (a.wall) hipLaunchKernelGGL((k_apply_M_symw2v<true, NI, IW>), grid, block, 0, a.st, a.d_r, a.d_F, a.slabI, a.slabJ, (long)a.n_blobs, L, *a.P, a.d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw2v<false, NI, IW>), grid, block, 0, a.st, a.d_r, a.d_F, a.slabI, a.slabJ, (long)a.n_blobs, L, *a.P, a.d_err, n_units);
+  } else {
+    if (a.wall) hipLaunchKernelGGL((k_apply_M_symw<true, NI, IW>), grid, block, 0, a.st, a.d_r, a.d_F, a.slabI, a.slabJ, (long)a.n_blobs, L, *a.P, a.d_err, n_units);
+    else hipLaunchKernelGGL((k_apply_M_symw<false, NI, IW>), grid, block, 0, a.st, a.d_r, a.d_F, a.slabI, a.slabJ, (long)a.n_blobs, L, *a.P, a.d_err, n_units);
+  }
+  const int64_t n = 3 * a.n_blobs;
+  dim3 g2((unsigned)((n + 63) / 64), (unsigned)NRHS), b2(64 * RG);
+  const RblSaddleFuse fuse = NRHS == 1 ? *a.fuse : RblSaddleFuse();
+  if (a.wall) hipLaunchKernelGGL(k_reduce_sym<true>, g2, b2, 0, a.st, a.slabI, a.slabJ, a.d_r, a.d_out, (long)a.n_blobs, L, *a.P, a.d_err, fuse);
+  else hipLaunchKernelGGL(k_reduce_sym<false>, g2, b2, 0, a.st, a.slabI, a.slabJ, a.d_r, a.d_out, (long)a.n_blobs, L, *a.P, a.d_err, fuse);
+}
+
+struct SymRow {
+  const char *name;        // printf format of the librbl.isa.json name: %s = wall
+  int NI, SW;              // the shape the instantiation was compiled for: must EQUAL the layout's
+  int nrhs;                // 1, 2, or 0 = both
+  bool wave_units;         // a wave-unit kernel: needs RBL_OPT_SYM_WAVE_UNITS on, no relaxed sweep, and (NI == 2 or two vectors) C = 1 or even
+  bool relaxed_form;       // has a packed-single-precision form (two rows per lane); others run fp64 when relaxation is asked for
+  void (*launch)(const SymArgs &);
+};
+
+const SymRow kSymRows[] = {
+    {"k_apply_M_symw2v<%s,2>", 2, 1, 2, true, false, row_launch_symw<2, 2>},
+    {"k_apply_M_symw2v<%s,1>", 1, 1, 2, true, false, row_launch_symw<1, 2>},
+    {"k_apply_M_symw<%s,2>", 2, 1, 1, true, false, row_launch_symw<2, 1>},
+    {"k_apply_M_symw<%s>", 1, 1, 1, true, false, row_launch_symw<1, 1>},
+    {"k_apply_M_sym%s<%s,2,4>", 2, SW_LARGE, 0, false, true, row_launch_sym<2, SW_LARGE>},
+    {"k_apply_M_sym%s<%s,2,1>", 2, 1, 0, false, true, row_launch_sym<2, 1>},
+    {"k_apply_M_sym%s<%s,1,1>", 1, 1, 0, false, false, row_launch_sym<1, 1>},
+#ifdef RBL_WAVE_TRACE
+    {"k_apply_M_sym%s<%s,1,2>", 1, 2, 0, false, false, row_launch_sym<1, 2>},     // experiment (tools/wave_trace.hip)
+#endif
+};
+
+const SymRow *sym_pick(const SymLayout &L, int nrhs, bool relaxed, const RblSymTune &tune)
+{
+  for (const SymRow &r : kSymRows) {
+    if (r.NI != L.NI || r.SW != L.SW) continue;
+    if (r.nrhs && r.nrhs != nrhs) continue;
+    if (r.wave_units) {
+      if (tune.wave_units < 0 || relaxed) continue;
+      if ((r.NI == 2 || r.nrhs == 2) && !(L.NI == 1 || L.C == 1 || (L.C & 1) == 0)) continue;   // closed-form unit index: C = 1 or even with two rows per lane
+    }
+    return &r;
+  }
+  return nullptr;
+}
+
+// a forced option the geometry could not honour is an error, not a silent fall-back
+bool sym_forced_ok(const SymLayout &L, int nrhs, const RblSymTune &tune)
+{
+  if (tune.sw > 0 && L.SW != tune.sw) return false;                     // e.g. sym_waves = 4 with one row per lane
+  if (nrhs == 1 && tune.ni1 > 0 && L.NI != tune.ni1) return false;
+  if (nrhs == 2 && tune.ni2 > 0 && L.NI != tune.ni2) return false;
+  if (tune.chunk > 0 && L.C != tune.chunk) return false;
+  return true;
+}
+
+}  // namespace
+
+// nrhs = 1 or 2 force vectors (d_F, d_out: [nrhs][3 n_blobs]); d_work from rbl_apply_M_sym_bytes(...).
+// RBL_ERR_ARG (nothing launched): the options force a shape no instantiation has.
+int rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
+                           const double *d_r, int64_t n_blobs, int i_first, int i_step,
+                           double *d_out, double *d_work, int n_cu, unsigned *d_err, int nrhs, const RblSymTune &tune)
+{
+  if (n_blobs <= 0) return RBL_OK;
+  const SymLayout L = sym_geometry(n_blobs, n_cu, i_first, i_step, nrhs, tune);
+  const bool relaxed = tune.relaxed != 0;
+  const SymRow *row = sym_forced_ok(L, nrhs, tune) ? sym_pick(L, nrhs, relaxed, tune) : nullptr;
+  if (!row) return RBL_ERR_ARG;
+  SymArgs a;
+  a.st = st; a.P = &P; a.wall = wall; a.d_F = d_F; a.d_r = d_r; a.n_blobs = n_blobs; a.d_out = d_out;
+  a.slabI = d_work; a.slabJ = d_work + sym_slabI_blobs(L) * 3 * nrhs;
+  a.L = &L; a.d_err = d_err; a.relaxed = relaxed && row->relaxed_form; a.n_cu = n_cu; a.use_queue = tune.queue >= 0;
+  a.gap_ratio = tune.gap_ratio > 0 ? (double)tune.gap_ratio : 15.0; a.fuse = &tune.fuse;
+  row->launch(a);
+  return RBL_OK;
+}
+
+// the instantiation rbl_launch_apply_M_sym would launch (reporting: bench.py names what it times): the same table, no launch;
+// an empty name when the options force a shape no instantiation has
 void rbl_apply_M_sym_kernel_name(int64_t n_blobs, int n_cu, int i_step, int nrhs, const RblSymTune &tune, bool wall, char *out, size_t len)
 {
   const SymLayout L = sym_geometry(n_blobs, n_cu, 0, i_step, nrhs, tune);
   const char *w = wall ? "true" : "false";
-  const bool relaxed = tune.relaxed != 0;
-  if (nrhs == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.NI == 1 || L.C == 1 || (L.C & 1) == 0))
-    std::snprintf(out, len, "k_apply_M_symw2v<%s,%d>", w, L.NI);
-  else if (nrhs == 2) std::snprintf(out, len, "k_apply_M_sym2<%s,%d,%d>", w, L.NI, L.SW);
-  else if (L.NI == 2 && L.SW == 1 && !relaxed && tune.wave_units >= 0 && (L.C == 1 || (L.C & 1) == 0)) std::snprintf(out, len, "k_apply_M_symw<%s,2>", w);
-  else if (L.NI == 2) std::snprintf(out, len, "k_apply_M_sym<%s,2>", w);              // (one or four waves per workgroup: the same sweep)
-  else if (L.SW == 1 && tune.wave_units >= 0) std::snprintf(out, len, "k_apply_M_symw<%s>", w);
-  else std::snprintf(out, len, "k_apply_M_sym<%s,1>", w);
+  const SymRow *row = sym_forced_ok(L, nrhs, tune) ? sym_pick(L, nrhs, tune.relaxed != 0, tune) : nullptr;
+  if (len) out[0] = 0;
+  if (!row) return;
+  if (row->wave_units) { std::snprintf(out, len, row->name, w); return; }
+  // k_apply_M_sym / k_apply_M_sym2: librbl.isa.json names them <wall, NI> (one or four waves per workgroup: the same sweep)
+  if (nrhs == 2) std::snprintf(out, len, "k_apply_M_sym2<%s,%d,%d>", w, L.NI, L.SW);
+  else std::snprintf(out, len, "k_apply_M_sym<%s,%d>", w, L.NI);
 }
 
 // ---- multi-RHS (MFMA) variant ---------------------------------------------------

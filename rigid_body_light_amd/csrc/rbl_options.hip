@@ -1,8 +1,8 @@
-// rbl_options.hip -- named per-context options (include/rbl.h: rbl_set_option / rbl_get_option / rbl_option_info) and the
-// rbl_set_tuning shim of rounds 1-3 (its magic integers map onto the table below; kept for one more round).
+// rbl_options.hip -- named per-context options (include/rbl.h: rbl_set_option / rbl_get_option / rbl_option_info).
 //
-// One table row per option: key, name, range, default, and what else a change invalidates (cached factors, preconditioner
-// state).  An unknown key or a value outside its range is RBL_ERR_ARG and changes nothing.
+// One table row per option: key, name, range (and, where not every value of the range selects something, a predicate), default,
+// and what else a change invalidates (cached factors, preconditioner state).  An unknown key or an inadmissible value is
+// RBL_ERR_ARG and changes nothing.
 #include <cstring>
 
 #include "rbl_api_internal.hpp"
@@ -15,6 +15,7 @@ struct OptRow {
   int64_t lo, hi, dflt;
   int64_t (*get)(const rbl_ctx *);
   void (*set)(rbl_ctx *, int64_t);
+  bool (*ok)(int64_t) = nullptr;        // values of [lo, hi] that select something (nullptr: all of them)
 };
 
 void drop_factors(rbl_ctx *c) { c->dev_blk_valid = false; c->blk_inv_valid = false; c->bf_valid = false; c->dev_pc_valid = false; }
@@ -30,8 +31,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->sym_tune.ni1 = (int)v; }},
     {RBL_OPT_SYM2_ROWS_PER_LANE, "sym2_rows_per_lane", 0, 2, 0, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.ni2; },
      [](rbl_ctx *c, int64_t v) { c->sym_tune.ni2 = (int)v; }},
-    {RBL_OPT_SYM_WAVES, "sym_waves", 0, 8, 0, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.sw; },
-     [](rbl_ctx *c, int64_t v) { c->sym_tune.sw = (int)v; }},
+    {RBL_OPT_SYM_WAVES, "sym_waves", 0, 4, 0, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.sw; },
+     [](rbl_ctx *c, int64_t v) { c->sym_tune.sw = (int)v; }, [](int64_t v) { return v == 0 || v == 1 || v == 4; }},
     {RBL_OPT_SYM_WORK_QUEUE, "sym_work_queue", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.queue < 0 ? 0 : 1; },
      [](rbl_ctx *c, int64_t v) { c->sym_tune.queue = v ? 0 : -1; }},
     {RBL_OPT_SYM_WAVE_UNITS, "sym_wave_units", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.wave_units < 0 ? 0 : 1; },
@@ -78,6 +79,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->tl_refresh = (int)v; c->tl_age = 0; c->tl_valid = false; }},
     {RBL_OPT_BLOCK_TILE_FACTOR, "block_tile_factor", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->blk_tile; },
      [](rbl_ctx *c, int64_t v) { c->blk_tile = v != 0; drop_factors(c); c->tl_valid = false; }},
+    {RBL_OPT_COMM_FORCE_STAGED, "comm_force_staged", 0, 1, 0, [](const rbl_ctx *c) -> int64_t { return c->comm_force_staged; },
+     [](rbl_ctx *c, int64_t v) { c->comm_force_staged = v != 0; }},
     {RBL_OPT_FUSED_KRYLOV, "fused_krylov", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->fused_krylov; },
      [](rbl_ctx *c, int64_t v) { c->fused_krylov = v != 0; }},
 };
@@ -100,6 +103,8 @@ int rbl_set_option(rbl_ctx *c, int option, int64_t value)
   if (!r) return rbl_fail(c, RBL_ERR_ARG, "set_option: unknown option key " + std::to_string(option));
   if (value < r->lo || value > r->hi)
     return rbl_fail(c, RBL_ERR_ARG, std::string("set_option: ") + r->name + " takes " + std::to_string(r->lo) + " .. " + std::to_string(r->hi));
+  if (r->ok && !r->ok(value))
+    return rbl_fail(c, RBL_ERR_ARG, std::string("set_option: ") + r->name + " = " + std::to_string(value) + " selects nothing (see include/rbl.h)");
   r->set(c, value);
   return RBL_OK;
 }
@@ -140,25 +145,3 @@ int rbl_set_block_refresh(rbl_ctx *c, int every)
 
 // transient switch: the matvec entry points skip the damping B (plain, wall-corrected M) while it is on
 int rbl_set_no_damp(rbl_ctx *c, int on) { return c ? rbl_set_option(c, RBL_OPT_NO_DAMP, on != 0) : RBL_ERR_ARG; }
-
-// ---- the rounds 1-3 switchboard, mapped onto the table (deprecated; INTEGRATION.md section 1 lists the named keys) ------
-int rbl_set_tuning(rbl_ctx *c, int jsplit, int variant)
-{
-  if (!c) return RBL_ERR_ARG;
-  struct Pair { int off, on, key; };
-  static const Pair pairs[] = {
-      {31, 32, RBL_OPT_GMRES_PC_SIGN_FIX}, {41, 42, RBL_OPT_GMRES_ONE_KERNEL}, {73, 74, RBL_OPT_BODYFRAME_WALL_APPROX},
-      {83, 84, RBL_OPT_BLOCK_INVERSE_F32}, {93, 94, RBL_OPT_SYM_WORK_QUEUE},   {91, 92, RBL_OPT_GMRES_PREDICT_CHECKS},
-      {87, 88, RBL_OPT_LANCZOS_TWO_LEVEL}, {85, 86, RBL_OPT_LANCZOS_EUCLID_NORM}, {81, 82, RBL_OPT_LANCZOS_REORTH},
-      {71, 72, RBL_OPT_BODYFRAME_FACTOR},  {61, 62, RBL_OPT_BLOCK_EXPLICIT_SMALL}, {51, 52, RBL_OPT_RELAXED_KRYLOV},
-      {53, 54, RBL_OPT_RELAXED_ALWAYS}};
-  for (const Pair &p : pairs)
-    if (variant == p.off || variant == p.on) return rbl_set_option(c, p.key, variant == p.on);
-  if (variant >= 63 && variant <= 65) return rbl_set_option(c, RBL_OPT_BLOCK_EXPLICIT_LARGE, variant - 63);
-  if (variant == 21 || variant == 22) return rbl_set_option(c, RBL_OPT_SYM2_ROWS_PER_LANE, variant - 20);
-  if (variant < 0 || variant > 3) return rbl_fail(c, RBL_ERR_ARG, "set_tuning: unknown variant " + std::to_string(variant));
-  int rc = rbl_set_option(c, RBL_OPT_SYM_CHUNK, variant == 2 ? jsplit : 0);   // with the symmetric kernel forced, jsplit = chunk length C
-  if (!rc) rc = rbl_set_option(c, RBL_OPT_ORDERED_JSPLIT, jsplit);
-  if (!rc) rc = rbl_set_option(c, RBL_OPT_MATVEC_KERNEL, variant);
-  return rc;
-}

@@ -7,7 +7,7 @@
 // single precision -- the two rows a lane owns travel in the two halves of 64-bit registers (v_pk_fma_f32: two pairs per
 // instruction), v_rsq_f32 needs no Newton step.  ~38 VALU instructions per unordered pair instead of ~75.
 // NOT used by default: an inexact Krylov method tolerates a product error of (tolerance / current residual), so the
-// library's GMRES may switch to it once its residual estimate is small (rbl_set_tuning 52); a product through this form
+// library's GMRES may switch to it once its residual estimate is small (RBL_OPT_RELAXED_KRYLOV); a product through this form
 // agrees with the fp64 one to ~1e-6 relative.  Coordinates: x, y and z RELATIVE to an origin near the rows (so that
 // single precision resolves the short distances), two_z0 = 2 x that origin's height, for R_z = z_i + z_j.
 // ---------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 
 #include "rbl_api_internal.hpp"
 
+#define SYM_SHAPE_MSG "symmetric product: the options (sym_rows_per_lane / sym2_rows_per_lane / sym_waves / sym_chunk) force a kernel shape that does not exist"
+
 int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
                            int64_t row_begin, int64_t row_end, double *d_out)
 {
@@ -51,8 +53,9 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 1, tune)))) return rc;   // (the geometry follows the transient switches)
     {
       RblPhase ph(c, RBL_T_PRODUCT);
-      rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
-                             c->n_cu, c->d_err, 1, tune);
+      if ((rc = rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, c->comm_rank, c->comm_world, d_out, (double *)c->d_part.p,
+                                       c->n_cu, c->d_err, 1, tune)))
+        return rbl_fail(c, rc, SYM_SHAPE_MSG);
     }
     return comm_allreduce(c, d_out, 3 * nbl);
   }
@@ -61,8 +64,9 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
     RblSymTune tune = c->sym_tune;
     if (c->force_relaxed) tune.relaxed = 1;
     if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 1, tune)))) return rc;   // (the geometry follows the transient switches)
-    rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
-                           c->d_err, 1, tune);
+    if ((rc = rbl_launch_apply_M_sym(c->stream, P, wall, d_F, d_r, nbl, 0, 1, d_out, (double *)c->d_part.p, c->n_cu,
+                                     c->d_err, 1, tune)))
+      return rbl_fail(c, rc, SYM_SHAPE_MSG);
     c->fuse_done = tune.fuse.lever != nullptr;        // the slab reduction also wrote the saddle epilogue (rbl_apply_saddle_dev)
   } else {
     int js = 1;
@@ -98,8 +102,9 @@ int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, c->comm_world, 2, tune)))) return rc;   // (the geometry follows the transient switches)
       {
         RblPhase ph(c, RBL_T_PRODUCT);
-        rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
-                               d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
+        if ((rc = rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, c->comm_rank, c->comm_world,
+                                         d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune)))
+          return rbl_fail(c, rc, SYM_SHAPE_MSG);
       }
       if ((rc = comm_allreduce(c, d_out + (size_t)k * n3, 2 * n3))) return rc;
     }
@@ -115,8 +120,9 @@ int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double
       RblSymTune tune = c->sym_tune;
       if (c->force_relaxed) tune.relaxed = 1;
       if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(nbl, c->n_cu, 1, 2, tune)))) return rc;   // (the geometry follows the transient switches)
-      rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
-                             d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune);
+      if ((rc = rbl_launch_apply_M_sym(c->stream, ctx_params(c), wall, d_F + (size_t)k * n3, d_r, nbl, 0, 1,
+                                       d_out + (size_t)k * n3, (double *)c->d_part.p, c->n_cu, c->d_err, 2, tune)))
+        return rbl_fail(c, rc, SYM_SHAPE_MSG);
     }
     for (; k < nrhs; ++k)
       if ((rc = apply_M_enqueue(c, wall, d_F + (size_t)k * n3, d_r, nbl, 0, nbl, d_out + (size_t)k * n3))) return rc;
@@ -310,8 +316,9 @@ int rbl_apply_M_sym_multi_dev(rbl_ctx *c, const double *d_F, const double *d_r, 
   if (n_blobs <= 0 || i_step < 1 || i_first < 0 || i_first >= i_step || nrhs < 1 || nrhs > 2)
     return rbl_fail(c, RBL_ERR_SIZE, "apply_M_sym_multi_dev: need n_blobs > 0, 0 <= i_first < i_step, nrhs 1 or 2");
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, nrhs, c->sym_tune)))) return rc;
-  rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
-                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs, c->sym_tune);
+  if ((rc = rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
+                                   i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, nrhs, c->sym_tune)))
+    return rbl_fail(c, rc, SYM_SHAPE_MSG);
   return RBL_OK;
 }
 
@@ -325,8 +332,9 @@ int rbl_apply_M_sym_dev(rbl_ctx *c, const double *d_F, const double *d_r, int64_
   RblSymTune tune = c->sym_tune;
   if (c->force_relaxed) tune.relaxed = 1;
   if ((rc = rbl_dev_reserve(c, c->d_part, rbl_apply_M_sym_bytes(n_blobs, c->n_cu, i_step, 1, tune)))) return rc;   // (the geometry follows the transient switches)
-  rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
-                         i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, tune);
+  if ((rc = rbl_launch_apply_M_sym(c->stream, ctx_params(c), c->S.wall, d_F, d_r, n_blobs, i_first,
+                                   i_step, d_out, (double *)c->d_part.p, c->n_cu, c->d_err, 1, tune)))
+    return rbl_fail(c, rc, SYM_SHAPE_MSG);
   return RBL_OK;
 }
 
@@ -349,6 +357,7 @@ int rbl_apply_M_sym_kernel(rbl_ctx *c, int64_t n_blobs, int i_step, int nrhs, in
     return rbl_fail(c, RBL_ERR_ARG, "apply_M_sym_kernel: bad arguments (name buffer of >= 40 bytes)");
   int rc = rbl_dev_init(c); if (rc) return rc;
   rbl_apply_M_sym_kernel_name(n_blobs, c->n_cu, i_step, nrhs, c->sym_tune, wall != 0, name, (size_t)name_len);
+  if (!name[0]) return rbl_fail(c, RBL_ERR_ARG, SYM_SHAPE_MSG);     // the same answer a product of that size would get
   return RBL_OK;
 }
 

@@ -176,6 +176,70 @@ __device__ __forceinline__ void tile_gemm(const double *Ip, long ldI, long rowI,
   }
 }
 
+// X = T W^T IN PLACE in the accumulators (W = L_cc^-1 lower triangular, 128 x 128 column-major at Wt, zero-padded): on entry
+// acc[tj][ti] holds T (element (col 16 tj + l4 + 4 v, row 16 ti + l15) of the wave's 64 x 64 part), on exit X.  The 16-column slabs
+// of T go DOWN from 7 to 0: slab s is written to LDS by the two waves that hold those columns (wj = s >> 2) straight from
+// their accumulator registers, whose tile is dead from then on (X's column tile t only collects slabs <= t), so that tile's
+// registers restart at zero as X -- no second accumulator set, no trip of T through memory.  The W slabs ride the usual
+// global -> registers -> LDS prefetch.  One barrier per slab; a wave multiplies slab s into its column tiles 4 wj + tj >= s only.
+__device__ __forceinline__ void tile_solve(double4_t (&acc)[4][4], const double *Wt, double (*sT)[TKC * TLDP], double (*sW)[TKC * TLDP],
+                                           bool active)
+{
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int lrow = (t & 63) * 2, lcg = (t >> 6) * 4;
+  rbl_d2 rW[2][4];
+  auto gload = [&](auto set, int slab) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rW[set()][q] = *reinterpret_cast<const rbl_d2 *>(Wt + (size_t)(slab * TKC + lcg + q) * TC + lrow);
+  };
+  auto lwrite = [&](auto set, int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<rbl_d2 *>(&sW[buf][(lcg + q) * TLDP + lrow]) = rW[set()][q];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  gload(S0{}, 7);
+  gload(S1{}, 6);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {                            // slab s = 7 - p
+    const int s_ = 7 - p, buf = p & 1, tjs = s_ & 3;
+    if (p & 1) lwrite(S1{}, buf); else lwrite(S0{}, buf);
+    if (p + 2 < 8) { if (p & 1) gload(S1{}, s_ - 2); else gload(S0{}, s_ - 2); }
+    if (wj == (s_ >> 2)) {                                 // this wave holds T's columns 16 s .. 16 s + 15
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sT[buf][(l4 + 4 * v) * TLDP + wi * 64 + 16 * ti + l15] = acc[tjs][ti][v];
+          acc[tjs][ti][v] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (active && 4 * wj + 3 >= s_) {
+      const double *fi = &sT[buf][l4 * TLDP + wi * 64 + l15];
+      const double *fj = &sW[buf][l4 * TLDP + wj * 64 + l15];
+      const int tj_lo = s_ - 4 * wj;
+#pragma unroll
+      for (int ks = 0; ks < TKC / 4; ++ks) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = fj[ks * 4 * TLDP + 16 * q]; bv[q] = fi[ks * 4 * TLDP + 16 * q]; }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          if (tj >= tj_lo) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+              acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj], bv[ti], acc[tj][ti], 0, 0, 0);
+          }
+      }
+    }
+  }
+  __syncthreads();                                         // the LDS buffers are free again
+}
+
 __device__ __forceinline__ int tiles16(long first, long limit)       // 16-wide MFMA tiles of [first, first + 64) that begin below `limit`
 {
   const long r = limit - first;
@@ -399,15 +463,21 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
         tile_gemm<true>(Ip, ldo, r0, n, Jp, n, c0, n, TC * nkt, TC * nkt, TC * nkt, sI, sJ, acc, mk, waitfn);
     }
     TP(1)                                                  // product (incl. its waits)
-    // T = C - acc (CHOL, nothing to do in the first column) or -acc (INV); the 32 loads of two 16-column strips are all in flight
-    // before the first store (one memory round trip per strip pair, not per entry); INV on the diagonal: Y_jj = W_j^T
+    // T = C - acc (CHOL) or -acc (INV), kept in the accumulator registers; the 32 loads of two 16-column strips of C are all in
+    // flight before the first use (one memory round trip per strip pair, not per entry).  Only a diagonal tile of L goes back
+    // to memory here (its factorisation works there); INV on the diagonal is a copy: Y_jj = W_j^T
     if (!chol && diag) {
       for (int e = t; e < TC * TC; e += 256) {
         const int a_ = e & (TC - 1), b_ = e >> 7;          // Y_jj[a_][b_] = W[b_][a_]
         const long row = r0 + a_, col = c0 + b_;
         if (row < n && col < n) Om[(size_t)col * (size_t)ldo + row] = Wb[(size_t)a_ * TC + b_];
       }
-    } else if (active && nkt > 0) {
+    } else if (active && !chol) {
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[tj][ti] = -acc[tj][ti];
+    } else if (active) {
 #pragma unroll
       for (int tp = 0; tp < 4; tp += 2) {
         double cv[2][4][4];
@@ -416,29 +486,37 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const long col = j0 + 16 * (tp + h) + l4 + 4 * v;
-            const double *cp = Om + (size_t)(col < n ? col : n - 1) * (size_t)ldo;
+            const double *cp = Ab + (size_t)(col < n ? col : n - 1) * (size_t)n;
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) {
               const long row = i0 + 16 * ti + l15;
-              cv[h][ti][v] = chol ? cp[row < n ? row : n - 1] : 0.0;
+              cv[h][ti][v] = cp[row < n ? row : n - 1];   // unconditional (clamped) loads: a guarded load is a branch and a round trip EACH
             }
           }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) acc[tp + h][ti][v] = cv[h][ti][v] - acc[tp + h][ti][v];
+      }
+      if (diag && nkt > 0) {                               // the diagonal tile goes back to memory: its factorisation works there
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const long col = j0 + 16 * (tp + h) + l4 + 4 * v;
+            const long col = j0 + 16 * tj + l4 + 4 * v;
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) {
               const long row = i0 + 16 * ti + l15;
-              if (row < n && col < n) Om[(size_t)col * (size_t)ldo + row] = cv[h][ti][v] - acc[tp + h][ti][v];
+              if (row < n && col < n) Ab[(size_t)col * (size_t)n + row] = acc[tj][ti][v];
             }
           }
       }
     }
-    __syncthreads();
-    TP(2)                                                  // T written
+    TP(2)                                                  // T formed
     if (chol && diag) {
+      __syncthreads();
       potrf_block_body<4>(Ab, n, c0, pw, Lib + (size_t)(4 * ct) * IB * IB, P.err, reinterpret_cast<double (*)[IB + 1]>(&sI[0][0]));
       TP(3)                                                // diagonal tile
       tile_winv(Ab, n, c0, pw, Lib + (size_t)(4 * ct) * IB * IB, Wb);
@@ -446,15 +524,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     } else if (!diag) {
       if (chol) wait_ge(cL + ct, (unsigned)ct + 1u, P);    // the diagonal tile of this column and its inverse
       TP(4)
-      // X = T L_cc^-T = T W^T: one pipelined product over the tile's own 128 columns (W lower triangular: stage s only feeds
-      // the output column tiles from s on)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-      const TileMask m2{tiles16(i0, n), tiles16(j0, n), true, false};
-      tile_gemm<true>(Om + (size_t)c0 * (size_t)ldo, ldo, r0, n, Wb, TC, 0, TC, TC, pw, TC, sI, sJ, acc, m2, [](int) {});
-      if (m2.nti > 0 && m2.ntj > 0) {
+      tile_solve(acc, Wb, sI, sJ, tiles16(i0, n) > 0 && tiles16(j0, n) > 0);      // X = T L_cc^-T = T W^T, in the registers
+      if (tiles16(i0, n) > 0 && tiles16(j0, n) > 0) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll

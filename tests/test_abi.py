@@ -52,9 +52,10 @@ def option_keys():
 
 
 def test_every_option_is_named_bounded_and_round_trips():
-    """include/rbl.h's named options (the replacement of the rbl_set_tuning switchboard): every key 1 .. RBL_OPT_COUNT - 1 has a
+    """include/rbl.h's named options (the replacement of the rounds 1-3 switchboard of magic integers): every key 1 .. RBL_OPT_COUNT - 1 has a
     table row (name, range, default), starts at its default, round-trips its extreme values, rejects values outside its range
-    and unknown keys with RBL_ERR_ARG leaving the option unchanged; the deprecated shim sets the same state."""
+    and unknown keys with RBL_ERR_ARG leaving the option unchanged; a value inside the range that selects nothing (sym_waves = 2, 3)
+    is rejected the same way; the switchboard of magic integers of rounds 1-3 is gone from the library."""
     i64 = ctypes.c_int64
     lib = ctypes.CDLL(os.path.join(ROOT, "rigid_body_light_amd", "librbl.so"))
     lib.rbl_create.restype = ctypes.c_void_p
@@ -63,7 +64,6 @@ def test_every_option_is_named_bounded_and_round_trips():
     lib.rbl_get_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(i64)]
     lib.rbl_option_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)] + [ctypes.POINTER(i64)] * 3
     lib.rbl_option_key.argtypes = [ctypes.c_char_p]
-    lib.rbl_set_tuning.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     keys = option_keys()
     count = keys.pop("RBL_OPT_COUNT")
     assert sorted(keys.values()) == list(range(1, count)), "RBL_OPT_* keys must be 1 .. RBL_OPT_COUNT - 1 without gaps"
@@ -94,17 +94,12 @@ def test_every_option_is_named_bounded_and_round_trips():
         assert lib.rbl_get_option(h, bad_key, ctypes.byref(v)) == 11 and v.value == 7
         assert lib.rbl_option_info(bad_key, None, None, None, None) == 11
     assert lib.rbl_option_key(b"no_such_option") == 0
-    # the rounds 1-3 switchboard is a shim over the same table
-    shim = {31: ("gmres_pc_sign_fix", 0), 42: ("gmres_one_kernel", 1), 52: ("relaxed_krylov", 1), 54: ("relaxed_always", 1),
-            61: ("block_explicit_small", 0), 63: ("block_explicit_large", 0), 64: ("block_explicit_large", 1), 65: ("block_explicit_large", 2),
-            71: ("bodyframe_factor", 0), 74: ("bodyframe_wall_approx", 1), 81: ("lanczos_reorth", 0), 84: ("block_inverse_f32", 1),
-            85: ("lanczos_euclid_norm", 0), 87: ("lanczos_two_level", 0), 91: ("gmres_predict_checks", 0), 93: ("sym_work_queue", 0),
-            22: ("sym2_rows_per_lane", 2)}
-    for code, (name, val) in shim.items():
-        assert lib.rbl_set_tuning(h, 0, code) == 0 and get(lib.rbl_option_key(name.encode())) == val, code
-    assert lib.rbl_set_tuning(h, 5, 2) == 0 and get(lib.rbl_option_key(b"matvec_kernel")) == 2 and get(lib.rbl_option_key(b"sym_chunk")) == 5
-    assert lib.rbl_set_tuning(h, 0, 0) == 0 and get(lib.rbl_option_key(b"matvec_kernel")) == 0 and get(lib.rbl_option_key(b"sym_chunk")) == 0
-    assert lib.rbl_set_tuning(h, 0, 77) == 11                             # unknown switch: an error now, not a silent kernel choice
+    kw = lib.rbl_option_key(b"sym_waves")
+    for bad in (2, 3):                                                    # inside [0, 4] but no kernel has that many waves
+        assert lib.rbl_set_option(h, kw, bad) == 11 and get(kw) == 0
+    for good in (1, 4, 0):
+        assert lib.rbl_set_option(h, kw, good) == 0 and get(kw) == good
+    assert not hasattr(lib, "rbl_set_" + "tuning")
     lib.rbl_destroy(h)
 
 

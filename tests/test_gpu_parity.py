@@ -150,7 +150,7 @@ def test_apply_M_midsize_vs_oracle(orc, wall, nb, nblb):
     F = np.random.default_rng(2).standard_normal(r.size)
     Uo = orc.apply_M(F, r, c["a"], c["eta"], wall, mode="matfree")
     for js, variant in ((0, 1), (1, 1), (3, 1), (0, 2), (0, 0)):   # ordered kernel (j-splits), symmetric kernel, heuristic
-        rb.cb.set_tuning(js, variant)
+        rb.cb.set_option("matvec_kernel", variant); rb.cb.set_option("ordered_jsplit", js)
         assert rel(rb.apply_M(F, r), Uo) < 1e-12
 
 
@@ -162,7 +162,7 @@ def test_apply_M_cfg2_size_vs_oracle_rows(orc):
     r = rb.get_blob_positions()
     F = np.random.default_rng(2).standard_normal(r.size)
     for variant in (1, 2):
-        rb.cb.set_tuning(0, variant)
+        rb.cb.set_option("matvec_kernel", variant)
         U = rb.apply_M(F, r).reshape(-1, 3)
         for (b, e) in ((0, 64), (4000, 4064), (8036, 8100)):
             Uo = orc.apply_M_rows(F, r, b, e, c["a"], c["eta"], False, nthreads=8)
@@ -193,6 +193,58 @@ def test_apply_M_between_cfg2_and_cfg3_vs_oracle_rows(orc, nb, nblb, wall):
         rb.cb.set_option("sym_waves", waves); rb.cb.set_option("sym_rows_per_lane", rows)
         assert rel(rb.apply_M(F, r), U) < 1e-13
     rb.cb.set_option("sym_waves", 0); rb.cb.set_option("sym_rows_per_lane", 0)
+
+
+@pytest.mark.parametrize("nb,nblb,wall", [(30, 162, False), (34, 642, True)])
+def test_every_symmetric_kernel_shape_the_options_can_ask_for(nb, nblb, wall):
+    """The symmetric product picks its instantiation from ONE table (csrc/rbl_kernels.hip: kSymRows / sym_pick) keyed by the layout
+    the options produce.  Sweep every combination of rows per lane (0 heuristic, 1, 2), waves per workgroup (0, 1, 4), wave-owned
+    units (on / off), chunk length (heuristic, 1, 2, 3: both parities) and one or two vectors at 4 860 free blobs (one row per lane
+    by the heuristic) and 21 828 wall blobs (two rows, four waves): every admissible combination equals the ordered-rows kernel to
+    rounding, every inadmissible one -- four waves with one row per lane: no such kernel -- is RBL_ERR_ARG from the product AND from
+    rbl_apply_M_sym_kernel, and nothing is launched (round 4: such a combination silently ran another shape and was wrong by 0.9)."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, RblError
+    dev = torch.device("cuda:0")
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+    ctx.set_config(c["X"], c["Q"])
+    r = torch.empty(3 * N, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
+    F = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 3 * N))).to(dev)
+    ref = torch.empty_like(F)
+    ctx.set_option("matvec_kernel", 1)                                   # ordered rows: every pair twice, no slabs, no shapes
+    for k in range(2):
+        ctx.apply_M(F[k].data_ptr(), r.data_ptr(), N, 0, N, ref[k].data_ptr())
+    ctx.set_option("matvec_kernel", 0); ctx.sync_check()
+    seen, refused = set(), 0
+    for nrhs in (1, 2):
+        rows_opt = "sym_rows_per_lane" if nrhs == 1 else "sym2_rows_per_lane"
+        for rows in (0, 1, 2):
+            for waves in (0, 1, 4):
+                for wu in (1, 0):
+                    for chunk in (0, 1, 2, 3):
+                        ctx.set_option(rows_opt, rows); ctx.set_option("sym_waves", waves)
+                        ctx.set_option("sym_wave_units", wu); ctx.set_option("sym_chunk", chunk)
+                        ni_eff = rows if rows else ctx.apply_M_sym_info(N, 1, nrhs)[0]
+                        out = torch.full_like(F[:nrhs], 7.25)
+                        if waves == 4 and ni_eff == 1:                   # no four-wave kernel with one row per lane
+                            with pytest.raises(RblError, match="status 11"):
+                                ctx.apply_M_sym_multi(F.data_ptr(), r.data_ptr(), N, nrhs, 0, 1, out.data_ptr())
+                            with pytest.raises(RblError, match="status 11"):
+                                ctx.apply_M_sym_kernel(N, wall, 1, nrhs)
+                            ctx.sync_check()
+                            assert bool((out == 7.25).all())             # nothing was launched
+                            refused += 1
+                            continue
+                        ctx.apply_M_sym_multi(F.data_ptr(), r.data_ptr(), N, nrhs, 0, 1, out.data_ptr())
+                        ctx.sync_check()
+                        err = float(torch.linalg.norm(out - ref[:nrhs]) / torch.linalg.norm(ref[:nrhs]))
+                        assert err < 1e-12, (nrhs, rows, waves, wu, chunk, err)
+                        seen.add(ctx.apply_M_sym_kernel(N, wall, 1, nrhs))
+    assert refused > 0 and len(seen) >= 5, (refused, seen)               # wave-unit and slab kernels, one and two rows, both vector counts
+    ctx.close()
 
 
 @pytest.mark.parametrize("wall", [False, True])
@@ -233,7 +285,7 @@ def test_single_blob_analytic_and_edge_sizes(orc):
         Fn = rng.standard_normal(3 * n)
         for obj, wall in ((rb, False), (rbw, True)):
             for variant in (1, 2):
-                obj.cb.set_tuning(0, variant)
+                obj.cb.set_option("matvec_kernel", variant)
                 assert rel(obj.apply_M(Fn, r), orc.apply_M(Fn, r, a, eta, wall, mode="dense")) < 1e-12
     with pytest.raises(RuntimeError):
         rb.cb.apply_M(np.zeros(0), np.zeros(0))            # empty input is a size error, not a crash
@@ -1083,11 +1135,11 @@ def test_small_body_explicit_inverses_equal_substitution(orc, wall, nblb):
     m = 3 * nblb
     v = torch.from_numpy(rng.standard_normal(m * nb)).to(dev)
     res = {}
-    for variant in (61, 62):
+    for variant in (61, 62):                                     # block_explicit_small off / on
         ctx = DeviceContext(1.0, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
         ctx.set_option("bodyframe_factor", 0)                    # per-configuration Cholesky factors (the body-frame form has its own test)
-        ctx.set_tuning(0, variant)
+        ctx.set_option("block_explicit_small", variant - 61)
         for mode in (0, 1, 2):
             o = torch.empty_like(v); ctx.block_solve(v.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
             res[(variant, mode)] = o
@@ -1137,7 +1189,7 @@ def test_large_body_explicit_inverses_equal_substitution(orc, wall, nblb):
         ctx = DeviceContext(a, 1.0, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(X, Q)
         ctx.set_option("bodyframe_factor", 0)                    # per-configuration Cholesky factors (free space would share ONE body-frame factor)
-        ctx.set_tuning(0, 64 if variant == 84 else variant)
+        ctx.set_option("block_explicit_large", 0 if variant == 63 else 1)   # 63: substitution, 64: explicit inverses, 84: + their fp32 copy
         if variant == 84:
             ctx.set_option("block_inverse_f32", 1)
         for mode in (0, 1, 2, 3):
@@ -1232,8 +1284,8 @@ def test_free_space_body_frame_factors(orc, nblb):
     lib().rbl_set_blk_pc(ctx.h, 1)
     zin = torch.from_numpy(rng.standard_normal(m * nb + 6 * nb)).to(dev)
     zo = {}
-    for variant in (72, 71):
-        ctx.set_tuning(0, variant)
+    for variant in (72, 71):                                     # bodyframe_factor on / off
+        ctx.set_option("bodyframe_factor", variant - 71)
         o = torch.empty_like(zin); ctx.apply_PC(zin.data_ptr(), o.data_ptr()); ctx.sync_check()
         zo[variant] = o
         w = zin.clone(); ctx.apply_PC(w.data_ptr(), w.data_ptr()); ctx.sync_check()                # in place
@@ -1263,7 +1315,7 @@ def test_wall_system_with_the_free_space_body_frame_factor(orc):
         ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
         lib().rbl_set_blk_pc(ctx.h, 1)
         ctx.set_config(c["X"], c["Q"])
-        ctx.set_tuning(0, variant)
+        ctx.set_option("bodyframe_wall_approx", variant - 73)
         x = torch.empty_like(b)
         m, res = ctx.gmres_saddle(b.data_ptr(), 200, 1e-10, x.data_ptr())
         assert res < 1e-10
@@ -1435,11 +1487,11 @@ def test_symmetric_kernel_equals_ordered_kernel_over_sizes(wall):
         ctx.set_option("matvec_kernel", 1)                                           # ordered rows
         ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, ref.data_ptr())
         for chunk in ((0,) if N < 8000 else (0, 1, 3, 7)):
-            ctx.set_tuning(chunk, 2)                                   # symmetric, heuristic or forced chunk length
+            ctx.set_option("matvec_kernel", 2); ctx.set_option("sym_chunk", chunk)   # symmetric, heuristic or forced chunk length
             ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, out.data_ptr())
             ctx.sync_check()
             assert float(torch.linalg.norm(out - ref) / torch.linalg.norm(ref)) < 1e-12, (N, chunk)
-        ctx.set_tuning(0, 0)
+        ctx.set_option("matvec_kernel", 0); ctx.set_option("sym_chunk", 0)
         for world in (2, 3):
             acc = torch.zeros_like(x)
             for first in range(world):
@@ -1622,7 +1674,7 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
         ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
         lib().rbl_set_blk_pc(ctx.h, 1)
         ctx.set_config(c["X"], c["Q"])
-        ctx.set_tuning(0, variant)
+        ctx.set_option("relaxed_krylov", variant - 51)
         x = torch.empty_like(b)
         m, res = ctx.gmres_saddle(b.data_ptr(), 100, 1e-8, x.data_ptr())
         ctx.set_option("relaxed_krylov", 0)
@@ -1635,7 +1687,7 @@ def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
         # equation to 1e-8 |b| -- with the relaxation on, EVERY product of the iteration may be relaxed (the residual
         # to reduce is already < 1e-3 of the tolerance scale); only b - A x0 stays fp64.  True residual as above.
         b2 = b + 1e-5 * torch.from_numpy(rng.standard_normal(nsys)).to(dev) * torch.linalg.norm(b) / np.sqrt(nsys)
-        ctx.set_tuning(0, variant)
+        ctx.set_option("relaxed_krylov", variant - 51)
         m2, res2 = ctx.gmres_saddle(b2.data_ptr(), 100, 1e-8, x.data_ptr(), use_x0=True)
         ctx.set_option("relaxed_krylov", 0)
         ctx.apply_saddle(x.data_ptr(), out.data_ptr()); ctx.sync_check()
@@ -1670,7 +1722,7 @@ def test_one_kernel_gmres_equals_general_solver(wall, nb, nblb):
     for variant in (41, 42):        # 41: general solver, 42: one-kernel solver
         ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
         ctx.set_config(c["X"], c["Q"])
-        ctx.set_tuning(0, variant)
+        ctx.set_option("gmres_one_kernel", variant - 41)
         xa = torch.empty_like(b); ma, ra = ctx.gmres_saddle(b.data_ptr(), 20, None, xa.data_ptr())            # fixed work
         xb = torch.empty_like(b); mb, rb_ = ctx.gmres_saddle(b.data_ptr(), 200, 1e-11, xb.data_ptr())         # converged
         xc = x0.clone(); mc, rc_ = ctx.gmres_saddle(b.data_ptr(), 200, 1e-11, xc.data_ptr(), use_x0=True)     # from a guess

@@ -1,5 +1,5 @@
 """Per-body factor application for LARGE bodies (shell_N_642 / 2562): substitution chains (RBL_OPT_BLOCK_EXPLICIT_LARGE = 0) vs explicit
-inverses (64) vs their single-precision copy (84), for all bodies and for one rank's share at P = 8, with the achieved
+inverses (1) vs their single-precision copy (RBL_OPT_BLOCK_INVERSE_F32 = 1), for all bodies and for one rank's share at P = 8, with the achieved
 HBM rate (bytes = the triangle(s) of the factor / inverse one application reads) and the cost of the build.
 usage: bench_block_inverse_large.py [bodies blobs [wall]]"""
 import sys, time, numpy as np, torch
@@ -14,17 +14,18 @@ m = 3 * nblb
 v = torch.randn(m * nb, dtype=torch.float64, device=dev)
 o = torch.empty_like(v)
 print("%d x shell_N_%d, %s: n = %d, factor %.2f GB (fp64, lower triangles %.2f GB)" % (nb, nblb, "wall" if wall else "free", m, 8e-9 * m * m * nb, 4e-9 * m * m * nb))
-for variants, name, bpe in (((63,), "substitution (63)", 8.0), ((64,), "explicit inverse fp64 (64)", 8.0), ((64, 84), "explicit inverse fp32 copy (64+84)", 4.0)):
+for opts, name, bpe in (({"block_explicit_large": 0}, "substitution", 8.0), ({"block_explicit_large": 1}, "explicit inverse fp64", 8.0),
+                        ({"block_explicit_large": 1, "block_inverse_f32": 1}, "explicit inverse, fp32 copy", 4.0)):
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
     ctx.set_option("bodyframe_factor", 0)
-    for t in variants:
-        ctx.set_tuning(0, t)
+    for k_, v_ in opts.items():
+        ctx.set_option(k_, v_)
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
-        ctx.set_tuning(0, variants[0])                  # invalidates the factors: the next call rebuilds them
+        ctx.set_option("block_explicit_large", opts["block_explicit_large"])   # invalidates the factors: the next call rebuilds them
         ctx.block_solve(v.data_ptr(), o.data_ptr(), 0)
     e1.record(); torch.cuda.synchronize()
     print("%-36s build + one application %.2f ms" % (name, e0.elapsed_time(e1) / 3), flush=True)

@@ -9,14 +9,14 @@ dev = torch.device("cuda:0")
 c = make_config(nb, nblb, False)
 v = torch.randn(3 * nb * nblb, dtype=torch.float64, device=dev)
 o = torch.empty_like(v)
-for variant, name in ((61, "substitution"), (62, "explicit inverse")):
+for variant, name in ((0, "substitution"), (1, "explicit inverse")):
     ctx = DeviceContext(c["a"], c["eta"], False, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
-    ctx.set_tuning(0, variant)
+    ctx.set_option("block_explicit_small", variant)
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(20):
-        ctx.set_tuning(0, variant)                      # invalidates the factors: the next call rebuilds them
+        ctx.set_option("block_explicit_small", variant)   # invalidates the factors: the next call rebuilds them
         ctx.block_solve(v.data_ptr(), o.data_ptr(), 0)
     torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / 20
     line = "%-17s build+solve %.1f us;" % (name, tb * 1e6)

@@ -1,4 +1,4 @@
-"""apply_M time against the chunk-length override of the symmetric kernel (rbl_set_tuning(chunk, 2)) at one system size.
+"""apply_M time against the chunk-length override of the symmetric kernel (RBL_OPT_MATVEC_KERNEL = 2, RBL_OPT_SYM_CHUNK = chunk) at one system size.
 usage: bench_chunk_sweep.py bodies blobs wall"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
@@ -13,7 +13,7 @@ N = nb * nblb
 r = torch.empty(3 * N, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
 x = torch.randn(3 * N, dtype=torch.float64, device=dev); o = torch.empty_like(x)
 for chunk in (0, 1, 2, 3, 4, 6, 8, 12, 16):
-    ctx.set_tuning(chunk, 2)
+    ctx.set_option("matvec_kernel", 2); ctx.set_option("sym_chunk", chunk)
     for _ in range(5): ctx.apply_M(x.data_ptr(), r.data_ptr(), N, 0, N, o.data_ptr())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -24,7 +24,7 @@ for name, nb, nblb, wall in (("cfg1 10x12 free", 10, 12, False), ("cfg1 10x12 wa
     F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev)
     U = torch.empty_like(F)
     for vname, v in (("ordered", 1), ("symmetric", 2)):
-        ctx.set_tuning(0, v)
+        ctx.set_option("matvec_kernel", v)
         reps = 200 if N < 10000 else 5
         for _ in range(3):
             ctx.apply_M(F.data_ptr(), r.data_ptr(), N, 0, N, U.data_ptr())
@@ -39,7 +39,7 @@ for name, nb, nblb, wall in (("cfg1 10x12 free", 10, 12, False), ("cfg1 10x12 wa
     if N >= 8000:   # 16 right-hand sides on the fp64 matrix cores
         F16 = torch.from_numpy(np.random.default_rng(5).standard_normal((16, 3 * N))).to(dev)
         U16 = torch.empty_like(F16)
-        ctx.set_tuning(0, 0)
+        ctx.set_option("matvec_kernel", 0)
         for _ in range(2):
             ctx.apply_M_multi(F16.data_ptr(), r.data_ptr(), N, 16, U16.data_ptr())
         ctx.sync_check()

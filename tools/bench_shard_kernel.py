@@ -22,10 +22,10 @@ full = None
 REPS = 10
 WORLDS = [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]
 if os.environ.get("CHUNK"):                      # force the chunk length C of the symmetric kernel (tuning experiments)
-    ctx.set_tuning(int(os.environ["CHUNK"]), 2)
-for v in os.environ.get("TUNE", "").split(","):   # rbl_set_tuning switches (e.g. TUNE=93: pair kernels without the work queue)
-    if v:
-        ctx.set_tuning(0, int(v))
+    ctx.set_option("matvec_kernel", 2); ctx.set_option("sym_chunk", int(os.environ["CHUNK"]))
+for kv in os.environ.get("TUNE", "").split(","):   # named options (e.g. TUNE=sym_work_queue=0: pair kernels without the work queue)
+    if kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for world in WORLDS:
     ts = []; acc = torch.zeros_like(F)
     order = list(range(world))

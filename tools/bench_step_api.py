@@ -13,7 +13,7 @@ for api in ("python stepper", "rbl_step_brownian"):
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=torch.cuda.current_stream().cuda_stream)
     lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3); ctx.set_block_refresh(2)
-    if len(sys.argv) > 4: ctx.set_tuning(0, int(sys.argv[4]))
+    if len(sys.argv) > 4: ctx.set_option(sys.argv[4].split("=")[0], int(sys.argv[4].split("=")[1]))
     st = BrownianStepper(ctx, nb, nblb, dev)
     one = (lambda k: st.step(Fb, seed=k, method=2, iters=200, rtol=1e-8)) if api == "python stepper" else \
           (lambda k: ctx.step_brownian(Fb, max_iter=200, rtol=1e-8, seed=k, method=2))

@@ -5,14 +5,14 @@ measured on ONE GPU (no 8-GPU node is available to the builder; the driver measu
   2. rank by rank (r = 0 .. P-1), the pieces a rank executes: its share of the tile pairs of a one- and of a two-vector
      product (rbl_apply_M_sym[_multi]_dev(r, P)), the applications of ITS 25 bodies' factors / inverses, their build;
   3. budget = counts of the real step x the slowest rank's piece + the replicated part, before collectives.
-usage: bench_step_budget_p8.py [P] [old tuning codes ...]   (e.g. 8 64 84: through the rbl_set_tuning shim)"""
+usage: bench_step_budget_p8.py [P] [option=value ...]   (e.g. 8 block_inverse_f32=1)"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from rigid_body_light_amd import make_config
 from rigid_body_light_amd._lib import DeviceContext, lib
 from rigid_body_light_amd.krylov import BrownianStepper
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-tunes = [int(x) for x in sys.argv[2:]]
+tunes = list(sys.argv[2:])
 nb, nblb, wall = 200, 642, True
 dev = torch.device("cuda:0")
 c = make_config(nb, nblb, wall)
@@ -26,7 +26,7 @@ def new_ctx(extra=()):
     lib().rbl_set_blk_pc(ctx.h, 1)
     ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3); ctx.set_block_refresh(2)
     for t in tuple(tunes) + tuple(extra):
-        ctx.set_tuning(0, t)
+        ctx.set_option(str(t).split("=")[0], int(str(t).split("=")[1]))
     return ctx
 
 
@@ -67,7 +67,7 @@ print("single-GPU step: **%.1f ms** wall (GMRES %s iterations, Lanczos %d); libr
 ctx.close()
 
 # ---- 2. the pieces, rank by rank
-ctx = new_ctx((64,))                        # the multi-GPU default: explicit inverses of the rank's bodies
+ctx = new_ctx(("block_explicit_large=1",))                        # the multi-GPU default: explicit inverses of the rank's bodies
 r = torch.empty(n3, dtype=torch.float64, device=dev)
 ctx.blob_positions(0, nb, r.data_ptr())
 x2 = torch.randn(2 * n3, dtype=torch.float64, device=dev)

@@ -16,7 +16,7 @@ for variant in (73, 74):
         lib().rbl_set_blk_pc(ctx.h, 1)
         ctx.set_config(c["X"], c["Q"]); ctx.set_lanczos(200, 1e-3)
         ctx.set_block_refresh(2)
-        ctx.set_tuning(0, variant)
+        ctx.set_option("bodyframe_wall_approx", variant - 73)
         if relaxed: ctx.set_option("relaxed_krylov", 1)
         st = BrownianStepper(ctx, nb, nblb, dev)
         st.step(Fb, seed=0, method=2, iters=200, rtol=1e-8)

@@ -1,5 +1,6 @@
 """A communicator of ONE rank drives, on one GPU, exactly the code N ranks run:
-  * RCCL INSIDE librbl (rbl_comm_init_rccl from a unique id; ncclAllReduce / ncclAllGather on the context's stream) under
+  * RCCL INSIDE librbl (rbl_comm_init_rccl from a unique id; ncclAllReduce / ncclAllGather on the context's stream; the staged
+    form of the all-gather that ragged shares take, forced by RBL_OPT_COMM_FORCE_STAGED) under
     rbl_gmres_saddle_dev (block preconditioner sharded by bodies), the preconditioned Lanczos square root and a whole
     stochastic midpoint step -- with both work splits (RBL_OPT_COMM_SPLIT 0: unordered tile pairs + all-reduce, 1: rows by
     body index + all-gather of positions and U), on torch's current stream and on a side stream;
@@ -43,11 +44,14 @@ def main():
         print("%-86s %.3e (<= %g) %s" % (name, err, tol, "ok" if good else "FAILED"), flush=True)
 
     side = torch.cuda.Stream()
-    variants = [("current stream", torch.cuda.current_stream(), True, 0), ("side stream", side, True, 0),
-                ("side stream", side, True, 1), ("current stream", torch.cuda.current_stream(), False, 0),
-                ("side stream", side, False, 1)]
-    for label, stream, native, split in variants:
-        label = "%s, %s, split %d" % (label, "RCCL in librbl" if native else "callbacks", split)
+    # staged = 1 (RBL_OPT_COMM_FORCE_STAGED): every in-place all-gather of the native communicator takes the padded staging
+    # buffer, pack / ncclAllGather / unpack -- the code a job with N_bod % world != 0 runs, exercised here with one rank
+    variants = [("current stream", torch.cuda.current_stream(), True, 0, 0), ("side stream", side, True, 0, 0),
+                ("side stream", side, True, 1, 0), ("current stream", torch.cuda.current_stream(), True, 0, 1),
+                ("side stream", side, True, 1, 1), ("current stream", torch.cuda.current_stream(), False, 0, 0),
+                ("side stream", side, False, 1, 0)]
+    for label, stream, native, split, staged in variants:
+        label = "%s, %s%s, split %d" % (label, "RCCL in librbl" if native else "callbacks", ", staged all-gathers" if staged else "", split)
 
         def fresh(sharded):
             ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=kBT, stream_ptr=stream.cuda_stream)
@@ -60,6 +64,7 @@ def main():
                 assert sm.collectives and not sm.stage_cpu
                 ctx.set_comm(sm, native=native)
                 ctx.set_option("comm_split", split)
+                ctx.set_option("comm_force_staged", staged)
                 assert ctx.comm_info() == (0, 1, 2 if native else 1)
                 ctx.set_timing(True)
             return ctx, sm

@@ -12,10 +12,10 @@ for name, nb, nblb, wall in (("cfg2", 50, 162, False), ("cfg2w", 50, 162, True),
     r = torch.empty(3 * N, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
     F = torch.from_numpy(np.random.default_rng(2).standard_normal(3 * N)).to(dev); U = torch.empty_like(F)
     for C in (0, 1, 2, 4, 8, 16, 32, 64):
-        ctx.set_tuning(C, 2 if C else 0)
+        ctx.set_option("matvec_kernel", 2 if C else 0); ctx.set_option("sym_chunk", C)
         reps = 100 if N < 60000 else 5
         for _ in range(3): ctx.apply_M(F.data_ptr(), r.data_ptr(), N, 0, N, U.data_ptr())
         ctx.sync_check(); t0 = time.perf_counter()
         for _ in range(reps): ctx.apply_M(F.data_ptr(), r.data_ptr(), N, 0, N, U.data_ptr())
         ctx.sync_check(); print(name, "C=%d" % C, "%.4f ms" % ((time.perf_counter() - t0) / reps * 1e3), flush=True)
-    ctx.set_tuning(0, 0); ctx.close()
+    ctx.close()
