@@ -323,6 +323,15 @@ int rbl_gmres_saddle_dev(rbl_ctx *ctx, const double *d_rhs, int max_iter, double
 /* the same solve for host vectors (one upload of rhs [and x0], one download of x): what a caller of the wrapper's apply_saddle /
  * apply_PC would otherwise loop over from outside (src/Rigid.py:69-80) */
 int rbl_gmres_saddle(rbl_ctx *ctx, const double *rhs, int max_iter, double rtol, double *x, int use_x0, int *iters, double *resid);
+/* nrhs right-hand sides of the SAME configuration in lock step (rhs, x: nrhs vectors of n3 + 6 N_bod doubles, one after the other):
+ * nrhs independent GMRES recurrences -- each column gets exactly the iterates rbl_gmres_saddle_dev would give it, its own iteration
+ * count and residual (iters, resid: nrhs entries, either may be NULL) -- whose mobility products run 16 at a time on the fp64
+ * matrix cores (the multi-vector kernel of rbl_apply_M_multi_dev) and whose block-preconditioner applications share passes over
+ * the per-body factors.  The customer: the body mobility matrix (6 N_bod unit loads), several noise realisations of one
+ * configuration.  The operator such loops iterate is the reference's src/Rigid.py:69-80. */
+int rbl_gmres_saddle_multi_dev(rbl_ctx *ctx, const double *d_rhs, int nrhs, int max_iter, double rtol, double *d_x, int *iters,
+                               double *resid);
+int rbl_gmres_saddle_multi(rbl_ctx *ctx, const double *rhs, int nrhs, int max_iter, double rtol, double *x, int *iters, double *resid);
 /* Whole time steps in one call, on the object's own configuration (the reference has no driver; these are what
  * rigid_body_light_amd/krylov.py's steppers do, for hosts without a Python loop).
  *   rbl_step_deterministic: solve [M -K; K^T 0][lambda; U] = [slip; -F_body] (rbl_gmres_saddle_dev; slip NULL = 0;

@@ -61,6 +61,7 @@ def lib():
         L.rbl_set_no_damp.argtypes = [vp, C.c_int]
         L.rbl_set_block_refresh.argtypes = [vp, C.c_int]
         L.rbl_gmres_saddle_dev.argtypes = [vp, vp, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl)]
+        L.rbl_gmres_saddle_multi_dev.argtypes = [vp, vp, C.c_int, C.c_int, dbl, vp, C.POINTER(C.c_int), C.POINTER(dbl)]
         L.rbl_Kinv_x_V.argtypes = [vp, vp, vp]
         L.rbl_set_comm.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rbl_set_comm_ops.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -308,6 +309,12 @@ class DeviceContext:
         self._chk(self.L.rbl_gmres_saddle_dev(self.h, d_rhs, int(max_iter), float(rtol or 0.0), d_x, int(bool(use_x0)),
                                               C.byref(it), C.byref(res)))
         return it.value, res.value
+
+    def gmres_saddle_multi(self, d_rhs, nrhs, max_iter, rtol, d_x):
+        """nrhs right-hand sides in lock step (device vectors, one after the other) -> (iterations[nrhs], residuals[nrhs])"""
+        it, res = (C.c_int * nrhs)(), (C.c_double * nrhs)()
+        self._chk(self.L.rbl_gmres_saddle_multi_dev(self.h, d_rhs, int(nrhs), int(max_iter), float(rtol or 0.0), d_x, it, res))
+        return list(it), list(res)
 
     def update_X_Q(self, U_host, n_bodies):
         """configuration displaced by U (displacement units), not committed -> (X, Q)"""

@@ -370,6 +370,20 @@ struct CManyBodies {
     return py::make_tuple(x, it, res);
   }
 
+  // nrhs right-hand sides in lock step (rhs: (nrhs, 3 N_blobs + 6 N_bod)): products on the fp64 matrix cores, 16 at a time
+  py::tuple solve_saddle_multi(darr rhs, int max_iter, double rtol)
+  {
+    const py::ssize_t n = n3() + 6 * (py::ssize_t)n_bod();
+    if (rhs.ndim() != 2 || rhs.shape(1) != n || rhs.shape(0) < 1)
+      throw std::runtime_error("solve_saddle_multi: rhs must have shape (nrhs, 3*N_blobs + 6*N_bod)");
+    const int nrhs = (int)rhs.shape(0);
+    darr x({(py::ssize_t)nrhs, n});
+    py::array_t<int> its(nrhs);
+    darr res(nrhs);
+    check(rbl_gmres_saddle_multi(ctx, rhs.data(), nrhs, max_iter, rtol, x.mutable_data(), its.mutable_data(), res.mutable_data()));
+    return py::make_tuple(x, its, res);
+  }
+
   py::tuple M_RFD_cfgs(darr U, double delta)                        // :798 (unbound in the reference)
   {
     if (U.size() != 6 * (py::ssize_t)n_bod()) throw std::runtime_error("M_RFD_cfgs: U must have length 6*N_bod");
@@ -464,6 +478,7 @@ PYBIND11_MODULE(c_rigid, m)
       .def("apply_saddle", &CManyBodies::apply_saddle, py::arg("x"))
       .def("solve_saddle", &CManyBodies::solve_saddle, py::arg("rhs"), py::arg("max_iter") = 100, py::arg("rtol") = 1.0e-8,
            py::arg("x0") = py::none())
+      .def("solve_saddle_multi", &CManyBodies::solve_saddle_multi, py::arg("rhs"), py::arg("max_iter") = 100, py::arg("rtol") = 1.0e-8)
       .def("M_RFD_cfgs", &CManyBodies::M_RFD_cfgs, py::arg("U"), py::arg("delta") = 1.0e-4)
       .def("M_RFD_from_U", &CManyBodies::M_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)
       .def("KT_RFD_from_U", &CManyBodies::KT_RFD_from_U, py::arg("U"), py::arg("W"), py::arg("delta") = 1.0e-3)

@@ -45,7 +45,9 @@ void comm_release(rbl_ctx *c);                // destroy a native communicator (
 // ---- rbl_products.hip ---------------------------------------------------------------------------------------------
 int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl, int64_t row_begin, int64_t row_end,
                     double *d_out);
-int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl, int nrhs, double *d_out);
+int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl, int nrhs, double *d_out,
+                          int64_t ldF = 0, int64_t ldO = 0);
+int apply_PC_multi_dev(rbl_ctx *c, const double *d_in, double *d_out, double *d_scratch, int nv, int64_t pitch);
 int ensure_xq_dev(rbl_ctx *c);
 int positions_dev(rbl_ctx *c, int b0, int b1, double *d_out);
 

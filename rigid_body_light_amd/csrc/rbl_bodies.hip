@@ -677,6 +677,37 @@ int rbl_apply_PC_dev(rbl_ctx *c, const double *d_in, double *d_out)
   return RBL_OK;
 }
 
+// out_v = P^-1 in_v for nv saddle vectors `pitch` doubles apart (in, out and the scratch vectors all laid out alike).  The block
+// preconditioner of per-configuration factors on one GPU sends all vectors through the factors together -- three share one pass
+// over the 5.9 GB of cfg 3 (rbl_launch_block_solve_multi), so 16 vectors cost six passes, not sixteen; every other
+// preconditioner (diagonal, body frame, sharded) is applied vector by vector.  d_scratch: nv vectors of >= n3 doubles.
+int apply_PC_multi_dev(rbl_ctx *c, const double *d_in, double *d_out, double *d_scratch, int nv, int64_t pitch)
+{
+  int rc = sync_bodies(c); if (rc) return rc;
+  const RblBodyState &S = c->S;
+  const bool together = S.block_pc && !comm_on(c) && !(bf_on(c) && c->bf_tables) && nv > 1 && d_scratch;
+  if (!together) {
+    for (int v = 0; v < nv; ++v)
+      if ((rc = rbl_apply_PC_dev(c, d_in + (size_t)v * (size_t)pitch, d_out + (size_t)v * (size_t)pitch))) return rc;
+    return RBL_OK;
+  }
+  if (!c->dev_pc_valid) {
+    if ((rc = pc_block_build(c))) return rc;
+    c->dev_pc_valid = true;
+  }
+  RblPhase ph(c, RBL_T_PERBODY);
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;
+  c->ktl_of = nullptr;
+  if ((rc = blk_solve(c, 0, S.N_bod, d_in, d_scratch, nv, pitch, 0))) return rc;                              // invM slip, all vectors
+  for (int v = 0; v < nv; ++v) {
+    const double *in = d_in + (size_t)v * (size_t)pitch;
+    double *out = d_out + (size_t)v * (size_t)pitch;
+    rbl_launch_pc_block_tail(c->stream, (const double *)c->d_lever.p, d_scratch + (size_t)v * (size_t)pitch, (const double *)c->d_pcMK.p, n3,
+                             (const double *)c->d_NL.p, in + n3, S.N_blb, 0, S.N_bod, c->pc_fsign, out + n3, out, nullptr, nullptr, in);
+  }
+  return RBL_OK;
+}
+
 // Everything a solver iteration needs that is NOT a plain kernel launch (uploads, workspace
 // growth, preconditioner build) done now, so that the iteration itself -- apply_saddle_dev,
 // apply_PC_dev, K ops -- is launch-only and can be captured in a hipGraph.

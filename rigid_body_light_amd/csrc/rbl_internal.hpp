@@ -250,7 +250,7 @@ int rbl_launch_apply_M_sym(hipStream_t st, const RblParams &P, bool wall, const 
 size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu);
 void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                              const double *d_r, int64_t n_blobs, int nrhs, double *d_out,
-                             double *d_work, int n_cu, unsigned *d_err);
+                             double *d_work, int n_cu, unsigned *d_err, int64_t ldF = 0, int64_t ldO = 0);
 void rbl_launch_blob_positions(hipStream_t st, const double *d_X, const double *d_Q,
                                const double *d_cfg, int N_blb, int body_begin, int body_end,
                                double *d_out);

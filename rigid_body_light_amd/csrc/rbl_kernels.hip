@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_apply_M_mrhs(const double *__restrict__
 // pack nrhs column-major RHS (n3 x nrhs) into Fp[j][b][16], damped, zero padded
 template <bool WALL>
 __global__ void k_pack_rhs(const double *__restrict__ F, const double *__restrict__ r, long N, long Npad,
-                           int nrhs, RblParams P, double *__restrict__ Fp)
+                           int nrhs, RblParams P, double *__restrict__ Fp, long ldF)
 {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over Npad*3*16
   if (idx >= Npad * 3 * MR) return;
@@ -1315,7 +1315,7 @@ __global__ void k_pack_rhs(const double *__restrict__ F, const double *__restric
   const long j = jb / 3;
   double v = 0.0;
   if (j < N && n < nrhs) {
-    v = F[(size_t)n * (size_t)(3 * N) + jb];
+    v = F[(size_t)n * (size_t)ldF + jb];
     if (WALL) v *= damp_of(P, r[3 * j + 2]);
   }
   Fp[idx] = v;
@@ -1323,7 +1323,7 @@ __global__ void k_pack_rhs(const double *__restrict__ F, const double *__restric
 
 template <bool WALL>
 __global__ void k_unpack_rhs(const double *__restrict__ Up, const double *__restrict__ r, long N, long Npad,
-                             int nrhs, int nsplit, RblParams P, double *__restrict__ out, unsigned *err)
+                             int nrhs, int nsplit, RblParams P, double *__restrict__ out, unsigned *err, long ldO)
 {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over N*3*nrhs, ia fastest
   if (idx >= 3 * N * nrhs) return;
@@ -1333,7 +1333,7 @@ __global__ void k_unpack_rhs(const double *__restrict__ Up, const double *__rest
   for (int k = 0; k < nsplit; ++k) s += Up[(size_t)k * (size_t)Npad * 3 * MR + (size_t)ia * MR + n];
   double sc = P.nf;
   if (WALL) sc *= damp_of(P, r[3 * (ia / 3) + 2]);
-  out[idx] = sc * s;
+  out[(size_t)n * (size_t)ldO + ia] = sc * s;
   if (!isfinite(s)) atomicOr(err, (unsigned)RBL_FLAG_NONFINITE);
 }
 
@@ -2199,11 +2199,14 @@ size_t rbl_apply_M_mrhs_bytes(int64_t n_blobs, int n_cu)
 }
 
 // d_F, d_out: column-major n3 x nrhs (nrhs <= 16).  d_work from rbl_apply_M_mrhs_bytes.
+// ldF / ldO: doubles between consecutive right-hand sides / results (0: packed, 3 n_blobs)
 void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, const double *d_F,
                              const double *d_r, int64_t n_blobs, int nrhs, double *d_out,
-                             double *d_work, int n_cu, unsigned *d_err)
+                             double *d_work, int n_cu, unsigned *d_err, int64_t ldF, int64_t ldO)
 {
   if (n_blobs <= 0 || nrhs <= 0) return;
+  if (ldF <= 0) ldF = 3 * n_blobs;
+  if (ldO <= 0) ldO = 3 * n_blobs;
   int64_t np, jc; int ns;
   mrhs_geometry(n_blobs, n_cu, &np, &ns, &jc);
   double *Fp = d_work, *Up = d_work + (size_t)np * 3 * MR;
@@ -2211,13 +2214,13 @@ void rbl_launch_apply_M_mrhs(hipStream_t st, const RblParams &P, bool wall, cons
   dim3 gp((unsigned)((npk + 255) / 256)), gu((unsigned)((nun + 255) / 256)), b(256);
   dim3 grid((unsigned)((n_blobs + 63) / 64), (unsigned)ns);
   if (wall) {
-    hipLaunchKernelGGL(k_pack_rhs<true>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp);
+    hipLaunchKernelGGL(k_pack_rhs<true>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp, (long)ldF);
     hipLaunchKernelGGL(k_apply_M_mrhs<true>, grid, b, 0, st, d_r, Fp, Up, (long)n_blobs, (long)np, (long)jc, P, d_err);
-    hipLaunchKernelGGL(k_unpack_rhs<true>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err);
+    hipLaunchKernelGGL(k_unpack_rhs<true>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err, (long)ldO);
   } else {
-    hipLaunchKernelGGL(k_pack_rhs<false>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp);
+    hipLaunchKernelGGL(k_pack_rhs<false>, gp, b, 0, st, d_F, d_r, (long)n_blobs, (long)np, nrhs, P, Fp, (long)ldF);
     hipLaunchKernelGGL(k_apply_M_mrhs<false>, grid, b, 0, st, d_r, Fp, Up, (long)n_blobs, (long)np, (long)jc, P, d_err);
-    hipLaunchKernelGGL(k_unpack_rhs<false>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err);
+    hipLaunchKernelGGL(k_unpack_rhs<false>, gu, b, 0, st, Up, d_r, (long)n_blobs, (long)np, nrhs, ns, P, d_out, d_err, (long)ldO);
   }
 }
 

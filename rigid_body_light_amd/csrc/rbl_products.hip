@@ -82,9 +82,33 @@ int apply_M_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r,
 // fp64-MFMA kernel in passes of 16; fewer are cheaper one by one on the symmetric kernel.
 // tune_variant 3 forces the MFMA kernel, 1/2 force the single-RHS kernels.
 int apply_M_multi_enqueue(rbl_ctx *c, bool wall, const double *d_F, const double *d_r, int64_t nbl,
-                                 int nrhs, double *d_out)
+                                 int nrhs, double *d_out, int64_t ldF, int64_t ldO)
 {
   const int64_t n3 = 3 * nbl;
+  if (ldF <= 0) ldF = n3;                               // doubles between consecutive vectors (default: packed)
+  if (ldO <= 0) ldO = n3;
+  if (ldF != n3 || ldO != n3) {                          // strided vectors (the lock-step GMRES): one at a time unless the MFMA kernel takes them
+    bool mf = nrhs >= 4;
+    if (c->tune_variant == 3) mf = true;
+    if (c->tune_variant == 1 || c->tune_variant == 2) mf = false;
+    if (comm_on(c) || !mf) {
+      for (int k = 0; k < nrhs; ++k) {
+        const int rc1 = apply_M_enqueue(c, wall, d_F + (size_t)k * (size_t)ldF, d_r, nbl, 0, nbl, d_out + (size_t)k * (size_t)ldO);
+        if (rc1) return rc1;
+      }
+      return RBL_OK;
+    }
+    int rc2;
+    RblPhase ph2(c, RBL_T_PRODUCT);
+    if ((rc2 = rbl_dev_reserve(c, c->d_part, rbl_apply_M_mrhs_bytes(nbl, c->n_cu)))) return rc2;
+    const RblParams P2 = ctx_params(c);
+    for (int k = 0; k < nrhs; k += 16) {
+      const int nb = (nrhs - k < 16) ? nrhs - k : 16;
+      rbl_launch_apply_M_mrhs(c->stream, P2, wall, d_F + (size_t)k * (size_t)ldF, d_r, nbl, nb, d_out + (size_t)k * (size_t)ldO,
+                              (double *)c->d_part.p, c->n_cu, c->d_err, ldF, ldO);
+    }
+    return RBL_OK;
+  }
   bool mfma = nrhs >= 4;
   if (c->tune_variant == 3) mfma = true;
   if (c->tune_variant == 1 || c->tune_variant == 2) mfma = false;

@@ -262,6 +262,146 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
   return finish_and_check(c);
 }
 
+// ---- k right-hand sides in lock step: the mobility product of every iteration on the fp64 matrix cores ---------------------------
+// The reference exposes the saddle operator for an outer Krylov loop (src/Rigid.py:69-80); with MANY right-hand sides for one
+// configuration -- the 6 N_bod unit loads of the body mobility matrix, several noise realisations -- the loops can advance
+// together: k independent right-preconditioned GMRES recurrences (each with its own Krylov basis, Hessenberg matrix and
+// stopping test: exactly the iterates rbl_gmres_saddle_dev would produce one by one), whose k products per iteration are ONE
+// launch of k_apply_M_mrhs (16 right-hand sides per pass through v_mfma_f64_16x16x4: 6.3 ms a vector at cfg 3 against 20.4 for
+// the one-vector kernel) and whose k block-preconditioner applications share passes over the per-body factors.  Columns that
+// have converged stop iterating (their slots ride along in the product, which costs the same for 13 as for 16).
+static int gmres_multi_batch(rbl_ctx *c, const double *d_rhs, int k, int m, double rtol, double *d_x, int *iters_out, double *resid_out)
+{
+  const RblBodyState &S = c->S;
+  const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N, nsys = n3 + (int64_t)6 * S.N_bod;
+  const int ldh = m + 1;
+  const int64_t slots = m + 4;                          // per column: V_0 .. V_m | z | w | scratch
+  const int64_t pitch = slots * nsys;
+  const size_t hcol = 1 + (size_t)ldh * m;              // beta | H (column-major) of one column
+  int rc;
+  const size_t need = sizeof(double) * ((size_t)pitch * k + hcol * k + (size_t)m * k + rbl_gmres_part_doubles() + rbl_lanczos_part_doubles());
+  if ((rc = rbl_dev_reserve(c, c->d_gm, need))) return rc;
+  double *base = (double *)c->d_gm.p, *Hall = base + (size_t)pitch * k, *d_y = Hall + hcol * k, *part = d_y + (size_t)m * k,
+         *part2 = part + rbl_gmres_part_doubles();
+  auto Vc = [&](int col, int j) { return base + (size_t)col * (size_t)pitch + (size_t)j * (size_t)nsys; };
+  auto Zc = [&](int col) { return Vc(col, m + 1); };
+  auto Wc = [&](int col) { return Vc(col, m + 2); };
+  auto Sc = [&](int col) { return Vc(col, m + 3); };
+  for (int col = 0; col < k; ++col)
+    rbl_launch_lanczos_init(c->stream, nsys, d_rhs + (size_t)col * (size_t)nsys, Hall + hcol * col, Vc(col, 0), part2);   // V_0 = b/|b|, beta = |b|
+  std::vector<double> Hh(hcol * (size_t)k);
+  std::vector<std::vector<double>> ys((size_t)k);
+  std::vector<int> used((size_t)k, 0), done((size_t)k, 0);
+  std::vector<double> resid((size_t)k, 1.0);
+  auto solve_ls = [&](int col, int kk, std::vector<double> &yout) -> double {       // Givens on a host copy, as in the one-vector solver
+    const double *hc = Hh.data() + hcol * (size_t)col;
+    std::vector<double> R(hc + 1, hc + 1 + (size_t)ldh * kk), g((size_t)kk + 1, 0.0), cs((size_t)kk), sn((size_t)kk);
+    const double beta = hc[0];
+    g[0] = beta;
+    for (int j = 0; j < kk; ++j) {
+      double *cl = R.data() + (size_t)j * ldh;
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * cl[i] + sn[i] * cl[i + 1];
+        cl[i + 1] = -sn[i] * cl[i] + cs[i] * cl[i + 1];
+        cl[i] = t;
+      }
+      const double den = std::hypot(cl[j], cl[j + 1]);
+      cs[j] = den > 0.0 ? cl[j] / den : 1.0;
+      sn[j] = den > 0.0 ? cl[j + 1] / den : 0.0;
+      cl[j] = den; cl[j + 1] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+    }
+    yout.assign((size_t)kk, 0.0);
+    for (int i = kk - 1; i >= 0; --i) {
+      double v = g[i];
+      for (int j = i + 1; j < kk; ++j) v -= R[(size_t)j * ldh + i] * yout[j];
+      const double d = R[(size_t)i * ldh + i];
+      yout[i] = d != 0.0 ? v / d : 0.0;
+    }
+    return beta > 0.0 ? std::fabs(g[kk]) / beta : 0.0;
+  };
+  int n_done = 0;
+  for (int j = 0; j < m && n_done < k; ++j) {
+    // z_c = P^-1 V_c,j : all columns together (converged ones ride along: their slots are never read again)
+    if ((rc = apply_PC_multi_dev(c, Vc(0, j), Zc(0), Sc(0), k, pitch))) return rc;
+    // w_c = [M lambda - K U ; K^T lambda] : ONE multi-vector product, then the O(N) body terms column by column
+    if ((rc = rbl_dev_reserve(c, c->d_sad, sizeof(double) * (size_t)n3 * (size_t)k))) return rc;
+    if ((rc = apply_M_multi_enqueue(c, S.wall, Zc(0), (const double *)c->d_pos.p, N, k, (double *)c->d_sad.p, pitch, n3))) return rc;
+    for (int col = 0; col < k; ++col) {
+      if (done[(size_t)col]) continue;
+      rbl_launch_K_x_U(c->stream, (const double *)c->d_lever.p, Zc(col) + n3, S.N_blb, N, Wc(col), (const double *)c->d_sad.p + (size_t)col * (size_t)n3, -1.0);
+      rbl_launch_KT_x_Lam(c->stream, (const double *)c->d_lever.p, Zc(col), S.N_blb, S.N_bod, Wc(col) + n3);
+      rbl_launch_arnoldi_step(c->stream, Vc(col, 0), nsys, j + 1, Wc(col), Hall + hcol * col + 1 + (size_t)j * ldh, Vc(col, j + 1), part);
+      used[(size_t)col] = j + 1;
+    }
+    if (rtol > 0.0) {
+      if ((rc = read_back(c, Hh.data(), Hall, sizeof(double) * hcol * (size_t)k))) return rc;
+      for (int col = 0; col < k; ++col) {
+        if (done[(size_t)col]) continue;
+        resid[(size_t)col] = solve_ls(col, j + 1, ys[(size_t)col]);
+        if (resid[(size_t)col] < rtol) { done[(size_t)col] = 1; ++n_done; }
+      }
+    }
+  }
+  if (!(rtol > 0.0) || n_done < k) {
+    if ((rc = read_back(c, Hh.data(), Hall, sizeof(double) * hcol * (size_t)k))) return rc;
+    for (int col = 0; col < k; ++col)
+      if (!done[(size_t)col]) resid[(size_t)col] = solve_ls(col, used[(size_t)col], ys[(size_t)col]);
+  }
+  for (int col = 0; col < k; ++col) {
+    const int u = used[(size_t)col];
+    for (int q = 0; q < u; ++q)
+      if (!std::isfinite(ys[(size_t)col][(size_t)q])) return rbl_fail(c, RBL_ERR_NONFINITE, "gmres (multi): non-finite Hessenberg solve");
+    if ((rc = upload_coef(c, d_y + (size_t)m * col, ys[(size_t)col].data(), u, -1))) return rc;       // (synchronous: once per column and solve)
+    rbl_launch_lanczos_combine(c->stream, nsys, Vc(col, 0), d_y + (size_t)m * col, u, Zc(col));      // z = V y
+    if (iters_out) iters_out[col] = u;
+    if (resid_out) resid_out[col] = resid[(size_t)col];
+  }
+  if ((rc = apply_PC_multi_dev(c, Zc(0), Wc(0), Sc(0), k, pitch))) return rc;                        // x = P^-1 z
+  for (int col = 0; col < k; ++col)
+    RBL_HIP(c, hipMemcpyAsync(d_x + (size_t)col * (size_t)nsys, Wc(col), sizeof(double) * (size_t)nsys, hipMemcpyDeviceToDevice, c->stream));
+  return RBL_OK;
+}
+
+int rbl_gmres_saddle_multi_dev(rbl_ctx *c, const double *d_rhs, int nrhs, int max_iter, double rtol, double *d_x, int *iters_out,
+                               double *resid_out)
+{
+  RblPhase ph_total(c, RBL_T_TOTAL);
+  int rc = need_config(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!d_rhs || !d_x || nrhs < 1 || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres_saddle_multi: bad arguments");
+  if (max_iter + 1 > rbl_gmres_max_vectors()) return rbl_fail(c, RBL_ERR_ARG, "gmres: at most 255 iterations (no restart)");
+  if ((rc = sync_bodies(c))) return rc;
+  const int64_t nsys = (int64_t)3 * c->S.N_bod * c->S.N_blb + (int64_t)6 * c->S.N_bod;
+  const double keep = c->pc_fsign;
+  if (c->gmres_pc_sign_fix) c->pc_fsign = 1.0;          // one eigenvalue cluster instead of two, as in the one-vector solver
+  for (int k0 = 0; k0 < nrhs && !rc; k0 += 16) {
+    const int kb = nrhs - k0 < 16 ? nrhs - k0 : 16;
+    rc = gmres_multi_batch(c, d_rhs + (size_t)k0 * (size_t)nsys, kb, max_iter, rtol, d_x + (size_t)k0 * (size_t)nsys,
+                           iters_out ? iters_out + k0 : nullptr, resid_out ? resid_out + k0 : nullptr);
+  }
+  c->pc_fsign = keep;
+  if (rc) return rc;
+  return finish_and_check(c);
+}
+
+// host vectors: rhs, x = nrhs vectors of n3 + 6 N_bod doubles, one after the other
+int rbl_gmres_saddle_multi(rbl_ctx *c, const double *rhs, int nrhs, int max_iter, double rtol, double *x, int *iters, double *resid)
+{
+  int rc = need_K(c); if (rc) return rc;
+  if ((rc = rbl_dev_init(c))) return rc;
+  if (!rhs || !x || nrhs < 1 || max_iter < 1) return rbl_fail(c, RBL_ERR_ARG, "gmres_saddle_multi: bad arguments");
+  const size_t nsys = (size_t)3 * c->S.N_bod * c->S.N_blb + (size_t)6 * c->S.N_bod;
+  if ((rc = rbl_dev_reserve(c, c->d_step, sizeof(double) * 2 * nsys * (size_t)nrhs))) return rc;
+  double *d_x = (double *)c->d_step.p, *d_rhs = d_x + nsys * (size_t)nrhs;
+  c->step_hist_n = 0; c->step_x_size = 0;                 // (d_step is shared with the time-step entry points' history)
+  if ((rc = copy_h2d(c, d_rhs, rhs, sizeof(double) * nsys * (size_t)nrhs))) return rc;
+  if ((rc = rbl_gmres_saddle_multi_dev(c, d_rhs, nrhs, max_iter, rtol, d_x, iters, resid))) return rc;
+  if ((rc = copy_d2h(c, x, d_x, sizeof(double) * nsys * (size_t)nrhs))) return rc;
+  return finish_and_check(c);
+}
+
 // host-vector form: one upload, the device-resident solve, one download
 int rbl_gmres_saddle(rbl_ctx *c, const double *rhs, int max_iter, double rtol, double *x, int use_x0, int *iters, double *resid)
 {

@@ -25,6 +25,7 @@ constexpr int TC = 128;          // tile edge
 constexpr int TKC = 16;          // K columns per pipeline stage
 constexpr int TLDP = 144;        // LDS column stride (doubles): conflict-free fragment reads, as in k_syrk_mfma
 constexpr int TQS = 32;          // unsigned words between two queue heads (one 128-byte line each)
+constexpr unsigned TGRP = 4;     // bodies of a queue that share an iteration's slots (see the queue order in k_tile_chol)
 constexpr unsigned SPIN_LIMIT = 4u << 20;   // polls of ~0.5 us before a wait gives up (seconds: a hang must end by itself)
 
 // Diagnostic build only (RBL_EXTRA_FLAGS=-DRBL_TILE_PROF, tools/tile_phase_profile.py): shader-clock stamps around the phases of a task,
@@ -354,10 +355,18 @@ __device__ __forceinline__ void publish(unsigned *cnt)
   }
 }
 
+// where in an iteration the chain tile (s + 1, s) sits: slot h + 1.  h = NT - 1 puts it LAST: the diagonal tile (s, s) it waits
+// for was claimed a whole iteration's worth of tasks earlier (with 25 bodies a queue: 400 tasks, six rounds of the XCD's 64
+// slots -- mid-iteration, 200 tasks, the tile sat idle for up to 0.4 ms behind the long products of late diagonal tiles: 6.7 % of
+// all workgroup time), and the NEXT diagonal tile, one slot later, meets it only in its last K chunk.
+#ifndef RBL_TILE_CRIT_SLOT
+#define RBL_TILE_CRIT_SLOT(NT) ((NT) - 1)
+#endif
+
 // slot u of iteration s of the queue order described in k_tile_chol -> task; false: an empty slot
 __host__ __device__ inline bool tile_task(int NT, int s, int u, bool &chol, int &ti, int &tj)
 {
-  const int h = (NT - 1) / 2;
+  const int h = RBL_TILE_CRIT_SLOT(NT);                  // the slot before the chain tile (s + 1, s)
   if (s == NT) { if (u > NT - 1) return false; chol = false; ti = u; tj = NT - 1; return true; }   // last iteration: INV(., NT - 1), NT tiles
   if (u == 0) { chol = true; ti = s; tj = s; return true; }
   if (u == h + 1) { if (s + 1 >= NT) return false; chol = true; ti = s + 1; tj = s; return true; }
@@ -411,14 +420,22 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     TP(0)                                                  // claim
     // Queue order (the same for every body of the queue, bodies interleaved): iteration s = 0 .. NT holds NT + 1 slots,
     //   slot 0       : the diagonal tile (s, s)                                  -- the critical chain ...
-    //   slot h + 1   : its successor (s + 1, s)                                  -- ... diag(s) -> (s + 1, s) -> diag(s + 1)
+    //   slot NT      : its successor (s + 1, s)                                  -- ... diag(s) -> (s + 1, s) -> diag(s + 1)
     //   other slots  : the BULK of column s - 1, one iteration behind the chain: CHOL(i, s - 1) for i >= s + 1, then INV(., s - 1)
     // so that what a task waits for was claimed a whole iteration (or half of one) earlier and a slot is not held idle while a
     // diagonal tile is factored.  Every task still comes after everything it depends on (see the header): any order with that
     // property is deadlock-free.
-    const unsigned u = idx % per, rr = idx / per;
+    // ... and the bodies of a queue go through an iteration in GROUPS of TGRP: slot-major inside a group (slot 0 of its bodies, slot 1
+    // of its bodies, ...), so that a body's chain tile, last slot, comes TGRP x NT tasks -- a full round of the XCD's 64 workgroup
+    // slots -- after its diagonal tile instead of right behind it in the queue (body-major, it idled there for the whole product
+    // and factorisation of the diagonal tile: 5 % of all workgroup time), while the tiles of a body's column still run side by
+    // side and share that column's row panel in the L2.
     const unsigned nb_q = nbq(q);
-    const int b = q + 8 * (int)(rr % nb_q), s = (int)(rr / nb_q);             // s = 0 .. NT
+    const unsigned s_u = idx / (nb_q * per), r_it = idx % (nb_q * per);
+    const unsigned grp = r_it / (TGRP * per), r_g = r_it - grp * (TGRP * per);
+    const unsigned gsz = (nb_q - grp * TGRP < TGRP) ? nb_q - grp * TGRP : TGRP;
+    const unsigned u = r_g / gsz;
+    const int b = q + 8 * (int)(grp * TGRP + r_g % gsz), s = (int)s_u;        // s = 0 .. NT
     bool chol; int ti_, tj_;                                                  // CHOL(ti_, tj_) or INV(row tile ti_ of Y, column tile tj_)
     if (!tile_task(NT, s, (int)u, chol, ti_, tj_)) continue;
     if (!chol && !with_inv) continue;
@@ -447,14 +464,27 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if (!chol) wait_ge(cL + ct, (unsigned)ct + 1u, P);     // INV: row ct of L is complete, diagonal tile and its inverse included
-    TP(4)
+    // Everything this task will ever wait for, looked at ONCE, up front (per wave, wave-uniform): the K chunks' counters and the
+    // diagonal tile of the column.  All there (the rule, thanks to the queue order): ONE agent-scope acquire for the whole task --
+    // an acquire costs microseconds on a busy CU (the guide prices it at 1.7 us x 4 at four blocks a CU) and round 5's first
+    // version paid two or three per task: 6.6 % of all workgroup time.  Otherwise the task polls as it goes and acquires after
+    // every poll that had to wait.
+    const unsigned needD = (chol && diag) ? 0u : (unsigned)ct + 1u;           // finished tiles of L's row ct this task needs at some point
+    const unsigned vA0 = ld_relaxed(cA), vB0 = ld_relaxed(cB);               // (ONE read each: a second read may already see more than the other counter holds)
+    unsigned haveK = (unsigned)__builtin_amdgcn_readfirstlane((int)(vA0 < vB0 ? vA0 : vB0));
+    bool haveD = __builtin_amdgcn_readfirstlane((int)(ld_relaxed(cL + ct) >= needD)) != 0;
+    TP(10)                                                 // the counters read
+    if (!chol && !haveD) { wait_ge(cL + ct, needD, P); haveD = true; }        // INV reads row ct of L from its first chunk on
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    TP(11)                                                 // the task's acquire (or the wait of an inverse tile for its row of L)
     if (nkt > 0) {
-      const bool ready_all = __builtin_amdgcn_readfirstlane((int)(ld_relaxed(cA) >= (unsigned)nkt && ld_relaxed(cB) >= (unsigned)nkt)) != 0;   // per wave
       auto waitfn = [&](int kc) {
-        if (ready_all) { if (kc == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return; }
+        if ((unsigned)kc < haveK) return;                                     // published before the last acquire of this wave
         wait_ge(cA, (unsigned)kc + 1u, P);
         if (cB != cA) wait_ge(cB, (unsigned)kc + 1u, P);
+        const unsigned a_ = ld_relaxed(cA), b_ = ld_relaxed(cB);              // (what else has arrived meanwhile is only trusted after ...
+        haveK = (unsigned)__builtin_amdgcn_readfirstlane((int)(a_ < b_ ? a_ : b_));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    //  ... an acquire that follows the read)
       };
       const double *Ip = Om + (size_t)(kt0 * TC) * (size_t)ldo, *Jp = Ab + (size_t)(kt0 * TC) * (size_t)n;
       if (mk.full() || (mk.nti == 4 && mk.ntj == 4 && !mk.lowtri) || !active)
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
       tile_winv(Ab, n, c0, pw, Lib + (size_t)(4 * ct) * IB * IB, Wb);
       TP(8)                                                // its 128 x 128 inverse
     } else if (!diag) {
-      if (chol) wait_ge(cL + ct, (unsigned)ct + 1u, P);    // the diagonal tile of this column and its inverse
+      if (!haveD) wait_ge(cL + ct, needD, P);              // the diagonal tile of this column and its inverse
       TP(4)
       tile_solve(acc, Wb, sI, sJ, tiles16(i0, n) > 0 && tiles16(j0, n) > 0);      // X = T L_cc^-T = T W^T, in the registers
       if (tiles16(i0, n) > 0 && tiles16(j0, n) > 0) {

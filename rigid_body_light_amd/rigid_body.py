@@ -7,7 +7,8 @@ pybind11 class `c_rigid.CManyBodies`.  Size rules are kept in one table (`_expec
 of per-method checks; shapes follow the shape X was given in (2-D in -> (-1, 3) out, flat in -> flat out,
 reference src/Rigid.py:54,60,66).
 
-Beyond the reference surface (its C++ has these, its Python does not): `solve_saddle`, `M_half_W`, `M_RFD`,
+Beyond the reference surface (its C++ has these, its Python does not): `solve_saddle`, `solve_saddle_multi`,
+`body_mobility_matrix`, `M_half_W`, `M_RFD`,
 `KTinv_RFD`, `M_RFD_cfgs`, `M_RFD_from_U`, `KT_RFD_from_U`, `evolve_rigid_bodies_RFD`, `apply_M_multi`,
 `dense_mobility`.
 """
@@ -120,6 +121,26 @@ class RigidBody:
         (src/Rigid.py:69-80).  -> (x, iterations, residual estimate)"""
         return self.cb.solve_saddle(self._require(rhs, "system"), int(max_iter), float(rtol),
                                     None if x0 is None else self._require(x0, "system"))
+
+    def solve_saddle_multi(self, rhs, max_iter=100, rtol=1.0e-8):
+        """The same solve for SEVERAL right-hand sides of this configuration at once, rhs (k, 3 N_blobs + 6 N_bodies): k GMRES
+        recurrences in lock step, each column the iterates `solve_saddle` would give it, the k mobility products of an iteration
+        ONE launch on the fp64 matrix cores (16 columns per pass).  -> (x (k, size), iterations (k,), residual estimates (k,))"""
+        rhs = np.ascontiguousarray(np.atleast_2d(np.asarray(rhs, dtype=np.float64)))
+        if rhs.shape[1] != 3 * self.total_blobs + 6 * self.N_bodies:
+            _fail("solve_saddle_multi: rhs must have shape (k, 3*total_blobs + 6*N_bodies)")
+        return self.cb.solve_saddle_multi(rhs, int(max_iter), float(rtol))
+
+    def body_mobility_matrix(self, max_iter=100, rtol=1.0e-8, columns=None):
+        """The (6 N_bodies) x (6 N_bodies) body mobility matrix N = (K^T M^-1 K)^-1 of the current configuration, U = N F: one
+        saddle solve [M -K; K^T 0][lambda; U] = [0; e_c] per unit load e_c (force / torque component c of one body), the 6 N_bodies
+        solves through `solve_saddle_multi`.  columns: only these unit loads (default all).  -> (N[:, columns], iterations)"""
+        nb6, n3 = 6 * self.N_bodies, 3 * self.total_blobs
+        cols = np.arange(nb6) if columns is None else np.asarray(columns, dtype=int).reshape(-1)
+        rhs = np.zeros((cols.size, n3 + nb6))
+        rhs[np.arange(cols.size), n3 + cols] = 1.0          # K^T lambda = e_c, M lambda = K U  =>  U = (K^T M^-1 K)^-1 e_c
+        x, its, _ = self.solve_saddle_multi(rhs, max_iter, rtol)
+        return np.ascontiguousarray(x[:, n3:].T), its
 
     # ------------------------------------------------------------------ beyond the reference's Python surface
     def M_half_W(self, W=None, seed=0, method="cholesky"):

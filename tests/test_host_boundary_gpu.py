@@ -219,3 +219,52 @@ def test_fused_krylov_iteration_equals_one_kernel_per_operation(nb, nblb, shared
         assert abs(a[1] - b[1]) < 1e-9 * max(a[1], 1e-12) + 1e-15
     assert 3 < out[1][0][0] < 200 and out[1][0][3] < 2e-9 and out[1][2][3] < 2e-9
     assert out[1][1][0] == 7 and abs(out[1][1][3] - out[1][1][1]) < 1e-6 * out[1][1][1]      # fixed work: estimate == true residual
+
+
+@pytest.mark.parametrize("nb,nblb,wall,block", [(10, 12, False, False), (6, 162, True, True), (6, 162, False, True)])
+def test_lock_step_gmres_for_many_right_hand_sides(orc, nb, nblb, wall, block):
+    """`solve_saddle_multi` (rbl_gmres_saddle_multi_dev): k right-hand sides of one configuration advance in lock step -- ONE
+    multi-vector mobility product per iteration on the fp64 matrix cores, shared passes over the per-body factors -- and every
+    column must be the solve `solve_saddle` gives it alone: same iteration count (+-1), same solution to 1e-10, its own residual
+    below the tolerance and the TRUE residual through apply_saddle too.  19 columns = two passes (16 + 3) of the product; columns
+    of very different scale converge at different iterations.  Then the customer: the body mobility matrix N = (K^T M^-1 K)^-1
+    from 6 N_bod unit loads against the oracle's dense M and K (the operator is the reference's
+    src/Rigid.py:69-80)."""
+    from oracle import oracle as O
+    c, rb = _body(nb, nblb, wall, block)
+    n3, nsys = 3 * nb * nblb, 3 * nb * nblb + 6 * nb
+    rng = np.random.default_rng(21)
+    k = 19
+    rhs = rng.standard_normal((k, nsys))
+    rhs[:, :n3] *= 0.1
+    rhs[3] *= 1e-6; rhs[7] *= 1e4                      # scale must not matter: the tolerance is relative, column by column
+    rhs[11, :n3] = 0.0                                 # a pure body load, as in a time step
+    x, its, res = rb.solve_saddle_multi(rhs, max_iter=200, rtol=1e-10)
+    assert x.shape == (k, nsys) and its.shape == (k,) and res.shape == (k,)
+    for col in range(k):
+        xs, it1, res1 = rb.solve_saddle(rhs[col], max_iter=200, rtol=1e-10)
+        bn = np.linalg.norm(rhs[col])
+        assert abs(int(its[col]) - it1) <= 1 and res[col] < 1e-10, (col, its[col], it1, res[col])
+        assert np.linalg.norm(x[col] - xs) <= 1e-9 * np.linalg.norm(xs), col          # (both are 1e-10 solves of the same system)
+        assert np.linalg.norm(rb.apply_saddle(x[col]) - rhs[col]) < 1e-9 * bn, col
+    # fixed work (rtol <= 0): exactly max_iter iterations for every column, no host test inside
+    xf, itf, _ = rb.solve_saddle_multi(rhs[:5], max_iter=12, rtol=0.0)
+    assert list(itf) == [12] * 5
+    for col in range(5):
+        x1, _, _ = rb.solve_saddle(rhs[col], max_iter=12, rtol=0.0)
+        assert np.linalg.norm(xf[col] - x1) <= 1e-9 * np.linalg.norm(x1)
+    with pytest.raises(RuntimeError):
+        rb.solve_saddle_multi(rhs[:, :-1])
+    # the body mobility matrix against dense numpy on the oracle's matrices
+    Nmat, itn = rb.body_mobility_matrix(rtol=1e-11)
+    cfg = c["cfg"] - c["cfg"].mean(axis=0)
+    r = orc.multi_body_pos(c["X"], c["Q"], cfg)
+    K = O.K_matrix(c["X"], c["Q"], cfg)
+    M = orc.rotne_prager_tensor(r, c["a"], c["eta"], wall)
+    if wall:                                            # apply_M's wall form is B M B (one flag for the wall term AND the damping, :641-659)
+        B = orc.damp(r, c["a"])
+        M = B[:, None] * M * B[None, :]
+    Nref = np.linalg.inv(K.T @ np.linalg.solve(M, K))
+    assert Nmat.shape == (6 * nb, 6 * nb) and np.all(itn > 0)
+    assert np.linalg.norm(Nmat - Nref) <= 1e-8 * np.linalg.norm(Nref)
+    assert np.linalg.norm(Nmat - Nmat.T) <= 1e-8 * np.linalg.norm(Nmat)            # symmetric positive definite, as a mobility must be

@@ -46,7 +46,7 @@ for rep in range(2):
     L.rbl_debug_tile_prof(buf, 1)
 x = np.array(list(buf), dtype=np.float64)
 names = {0: "claim a task", 1: "product of a factor tile (waits incl.)", 2: "C update + barrier", 3: "diagonal tile (potrf)", 4: "wait for a diagonal tile",
-         5: "triangular solve", 6: "publish (drain, barrier, release, add)", 8: "128 x 128 inverse of a diagonal tile", 7: "product + store of an inverse tile", 9: "end-of-task barrier"}
+         5: "triangular solve", 6: "publish (drain, barrier, release, add)", 8: "128 x 128 inverse of a diagonal tile", 7: "product + store of an inverse tile", 9: "end-of-task barrier", 10: "reading the counters", 11: "the acquire of a task (INV: wait for its row of L)"}
 tot = x.sum()
 NT = (m + 127) // 128
 print("%d x shell_N_%d, inverse %d: build + one application %.2f ms; %d tasks; summed workgroup time %.1f ms at 2.4 GHz over 512 resident workgroups = %.2f ms each"
