@@ -253,6 +253,16 @@ int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv
   RblPhase ph(c, RBL_T_PERBODY);
   const int64_t m = 3 * (int64_t)c->S.N_blb, msz = m * m;
   const size_t off = (size_t)b0 * (size_t)m;
+  // the forms that go through the scratch vectors (body-frame factor, explicit inverses) lay them out `pitch` apart like the
+  // caller's: fine for vectors one blob-vector apart (every caller before the lock-step GMRES), out of the scratch's bounds for
+  // vectors further apart -- those go one at a time
+  if (nv > 1 && pitch != m * (int64_t)c->S.N_bod && (bf_on(c) || c->blk_inv_valid)) {
+    for (int v = 0; v < nv; ++v) {
+      const int rc1 = blk_solve(c, b0, nbo, in + (size_t)v * (size_t)pitch, out + (size_t)v * (size_t)pitch, 1, 0, mode, allow_f32);
+      if (rc1) return rc1;
+    }
+    return RBL_OK;
+  }
   if (bf_on(c)) {
     const size_t tmpn = (size_t)m * (size_t)c->S.N_bod;
     int rc = ensure_xq_dev(c); if (rc) return rc;       // the rotations read the quaternions on the device: current ones (M_RFD displaces them)
@@ -490,7 +500,8 @@ int pc_block_factors(rbl_ctx *c, int b0, int b1)
   double *Lb = (double *)c->d_blkL.p + (size_t)b0 * (size_t)msz;
   for (int q0 = b0; q0 < b1; q0 += 65535)               // bodies ride in gridDim.z
     rbl_launch_build_M_batched(c->stream, P, S.wall, (const double *)c->d_pos.p + (size_t)q0 * (size_t)m, S.N_blb,
-                               (b1 - q0 < 65535) ? b1 - q0 : 65535, Lb + (size_t)(q0 - b0) * (size_t)msz, msz, c->d_err);
+                               (b1 - q0 < 65535) ? b1 - q0 : 65535, Lb + (size_t)(q0 - b0) * (size_t)msz, msz, c->d_err,
+                               (c->blk_tile && rbl_tile_cholesky_fits(m)) ? 128 : 0);    // (the tile factorisation never reads above its diagonal tiles)
   const bool want_inv = c->blk_explicit && rbl_block_inverse_large_fits(m) && (c->blk_large == 1 || (c->blk_large == 2 && comm_on(c)));
   c->blk_inv_valid = false; c->blk_f32_valid = false;
   if (c->blk_tile && rbl_tile_cholesky_fits(m)) {
@@ -685,15 +696,15 @@ int apply_PC_multi_dev(rbl_ctx *c, const double *d_in, double *d_out, double *d_
 {
   int rc = sync_bodies(c); if (rc) return rc;
   const RblBodyState &S = c->S;
+  if (S.block_pc && !c->dev_pc_valid) {                  // (FIRST: whether the body-frame tables serve this preconditioner is only known once it is built)
+    if ((rc = pc_block_build(c))) return rc;
+    c->dev_pc_valid = true;
+  }
   const bool together = S.block_pc && !comm_on(c) && !(bf_on(c) && c->bf_tables) && nv > 1 && d_scratch;
   if (!together) {
     for (int v = 0; v < nv; ++v)
       if ((rc = rbl_apply_PC_dev(c, d_in + (size_t)v * (size_t)pitch, d_out + (size_t)v * (size_t)pitch))) return rc;
     return RBL_OK;
-  }
-  if (!c->dev_pc_valid) {
-    if ((rc = pc_block_build(c))) return rc;
-    c->dev_pc_valid = true;
   }
   RblPhase ph(c, RBL_T_PERBODY);
   const int64_t N = (int64_t)S.N_bod * S.N_blb, n3 = 3 * N;

@@ -380,6 +380,6 @@ void rbl_launch_tl_eaddq(hipStream_t st, const double *d_Q, int64_t n3, int N_bl
 void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb, const double *d_s, const double *d_t, int64_t tpitch,
                         const double *d_w, double *d_wo, int64_t wpitch, int nvec);
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
-                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err);
+                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err, int lower_tiles = 0);
 
 #pragma GCC visibility pop

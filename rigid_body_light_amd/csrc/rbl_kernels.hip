@@ -1350,8 +1350,11 @@ template <bool WALL>
 __global__ __launch_bounds__(256) void k_build_M(const double *__restrict__ r,
                                                  double *__restrict__ M, long N,
                                                  int scale_damp, RblParams P, unsigned *err,
-                                                 long strideR, long strideM)
+                                                 long strideR, long strideM, int lower_tiles)
 {
+  // lower_tiles > 0 (the per-body matrices a factorisation follows): blocks that lie entirely ABOVE the diagonal tiles of that
+  // edge are not written -- a factorisation reads the lower triangle and whole diagonal tiles only: half the bytes
+  if (lower_tiles > 0 && 3 * ((long)blockIdx.x * 256 + 256) <= ((3 * (long)blockIdx.y * JB) / lower_tiles) * lower_tiles) return;
   r += (size_t)blockIdx.z * (size_t)strideR;   // batched: one blob set / one matrix per blockIdx.z
   M += (size_t)blockIdx.z * (size_t)strideM;
   __shared__ double col[3][768];
@@ -2241,24 +2244,26 @@ void rbl_launch_build_M(hipStream_t st, const RblParams &P, bool wall, bool scal
   dim3 grid((unsigned)((n_blobs + 255) / 256), (unsigned)((n_blobs + JB - 1) / JB)), block(256);
   if (wall)
     hipLaunchKernelGGL(k_build_M<true>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
-                       scale_damp ? 1 : 0, P, d_err, 0L, 0L);
+                       scale_damp ? 1 : 0, P, d_err, 0L, 0L, 0);
   else
     hipLaunchKernelGGL(k_build_M<false>, grid, block, 0, st, d_r, d_M, (long)n_blobs,
-                       scale_damp ? 1 : 0, P, d_err, 0L, 0L);
+                       scale_damp ? 1 : 0, P, d_err, 0L, 0L, 0);
 }
 
 // `batch` independent blob sets of n_blobs each (one rigid body each), matrices strideM apart
+// lower_tiles: 0 = the whole matrices; t > 0 = only what a factorisation in tiles of t x t reads (the lower triangle and whole
+// diagonal tiles: blocks entirely above them stay unwritten)
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
-                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err)
+                                int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err, int lower_tiles)
 {
   if (n_blobs <= 0 || batch <= 0) return;
   dim3 grid((unsigned)((n_blobs + 255) / 256), (unsigned)((n_blobs + JB - 1) / JB), (unsigned)batch), block(256);
   if (wall)
     hipLaunchKernelGGL(k_build_M<true>, grid, block, 0, st, d_r, d_M, (long)n_blobs, 0, P, d_err,
-                       (long)(3 * n_blobs), (long)strideM);
+                       (long)(3 * n_blobs), (long)strideM, lower_tiles);
   else
     hipLaunchKernelGGL(k_build_M<false>, grid, block, 0, st, d_r, d_M, (long)n_blobs, 0, P, d_err,
-                       (long)(3 * n_blobs), (long)strideM);
+                       (long)(3 * n_blobs), (long)strideM, lower_tiles);
 }
 
 void rbl_launch_pair_blocks(hipStream_t st, const RblParams &P, bool wall, int mode,
