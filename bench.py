@@ -85,7 +85,10 @@ NOTES = {
     "summary.dropin_cfg2_scipy_gmres_ms": "median of five SciPy solves at cfg 2 before and after cfg 5 mapped 189 GB in this process, host BLAS pool limited "
                                           "to blas_threads (the box's CPU share); host_default_threads_min_max = the same solves with the pool at its default "
                                           "(every core of the host): the 12-vs-92 ms spread of round 4 is BLAS oversubscription, not cfg 5 and not the operators",
-    "summary.multi_rhs": "rbl_gmres_saddle_multi_dev: k right-hand sides in lock step on the fp64-MFMA product, against k sequential solves",
+    "summary.multi_rhs": "rbl_gmres_saddle_multi_dev at the headline configuration: 16 right-hand sides (sets of body loads) in lock step, their products ONE "
+                         "launch of the fp64-MFMA kernel per iteration, against sequential rbl_gmres_saddle_dev solves (two timed, scaled to 16): "
+                         "ratio_to_sequential = lock_step_ms / (16 x sequential_ms_per_solve); column_vs_sequential_solve = largest relative "
+                         "difference of a column to its own sequential solve",
 }
 
 
@@ -301,6 +304,7 @@ def phase_block(ctx, steps, dev, world):
     out = {}
     for i, k in enumerate(names):
         out[k + "_ms"] = {"min": float(arr[:, i].min()), "max": float(arr[:, i].max()), "per_rank": [round(float(x), 4) for x in arr[:, i]]}
+    out["collectives_per_step"] = tm["collective"][1] / float(max(steps, 1))     # (brackets around the collectives of rank 0: their count)
     out["note"] = ("GPU milliseconds per time step and rank between hipEvents on the context's stream (rbl_get_timings): product = pair "
                    "kernels + slab reduction of this rank's tile pairs; per_body = applications of the rank's own per-body factors; factor "
                    "= their build; collective = the all-reduce callback incl. the wait for the slowest rank; total = the solver calls "
@@ -938,7 +942,8 @@ def summary_of(d):
             s["brownian_converged_detail"] = {"ms": b["ms_per_timestep"], "apply_M_per_step": ts.get("brownian_converged_apply_M_per_step"),
                                               "gmres_its": b["gmres_iterations"][-1], "lanczos_pair_its": b["lanczos_iterations_last_step"][0],
                                               "root_identity_error": b.get("root_identity_error"), "gmres_residual_max": b["gmres_residual_max"],
-                                              "phases_ms": {k[:-3]: v["max"] for k, v in (b.get("phases") or {}).items() if k.endswith("_ms")}}
+                                              "phases_ms": {k[:-3]: v["max"] for k, v in (b.get("phases") or {}).items() if k.endswith("_ms")},
+                                              "collectives_per_step": (b.get("phases") or {}).get("collectives_per_step")}
         s["deterministic_fixed_work_residual"] = ts.get("deterministic_fixed_work_residual")
     cbt = d.get("cpu_baseline_timestep")
     if cbt:
@@ -1024,6 +1029,40 @@ def finish(record, args, phase="all"):
     sys.stderr.write("BENCH_DETAIL " + json.dumps(record) + "\n")
     sys.stderr.flush()
     emit(json.dumps(slim_line(record)))
+
+
+def multi_rhs_block(dev, stream, k=16):
+    """k right-hand sides of the headline configuration (200 x shell_N_642, wall, block PC) through the lock-step GMRES on the fp64-MFMA
+    product (rbl_gmres_saddle_multi_dev) against sequential rbl_gmres_saddle_dev solves (two timed, scaled to k); every column is a
+    different set of body loads, rtol 1e-8.  The MFMA-busy share of the solve comes from the PMC passes under profiles/."""
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, nblb, wall = CONFIGS["cfg3"]
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb; n3 = 3 * N; nsys = n3 + 6 * nb
+    ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=stream.cuda_stream)
+    lib().rbl_set_blk_pc(ctx.h, 1)
+    ctx.set_config(c["X"], c["Q"])
+    rhs = np.zeros((k, nsys))
+    rhs[:, n3:] = np.random.default_rng(3).standard_normal((k, 6 * nb))
+    rhs_d = torch.from_numpy(rhs).to(dev)
+    xs = torch.empty_like(rhs_d); xm = torch.empty_like(rhs_d)
+    ctx.gmres_saddle(rhs_d[0].data_ptr(), 200, 1e-8, xs[0].data_ptr()); ctx.sync_check()      # builds the preconditioner
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    its_s = [ctx.gmres_saddle(rhs_d[j].data_ptr(), 200, 1e-8, xs[j].data_ptr())[0] for j in range(2)]
+    torch.cuda.synchronize(); t_seq = (time.perf_counter() - t0) / 2.0
+    ctx.gmres_saddle_multi(rhs_d.data_ptr(), k, 200, 1e-8, xm.data_ptr())                     # (workspace growth outside the timing)
+    ctx.set_timing(True); ctx.reset_timings()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    its_m, res_m = ctx.gmres_saddle_multi(rhs_d.data_ptr(), k, 200, 1e-8, xm.data_ptr())
+    torch.cuda.synchronize(); t_multi = time.perf_counter() - t0
+    tm = ctx.timings(); ctx.set_timing(False)
+    err = max(float(torch.linalg.norm(xm[j] - xs[j]) / torch.linalg.norm(xs[j])) for j in range(2))
+    ctx.close()
+    return {"rhs": k, "lock_step_ms": t_multi * 1e3, "sequential_ms_per_solve": t_seq * 1e3, "ratio_to_sequential": t_multi / (k * t_seq),
+            "ms_per_solve": t_multi * 1e3 / k, "gmres_iterations": int(max(its_m)), "residual_max": float(max(res_m)),
+            "column_vs_sequential_solve": err, "product_ms": tm["product"][0], "per_body_ms": tm["per_body"][0],
+            "workload": "%d x shell_N_%d, wall, block PC, rtol 1e-8, %d sets of body loads" % (nb, nblb, k)}
 
 
 class LineGuard:
@@ -1411,6 +1450,7 @@ def main():
     others = None
     dropin = None
     dropin_after = None
+    multi = None
     if world == 1 and args.other_configs and args.config == "cfg3" and phase != "main" and not args.variant and not args.jsplit:
         try:                                                 # (before cfg 5 maps 189 GB: small host-boundary calls measured after it run several times slower)
             dropin = dropin_block(dev)
@@ -1426,6 +1466,13 @@ def main():
             traceback.print_exc()
             others = {"error": repr(e)}
             failed = failed or "other-configs part failed"
+        try:
+            multi = multi_rhs_block(dev, stream)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            multi = {"error": repr(e)}
+            failed = failed or "multi-RHS part failed"
         try:                                                 # the same small host-boundary calls once more, now that cfg 5 has mapped and freed 189 GB
             dropin_after = dropin_block(dev, names=("cfg2",))
         except Exception as e:
@@ -1444,6 +1491,8 @@ def main():
             line["dropin"] = dropin
         if dropin_after is not None:
             line["dropin_after_cfg5"] = dropin_after
+        if multi is not None:
+            line["multi_rhs"] = multi
         if world == 1 and args.cpu_budget > 0:
             cb = cpu_baseline(c, nb, nblb, wall, args.cpu_budget)
             line["cpu_baseline"] = cb["1core"]
