@@ -583,8 +583,13 @@ template <int NV, bool GLOBAL = false>
 __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
                                                      const double *in, double *out, long vec_stride, long rhs_pitch,
-                                                     int mode /* 0: L L^T, 1: L only, 2: L^T only */)
+                                                     int mode /* 0: L L^T, 1: L only, 2: L^T only; | 0x200: the matrix also holds L^T above its diagonal */)
 {
+  // MIRROR (| 0x200; nobody sets it): the upper triangle holds L^T and the backward sweep reads COLUMNS of it like the forward
+  // sweep.  Round 5 built it (the tile factorisation wrote the mirror) and measured 0.77 against 0.81 ms a backward sweep at
+  // cfg 3 for 2 ms more per factorisation: what made the backward sweep slow was its chain of Linv loads, fixed below
+  const bool mirror = (mode & 0x200) != 0;
+  mode &= 0xff;
   extern __shared__ double y_lds[];                  // NV x n doubles + NV x IB scratch (GLOBAL: the scratch only)
   const int b = blockIdx.x, t = threadIdx.x;
   double *const y = GLOBAL ? out + (size_t)b * (size_t)vec_stride : y_lds;     // vector v at y + v * ypitch
@@ -606,10 +611,16 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
     if (t < IB * NV) {
+      // all 32 entries of the row of Linv in flight together (a loop with a data-dependent trip count waits for every load in turn:
+      // that chain, not the bytes, was most of a step -- the backward sweep's strided form took 17 us a step, 1.04 ms a sweep)
+      double li[IB];
+#pragma unroll
+      for (int m = 0; m < IB; ++m) li[m] = Li[tt * IB + m];
       double acc = 0.0;
       const double *yv = y + (size_t)tv * ypitch + k;
-      if (tt < nb)
-        for (int m = 0; m <= tt; ++m) acc = __builtin_fma(Li[tt * IB + m], yv[m], acc);
+#pragma unroll
+      for (int m = 0; m < IB; ++m)
+        if (m <= tt && tt < nb) acc = __builtin_fma(li[m], yv[m], acc);
       tbuf[t] = acc;
     }
     __syncthreads();
@@ -649,15 +660,36 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     const int nb = (int)((n - k < IB) ? n - k : IB);
     const double *Li = Lib + (size_t)s * IB * IB;
     if (t < IB * NV) {
+      double li[IB];
+#pragma unroll
+      for (int m = 0; m < IB; ++m) li[m] = Li[m * IB + tt];                                // column tt of Linv, all loads in flight
       double acc = 0.0;
       const double *yv = y + (size_t)tv * ypitch + k;
-      if (tt < nb)
-        for (int m = tt; m < nb; ++m) acc = __builtin_fma(Li[m * IB + tt], yv[m], acc);   // Linv^T
+#pragma unroll
+      for (int m = 0; m < IB; ++m)
+        if (m >= tt && m < nb && tt < nb) acc = __builtin_fma(li[m], yv[m], acc);           // Linv^T
       tbuf[t] = acc;
     }
     __syncthreads();
     if (t < IB * NV && tt < nb) y[(size_t)tv * ypitch + k + tt] = tbuf[t];
-    if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
+    if (nb == IB && mirror) {   // columns before the block: y[c] -= sum_r L^T[c][k+r] x_r, L^T read by columns like the forward sweep
+      for (long r = t; r < k; r += BS_T) {
+        const double *col = Lb + (size_t)k * (size_t)n + r;
+        double lv[IB];
+#pragma unroll
+        for (int m = 0; m < IB; ++m) lv[m] = col[(size_t)m * n];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double a0 = y[(size_t)v * ypitch + r], a1 = 0.0;
+#pragma unroll
+          for (int m = 0; m < IB; m += 2) {
+            a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
+            a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
+          }
+          y[(size_t)v * ypitch + r] = a0 + a1;
+        }
+      }
+    } else if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
       // The 32 entries of a column are one 256-byte run.  Sixteen lanes share a column (16 bytes = two rows each), so a
       // wave's load instruction covers four whole runs -- eight cache lines for 1 KB, as coalesced as the forward sweep --
       // and the 32-term sum closes with four DPP steps inside the 16-lane row.  (One column per lane, the round-1 form,
@@ -1536,6 +1568,7 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
   // d_Q (with | 0x100 and n <= 512 only): the shared factor is a body-frame one, G_b = R_b L -- rotations fused into the sweep
   const int64_t nsteps = (n + IB - 1) / IB;
   const bool shared = (mode & 0x100) != 0;           // one factor for every body of the batch (strideA = 0 by the caller)
+  const int mirror = mode & 0x200;                   // the matrices hold L^T above the diagonal (large bodies, tile factorisation)
   mode &= 0xff;
   const long strideL = shared ? 0 : (long)(nsteps * IB * IB);
   for (int v0 = 0; v0 < nv;) {
@@ -1547,7 +1580,7 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     if (lds > 65536) {         // one vector of a body does not fit LDS (> 2 730 blobs): the output vector in HBM is the working vector
       if (d_Q) return RBL_ERR_ARG;
       hipLaunchKernelGGL((k_block_solve<1, true>), dim3(batch), dim3(BS_T), sizeof(double) * IB, st, d_L, (long)n, (long)strideA, d_Linv,
-                         strideL, in, out, (long)vec_stride, (long)rhs_pitch, mode);
+                         strideL, in, out, (long)vec_stride, (long)rhs_pitch, mode | mirror);
       v0 += 1;
       continue;
     }
@@ -1569,13 +1602,13 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     }
     if (g == 3)
       hipLaunchKernelGGL(k_block_solve<3>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode);
+                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
     else if (g == 2)
       hipLaunchKernelGGL(k_block_solve<2>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode);
+                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
     else
       hipLaunchKernelGGL(k_block_solve<1>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode);
+                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
     v0 += g;
   }
   return RBL_OK;

@@ -1,7 +1,7 @@
 """Per-body factor application for LARGE bodies (shell_N_642 / 2562): substitution chains (RBL_OPT_BLOCK_EXPLICIT_LARGE = 0) vs explicit
 inverses (1) vs their single-precision copy (RBL_OPT_BLOCK_INVERSE_F32 = 1), for all bodies and for one rank's share at P = 8, with the achieved
 HBM rate (bytes = the triangle(s) of the factor / inverse one application reads) and the cost of the build.
-usage: bench_block_inverse_large.py [bodies blobs [wall]]"""
+usage: bench_block_inverse_large.py [bodies blobs [wall|free] [option=value ...]]"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from rigid_body_light_amd import make_config
@@ -19,6 +19,8 @@ for opts, name, bpe in (({"block_explicit_large": 0}, "substitution", 8.0), ({"b
     ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.set_config(c["X"], c["Q"])
     ctx.set_option("bodyframe_factor", 0)
+    for kv in sys.argv[4:]:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for k_, v_ in opts.items():
         ctx.set_option(k_, v_)
     ctx.block_solve(v.data_ptr(), o.data_ptr(), 0); ctx.sync_check()
