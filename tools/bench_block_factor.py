@@ -3,7 +3,7 @@ rbl_tilechol.hip) against the batched panel kernels of rounds 1-4 (0), factor on
 rank's share at P = 8; the two paths' factor applications are compared entry by entry.
 usage: bench_block_factor.py [bodies blobs [wall|free]]"""
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from rigid_body_light_amd import make_config
 from rigid_body_light_amd._lib import DeviceContext
 nb, nblb = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (200, 642)

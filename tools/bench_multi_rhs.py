@@ -2,7 +2,7 @@
 sequential rbl_gmres_saddle_dev solves, block PC, rtol 1e-8; every column compared with its sequential solve.
 usage: bench_multi_rhs.py [bodies blobs [wall|free] [k]]"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from rigid_body_light_amd import make_config
 from rigid_body_light_amd._lib import DeviceContext, lib
 nb, nblb = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (200, 642)
@@ -22,9 +22,10 @@ xs = torch.empty_like(rhs_d); xm = torch.empty_like(rhs_d)
 ctx.gmres_saddle(rhs_d[0].data_ptr(), 200, 1e-8, xs[0].data_ptr()); ctx.sync_check()       # builds the preconditioner
 torch.cuda.synchronize(); t0 = time.perf_counter()
 its_s = []
-for j in range(k):
+nseq = 1 if os.environ.get("ONLY_MULTI") else k           # ONLY_MULTI=1 (counter passes): no sequential solves beyond the one that compares
+for j in range(nseq):
     m, r = ctx.gmres_saddle(rhs_d[j].data_ptr(), 200, 1e-8, xs[j].data_ptr()); its_s.append(m)
-torch.cuda.synchronize(); ts = time.perf_counter() - t0
+torch.cuda.synchronize(); ts = (time.perf_counter() - t0) * k / nseq
 ctx.gmres_saddle_multi(rhs_d.data_ptr(), k, 200, 1e-8, xm.data_ptr())                      # (workspace growth outside the timing)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 its_m, res_m = ctx.gmres_saddle_multi(rhs_d.data_ptr(), k, 200, 1e-8, xm.data_ptr())
@@ -32,7 +33,7 @@ torch.cuda.synchronize(); tm = time.perf_counter() - t0
 ctx.set_timing(True); ctx.reset_timings()
 ctx.gmres_saddle_multi(rhs_d.data_ptr(), k, 200, 1e-8, xm.data_ptr())
 tmg = ctx.timings(); ctx.set_timing(False)
-err = max(float(torch.linalg.norm(xm[j] - xs[j]) / torch.linalg.norm(xs[j])) for j in range(k))
+err = max(float(torch.linalg.norm(xm[j] - xs[j]) / torch.linalg.norm(xs[j])) for j in range(nseq))
 print("%d x shell_N_%d %s, %d right-hand sides, block PC, rtol 1e-8" % (nb, nblb, "wall" if wall else "free", k))
 print("  sequential: %.1f ms (%.1f ms a solve), iterations %s" % (ts * 1e3, ts * 1e3 / k, its_s))
 print("  lock step : %.1f ms (%.1f ms a solve), iterations %s, max residual %.2e" % (tm * 1e3, tm * 1e3 / k, its_m, max(res_m)))
