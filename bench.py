@@ -63,7 +63,7 @@ NOTES = {
     "cpu_baseline": "oracle/rbl_oracle.c orc_apply_M_rows (port of the reference arithmetic, matrix-free because the reference's dense 3N x 3N "
                     "matrix would need 1.19 TB at this size; gcc -O3) on a bounded row sample of the same workload, scaled by N / rows",
     "summary.timesteps_per_sec": "SURVEY.md 8(d): deterministic_fixed_work = 20 GMRES iterations (21 apply_M, diagonal PC; NOT converged: see "
-                                 "deterministic_fixed_work_residual); deterministic_converged = block PC, GMRES to 1e-8 from the quadratic extrapolation "
+                                 "fixed_work_residual); deterministic_converged = block PC, GMRES to 1e-8 from the quadratic extrapolation "
                                  "of the last solutions (constant body force), per-body factors rebuilt every 4th step; brownian_converged = stochastic "
                                  "midpoint step, fresh noise every step: 2 M^{1/2}W (preconditioned lock-step Lanczos to 1e-3, two-level factor) + M_RFD "
                                  "+ Kinv at q^n, block-PC GMRES to 1e-8 from zero at q^{n+1/2}, update from q^n -- the physically meaningful step of "
@@ -83,7 +83,7 @@ NOTES = {
                               "(restart 40, rtol 1e-8) over them (the reference's usage model, src/Rigid.py:69-80), and the library's own solver on "
                               "the same right-hand side",
     "summary.dropin_cfg2_scipy_gmres_ms": "median of five SciPy solves at cfg 2 before and after cfg 5 mapped 189 GB in this process, host BLAS pool limited "
-                                          "to blas_threads (the box's CPU share); host_default_threads_min_max = the same solves with the pool at its default "
+                                          "to blas_threads (the box's CPU share); default_threads_min_max = the same solves with the pool at its default "
                                           "(every core of the host): the 12-vs-92 ms spread of round 4 is BLAS oversubscription, not cfg 5 and not the operators",
     "summary.multi_rhs": "rbl_gmres_saddle_multi_dev at the headline configuration: 16 right-hand sides (sets of body loads) in lock step, their products ONE "
                          "launch of the fp64-MFMA kernel per iteration, against sequential rbl_gmres_saddle_dev solves (two timed, scaled to 16): "
@@ -224,7 +224,7 @@ def pmc_traffic(kernel, config, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only while the built
     library holds the same kernel code as the profiled one: the file records the sha256 of the profiled instance's
     instruction text, tools/isa_stats.py computes the same for every build (librbl.isa.json)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_bench_%s_pmc.json" % (rnd, config))
         try:
             d = json.load(open(path))
@@ -939,12 +939,15 @@ def summary_of(d):
             s["brownian_gmres_rtol_matched_to_root"] = m
         b = bro.get("lanczos_0.001")
         if b:
-            s["brownian_converged_detail"] = {"ms": b["ms_per_timestep"], "apply_M_per_step": ts.get("brownian_converged_apply_M_per_step"),
-                                              "gmres_its": b["gmres_iterations"][-1], "lanczos_pair_its": b["lanczos_iterations_last_step"][0],
-                                              "root_identity_error": b.get("root_identity_error"), "gmres_residual_max": b["gmres_residual_max"],
-                                              "phases_ms": {k[:-3]: v["max"] for k, v in (b.get("phases") or {}).items() if k.endswith("_ms")},
-                                              "collectives_per_step": (b.get("phases") or {}).get("collectives_per_step")}
-        s["deterministic_fixed_work_residual"] = ts.get("deterministic_fixed_work_residual")
+            ph = b.get("phases") or {}
+            det = {"ms": b["ms_per_timestep"], "apply_M_per_step": ts.get("brownian_converged_apply_M_per_step"),
+                   "gmres_its": b["gmres_iterations"][-1], "lanczos_pair_its": b["lanczos_iterations_last_step"][0],
+                   "root_identity_error": b.get("root_identity_error"), "gmres_residual_max": b["gmres_residual_max"],
+                   "phases_ms": {k: ph[k + "_ms"]["max"] for k in ("product", "per_body", "factor", "collective") if k + "_ms" in ph and ph[k + "_ms"]["max"] > 0.0}}
+            if ph.get("collectives_per_step"):
+                det["collectives_per_step"] = ph["collectives_per_step"]
+            s["brownian_converged_detail"] = det
+        t["fixed_work_residual"] = ts.get("deterministic_fixed_work_residual")
     cbt = d.get("cpu_baseline_timestep")
     if cbt:
         s["cpu_timesteps_per_sec"] = {lab: {k: v for k, v in cbt[lab].items() if k != "unit"} for lab in ("1core", "allcores") if lab in cbt}
@@ -974,13 +977,14 @@ def summary_of(d):
                                "scipy_operator_calls": dr["scipy_gmres"]["operator_calls"], "rbl_gmres_saddle": dr["rbl_gmres_saddle"]["ms"]}
     d2, d2b = _get(d, "dropin", "cfg2"), _get(d, "dropin_after_cfg5", "cfg2")
     if d2:
+        dflt = d2["scipy_gmres"].get("default_blas_threads")
         s["dropin_cfg2_scipy_gmres_ms"] = {"before_cfg5": d2["scipy_gmres"]["ms"], "after_cfg5": d2b["scipy_gmres"]["ms"] if d2b else None,
                                            "blas_threads": d2["scipy_gmres"].get("blas_threads"),
-                                           "host_default_threads_min_max": [min(d2["scipy_gmres"]["default_blas_threads"]["all_solves_ms"][1:]),
-                                                                            max(d2["scipy_gmres"]["default_blas_threads"]["all_solves_ms"][1:])]
-                                           if "default_blas_threads" in d2["scipy_gmres"] else None}
-    if d.get("multi_rhs"):
-        s["multi_rhs"] = {k: v for k, v in d["multi_rhs"].items() if not isinstance(v, (str, dict, list))}
+                                           "default_threads_min_max": [min(dflt["all_solves_ms"][1:]), max(dflt["all_solves_ms"][1:])] if dflt else None}
+    if d.get("multi_rhs") and "error" not in d["multi_rhs"]:
+        m = d["multi_rhs"]
+        s["multi_rhs"] = {k: m[k] for k in ("rhs", "lock_step_ms", "sequential_ms_per_solve", "ratio_to_sequential", "gmres_iterations",
+                                            "column_vs_sequential_solve") if k in m}
     errs = [k for k in ("timestep", "configs", "dropin", "multi_rhs") if isinstance(d.get(k), dict) and "error" in d[k]]
     if errs:
         s["failed_parts"] = errs

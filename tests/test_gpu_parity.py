@@ -668,6 +668,58 @@ def test_cfg2_full_size_lanczos_square_roots():
     ctx.close()
 
 
+@pytest.mark.parametrize("nblb", [171, 213, 300, 427, 512])
+def test_tile_factorisation_at_awkward_sizes(orc, nblb):
+    """The dataflow tile factorisation (csrc/rbl_tilechol.hip) at the sizes its indexing has to survive: n = 3 N_blb just above the
+    512 where it takes over (513: ODD, five tile rows, the last ONE row high), 639 (odd), 900 (last tile row 4 rows), 1 281 = 10 x 128 + 1,
+    1 536 = 12 x 128 exactly (no ragged tile at all).  Three bodies at different heights above the wall; factor only and factor +
+    explicit inverse; every per-body operation against dense numpy on the oracle's mobility of each body, and against the batched
+    panel kernels of rounds 1-4 (RBL_OPT_BLOCK_TILE_FACTOR = 0) entry by entry.  Reference: Block_diag_invM, c_rigid_obj.cpp:461-487."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext
+    k = np.arange(nblb) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / nblb); th = np.pi * (1.0 + 5.0 ** 0.5) * k
+    cfg = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)   # Fibonacci sphere, radius 1
+    a, eta, wall = 0.04, 1.0, True
+    X = np.array([[0.0, 0.0, 1.5], [3.0, 0.5, 2.5], [-2.5, 3.0, 4.0]]); nb = 3
+    Q = np.array([[0.8, 0.2, -0.4, 0.4], [1.0, 0.0, 0.0, 0.0], [0.3, -0.5, 0.1, 0.8]]); Q /= np.linalg.norm(Q, axis=1)[:, None]
+    n = 3 * nblb
+    r = orc.multi_body_pos(X, Q, cfg - cfg.mean(axis=0))
+    Ms = [orc.rotne_prager_tensor(r[b * n:(b + 1) * n], a, eta, wall) for b in range(nb)]       # each body's own mobility block
+    rng = np.random.default_rng(nblb)
+    v = rng.standard_normal(nb * n)
+    dev = torch.device("cuda:0")
+    dv = torch.from_numpy(v).to(dev)
+    ref0 = np.concatenate([np.linalg.solve(Ms[b], v[b * n:(b + 1) * n]) for b in range(nb)])
+    outs = {}
+    for tile in (1, 0):
+        for inv in (0, 1):
+            ctx = DeviceContext(a, eta, wall, cfg=cfg, stream_ptr=torch.cuda.current_stream().cuda_stream)
+            ctx.set_config(X, Q)
+            ctx.set_option("block_tile_factor", tile); ctx.set_option("block_explicit_large", inv)
+            res = []
+            for mode in (0, 1, 2, 3):
+                o = torch.full_like(dv, 3.5)
+                ctx.block_solve(dv.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
+                res.append(o.cpu().numpy())
+            y1 = torch.from_numpy(res[1]).to(dev)
+            back = torch.empty_like(dv); x2 = torch.empty_like(dv)
+            ctx.block_solve(y1.data_ptr(), back.data_ptr(), 3)                                   # L (L^-1 v) = v
+            ctx.block_solve(y1.data_ptr(), x2.data_ptr(), 2); ctx.sync_check()                   # L^-T (L^-1 v) = M^-1 v
+            ctx.close()
+            assert np.linalg.norm(res[0] - ref0) < 1e-9 * np.linalg.norm(ref0), (tile, inv)      # (L L^T)^-1 v = M^-1 v
+            assert np.linalg.norm(back.cpu().numpy() - v) < 1e-10 * np.linalg.norm(v), (tile, inv)
+            assert np.linalg.norm(x2.cpu().numpy() - ref0) < 1e-9 * np.linalg.norm(ref0), (tile, inv)
+            for b in range(nb):
+                sl = slice(b * n, (b + 1) * n)
+                assert abs(res[1][sl] @ res[1][sl] - v[sl] @ ref0[sl]) < 1e-10 * abs(v[sl] @ ref0[sl])   # |L^-1 v|^2 = v^T M^-1 v
+            outs[(tile, inv)] = res
+    for inv in (0, 1):
+        for mode in range(4):
+            a_, b_ = outs[(1, inv)][mode], outs[(0, inv)][mode]
+            assert np.linalg.norm(a_ - b_) < 1e-11 * np.linalg.norm(b_), (inv, mode)
+
+
 @pytest.mark.parametrize("wall", [False, True])
 def test_block_pc_for_a_body_beyond_the_lds_limit(orc, wall):
     """Bodies of more than 2 730 blobs do not fit a workgroup's 64 KB of LDS with their substitution vector (rounds 1-3 refused them

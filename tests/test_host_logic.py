@@ -271,6 +271,14 @@ def test_bench_slim_line_ends_with_the_whole_metric():
                                                                   "cfg5_cholesky_mfma", "cfg5_LW_hbm"}
     assert s["dropin_cfg3_ms"]["scipy_gmres"] > s["dropin_cfg3_ms"]["rbl_gmres_saddle"]
     assert not any(isinstance(v, str) and len(v) > 120 for v in json.loads(text)["summary"].values())
+    # ... and on round 5's own record, which carries every block the summary can hold (matched tolerances, multi-RHS solve, both SciPy figures)
+    full5 = json.load(open(os.path.join(root, "profiles", "r05_bench_detail_final.json")))
+    text5 = json.dumps(bench.slim_line(full5))
+    assert len(text5) < 4500 and text5[-2000:].index('"summary"') >= 0
+    s5 = json.loads(text5)["summary"]
+    assert s5["multi_rhs"]["ratio_to_sequential"] < 0.35 and s5["multi_rhs"]["column_vs_sequential_solve"] < 1e-10
+    assert s5["brownian_gmres_rtol_matched_to_root"]["tol_1e-3"]["U_err_vs_1e-8_solve"] < 1e-2
+    assert s5["timesteps_per_sec"]["fixed_work_residual"] > 1e-5                      # (the fixed-work step says it is not converged)
     # every prose key of the old line now lives in the notes, and the notes explain every block of the summary
     for k in ("timesteps_per_sec", "cpu_timesteps_per_sec", "roofline_frac", "dropin_cfg3_ms", "brownian_gmres_rtol_matched_to_root"):
         assert "summary." + k in bench.NOTES
