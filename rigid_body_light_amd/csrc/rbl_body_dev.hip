@@ -80,26 +80,13 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double (*s)[BT], i
   __syncthreads();
 }
 
-template <int CTRL>
-__device__ __forceinline__ double nf_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
-{
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 // RblNormFold: |w| and 1 / |w| (0 for a vanishing vector, like k_lz_c) from the partial sums of |w|^2: every wave of every workgroup
 // adds them in the same order (lanes strided, 16-lane rows by DPP, the four rows by scalar reads) -- one value everywhere, no barrier
 __device__ __forceinline__ void bf_fold_norm(const RblNormFold &nf, int lane, double &nrm, double &inv)
 {
   double a = 0.0;
   for (int i = lane; i < nf.np; i += 64) a += nf.part[i];
-  a += nf_dpp<0xB1>(a); a += nf_dpp<0x4E>(a); a += nf_dpp<0x141>(a); a += nf_dpp<0x140>(a);
-  const int lo = __double2loint(a), hi = __double2hiint(a);
-  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-  nrm = sqrt((r0 + r1) + (r2 + r3));
+  nrm = sqrt(rbl_wave_sum64(a));                     // (the ONE order every wave adds in: rbl_internal.hpp)
   inv = nrm > 1e-300 ? 1.0 / nrm : 0.0;
 }
 

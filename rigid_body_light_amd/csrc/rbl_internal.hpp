@@ -383,4 +383,37 @@ void rbl_launch_tl_addq(hipStream_t st, const double *d_Q, int64_t n3, int N_blb
 void rbl_launch_build_M_batched(hipStream_t st, const RblParams &P, bool wall, const double *d_r,
                                 int64_t n_blobs, int batch, double *d_M, int64_t strideM, unsigned *d_err, int lower_tiles = 0);
 
+// ---- ONE wave-wide sum of doubles, in ONE order --------------------------------------------------------------------------------
+// The bitwise-equal-everywhere claims of the fused reductions (RblNormFold: every wave of every workgroup must get the SAME |w| from
+// the same partial sums; k_reduce_sym's Gram-Schmidt partials; k_arnoldi_upd) rest on every user adding in the same order: the four
+// 16-lane rows by DPP (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the rows' sums as (r0 + r1) + (r2 + r3)
+// through scalar reads.  Three copies of this lived in two translation units; they are these two functions now.
+#if defined(__HIPCC__)
+template <int CTRL>
+__device__ __forceinline__ double rbl_dpp_row(double v)      // DPP move of both halves of a double inside a 16-lane row
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rbl_row_sum16(double v)    // every lane of a 16-lane row gets the row's sum
+{
+  v += rbl_dpp_row<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += rbl_dpp_row<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += rbl_dpp_row<0x141>(v);      // row_half_mirror
+  v += rbl_dpp_row<0x140>(v);      // row_mirror
+  return v;
+}
+__device__ __forceinline__ double rbl_wave_sum64(double v)   // every lane gets the sum over the 64 lanes
+{
+  v = rbl_row_sum16(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+#endif
+
 #pragma GCC visibility pop

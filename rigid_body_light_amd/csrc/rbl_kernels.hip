@@ -1111,28 +1111,7 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
 // fixed order.  Many short independent load streams instead of one long one per entry.
 constexpr int RG = 16;
 
-template <int CTRL>
-__device__ __forceinline__ double ws_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
-{
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-// sum over the 64 lanes (every lane gets it), fixed order: the four 16-lane rows by DPP (a __shfl_xor butterfly on doubles is
-// twelve dependent ds_bpermute round trips), then the rows' sums through four scalar reads
-__device__ __forceinline__ double wave_sum64(double v)
-{
-  v += ws_dpp<0xB1>(v);       // quad_perm [1,0,3,2]
-  v += ws_dpp<0x4E>(v);       // quad_perm [2,3,0,1]
-  v += ws_dpp<0x141>(v);      // row_half_mirror
-  v += ws_dpp<0x140>(v);      // row_mirror
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-  return (r0 + r1) + (r2 + r3);
-}
+// (the 64-lane sum in its one fixed order: rbl_wave_sum64, rbl_internal.hpp)
 
 template <bool WALL>
 __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict__ slabI,
@@ -1196,14 +1175,14 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
     const double wv = sh[0][tx];
     for (int kk = q; kk < fuse.dotK; kk += RG) {
       double a = live ? fuse.dotV[(size_t)kk * (size_t)fuse.dotStride + idx] * wv : 0.0;
-      a = wave_sum64(a);
+      a = rbl_wave_sum64(a);
       if (tx == 0) fuse.dotPart[(size_t)kk * fuse.dotNp + blockIdx.x] = a;
     }
     if (blockIdx.x == 0)                                   // the body rows' share, last slot
       for (int kk = q; kk < fuse.dotK; kk += RG) {
         double a = 0.0;
         for (int i = tx; i < fuse.nb6; i += 64) a = __builtin_fma(fuse.dotV[(size_t)kk * (size_t)fuse.dotStride + 3 * N + i], fuse.ktl[i], a);
-        a = wave_sum64(a);
+        a = rbl_wave_sum64(a);
         if (tx == 0) fuse.dotPart[(size_t)kk * fuse.dotNp + fuse.dotNp - 1] = a;
       }
   }
@@ -1720,13 +1699,6 @@ constexpr int GM_MAXK = 256;     // basis vectors an Arnoldi step can orthogonal
 //                             the partials of h2 = V^T w (second pass) over them
 //   k_arnoldi_upd<true>       w -= V h2, Hcol += h2; partials of |w|^2
 //   k_lz_c                    H[j+1][j] = |w|, V_{j+1} = w / |w|
-template <int CTRL>
-__device__ __forceinline__ double ar_dpp(double v)       // DPP move of both halves of a double inside a 16-lane row
-{
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 
 // A thread owns up to AR_EPT elements (the launcher sizes the grid for that) and keeps them in registers; the basis is
 // read eight vectors at a time with all loads issued before the first multiply-add (a loop of load -> fma over a
@@ -1767,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int v = v0 + 4 * u;
-        double a = wave_sum64(acc[u]);
+        double a = rbl_wave_sum64(acc[u]);
         if (lane == 0 && v < k) {
           h[v] = a;
           if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
@@ -1778,10 +1750,7 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
   for (int v = t >> 4; v < k; v += 16) {
     double a = 0.0;
     for (int b = t & 15; b < npin; b += 16) a += pin[(size_t)v * npin + b];
-    a += ar_dpp<0xB1>(a);
-    a += ar_dpp<0x4E>(a);
-    a += ar_dpp<0x141>(a);
-    a += ar_dpp<0x140>(a);
+    a = rbl_row_sum16(a);
     if ((t & 15) == 0) {
       h[v] = a;
       if (blockIdx.x == 0) Hcol[v] = LAST ? Hcol[v] + a : a;
@@ -1849,10 +1818,7 @@ __global__ __launch_bounds__(256) void k_arnoldi_upd(const double *__restrict__ 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       double r = a[u];
-      r += ar_dpp<0xB1>(r);                          // sums inside the 16-lane rows by DPP
-      r += ar_dpp<0x4E>(r);
-      r += ar_dpp<0x141>(r);
-      r += ar_dpp<0x140>(r);
+      r = rbl_row_sum16(r);                          // sums inside the 16-lane rows by DPP
       if ((t & 15) == 0 && v0 + u < k) sw[t >> 4][v0 + u] = r;
     }
   }

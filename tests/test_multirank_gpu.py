@@ -111,6 +111,17 @@ def test_two_rank_sharded_brownian_step_matches_single_process(monkeypatch, nati
     assert "world 2" in p.stdout and _max_diff(p.stdout, 2) < 1e-10
 
 
+@pytest.mark.parametrize("world,split", [(2, "0"), (3, "0"), (2, "1")])
+def test_lock_step_multi_rhs_gmres_on_a_sharded_context(monkeypatch, world, split):
+    """rbl_gmres_saddle_multi_dev on a multi-rank context (gloo rehearsal, several ranks on one GPU; 7 bodies: ragged shares at 2 and 3
+    ranks): every product of every column is the rank's share + one all-reduce (rows + all-gather with split 1), every preconditioner
+    application the owners' bodies + one all-gather; the five columns equal the single-process solves to 1e-9."""
+    monkeypatch.setenv("RBL_CHECK_SPLIT", split)
+    p = _torchrun(world, ["tools/check_sharded_multi_rhs.py"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "world %d" % world in p.stdout
+
+
 @pytest.mark.parametrize("split,allreduce_only", [("1", "0"), ("0", "1"), ("1", "1")])
 def test_two_rank_step_with_row_split_and_with_the_allreduce_only_callbacks(monkeypatch, split, allreduce_only):
     """the library's sharded step with the ROW split (own bodies' geometry + all-gather of positions, ordered-pair kernel on own
