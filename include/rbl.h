@@ -484,7 +484,11 @@ enum {
   RBL_OPT_COMM_FORCE_STAGED = 31,  /* [0] test hook: the in-place all-gathers of a native (RCCL) communicator take the STAGED form (segments
                                       padded to the largest share, one ncclAllGather, unpacked) even when the shares are equal -- what a job
                                       with N_bod % world != 0 runs, exercised with one rank                                                 */
-  RBL_OPT_COUNT = 32
+  RBL_OPT_BLOCK_SOLVE_PIPE = 32,   /* [1] substitution through the factors of bodies with 3 N_blb > 512: ONE software pipeline per body (the
+                                      dependent chain of diagonal solves in one wave, fifteen waves streaming the factor with the next
+                                      step's loads already in flight, one barrier a step: k_block_solve_pipe); 0: the two-barrier kernel
+                                      of rounds 1-4 (k_block_solve).  Same sums per row in another association                            */
+  RBL_OPT_COUNT = 33
 };
 int rbl_set_option(rbl_ctx *ctx, int option, int64_t value);
 int rbl_get_option(const rbl_ctx *ctx, int option, int64_t *value);

@@ -329,7 +329,7 @@ int blk_solve(rbl_ctx *c, int b0, int nbo, const double *in, double *out, int nv
   const size_t lstride = rbl_cholesky_batched_work_bytes(m, 1) / sizeof(double);
   return rbl_launch_block_solve_multi(c->stream, (const double *)c->d_blkL.p + (size_t)b0 * (size_t)msz, m, nbo, msz,
                                       (const double *)c->d_blkLinv.p + (size_t)b0 * lstride, in + off, out + off, m, nv, pitch,
-                                      mode | (c->blk_mirror ? 0x200 : 0));
+                                      mode | (c->blk_pipe ? 0 : 0x200));
 }
 
 // out = G_b in for bodies [b0, b0 + nbo) of ONE vector (in / out: the full vectors; not in place)

@@ -583,13 +583,8 @@ template <int NV, bool GLOBAL = false>
 __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__ L, long n, long strideA,
                                                      const double *__restrict__ Linv, long strideL,
                                                      const double *in, double *out, long vec_stride, long rhs_pitch,
-                                                     int mode /* 0: L L^T, 1: L only, 2: L^T only; | 0x200: the matrix also holds L^T above its diagonal */)
+                                                     int mode /* 0: L L^T, 1: L only, 2: L^T only */)
 {
-  // MIRROR (| 0x200; nobody sets it): the upper triangle holds L^T and the backward sweep reads COLUMNS of it like the forward
-  // sweep.  Round 5 built it (the tile factorisation wrote the mirror) and measured 0.77 against 0.81 ms a backward sweep at
-  // cfg 3 for 2 ms more per factorisation: what made the backward sweep slow was its chain of Linv loads, fixed below
-  const bool mirror = (mode & 0x200) != 0;
-  mode &= 0xff;
   extern __shared__ double y_lds[];                  // NV x n doubles + NV x IB scratch (GLOBAL: the scratch only)
   const int b = blockIdx.x, t = threadIdx.x;
   double *const y = GLOBAL ? out + (size_t)b * (size_t)vec_stride : y_lds;     // vector v at y + v * ypitch
@@ -672,24 +667,7 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
     }
     __syncthreads();
     if (t < IB * NV && tt < nb) y[(size_t)tv * ypitch + k + tt] = tbuf[t];
-    if (nb == IB && mirror) {   // columns before the block: y[c] -= sum_r L^T[c][k+r] x_r, L^T read by columns like the forward sweep
-      for (long r = t; r < k; r += BS_T) {
-        const double *col = Lb + (size_t)k * (size_t)n + r;
-        double lv[IB];
-#pragma unroll
-        for (int m = 0; m < IB; ++m) lv[m] = col[(size_t)m * n];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          double a0 = y[(size_t)v * ypitch + r], a1 = 0.0;
-#pragma unroll
-          for (int m = 0; m < IB; m += 2) {
-            a0 = __builtin_fma(-lv[m], tbuf[v * IB + m], a0);
-            a1 = __builtin_fma(-lv[m + 1], tbuf[v * IB + m + 1], a1);
-          }
-          y[(size_t)v * ypitch + r] = a0 + a1;
-        }
-      }
-    } else if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
+    if (nb == IB) {   // columns before the block: y[c] -= sum_r L[k+r][c] x_r
       // The 32 entries of a column are one 256-byte run.  Sixteen lanes share a column (16 bytes = two rows each), so a
       // wave's load instruction covers four whole runs -- eight cache lines for 1 KB, as coalesced as the forward sweep --
       // and the 32-term sum closes with four DPP steps inside the 16-lane row.  (One column per lane, the round-1 form,
@@ -743,6 +721,426 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
   for (int v = 0; v < NV; ++v) {
     double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
     for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * ypitch + e];
+  }
+}
+
+// ---- the same substitution as ONE software pipeline (round 5; bodies of more than 170 blobs whose vectors fit LDS) ----------
+// k_block_solve spends a step as: inverse of the diagonal block from HBM (a round trip), barrier, every thread's loads of the
+// step issued together, a wait for the slowest, the sums, barrier -- 11 us a step at n = 1926 where the step's bytes take 5-8.
+// Here the dependent chain lives in ONE wave and the other fifteen only stream:
+//   * the diag wave owns, in step s, the 32 x 32 block BELOW (forward) / LEFT OF (backward) the diagonal block -- the only
+//     entries of the step whose results the NEXT step's diagonal solve needs -- and then solves that next diagonal block
+//     with its stored inverse: x_{s+1} is in LDS when the step's barrier falls, so a step is ONE barrier and no wave waits
+//     for a diagonal solve.  Its loads for step s + 1 are issued as soon as step s's registers are free.
+//   * the streaming waves hold two register sets; the loads of unit u + 1 -- of the NEXT step when u is the step's last:
+//     addresses never depend on the solution -- are issued before unit u is summed, so the memory pipe is never drained, not
+//     even across the barrier.  Forward: a unit = 960 rows x 16 columns, one row per lane (512-byte runs per instruction);
+//     backward: 480 columns x 32 rows, sixteen lanes per column with two rows each (four 256-byte runs per instruction), the
+//     32-term sums closed inside the 16-lane row by DPP.
+// Per row the terms are added in a fixed order (columns ascending forward, blocks descending backward): results are bitwise
+// reproducible run to run; they differ from k_block_solve's in the last bits (other association).
+// Needs n >= 3 IB; Linv blocks of a ragged last step are padded with the identity (potf2_wave), y with zeros.
+constexpr int BP_SW = BS_T / 64 - 1;   // streaming waves
+constexpr int BP_ST = 64 * BP_SW;      // streaming threads = rows of a forward unit
+constexpr int BP_BQ = 8;               // 16-byte loads per lane of a backward unit
+constexpr int BP_BC = 4 * BP_SW * BP_BQ;   // columns of a backward unit
+constexpr unsigned BP_OOB = 0xF0000000u;   // an offset beyond any factor's descriptor (8190^2 x 8 B = 0.5 GB): such a load returns 0
+constexpr int BP_SLOT = 2 * IB * IB;       // a ring slot: the block beside a diagonal block | the inverse of the next diagonal block
+constexpr int BP_RING = 3;                 // slots: the step at work, one landed or landing, one just asked for
+constexpr int BP_K = 16;                   // LDS-direct loads a step: 2 x 8 KB at 16 bytes a lane.  Two steps' worth stay below the 63 a wave
+                                           // can have in flight (with 4-byte loads, 40 a step, the ISSUE of a step's loads waited for the last one's)
+static_assert(BP_K == 16, "the counted waits in k_block_solve_pipe say vmcnt(16)");
+typedef __attribute__((address_space(3))) void rbl_lds_void;
+constexpr size_t BP_LDS_MAX = 160 * 1024;  // a workgroup may hold the CU's whole LDS (one workgroup of 1024 threads a CU anyway)
+
+#if defined(RBL_PIPE_PROF)   // diagnostic build only (tools/pipe_step_profile.py): shader-clock stamp of streaming thread 0 after every barrier
+__device__ unsigned long long g_pipe_prof[256 * 512];
+#define PIPE_STAMP() do { if (t == 0 && b < 128 && pstamp < 512) g_pipe_prof[b * 512 + pstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PIPE_DSTAMP() do { if (lane == 0 && b < 128 && pstamp < 512) g_pipe_prof[(128 + b) * 512 + pstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PIPE_STAMP() do { } while (0)
+#define PIPE_DSTAMP() do { } while (0)
+#endif
+
+template <int NV>
+__global__ __launch_bounds__(BS_T) void k_block_solve_pipe(const double *__restrict__ L, long n, long strideA,
+                                                          const double *__restrict__ Linv, long strideL, const double *in,
+                                                          double *out, long vec_stride, long rhs_pitch,
+                                                          int mode /* 0: L L^T, 1: L only, 2: L^T only */)
+{
+  extern __shared__ double y_lds[];                  // NV x npad doubles (the vectors, zero padded) + 2 x NV x IB (x of two steps)
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int nsteps = (int)((n + IB - 1) / IB);
+  const long npad = (long)nsteps * IB;
+#if defined(RBL_PIPE_PROF)
+  int pstamp = 0;
+#endif
+  double *const y = y_lds;                           // y[v * npad + e]
+  double *const xb = y_lds + (size_t)NV * npad;      // xb[((s & 1) * NV + v) * IB + m]
+  double *const ring = xb + 2 * NV * IB;             // the diag wave's prefetch ring: BP_RING slots of BP_SLOT doubles, filled by LDS-direct loads
+  const double *Lb = L + (size_t)b * (size_t)strideA;
+  const double *Lib = Linv + (size_t)b * (size_t)strideL;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Lb), (short)0, (int)((size_t)n * (size_t)n * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsLi =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Lib), (short)0, (int)((size_t)nsteps * IB * IB * 8), 0x00020000);
+  const unsigned ldb = (unsigned)n * 8u;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double *vin = in + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    for (long e = t; e < npad; e += BS_T) y[(size_t)v * npad + e] = e < n ? vin[e] : 0.0;
+  }
+  __syncthreads();
+  // The two roles run their own loops (a wave-uniform branch; every wave meets the same number of barriers): each loop's
+  // registers are its own -- one loop with a branch per step made the compiler carry both roles' register sets through every merge
+  const bool diag = wave == BP_SW;
+  const int dr = lane >> 1, dh = lane & 1;           // diag wave: row (forward) / column (backward) of the block, and which 16 of its 32 terms
+  const int sub = lane >> 4, h = lane & 15;          // streaming lane of the backward sweep: column of its wave's four, rows 2 h, 2 h + 1
+
+  // ---- forward: L y' = v ------------------------------------------------------------------------------------------------------
+  if (mode != 2 && diag) {
+    __builtin_amdgcn_s_setprio(3);                   // the chain every other wave waits for
+    // D(s) = the 32 x 32 block below diagonal block s + the inverse of diagonal block s + 1, into ring slot s mod 3
+    auto issue = [&](int s_) {
+      const int s = __builtin_amdgcn_readfirstlane(s_);   // (wave-uniform by construction; said so)
+      double *slot = ring + (size_t)(s % BP_RING) * BP_SLOT;
+      // four columns of the block per load, as they lie: sixteen lanes a column, two rows (16 bytes) a lane.  Rows beyond the matrix
+      // (the ragged last block) read whatever follows -- the next column's top, or zeros past the descriptor's end -- and are never used
+      const unsigned vo = (unsigned)(lane >> 4) * ldb + (unsigned)(32 * s + 32 + 2 * (lane & 15)) * 8u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rbl_lds_void *)(slot + 128 * q), 16, (int)vo, (int)((unsigned)(32 * s + 4 * q) * ldb), 0, 0);
+      // the inverse, 16 bytes a lane, pair-transposed: LDS chunk c = 64 q + lane <- entries 2 m2, 2 m2 + 1 of row c mod 32, m2 = c / 32
+      // (row dr's sixteen pairs are then 512 bytes apart and the 32 rows of a pair consecutive: conflict-free 16-byte reads)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = 64 * q + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsLi, (rbl_lds_void *)(slot + IB * IB + 128 * q), 16,
+                                                 (int)(((unsigned)(c & 31) * IB + 2u * (unsigned)(c >> 5)) * 8u), (int)((unsigned)(s + 1) * IB * IB * 8u), 0, 0);
+      }
+    };
+    auto solve_next = [&](int sn, const double *lis) {   // x_sn = Linv_sn y_sn (y_sn final in LDS; lis: Linv_sn's pair-transposed image)
+      double *xn = xb + (size_t)((sn & 1) * NV) * IB;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const double *yv = y + (size_t)v * npad + 32L * sn + 16 * dh;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const rbl_d2 w2 = *reinterpret_cast<const rbl_d2 *>(lis + ((size_t)(8 * dh + jj) * IB + dr) * 2);
+          a[(2 * jj) & 3] = __builtin_fma(16 * dh + 2 * jj <= dr ? w2.x : 0.0, yv[2 * jj], a[(2 * jj) & 3]);
+          a[(2 * jj + 1) & 3] = __builtin_fma(16 * dh + 2 * jj + 1 <= dr ? w2.y : 0.0, yv[2 * jj + 1], a[(2 * jj + 1) & 3]);
+        }
+        double r = (a[0] + a[1]) + (a[2] + a[3]);
+        r += dpp_row<0xB1>(r);                       // the other half of the row's sum sits in the neighbouring lane
+        if (dh == 0) { xn[v * IB + dr] = r; y[(size_t)v * npad + 32L * sn + dr] = r; }
+      }
+    };
+    {                                                // x_0 = Linv_0 y_0: the inverse of block 0 through the last slot's image
+      double *slot = ring + (size_t)(BP_RING - 1) * BP_SLOT;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = 64 * q + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsLi, (rbl_lds_void *)(slot + IB * IB + 128 * q), 16,
+                                                 (int)(((unsigned)(c & 31) * IB + 2u * (unsigned)(c >> 5)) * 8u), 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      solve_next(0, slot + IB * IB);
+    }
+    issue(0);
+    issue(nsteps > 2 ? 1 : 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (a raw barrier: __syncthreads() would drain the ring's loads)
+    for (int s = 0; s + 1 < nsteps; ++s) {
+      const double *x = xb + (size_t)((s & 1) * NV) * IB;
+      const double *slot = ring + (size_t)(s % BP_RING) * BP_SLOT;
+      const long r0 = 32L * (s + 1);
+      PIPE_DSTAMP();
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // D(s) has landed; D(s + 1) may still be on its way (BP_K loads a step)
+      PIPE_DSTAMP();
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {                 // y_head -= L_head x_s
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j & 3] = __builtin_fma(slot[(16 * dh + j) * IB + dr], x[v * IB + 16 * dh + j], a[j & 3]);
+        double r = (a[0] + a[1]) + (a[2] + a[3]);
+        r += dpp_row<0xB1>(r);
+        if (dh == 0 && r0 + dr < n) y[(size_t)v * npad + r0 + dr] -= r;      // (the padding of a ragged last block stays zero)
+      }
+      __builtin_amdgcn_wave_barrier();               // one wave: its LDS accesses execute in program order
+      solve_next(s + 1, slot + IB * IB);
+      PIPE_DSTAMP();
+      issue(s + 2 < nsteps - 1 ? s + 2 : nsteps - 2);   // two steps ahead, into the slot step s - 1 used (past the end: the last block again, never read)
+      PIPE_DSTAMP();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+  } else if (mode != 2) {
+    // A unit = 1920 rows (two a lane: 16-byte loads, 1 KB an instruction -- with 8-byte loads the CU's address path, 16 clocks an
+    // instruction whatever it fetches, capped a body at 50 GB/s) x 8 columns.  A step is four units a row group: sets A, B, A, B.
+    // A wave whose 128 rows lie beyond the matrix sits the step out (it has nothing to ask for in any later step either).
+    constexpr int FR = 2 * BP_ST;
+    const long wrow = 64 + 128L * wave;              // the wave's first row of a row group, counted from the step's diagonal block
+    auto niw = [&](int s) { const long R = n - 32L * s - wrow; return R > 0 ? (int)((R + FR - 1) / FR) : 0; };
+    double A[16], B[16];
+    // every load of an active wave is issued by every lane: a lane without rows (or a fetch past the sweep's end) points beyond the
+    // descriptor's range and gets zeros without a memory access -- no branch around the loads, a register set is simply overwritten
+    auto fload = [&](double (&buf)[16], int s_, int i_, int k, bool any_) {
+      const int s = __builtin_amdgcn_readfirstlane(s_), i = __builtin_amdgcn_readfirstlane(i_);   // (wave-uniform by construction; said so)
+      const bool any = __builtin_amdgcn_readfirstlane((int)any_) != 0;
+      const long r = 32L * s + 64 + 2L * t + (long)FR * i;
+      const unsigned vo = any && r < n ? (unsigned)r * 8u : BP_OOB;
+      const unsigned so = any ? (unsigned)(32 * s + 8 * k) * ldb : 0u;           // (a column that exists even when the fetch is a dummy)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const rbl_d2 w2 = buf_ld2(rs, vo, so + (unsigned)j * ldb);
+        buf[2 * j] = w2.x; buf[2 * j + 1] = w2.y;
+      }
+    };
+    fload(A, 0, 0, 0, niw(0) > 0);
+    fload(B, 0, 0, 1, niw(0) > 0);
+    __syncthreads();
+    PIPE_STAMP();
+    for (int s = 0; s + 1 < nsteps; ++s) {
+      const double *x = xb + (size_t)((s & 1) * NV) * IB;
+      const int ni = niw(s), nin = niw(s + 1);
+      for (int i = 0; i < ni; ++i) {
+        const long r = 32L * s + 64 + 2L * t + (long)FR * i;
+        const long rl = r + 1 < npad ? r : npad - 2;  // (a lane without rows sums zeros into a copy of the last rows and stores nothing)
+        const bool more = i + 1 < ni;                // the row group after this one: the step's next 1920 rows, or the next step's first
+        const int sn = more ? s : s + 1, in = more ? i + 1 : 0;
+        const bool any = more || nin > 0;
+        double a0[NV], a1[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const rbl_d2 y2 = *reinterpret_cast<const rbl_d2 *>(y + (size_t)v * npad + rl);
+          a0[v] = y2.x; a1[v] = y2.y;
+        }
+        // A set is refilled as soon as it has been summed, with the unit after next: every load is asked for two units ahead.
+        // (the scheduler, left alone, hoists a refill above the sums that still read the set -- into a third set, spilled: the
+        // fences keep "sum a set, refill it" as written; the empty asm pins the sums where they are written)
+        auto quarter = [&](const double (&buf)[16], int k) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            double p0 = a0[v], p1 = a1[v];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const double xj = x[v * IB + 8 * k + j];
+              p0 = __builtin_fma(-buf[2 * j], xj, p0);
+              p1 = __builtin_fma(-buf[2 * j + 1], xj, p1);
+            }
+            asm volatile("" : "+v"(p0), "+v"(p1));
+            a0[v] = p0; a1[v] = p1;
+          }
+        };
+        quarter(A, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(A, s, i, 2, true);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(B, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(B, s, i, 3, true);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(A, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(A, sn, in, 0, any);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(B, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(B, sn, in, 1, any);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (r < n) y[(size_t)v * npad + r] = a0[v];
+          if (r + 1 < n) y[(size_t)v * npad + r + 1] = a1[v];
+        }
+      }
+      __syncthreads();
+      PIPE_STAMP();
+    }
+  }
+
+  // ---- backward: L^T x = y' ----------------------------------------------------------------------------------------------------
+  int s0 = nsteps - 1;
+  if (mode != 1) {                                   // the top block, and -- when it is a ragged one -- its few rows by the plain form
+    auto top = [&](int sn) {                         // x_sn = Linv_sn^T y_sn by the diag wave, with loads of its own
+      if (diag) {
+        double *xn = xb + (size_t)((sn & 1) * NV) * IB;
+        const double *p = Lib + (size_t)sn * IB * IB + (size_t)(16 * dh) * IB + dr;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const double *yv = y + (size_t)v * npad + 32L * sn + 16 * dh;
+          double a = 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) a = __builtin_fma(16 * dh + j >= dr ? p[j * IB] : 0.0, yv[j], a);
+          a += dpp_row<0xB1>(a);
+          if (dh == 0) { xn[v * IB + dr] = a; y[(size_t)v * npad + 32L * sn + dr] = a; }
+        }
+      }
+      __syncthreads();
+    };
+    top(s0);
+    const int nb = (int)(n - 32L * s0);
+    if (nb < IB) {
+      const double *x = xb + (size_t)((s0 & 1) * NV) * IB;
+      const long k = 32L * s0;
+      for (long c = t; c < k; c += BS_T) {
+        const double *row = Lb + (size_t)c * (size_t)n + k;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double acc = y[(size_t)v * npad + c];
+          for (int m = 0; m < nb; ++m) acc = __builtin_fma(-row[m], x[v * IB + m], acc);
+          y[(size_t)v * npad + c] = acc;
+        }
+      }
+      __syncthreads();
+      top(--s0);
+    }
+  }
+  if (mode != 1 && diag) {
+    __builtin_amdgcn_s_setprio(3);
+    // D(s) = the 32 x 32 block left of diagonal block s, pair-transposed (LDS chunk c = 64 q + lane <- rows 2 rp, 2 rp + 1 of column
+    // c mod 32, rp = c / 32: lane dr then reads column dr in 16-byte pieces 512 bytes apart, the 32 columns of a piece consecutive)
+    // + the inverse of diagonal block s - 1 as it lies, into ring slot s mod 3.  Blocks s0 .. 1 are full ones
+    auto issue = [&](int s_) {
+      const int s = __builtin_amdgcn_readfirstlane(s_);   // (wave-uniform by construction; said so)
+      double *slot = ring + (size_t)(s % BP_RING) * BP_SLOT;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = 64 * q + lane;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rbl_lds_void *)(slot + 128 * q), 16, (int)((unsigned)(c & 31) * ldb + (unsigned)(c >> 5) * 16u),
+                                                 (int)((unsigned)(32 * (s - 1)) * ldb + (unsigned)(32 * s) * 8u), 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsLi, (rbl_lds_void *)(slot + IB * IB + 128 * q), 16, lane * 16,
+                                                 (int)((unsigned)(s - 1) * IB * IB * 8u + 1024u * q), 0, 0);
+    };
+    issue(s0);
+    issue(s0 > 1 ? s0 - 1 : 1);
+    for (int s = s0; s > 0; --s) {
+      const double *x = xb + (size_t)((s & 1) * NV) * IB;
+      double *xn = xb + (size_t)(((s - 1) & 1) * NV) * IB;
+      const double *slot = ring + (size_t)(s % BP_RING) * BP_SLOT;
+      const double *lis = slot + IB * IB;
+      const long r0 = 32L * (s - 1);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {                 // y_head -= L_head^T x_s
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const rbl_d2 w2 = *reinterpret_cast<const rbl_d2 *>(slot + ((size_t)(8 * dh + jj) * IB + dr) * 2);
+          a[(2 * jj) & 3] = __builtin_fma(w2.x, x[v * IB + 16 * dh + 2 * jj], a[(2 * jj) & 3]);
+          a[(2 * jj + 1) & 3] = __builtin_fma(w2.y, x[v * IB + 16 * dh + 2 * jj + 1], a[(2 * jj + 1) & 3]);
+        }
+        double r = (a[0] + a[1]) + (a[2] + a[3]);
+        r += dpp_row<0xB1>(r);
+        if (dh == 0) y[(size_t)v * npad + r0 + dr] -= r;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {                 // x_{s-1} = Linv_{s-1}^T y_head
+        const double *yv = y + (size_t)v * npad + r0 + 16 * dh;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j & 3] = __builtin_fma(16 * dh + j >= dr ? lis[(16 * dh + j) * IB + dr] : 0.0, yv[j], a[j & 3]);
+        double r = (a[0] + a[1]) + (a[2] + a[3]);
+        r += dpp_row<0xB1>(r);
+        if (dh == 0) { xn[v * IB + dr] = r; y[(size_t)v * npad + r0 + dr] = r; }
+      }
+      issue(s - 2 > 0 ? s - 2 : 1);                  // (past the end: block 1 again, never read)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+  } else if (mode != 1) {
+    // A unit = 480 columns x the step's 32 rows: a wave takes 32 consecutive columns of it, sixteen lanes a column with two rows
+    // (16 bytes) each, four columns (four 256-byte runs) an instruction.  A wave whose columns lie beyond the step's sits it out.
+    const long wcol = 32L * wave;
+    auto nuw = [&](int s) { const long K = 32L * (s - 1) - wcol; return K > 0 ? (int)((K + BP_BC - 1) / BP_BC) : 0; };
+    double A[2 * BP_BQ], B[2 * BP_BQ];
+    auto bload = [&](double (&buf)[2 * BP_BQ], int s_, int u_, bool any_) {
+      // (wave-uniform by construction; said so, or one instantiation addresses every load through a loop over "distinct" offsets)
+      const int s = __builtin_amdgcn_readfirstlane(s_), u = __builtin_amdgcn_readfirstlane(u_);
+      const bool any = __builtin_amdgcn_readfirstlane((int)any_) != 0;
+      // ("no such unit": the vector offset carries the out-of-range marker and the scalar one is zero -- whichever of the two the
+      // descriptor's range check looks at, it refuses the access)
+      const unsigned vo = any ? (unsigned)(wcol + sub) * ldb + (unsigned)(2 * h) * 8u : BP_OOB;
+      const unsigned so = any ? (unsigned)(BP_BC * u) * ldb + (unsigned)(32 * s) * 8u : 0u;
+#pragma unroll
+      for (int q = 0; q < BP_BQ; ++q) {
+        const rbl_d2 w2 = buf_ld2(rs, vo, so + (unsigned)(4 * q) * ldb);
+        buf[2 * q] = w2.x; buf[2 * q + 1] = w2.y;
+      }
+    };
+    auto bsum = [&](const double (&buf)[2 * BP_BQ], int s_, int u_) {
+      const int s = __builtin_amdgcn_readfirstlane(s_), u = __builtin_amdgcn_readfirstlane(u_);
+      const double *x = xb + (size_t)((s & 1) * NV) * IB;
+      double x0[NV], x1[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) { x0[v] = x[v * IB + 2 * h]; x1[v] = x[v * IB + 2 * h + 1]; }
+      const long c0 = (long)BP_BC * u + wcol + sub;
+#pragma unroll
+      for (int q = 0; q < BP_BQ; ++q) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          double a = __builtin_fma(buf[2 * q], x0[v], buf[2 * q + 1] * x1[v]);
+          a = rbl_row_sum16(a);
+          if (h == 0) y[(size_t)v * npad + c0 + 4 * q] -= a;
+        }
+      }
+    };
+    // Set A takes a step's even units, set B the odd ones; a set is refilled as soon as it has been summed -- with the step's unit
+    // after next, or the next step's first (A) / second (B) -- so every load is asked for a whole pair of units ahead.
+    bload(A, s0, 0, nuw(s0) > 0);
+    bload(B, s0, 1, nuw(s0) > 1);
+    PIPE_STAMP();
+    int s = s0;
+    for (; s > 0 && nuw(s) > 1; --s) {
+      const int nu = nuw(s), nun = nuw(s - 1);
+      for (int u = 0; u < nu; u += 2) {
+        bsum(A, s, u);
+        __builtin_amdgcn_sched_barrier(0);
+        { const bool more = u + 2 < nu; bload(A, more ? s : s - 1, more ? u + 2 : 0, more || nun > 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < nu) {
+          bsum(B, s, u + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          { const bool more = u + 3 < nu; bload(B, more ? s : s - 1, more ? u + 3 : 1, more || nun > 1); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+      PIPE_STAMP();
+    }
+    // The wave's last steps have one unit each and little to stream: what a step costs is the round trip of its loads.  The two
+    // sets take turns, step by step, so each step's columns are asked for TWO steps ahead
+    if (s > 0) {
+      bload(B, s - 1, 0, nuw(s - 1) > 0);
+      while (s > 0) {
+        if (nuw(s) > 0) bsum(A, s, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bload(A, s - 2, 0, nuw(s - 2) > 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        PIPE_STAMP();
+        if (--s == 0) break;
+        if (nuw(s) > 0) bsum(B, s, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bload(B, s - 2, 0, nuw(s - 2) > 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        PIPE_STAMP();
+        --s;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    double *o = out + (size_t)v * (size_t)rhs_pitch + (size_t)b * (size_t)vec_stride;
+    for (long e = t; e < n; e += BS_T) o[e] = y[(size_t)v * npad + e];
   }
 }
 
@@ -1568,7 +1966,7 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
   // d_Q (with | 0x100 and n <= 512 only): the shared factor is a body-frame one, G_b = R_b L -- rotations fused into the sweep
   const int64_t nsteps = (n + IB - 1) / IB;
   const bool shared = (mode & 0x100) != 0;           // one factor for every body of the batch (strideA = 0 by the caller)
-  const int mirror = mode & 0x200;                   // the matrices hold L^T above the diagonal (large bodies, tile factorisation)
+  const bool classic = (mode & 0x200) != 0;          // RBL_OPT_BLOCK_SOLVE_PIPE = 0: the two-barrier kernel (k_block_solve) for A/B runs
   mode &= 0xff;
   const long strideL = shared ? 0 : (long)(nsteps * IB * IB);
   for (int v0 = 0; v0 < nv;) {
@@ -1580,7 +1978,7 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
     if (lds > 65536) {         // one vector of a body does not fit LDS (> 2 730 blobs): the output vector in HBM is the working vector
       if (d_Q) return RBL_ERR_ARG;
       hipLaunchKernelGGL((k_block_solve<1, true>), dim3(batch), dim3(BS_T), sizeof(double) * IB, st, d_L, (long)n, (long)strideA, d_Linv,
-                         strideL, in, out, (long)vec_stride, (long)rhs_pitch, mode | mirror);
+                         strideL, in, out, (long)vec_stride, (long)rhs_pitch, mode);
       v0 += 1;
       continue;
     }
@@ -1600,19 +1998,55 @@ int rbl_launch_block_solve_multi(hipStream_t st, const double *d_L, int64_t n, i
       v0 += g;
       continue;
     }
+    if (!classic && n >= 3 * IB) {   // the one-barrier pipeline (k_block_solve_pipe); its LDS: zero-padded vectors + x of two steps + the diag wave's ring
+      auto pipe_lds = [&](int nvp) { return sizeof(double) * ((size_t)nvp * (size_t)(nsteps * IB + 2 * IB) + (size_t)BP_RING * BP_SLOT); };
+      int gp = g;
+      while (gp > 1 && pipe_lds(gp) > BP_LDS_MAX) --gp;
+      const size_t ldp = pipe_lds(gp);
+      if (ldp <= BP_LDS_MAX) {
+        static const bool lds_raised = [] {          // more than the default 64 KB of dynamic LDS: asked for once per kernel
+          bool ok = hipFuncSetAttribute((const void *)k_block_solve_pipe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_MAX) == hipSuccess;
+          ok = hipFuncSetAttribute((const void *)k_block_solve_pipe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_MAX) == hipSuccess && ok;
+          return hipFuncSetAttribute((const void *)k_block_solve_pipe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_MAX) == hipSuccess && ok;
+        }();
+        if (!lds_raised) return RBL_ERR_HIP;
+        if (gp == 3)
+          hipLaunchKernelGGL(k_block_solve_pipe<3>, dim3(batch), dim3(BS_T), ldp, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                             out, (long)vec_stride, (long)rhs_pitch, mode);
+        else if (gp == 2)
+          hipLaunchKernelGGL(k_block_solve_pipe<2>, dim3(batch), dim3(BS_T), ldp, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                             out, (long)vec_stride, (long)rhs_pitch, mode);
+        else
+          hipLaunchKernelGGL(k_block_solve_pipe<1>, dim3(batch), dim3(BS_T), ldp, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in,
+                             out, (long)vec_stride, (long)rhs_pitch, mode);
+        v0 += gp;
+        continue;
+      }
+    }
     if (g == 3)
       hipLaunchKernelGGL(k_block_solve<3>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
+                         (long)vec_stride, (long)rhs_pitch, mode);
     else if (g == 2)
       hipLaunchKernelGGL(k_block_solve<2>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
+                         (long)vec_stride, (long)rhs_pitch, mode);
     else
       hipLaunchKernelGGL(k_block_solve<1>, dim3(batch), dim3(BS_T), lds, st, d_L, (long)n, (long)strideA, d_Linv, strideL, in, out,
-                         (long)vec_stride, (long)rhs_pitch, mode | mirror);
+                         (long)vec_stride, (long)rhs_pitch, mode);
     v0 += g;
   }
   return RBL_OK;
 }
+
+#if defined(RBL_PIPE_PROF)
+extern "C" __attribute__((visibility("default"))) int rbl_debug_pipe_prof(unsigned long long *out, int clear)
+{
+  if (clear) {
+    static unsigned long long z[256 * 512];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_prof), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_prof), sizeof(unsigned long long) * 256 * 512);
+}
+#endif
 
 size_t rbl_trmv_part_bytes(int64_t n)
 {

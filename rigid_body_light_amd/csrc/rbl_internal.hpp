@@ -112,7 +112,7 @@ struct rbl_ctx {
   RblDevBuf d_commStage;                            // padded slots of a ragged in-place all-gather (rbl_comm.hip)
   RblDevBuf d_blkXf, d_blkAug;                      // large bodies: single-precision copy of the inverses; scratch of their inversion
   bool comm_force_staged = false;                   // RBL_OPT_COMM_FORCE_STAGED (test hook)
-  bool blk_mirror = false;                          // d_blkL holds L^T above the diagonals (k_block_solve's mirror form; measured: -5 % on the backward sweep for +2 ms a build: nobody sets it)
+  bool blk_pipe = true;                             // substitution through large bodies' factors: the one-barrier pipeline (k_block_solve_pipe); false: k_block_solve
   bool blk_tile = true;                             // RBL_OPT_BLOCK_TILE_FACTOR: large bodies factored (and inverted) by the dataflow tile kernel
   int blk_large = 2;                                // explicit inverses of bodies with 3 N_blb > 512: 0 never, 1 always, 2 when it pays
                                                     // (multi-GPU contexts: few bodies per rank; shared body-frame factor: built once) -- RBL_OPT_BLOCK_EXPLICIT_LARGE

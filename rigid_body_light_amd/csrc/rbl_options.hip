@@ -79,6 +79,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->tl_refresh = (int)v; c->tl_age = 0; c->tl_valid = false; }},
     {RBL_OPT_BLOCK_TILE_FACTOR, "block_tile_factor", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->blk_tile; },
      [](rbl_ctx *c, int64_t v) { c->blk_tile = v != 0; drop_factors(c); c->tl_valid = false; }},
+    {RBL_OPT_BLOCK_SOLVE_PIPE, "block_solve_pipe", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->blk_pipe; },
+     [](rbl_ctx *c, int64_t v) { c->blk_pipe = v != 0; }},
     {RBL_OPT_COMM_FORCE_STAGED, "comm_force_staged", 0, 1, 0, [](const rbl_ctx *c) -> int64_t { return c->comm_force_staged; },
      [](rbl_ctx *c, int64_t v) { c->comm_force_staged = v != 0; }},
     {RBL_OPT_FUSED_KRYLOV, "fused_krylov", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->fused_krylov; },

@@ -720,6 +720,55 @@ def test_tile_factorisation_at_awkward_sizes(orc, nblb):
             assert np.linalg.norm(a_ - b_) < 1e-11 * np.linalg.norm(b_), (inv, mode)
 
 
+@pytest.mark.parametrize("nblb", [171, 213, 512, 642, 1000, 2562])
+def test_pipelined_substitution_equals_the_two_barrier_kernel(orc, nblb):
+    """k_block_solve_pipe (one wave owns the chain of diagonal solves, fifteen stream the factor with the next step's loads in flight;
+    RBL_OPT_BLOCK_SOLVE_PIPE, default) against k_block_solve (= 0) on the same factors: every mode, out of place and in place, one
+    vector (block_solve), three (the six columns of M^-1 K inside apply_PC) and two (the preconditioned Lanczos root); n = 513 and 639
+    (ragged last step of 1 and 31 rows), 1 536 (no ragged step), 1 926 (cfg 3's bodies), 3 000 and 7 686 (two and four row groups of
+    1 920 rows a step in the forward sweep, up to sixteen units of 480 columns in the backward one).  Both add each row's terms in a fixed order:
+    equal to rounding, and the pipeline bitwise equal to itself run to run.  Reference: apply_PC, c_rigid_obj.cpp:589-616."""
+    import torch
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    k = np.arange(nblb) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / nblb); th = np.pi * (1.0 + 5.0 ** 0.5) * k
+    cfg = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)
+    a, eta, wall = 0.8 * (4.0 * np.pi / nblb) ** 0.5 / 2.0, 1.0, True
+    X = np.array([[0.0, 0.0, 1.5], [3.0, 0.5, 2.5], [-2.5, 3.0, 4.0]]); nb = 3
+    Q = np.array([[0.8, 0.2, -0.4, 0.4], [1.0, 0.0, 0.0, 0.0], [0.3, -0.5, 0.1, 0.8]]); Q /= np.linalg.norm(Q, axis=1)[:, None]
+    n = 3 * nblb
+    rng = np.random.default_rng(nblb + 1)
+    dev = torch.device("cuda:0")
+    dv = torch.from_numpy(rng.standard_normal(nb * n)).to(dev)
+    db = torch.from_numpy(rng.standard_normal(nb * n + 6 * nb)).to(dev)
+    dW = torch.from_numpy(rng.standard_normal(nb * n)).to(dev)
+    outs = {}
+    for pipe in (1, 0, 1):
+        ctx = DeviceContext(a, eta, wall, cfg=cfg, dt=0.01, stream_ptr=torch.cuda.current_stream().cuda_stream)
+        ctx.set_config(X, Q)
+        ctx.set_option("block_solve_pipe", pipe)
+        assert ctx.get_option("block_solve_pipe") == pipe
+        res = []
+        for mode in (0, 1, 2):
+            o = torch.full_like(dv, 3.5)
+            ctx.block_solve(dv.data_ptr(), o.data_ptr(), mode); ctx.sync_check()
+            w = dv.clone(); ctx.block_solve(w.data_ptr(), w.data_ptr(), mode); ctx.sync_check()
+            assert torch.equal(w, o), (pipe, mode)
+            res.append(o.cpu().numpy())
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        o = torch.empty_like(db); ctx.apply_PC(db.data_ptr(), o.data_ptr()); ctx.sync_check()
+        res.append(o.cpu().numpy())
+        r = torch.empty(nb * n, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
+        o = torch.empty_like(dW); ctx.set_lanczos(100, 1e-8)
+        ctx.M_half_W(r.data_ptr(), nb * nblb, dW.data_ptr(), "lanczos_pc", o.data_ptr()); ctx.sync_check()
+        res.append(o.cpu().numpy())
+        ctx.close()
+        outs.setdefault(pipe, []).append(res)
+    for i, (p1, p2, c0) in enumerate(zip(outs[1][0], outs[1][1], outs[0][0])):
+        assert np.array_equal(p1, p2), i                                             # run to run: bitwise
+        assert np.linalg.norm(p1 - c0) < (1e-11 if i < 4 else 1e-7) * np.linalg.norm(c0), i
+
+
 @pytest.mark.parametrize("wall", [False, True])
 def test_block_pc_for_a_body_beyond_the_lds_limit(orc, wall):
     """Bodies of more than 2 730 blobs do not fit a workgroup's 64 KB of LDS with their substitution vector (rounds 1-3 refused them
