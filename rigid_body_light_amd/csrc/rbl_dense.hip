@@ -731,17 +731,25 @@ __global__ __launch_bounds__(BS_T) void k_block_solve(const double *__restrict__
 //   * the diag wave owns, in step s, the 32 x 32 block BELOW (forward) / LEFT OF (backward) the diagonal block -- the only
 //     entries of the step whose results the NEXT step's diagonal solve needs -- and then solves that next diagonal block
 //     with its stored inverse: x_{s+1} is in LDS when the step's barrier falls, so a step is ONE barrier and no wave waits
-//     for a diagonal solve.  Its loads for step s + 1 are issued as soon as step s's registers are free.
-//   * the streaming waves hold two register sets; the loads of unit u + 1 -- of the NEXT step when u is the step's last:
-//     addresses never depend on the solution -- are issued before unit u is summed, so the memory pipe is never drained, not
-//     even across the barrier.  Forward: a unit = 960 rows x 16 columns, one row per lane (512-byte runs per instruction);
-//     backward: 480 columns x 32 rows, sixteen lanes per column with two rows each (four 256-byte runs per instruction), the
-//     32-term sums closed inside the 16-lane row by DPP.
+//     for a diagonal solve.  What it reads arrives by LDS-direct loads (buffer_load ... lds: no registers) in a ring of three
+//     slots, asked for TWO steps ahead and retired by a counted s_waitcnt vmcnt(16): the chain never sees a memory round trip
+//     (in-kernel stamps, tools/pipe_step_profile.py: 0.06 us waiting, 0.6 us of sums, 0.2 us issuing a step).
+//   * the streaming waves hold two register sets and refill a set as soon as it has been summed -- with data of the NEXT
+//     step when the step is over: addresses never depend on the solution -- so every load is asked for two units ahead and
+//     the memory pipe is never drained, not even across the barrier.  Forward: a unit = 1920 rows x 8 columns, two rows
+//     (16 bytes) a lane, 1 KB runs an instruction; backward: 480 columns x 32 rows, a wave on 32 consecutive columns, sixteen
+//     lanes a column with two rows each (four 256-byte runs an instruction), the 32-term sums closed inside the 16-lane row
+//     by DPP; its last steps (one unit each) alternate the two sets step by step, i.e. ask two STEPS ahead.  A wave whose rows
+//     / columns lie beyond the step's sits the step out: a CU's address path takes 16 clocks an instruction whatever it
+//     fetches, and a step's worth of instructions that fetch nothing used to cost what a full step costs (4.7 us).
+// Measured at cfg 3 (200 x 1926, tools/bench_block_pipe.py): L^-1 v 0.61 -> 0.51 ms = 5.9 TB/s, L^-T v 0.75 -> 0.60 ms (its
+// 256-byte runs start anywhere in a 128-byte line: the L2 fetches 1.33 x the forward sweep's bytes, profiles/r05_block_pipe*),
+// (L L^T)^-1 v 1.33 -> 1.09 ms; a rank's 25 bodies 1.03 -> 0.68 ms.
 // Per row the terms are added in a fixed order (columns ascending forward, blocks descending backward): results are bitwise
 // reproducible run to run; they differ from k_block_solve's in the last bits (other association).
 // Needs n >= 3 IB; Linv blocks of a ragged last step are padded with the identity (potf2_wave), y with zeros.
 constexpr int BP_SW = BS_T / 64 - 1;   // streaming waves
-constexpr int BP_ST = 64 * BP_SW;      // streaming threads = rows of a forward unit
+constexpr int BP_ST = 64 * BP_SW;      // streaming threads (a forward unit: two rows each)
 constexpr int BP_BQ = 8;               // 16-byte loads per lane of a backward unit
 constexpr int BP_BC = 4 * BP_SW * BP_BQ;   // columns of a backward unit
 constexpr unsigned BP_OOB = 0xF0000000u;   // an offset beyond any factor's descriptor (8190^2 x 8 B = 0.5 GB): such a load returns 0

@@ -1,6 +1,6 @@
 """Substitution through the per-body factors of large bodies: the one-barrier pipeline (RBL_OPT_BLOCK_SOLVE_PIPE = 1, k_block_solve_pipe)
 against the two-barrier kernel of rounds 1-4 (0), per mode, for all bodies and for a rank's share at P = 8; bytes = the factor's
-lower triangle once per sweep.  usage: bench_block_pipe.py [bodies blobs [wall|free]]"""
+lower triangle once per sweep.  usage: [ONLY_MODE=0|1|2] bench_block_pipe.py [bodies blobs [wall|free]]"""
 import sys, numpy as np, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from rigid_body_light_amd import make_config
@@ -21,6 +21,8 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 res = {}
 for b0, b1, what in ((0, nb, "all %d bodies" % nb), (0, max(nb // 8, 1), "%d bodies" % max(nb // 8, 1))):
     for mode, name, sweeps in ((0, "(L L^T)^-1 v", 2), (1, "L^-1 v", 1), (2, "L^-T v", 1)):
+        if os.environ.get("ONLY_MODE", str(mode)) != str(mode):      # (counter passes: one mode a run, the kernels share a name)
+            continue
         line = "%-12s %-14s" % (what, name)
         for pipe in (0, 1):
             ctx.set_option("block_solve_pipe", pipe)
