@@ -641,7 +641,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
     return out
 
 
-def other_configs(dev, stream):
+def other_configs(dev, stream, cpu=True):
     """The other BASELINE.json configurations, timed in the default N = 1 run (device-resident inputs, wall clock around
     stream-synchronised loops): each entry says what bounds it and how close it gets."""
     from rigid_body_light_amd import make_config
@@ -681,6 +681,21 @@ def other_configs(dev, stream):
             d["roofline"] = {"bound": "fp64-valu" if N >= 4096 else "launch latency (one wave's sweep; 14 400 pairs)", "kernel": kname,
                              "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS,
                              "timed": "wall clock over 200 back-to-back launches incl. the slab reduction"}
+        if cpu:
+            # the reference's OWN apply_M on one host core: dense 3N x 3N build + matrix-vector product (c_rigid_obj.cpp:413-459, :641-659),
+            # possible at this size (cfg 2: a 4.7 GB matrix); the oracle's restatement of it, outside every timed GPU region
+            from oracle import Oracle
+            orc = Oracle()
+            rh, Fh = r.cpu().numpy(), F.cpu().numpy()
+            reps = 20 if N < 1000 else 1
+            orc.apply_M(Fh, rh, c["a"], c["eta"], wall, mode="dense") if N < 1000 else None
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                Uh = orc.apply_M(Fh, rh, c["a"], c["eta"], wall, mode="dense")
+            td = (time.perf_counter() - t0) / reps
+            d["cpu_reference_dense_apply_M"] = {"seconds": td, "cores": 1, "kind": "port of the reference's dense build + product",
+                                                "gpu_over_cpu": td / t,
+                                                "max_rel_diff_to_gpu": float(np.abs(Uh - U.cpu().numpy()).max() / np.abs(Uh).max())}
         return ctx, c, nb, nblb, d
 
     # cfg 1: 10 x shell_N_12, free space, deterministic (the reference's own CPU-runnable case)
@@ -961,6 +976,9 @@ def summary_of(d):
             fr[lab] = d["configs"]["cfg5"][k]["roofline"]["frac"]
     s["roofline_frac"] = fr
     cm = {}
+    for name, key, scale in (("cfg1", "cfg1_cpu_dense_apply_M_us", 1e6), ("cfg2", "cfg2_cpu_dense_apply_M_ms", 1e3)):
+        if _get(d, "configs", name, "cpu_reference_dense_apply_M", "seconds") is not None:
+            cm[key] = d["configs"][name]["cpu_reference_dense_apply_M"]["seconds"] * scale
     if _get(d, "configs", "cfg1", "apply_M_us") is not None:
         cm["cfg1_apply_M_us"] = d["configs"]["cfg1"]["apply_M_us"]
         cm["cfg1_converged_step_ms"] = _get(d, "configs", "cfg1", "deterministic_converged", "ms_per_timestep")
@@ -1464,7 +1482,7 @@ def main():
             dropin = {"error": repr(e)}
             failed = failed or "drop-in part failed"
         try:
-            others = other_configs(dev, stream)
+            others = other_configs(dev, stream, cpu=args.cpu_budget > 0)
         except Exception as e:
             import traceback
             traceback.print_exc()
