@@ -68,7 +68,9 @@ NOTES = {
                                  "midpoint step, fresh noise every step: 2 M^{1/2}W (preconditioned lock-step Lanczos to 1e-3, two-level factor) + M_RFD "
                                  "+ Kinv at q^n, block-PC GMRES to 1e-8 from zero at q^{n+1/2}, update from q^n -- the physically meaningful step of "
                                  "configs[3]; brownian_relaxed_products = the same with far tile pairs in packed single precision inside the inexact "
-                                 "Krylov iterations (opt-in); brownian_lanczos_1e-6 = the same with the roots to 1e-6",
+                                 "Krylov iterations (opt-in); brownian_relaxed_root_only = packed single precision inside the two roots only "
+                                 "(their tolerance is 1e-3, the product error 1e-6), every GMRES product fp64 (opt-in, RBL_OPT_RELAXED_KRYLOV = 2); "
+                                 "brownian_lanczos_1e-6 = the same with the roots to 1e-6",
     "summary.brownian_gmres_rtol_matched_to_root": "NOT a headline: the Brownian step with the GMRES tolerance set to the root's (1e-3, 1e-4) instead of "
                                                    "1e-8; U_err_vs_1e-8_solve = |U - U_ref| / |U_ref| of the body velocities against the 1e-8 solve of the "
                                                    "SAME right-hand side (measured after the timed steps), root_err = measured root identity error",
@@ -572,6 +574,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         variants.append((1e-3, False, False, 1, 1e-8))       # the same step with the row split (all-gather of positions and U)
     else:                                                    # GMRES tolerance matched to the root's (never the headline): what it costs and errs
         variants += [(1e-3, False, False, 0, 1e-3), (1e-4, False, False, 0, 1e-4)]
+        variants.append((1e-3, 2, False, 0, 1e-8))           # relaxed products inside the root only (RBL_OPT_RELAXED_KRYLOV = 2), GMRES all fp64
     for ltol, relaxed, energy, split, grtol in variants:
         bctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], kBT=1.0, stream_ptr=stream.cuda_stream)
         lib().rbl_set_blk_pc(bctx.h, 1)
@@ -579,8 +582,8 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         bctx.set_block_refresh(2)      # the per-body factors of q^n also serve the predictor configuration q^{n+1/2}
         bctx.set_option("two_level_refresh", 8)   # the root's factored coarse operator kept for 8 configuration changes (4 steps): exact for any
         apply_opts(bctx, args)
-        if relaxed:                    # inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1): see the `relaxation` note below
-            bctx.set_option("relaxed_krylov", 1)
+        if relaxed:                    # inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1; 2: in the root only): see the `relaxation` note below
+            bctx.set_option("relaxed_krylov", int(relaxed))
         if energy:                     # stop the root on its energy-norm estimate (RBL_OPT_LANCZOS_EUCLID_NORM = 0): see `lanczos_norm` below
             bctx.set_option("lanczos_euclid_norm", 0)
         if multi:
@@ -597,7 +600,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
         one(0)
         d = timed(one, 1, tctx=bctx)
         d.update({"lanczos_tol": ltol, "lanczos_iterations_last_step": lz(), "lanczos_error_estimate_last_step": bctx.lanczos_report()[1],
-                  "relaxed_products": relaxed})
+                  "relaxed_products": ["no", "GMRES (late iterations) and the root", "the root only"][int(relaxed)]})
         if not multi:                  # measured, outside the timed region: one more pair of roots + one product
             d["root_identity_error"] = root_identity_error(bctx, nb, nblb, c["a"], dev)
         d["lanczos_stopping_norm"] = "energy" if energy else "euclidean"
@@ -614,7 +617,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
             d["velocity_error_vs_1e-8_solve"] = float(torch.linalg.norm(x_lo[n3:] - x_hi[n3:]) / torch.linalg.norm(x_hi[n3:]))
             d["constraint_force_error_vs_1e-8_solve"] = float(torch.linalg.norm(x_lo[:n3] - x_hi[:n3]) / torch.linalg.norm(x_hi[:n3]))
             d["gmres_iterations_of_the_two_solves"] = [int(m_lo), int(m_hi)]
-        bro["lanczos_%g%s%s%s%s" % (ltol, "_relaxed" if relaxed else "", "_energy_norm" if energy else "", "_rows" if split else "",
+        bro["lanczos_%g%s%s%s%s" % (ltol, "_relaxed_root" if relaxed == 2 else "_relaxed" if relaxed else "", "_energy_norm" if energy else "", "_rows" if split else "",
                                     "_gmres_%g" % grtol if grtol > 1e-8 else "")] = d
         del bst
         bctx.close()
@@ -626,7 +629,7 @@ def timestep_variants(args, ctx, sm, c, nb, nblb, wall, dev, world, stream, barr
                                 "rounds 1-2 effectively used that one (fewer iterations, larger Euclidean error)",
                 "root_identity_error": "|root(s) - B M v| / |B M v| with s = G^-1 B^-1 root(W), v = G^-T W for the root x = B G (G^-1 M G^-T)^{1/2} W "
                                        "the step uses (G: two-level factor), measured after the timed steps at the entry's Lanczos tolerance (zero for an exact root)",
-                "relaxation": "the *_relaxed entry is opt-in (RBL_OPT_RELAXED_KRYLOV = 1), everything else is fp64 throughout: an inexact Krylov "
+                "relaxation": "the *_relaxed entries are opt-in (RBL_OPT_RELAXED_KRYLOV = 1; *_relaxed_root = 2: the Lanczos roots only, every GMRES product fp64), everything else is fp64 throughout: an inexact Krylov "
                               "iteration tolerates a relative product error of (tolerance / current residual), so GMRES iterations whose "
                               "residual estimate is below 1e-3 and the Lanczos iterations (tolerance 1e-3) evaluate far tile pairs in packed "
                               "single precision (product error ~1e-6, 1.8x faster); the solution still satisfies the fp64 system to 1e-8 "
@@ -941,7 +944,8 @@ def summary_of(d):
     if ts:
         t = {k: ts[k] for k in ("deterministic_fixed_work", "deterministic_converged", "brownian_converged") if k in ts}
         bro = _get(d, "timestep", "brownian_converged") or {}
-        for key, name in (("lanczos_0.001_relaxed", "brownian_relaxed_products"), ("lanczos_1e-06", "brownian_lanczos_1e-6")):
+        for key, name in (("lanczos_0.001_relaxed", "brownian_relaxed_products"), ("lanczos_0.001_relaxed_root", "brownian_relaxed_root_only"),
+                          ("lanczos_1e-06", "brownian_lanczos_1e-6")):
             if key in bro:
                 t[name] = bro[key]["timesteps_per_sec"]
         s["timesteps_per_sec"] = t

@@ -442,9 +442,11 @@ enum {
                                       count and the residual's rate; 0: every 4th iteration                                         */
   RBL_OPT_GMRES_OVERLAP_CHECK = 11, /* [1] the host reads the Hessenberg columns of a convergence test while the GPU already applies the
                                       preconditioner of the next iteration (no idle stream at the test); 0: drain, then go on          */
-  RBL_OPT_RELAXED_KRYLOV = 12,     /* [0] inexact Krylov: once GMRES's residual estimate is below rtol x 1e5 (and in Lanczos runs to
+  RBL_OPT_RELAXED_KRYLOV = 12,     /* [0] inexact Krylov: 1 = once GMRES's residual estimate is below rtol x 1e5 (and in Lanczos runs to
                                       tolerances >= 1e-4) far tile pairs are evaluated in packed single precision (relative product
-                                      error <= 3e-6, ~1.8x faster); the solution still satisfies the fp64 system to rtol             */
+                                      error <= 3e-6, ~1.8x faster); the solution still satisfies the fp64 system to rtol.  2 = in those
+                                      Lanczos runs only (a root asked for to 1e-3 does not see a product error of 1e-6): every GMRES
+                                      product stays fp64                                                                             */
   RBL_OPT_RELAXED_ALWAYS = 13,     /* [0] test hook: every full product through that relaxed kernel                                   */
   RBL_OPT_BLOCK_EXPLICIT_SMALL = 14, /* [1] per-body factors of bodies with <= 170 blobs applied through explicit inverses L^-1       */
   RBL_OPT_BLOCK_EXPLICIT_LARGE = 15, /* [2] explicit inverses of larger bodies (the reference's own form of Block_diag_invM,

@@ -162,7 +162,7 @@ struct rbl_ctx {
   bool gmres_small = true;
   // inexact-Krylov relaxation (off by default): once GMRES's residual estimate is below rtol x 1e5 its products may carry
   // a relative error of ~1e-6 without the solution losing accuracy -- far tile pairs then run in packed single precision
-  bool gmres_relax = false;
+  int gmres_relax = 0;                              // RBL_OPT_RELAXED_KRYLOV: 0 fp64 throughout, 1 inexact GMRES + Lanczos products, 2 the Lanczos roots only
   bool force_relaxed = false;   // test / benchmark hook: every full product through the relaxed kernel
   // multi-GPU (rbl_set_comm): this context is rank comm_rank of comm_world; every full mobility product inside the
   // library becomes this rank's share of the unordered tile pairs followed by comm_fn (sum all-reduce over the ranks)

@@ -45,8 +45,8 @@ const OptRow kOptions[] = {
      [](rbl_ctx *c, int64_t v) { c->gmres_predict = v != 0; c->gmres_last_used = 0; }},
     {RBL_OPT_GMRES_OVERLAP_CHECK, "gmres_overlap_check", 0, 1, 1, [](const rbl_ctx *c) -> int64_t { return c->gmres_overlap; },
      [](rbl_ctx *c, int64_t v) { c->gmres_overlap = v != 0; }},
-    {RBL_OPT_RELAXED_KRYLOV, "relaxed_krylov", 0, 1, 0, [](const rbl_ctx *c) -> int64_t { return c->gmres_relax; },
-     [](rbl_ctx *c, int64_t v) { c->gmres_relax = v != 0; }},
+    {RBL_OPT_RELAXED_KRYLOV, "relaxed_krylov", 0, 2, 0, [](const rbl_ctx *c) -> int64_t { return c->gmres_relax; },
+     [](rbl_ctx *c, int64_t v) { c->gmres_relax = (int)v; }},
     {RBL_OPT_RELAXED_ALWAYS, "relaxed_always", 0, 1, 0, [](const rbl_ctx *c) -> int64_t { return c->force_relaxed; },
      [](rbl_ctx *c, int64_t v) { c->force_relaxed = v != 0; }},
     {RBL_OPT_RELAXED_GAP_RATIO, "relaxed_gap_ratio", 0, 64, 0, [](const rbl_ctx *c) -> int64_t { return c->sym_tune.gap_ratio; },

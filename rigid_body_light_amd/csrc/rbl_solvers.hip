@@ -188,7 +188,7 @@ static int gmres_saddle_core_(rbl_ctx *c, const double *d_rhs, int max_iter, dou
     z_ready = false;
     // inexact Krylov: the j-th product may be in error by ~ rtol / |r_{j-1}| (relative); the relaxed kernel's ~1e-6 is
     // admissible once the residual estimate is below rtol x 1e5 (an order of magnitude in hand)
-    c->sym_tune.relaxed = (c->gmres_relax && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
+    c->sym_tune.relaxed = (c->gmres_relax == 1 && rtol > 0.0 && check_every == 1 && resid <= rtol * 1.0e5) ? 1 : 0;
     c->fuse_dotV = V; c->fuse_dotK = j + 1; c->fuse_dotPart = part;   // (small systems: the product's last kernel starts the Gram-Schmidt pass)
     rc = rbl_apply_saddle_dev(c, z, w);
     const int fused_np = c->fuse_dots_np;

@@ -1754,6 +1754,46 @@ def test_relaxed_product_in_a_wide_suspension(wall):
     ctx.close()
 
 
+def test_relaxed_products_in_the_root_only():
+    """RBL_OPT_RELAXED_KRYLOV = 2: the packed-single-precision far field serves the Lanczos square roots (asked for to 1e-3: a product
+    error of 1e-6 is three orders below what the root is accurate to) and nothing else.  On 60 x shell_N_162 above a wall: GMRES under
+    2 is bitwise GMRES under 0 (every product fp64); the preconditioned root under 2 is bitwise the root under 1, differs from the
+    all-fp64 root by far less than the tolerance, and passes the same identity check; a root asked for to 1e-6 stays fp64 under both."""
+    import torch
+    from rigid_body_light_amd import make_config
+    from rigid_body_light_amd._lib import DeviceContext, lib
+    nb, nblb, wall = 60, 162, True
+    c = make_config(nb, nblb, wall)
+    N = nb * nblb; n3 = 3 * N; nsys = n3 + 6 * nb
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    b = torch.from_numpy(np.concatenate([0.01 * rng.standard_normal(n3), np.tile([0.0, 0, -1.0, 0, 0, 0], nb)])).to(dev)
+    W = torch.from_numpy(rng.standard_normal(n3)).to(dev)
+    got = {}
+    for opt in (0, 1, 2):
+        ctx = DeviceContext(c["a"], c["eta"], wall, cfg=c["cfg"], dt=c["dt"], stream_ptr=torch.cuda.current_stream().cuda_stream)
+        lib().rbl_set_blk_pc(ctx.h, 1)
+        ctx.set_config(c["X"], c["Q"])
+        ctx.set_option("relaxed_krylov", opt)
+        assert ctx.get_option("relaxed_krylov") == opt
+        x = torch.empty_like(b)
+        m, res = ctx.gmres_saddle(b.data_ptr(), 100, 1e-8, x.data_ptr())
+        r = torch.empty(n3, dtype=torch.float64, device=dev); ctx.blob_positions(0, nb, r.data_ptr())
+        roots = []
+        for tol in (1e-3, 1e-6):
+            ctx.set_lanczos(200, tol)
+            o = torch.empty_like(W); ctx.M_half_W(r.data_ptr(), N, W.data_ptr(), "lanczos_pc", o.data_ptr()); ctx.sync_check()
+            roots.append(o.cpu().numpy())
+        got[opt] = (x.cpu().numpy(), m, roots)
+        ctx.close()
+    assert np.array_equal(got[2][0], got[0][0]) and got[2][1] == got[0][1]          # GMRES: fp64 throughout
+    assert not np.array_equal(got[1][0], got[0][0])                                   # (under 1 its late products ARE relaxed)
+    assert np.array_equal(got[2][2][0], got[1][2][0])                                 # the 1e-3 root: the relaxed products of option 1
+    d = np.linalg.norm(got[2][2][0] - got[0][2][0]) / np.linalg.norm(got[0][2][0])
+    assert 0.0 < d < 1e-5, d                                                          # ... which move it by far less than its tolerance
+    assert np.array_equal(got[2][2][1], got[0][2][1]) and np.array_equal(got[1][2][1], got[0][2][1])   # a 1e-6 root is not relaxed
+
+
 @pytest.mark.parametrize("nb,nblb", [(60, 162), (200, 642)])
 def test_relaxed_gmres_reaches_the_fp64_tolerance(nb, nblb):
     """Inexact Krylov (RBL_OPT_RELAXED_KRYLOV = 1): GMRES with the block-diagonal PC to 1e-8 on a wall system (9 720 blobs and
