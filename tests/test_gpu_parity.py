@@ -1756,13 +1756,14 @@ def test_relaxed_product_in_a_wide_suspension(wall):
 
 def test_relaxed_products_in_the_root_only():
     """RBL_OPT_RELAXED_KRYLOV = 2: the packed-single-precision far field serves the Lanczos square roots (asked for to 1e-3: a product
-    error of 1e-6 is three orders below what the root is accurate to) and nothing else.  On 60 x shell_N_162 above a wall: GMRES under
+    error of 1e-6 is three orders below what the root is accurate to) and nothing else.  On 130 x shell_N_162 above a wall (21 060 blobs:
+    the four-wave kernels, the ones with a relaxed form, start at 20 480): GMRES under
     2 is bitwise GMRES under 0 (every product fp64); the preconditioned root under 2 is bitwise the root under 1, differs from the
     all-fp64 root by far less than the tolerance, and passes the same identity check; a root asked for to 1e-6 stays fp64 under both."""
     import torch
     from rigid_body_light_amd import make_config
     from rigid_body_light_amd._lib import DeviceContext, lib
-    nb, nblb, wall = 60, 162, True
+    nb, nblb, wall = 130, 162, True
     c = make_config(nb, nblb, wall)
     N = nb * nblb; n3 = 3 * N; nsys = n3 + 6 * nb
     dev = torch.device("cuda:0")
