@@ -1037,12 +1037,26 @@ __global__ __launch_bounds__(TS *SW, (WALL && NI == 2 && SW > 1 && PREC == 0) ? 
       ui1[0].x += (double)a1x.x; ui1[0].y += (double)a1y.x; ui1[0].z += (double)a1z.x;
       ui1[NI - 1].x += (double)a1x.y; ui1[NI - 1].y += (double)a1y.y; ui1[NI - 1].z += (double)a1z.y;
     } else if (J >= It0 + NI) {
+      // both rows of the lane meet column jj: their contributions to its sums are added in registers (the pair routine accumulates
+      // onto what it is handed: no instruction more) and go to LDS once -- 6 atomics a column instead of 12; at two waves a SIMD the
+      // two-vector kernel waits for its LDS 5.7 x as long as the one-vector one (profiles/r05_two_vector_pmc.md)
       auto sweep = [&](auto nearchk) {
 #pragma unroll 2
         for (int s = 0; s < TS; ++s) {
           const int jj = (lane + s) & (TS - 1);
+          const double2_t pa = sP0[jj], pb = sP1[jj], pd = sP2[jj], pe = sP3[jj], pf = sP4[jj];
+          RblV3 v0{0.0, 0.0, 0.0}, v1{0.0, 0.0, 0.0};
 #pragma unroll
-          for (int a = 0; a < NI; ++a) pair_step(jj, a, nearchk);
+          for (int a = 0; a < NI; ++a)
+            rbl_pair_sym2<WALL, true, decltype(nearchk)::value>(Pu, xi[a], yi[a], zi[a], Fi0[a], Fi1[a], pa.x, pa.y, pb.x,
+                                                                RblV3{pb.y, pd.x, pd.y}, RblV3{pe.x, pe.y, pf.x}, ui0[a],
+                                                                ui1[a], v0, v1, flags, WK);
+          __hip_atomic_fetch_add(&sU[wave][0][0][jj], v0.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][0][1][jj], v0.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][0][2][jj], v0.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][1][0][jj], v1.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][1][1][jj], v1.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&sU[wave][1][2][jj], v1.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
       if (far_tile) sweep(std::false_type{});
