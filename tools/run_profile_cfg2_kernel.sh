@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC look at the mid-size product kernel (cfg 2: k_apply_M_sym<false,1,1,0>, 8 128 one-tile-pair units): issue share, waves in flight.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03m
+O=$R/gpurun_out/${CFG2_OUT:-r03m}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --config cfg2 --steps 50 --warmup 5 --cpu-budget 0 --timestep-steps 0 --other-configs 0"
