@@ -33,8 +33,12 @@ constexpr unsigned SPIN_LIMIT = 4u << 20;   // polls of ~0.5 us before a wait gi
 #ifdef RBL_TILE_PROF
 __device__ unsigned long long g_tile_prof[16];
 #define TP(i) { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_tile_prof[i], now_ - tp_prev); tp_prev = now_; } }
+// ... and the timeline of body 0: when (100 MHz wall clock) each of its tasks was claimed and published, [kind][row tile][column tile][claim | publish]
+__device__ unsigned long long g_tile_line[2][32][32][2];
+#define TLINE(w) { if (threadIdx.x == 0 && b == 0 && ti_ < 32 && tj_ < 32) g_tile_line[chol ? 0 : 1][ti_][tj_][w] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define TP(i)
+#define TLINE(w)
 #endif
 
 struct TileChol {
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     bool chol; int ti_, tj_;                                                  // CHOL(ti_, tj_) or INV(row tile ti_ of Y, column tile tj_)
     if (!tile_task(NT, s, (int)u, chol, ti_, tj_)) continue;
     if (!chol && !with_inv) continue;
+    TLINE(0)
     double *Ab = P.A + (size_t)b * (size_t)P.strideA;
     double *Lib = P.Linv + (size_t)b * (size_t)P.strideL;
     unsigned *cL = P.cntL + (size_t)b * NT, *cY = P.cntY + (size_t)b * NT;
@@ -571,6 +576,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
       TP(5)                                                // triangular solve
     }
     publish(cOut);
+    TLINE(1)
     TP(6)                                                  // publish
     __syncthreads();                                       // LDS and s_task are free for the next task
   }
@@ -609,6 +615,11 @@ extern "C" __attribute__((visibility("default"))) int rbl_debug_tile_prof(unsign
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_prof), z, sizeof(z)); }
   return 0;
+}
+extern "C" __attribute__((visibility("default"))) int rbl_debug_tile_line(unsigned long long *out)
+{
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_line), sizeof(unsigned long long) * 2 * 32 * 32 * 2) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -664,6 +675,12 @@ int rbl_launch_tile_cholesky(hipStream_t st, double *d_M, int64_t n, int batch, 
   P.err = d_err; P.batch = batch; P.NT = (int)NT;
   const size_t tasks = (size_t)batch * (size_t)(NT + 1) * (size_t)(NT + 1);
   size_t grid = 2 * (size_t)(n_cu > 0 ? n_cu : 256);      // two workgroups per CU are resident; later ones find the queues dry
+  // A small batch, factor only (a stage's tasks fit one workgroup a CU): ONE workgroup a CU.  A diagonal tile's factorisation is a
+  // chain of short fp64 operations; a co-resident workgroup's MFMA stream on the same SIMDs (one pipe for both) doubles its time --
+  // body 0's timeline in tools/tile_phase_profile.py: 196 us from the chain tile to the diagonal tile alone, 390 us beside inverse
+  // tiles -- and the chain of diagonal tiles is all a small batch waits for (25 x 1926: 3.47 -> 2.96 ms).  With the inverse the
+  // launch is work-bound at either grid (4.9 ms).
+  if (!d_X && (size_t)batch * (size_t)NT <= grid) grid /= 2;
   if (grid > tasks) grid = tasks;
   hipLaunchKernelGGL(k_tile_chol, dim3((unsigned)grid), dim3(256), 0, st, P);
   if (d_X) {

@@ -53,3 +53,14 @@ print("%d x shell_N_%d, inverse %d: build + one application %.2f ms; %d tasks; s
       % (nb, nblb, inv, e0.elapsed_time(e1), nb * NT * (NT + 1) // (1 if inv else 2), tot / 2.4e6, tot / 2.4e6 / 512))
 for i, nm in names.items():
     print("  %-42s %6.2f %%" % (nm, 100 * x[i] / tot))
+
+# timeline of body 0 (microseconds after its first claim): the factor front diag(s), and the inverse tiles of rows 0 and s - 1 in column s
+tl = (ctypes.c_ulonglong * (2 * 32 * 32 * 2))()
+if hasattr(L, "rbl_debug_tile_line") and L.rbl_debug_tile_line(tl) == 0 and NT <= 32:
+    T = np.array(list(tl), dtype=np.float64).reshape(2, 32, 32, 2) / 100.0
+    t0 = T[0, 0, 0, 0]
+    print("body 0, us after its first claim: diagonal tile (s, s) claimed / published | chain tile (s + 1, s) published | INV(0, s) claimed / published | INV(s, s) published")
+    for s_ in range(NT):
+        ch = T[0, s_ + 1, s_, 1] - t0 if s_ + 1 < NT else float("nan")
+        iv = (T[1, 0, s_, 0] - t0, T[1, 0, s_, 1] - t0, T[1, s_, s_, 1] - t0) if inv else (float("nan"),) * 3
+        print("  s = %2d   %8.1f %8.1f | %8.1f | %8.1f %8.1f | %8.1f" % (s_, T[0, s_, s_, 0] - t0, T[0, s_, s_, 1] - t0, ch, iv[0], iv[1], iv[2]))
