@@ -25,6 +25,7 @@ constexpr int TC = 128;          // tile edge
 constexpr int TKC = 16;          // K columns per pipeline stage
 constexpr int TLDP = 144;        // LDS column stride (doubles): conflict-free fragment reads, as in k_syrk_mfma
 constexpr int TQS = 32;          // unsigned words between two queue heads (one 128-byte line each)
+constexpr int TCU = 2048;        // per-CU words (XCC 3 bits, SE / SH / CU 8 bits of HW_ID)
 constexpr unsigned TGRP = 4;     // bodies of a queue that share an iteration's slots (see the queue order in k_tile_chol)
 constexpr unsigned SPIN_LIMIT = 4u << 20;   // polls of ~0.5 us before a wait gives up (seconds: a hang must end by itself)
 
@@ -51,6 +52,7 @@ struct TileChol {
   unsigned *abort_;                           // set when a wait ran out
   unsigned *err;
   int batch, NT;
+  unsigned *cu_busy;                          // small batches with the inverse: per physical CU, chain tiles at work there (NULL: off)
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -397,6 +399,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
   const unsigned per = (unsigned)(NT + 1);                 // tasks per body and stage
   auto nbq = [&](int q) -> unsigned { return P.batch > q ? (unsigned)((P.batch - q + 7) / 8) : 0u; };
   const bool with_inv = P.Y != nullptr;
+  // this workgroup's physical CU: HW_REG_HW_ID bits 8 .. 15 (CU, SH, SE) under the XCC
+  unsigned *const cu_word = P.cu_busy ? P.cu_busy + (((xcc << 8) | (((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu)) & (TCU - 1)) : nullptr;
 
 #ifdef RBL_TILE_PROF
   unsigned long long tp_prev = clock64();
@@ -405,6 +409,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     TP(9)                                                  // end-of-task barrier of the previous task
     if (t == 0) {
       int q = -1; unsigned idx = 0;
+      if (cu_word)                                         // a chain tile is at work on this CU: leave the SIMDs to it
+        for (int n_ = 0; n_ < 1024 && ld_relaxed(cu_word) != 0u; ++n_) __builtin_amdgcn_s_sleep(32);
       if (!ld_relaxed(P.abort_)) {
         for (int a = 0; a < 8 && q < 0; ++a) {
           const int qq = (int)((xcc + (unsigned)a) & 7u);
@@ -457,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
     const long r0 = (long)rt * TC, c0 = (long)ct * TC;
     const long i0 = r0 + wi * 64, j0 = c0 + wj * 64;
     const bool diag = rt == ct;
+    const bool on_chain = cu_word != nullptr && chol && (diag || rt == ct + 1);      // diag(s) -> (s + 1, s) -> diag(s + 1): what a small batch waits for
+    if (on_chain && t == 0) __hip_atomic_fetch_add(cu_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned *cA = chol ? cL + rt : cY + rt, *cB = chol ? cL + ct : cA;       // counters the K chunks wait on (cA: chunk kc needs >= kc + 1)
     unsigned *cOut = cA;                                                      // ... and the one this tile adds to
     const int pw = (int)((n - c0 < TC) ? (n - c0) : TC);
@@ -575,6 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chol(const TileChol P)
       }
       TP(5)                                                // triangular solve
     }
+    if (on_chain && t == 0) __hip_atomic_fetch_add(cu_word, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     publish(cOut);
     TLINE(1)
     TP(6)                                                  // publish
@@ -644,7 +653,7 @@ bool rbl_tile_cholesky_fits(int64_t n) { return n > 512 && (size_t)n * (size_t)(
 static size_t tile_counter_bytes(int64_t n, int batch)
 {
   const int64_t NT = (n + TC - 1) / TC;
-  size_t words = 8 * TQS + 32 + 2 * (size_t)batch * (size_t)NT;      // queue heads, abort word (own line), counters
+  size_t words = 8 * TQS + 32 + 2 * (size_t)batch * (size_t)NT + TCU;      // queue heads, abort word (own line), counters, the per-CU words
   words = (words + 63) / 64 * 64;                                    // (a multiple of 256 bytes: the W tiles behind it stay aligned)
   return words * sizeof(unsigned);
 }
@@ -673,6 +682,7 @@ int rbl_launch_tile_cholesky(hipStream_t st, double *d_M, int64_t n, int batch, 
   P.heads = w; P.abort_ = w + 8 * TQS; P.cntL = w + 8 * TQS + 32; P.cntY = P.cntL + (size_t)batch * (size_t)NT;
   P.W = (double *)((char *)d_work + tile_counter_bytes(n, batch));
   P.err = d_err; P.batch = batch; P.NT = (int)NT;
+  P.cu_busy = nullptr;
   const size_t tasks = (size_t)batch * (size_t)(NT + 1) * (size_t)(NT + 1);
   size_t grid = 2 * (size_t)(n_cu > 0 ? n_cu : 256);      // two workgroups per CU are resident; later ones find the queues dry
   // A small batch, factor only (a stage's tasks fit one workgroup a CU): ONE workgroup a CU.  A diagonal tile's factorisation is a
@@ -681,6 +691,11 @@ int rbl_launch_tile_cholesky(hipStream_t st, double *d_M, int64_t n, int batch, 
   // tiles -- and the chain of diagonal tiles is all a small batch waits for (25 x 1926: 3.47 -> 2.96 ms).  With the inverse the
   // launch is work-bound at either grid (4.9 ms).
   if (!d_X && (size_t)batch * (size_t)NT <= grid) grid /= 2;
+  // ... with the inverse tiles in the launch (work for every slot: 256 slots cannot hold a stage's 800 tasks) the chain keeps its
+  // CUs another way: while a tile of the chain diag(s) -> (s + 1, s) -> diag(s + 1) is at work on a CU, the CU's other workgroup
+  // claims nothing (bounded: a millisecond at most).  Factor + inverse, on and off alternating on one box: 25 x 1926 4.94-5.02 ->
+  // 4.51-4.60 ms, 50 x 1926 7.23 -> 7.07; from 100 bodies on nothing or a loss (there the chain is not what the launch waits for)
+  else if (d_X && (size_t)batch * (size_t)NT <= 2 * grid) P.cu_busy = P.cntY + (size_t)batch * (size_t)NT;
   if (grid > tasks) grid = tasks;
   hipLaunchKernelGGL(k_tile_chol, dim3((unsigned)grid), dim3(256), 0, st, P);
   if (d_X) {
