@@ -74,8 +74,8 @@ NOTES = {
     "summary.brownian_gmres_rtol_matched_to_root": "NOT a headline: the Brownian step with the GMRES tolerance set to the root's (1e-3, 1e-4) instead of "
                                                    "1e-8; U_err_vs_1e-8_solve = |U - U_ref| / |U_ref| of the body velocities against the 1e-8 solve of the "
                                                    "SAME right-hand side (measured after the timed steps), root_err = measured root identity error",
-    "summary.brownian_converged_detail": "iterations, products per step, measured root identity error |root(s) - B M v| / |B M v| and the per-phase GPU "
-                                         "milliseconds (rbl_get_timings) of brownian_converged",
+    "summary.brownian_converged_detail": "iterations, products per step, root_err = measured root identity error |root(s) - B M v| / |B M v|, gmres_res_max = "
+                                         "largest GMRES residual of the timed steps, and the per-phase GPU milliseconds (rbl_get_timings) of brownian_converged",
     "summary.cpu_timesteps_per_sec": "the CPU port's measured seconds per apply_M x the MEASURED product count of each GPU step (O(N) work not counted: a "
                                      "lower bound on the CPU time), 1 core (the reference is single-threaded) and the box's host cores",
     "summary.roofline_frac": "cfg3_apply_M = roofline.frac; cfg1 / cfg2 apply_M against the fp64 peak with their own kernels' executed flops (wall clock "
@@ -85,7 +85,7 @@ NOTES = {
                               "(restart 40, rtol 1e-8) over them (the reference's usage model, src/Rigid.py:69-80), and the library's own solver on "
                               "the same right-hand side",
     "summary.dropin_cfg2_scipy_gmres_ms": "median of five SciPy solves at cfg 2 before and after cfg 5 mapped 189 GB in this process, host BLAS pool limited "
-                                          "to blas_threads (the box's CPU share); default_threads_min_max = the same solves with the pool at its default "
+                                          "to blas_threads (the box's CPU share); default_pool_min_max = the same solves with the pool at its default "
                                           "(every core of the host): the 12-vs-92 ms spread of round 4 is BLAS oversubscription, not cfg 5 and not the operators",
     "summary.multi_rhs": "rbl_gmres_saddle_multi_dev at the headline configuration: 16 right-hand sides (sets of body loads) in lock step, their products ONE "
                          "launch of the fp64-MFMA kernel per iteration, against sequential rbl_gmres_saddle_dev solves (two timed, scaled to 16): "
@@ -961,7 +961,7 @@ def summary_of(d):
             ph = b.get("phases") or {}
             det = {"ms": b["ms_per_timestep"], "apply_M_per_step": ts.get("brownian_converged_apply_M_per_step"),
                    "gmres_its": b["gmres_iterations"][-1], "lanczos_pair_its": b["lanczos_iterations_last_step"][0],
-                   "root_identity_error": b.get("root_identity_error"), "gmres_residual_max": b["gmres_residual_max"],
+                   "root_err": b.get("root_identity_error"), "gmres_res_max": b["gmres_residual_max"],
                    "phases_ms": {k: ph[k + "_ms"]["max"] for k in ("product", "per_body", "factor", "collective") if k + "_ms" in ph and ph[k + "_ms"]["max"] > 0.0}}
             if ph.get("collectives_per_step"):
                 det["collectives_per_step"] = ph["collectives_per_step"]
@@ -1002,7 +1002,7 @@ def summary_of(d):
         dflt = d2["scipy_gmres"].get("default_blas_threads")
         s["dropin_cfg2_scipy_gmres_ms"] = {"before_cfg5": d2["scipy_gmres"]["ms"], "after_cfg5": d2b["scipy_gmres"]["ms"] if d2b else None,
                                            "blas_threads": d2["scipy_gmres"].get("blas_threads"),
-                                           "default_threads_min_max": [min(dflt["all_solves_ms"][1:]), max(dflt["all_solves_ms"][1:])] if dflt else None}
+                                           "default_pool_min_max": [min(dflt["all_solves_ms"][1:]), max(dflt["all_solves_ms"][1:])] if dflt else None}
     if d.get("multi_rhs") and "error" not in d["multi_rhs"]:
         m = d["multi_rhs"]
         s["multi_rhs"] = {k: m[k] for k in ("rhs", "lock_step_ms", "sequential_ms_per_solve", "ratio_to_sequential", "gmres_iterations",
