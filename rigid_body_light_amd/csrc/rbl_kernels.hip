@@ -1127,6 +1127,9 @@ constexpr int RG = 16;
 
 // (the 64-lane sum in its one fixed order: rbl_wave_sum64, rbl_internal.hpp)
 
+#ifndef RBL_REDUCE_UNROLL
+#define RBL_REDUCE_UNROLL 4     // slab entries in flight per thread of k_reduce_sym (cfg 3, one box, tools/build_variant.sh: 4: 134 us, 8: 145, 16: 159)
+#endif
 template <bool WALL>
 __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict__ slabI,
                                                        const double *__restrict__ slabJ,
@@ -1155,10 +1158,10 @@ __global__ __launch_bounds__(64 * RG) void k_reduce_sym(const double *__restrict
   const int nJ = (nE + L.SW - 1) / L.SW;                 // row groups whose first super-tile precedes J
   double s = 0.0;
   int e = q;
-#pragma unroll 4
+#pragma unroll RBL_REDUCE_UNROLL
   for (; e < nI; e += RG) s += slabI[sym_idxI(L, c0 + e, v, j) + k];
   e -= nI;
-#pragma unroll 4
+#pragma unroll RBL_REDUCE_UNROLL
   for (; e < nJ; e += RG) s += slabJ[sym_idxJ(L, e, v, j) + k];
   sh[q][tx] = s;
   __syncthreads();
